@@ -1,0 +1,142 @@
+/*
+ * ionotomo_hip.h -- C-ABI of libionotomo_hip.so: the MI355X (gfx950) ray-integral engine.
+ *
+ * The reference (Joshuaalbert/IonoTomo) is pure Python and has no FFI; the boundary of its
+ * hot path is a set of Python call signatures.  Each entry point below names the reference
+ * function (file:line, relative to /root/reference/src/ionotomo/) whose numeric work it
+ * replaces; ionotomo_amd/ re-creates those Python signatures on top of this ABI via ctypes
+ * (INTEGRATION.md shows the binding a reference maintainer would add).
+ *
+ * Conventions
+ *   - plain C: opaque context, plain pointers and sizes, int return code (0 = OK, < 0 error;
+ *     iono_last_error() gives the text).  Nothing throws or aborts across the ABI.
+ *   - one iono_ctx per GPU per process, created AFTER fork; a ctx is not thread-safe,
+ *     independent ctxs are.
+ *   - "host" entry points take host pointers, run synchronously and return results in
+ *     caller-allocated host arrays.  "_dev" entry points take DEVICE pointers, enqueue on the
+ *     ctx stream (iono_ctx_set_stream lets the caller supply e.g. torch's current stream) and
+ *     return immediately; the caller owns all buffers.  No library-allocated memory is ever
+ *     returned.
+ *   - all real data is float64 except the grid values, which may be STORED as float32
+ *     (IONO_F32) -- arithmetic and accumulation stay float64.
+ *   - grid values are C-ordered M[i][j][k] at flat index k + nz*(j + ny*i)
+ *     (notebooks/TricubicInterpolation.ipynb c0:113-115).
+ *   - rays are R independent rays; the Python layer flattens [Na,Nt,Nd] -> R.
+ */
+#ifndef IONOTOMO_HIP_H
+#define IONOTOMO_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct iono_ctx iono_ctx;
+
+enum {
+    IONO_OK = 0,
+    IONO_ERR_OOB = -1,       /* a sample lies outside the grid  -> Python ValueError (scipy bounds_error=True, geometry/tri_cubic.py:22,59) */
+    IONO_ERR_NONFINITE = -2, /* NaN/Inf in grid values          -> Python AssertionError (geometry/tri_cubic.py:51) */
+    IONO_ERR_SHAPE = -3,
+    IONO_ERR_HIP = -4,       /* HIP runtime failure             -> Python RuntimeError */
+    IONO_ERR_ARG = -5
+};
+
+enum { IONO_F64 = 0, IONO_F32 = 1 };                     /* grid storage type */
+enum { IONO_INTERP_TRILINEAR = 0,                        /* what TriCubic.interp ships: scipy RGI 'linear' (geometry/tri_cubic.py:69-70) */
+       IONO_INTERP_TRICUBIC = 1 };                       /* Lekien-Marsden, 4th-order FD slopes (notebooks/TricubicInterpolation.ipynb c0:138-1257) */
+enum { IONO_QUAD_SIMPSON_AVG = 0,                        /* odd N composite Simpson; even N reference-era simps(even='avg') (tomography/integrate.py:130-153) */
+       IONO_QUAD_SIMPSON_SCIPY = 1,                      /* even N: scipy>=1.11 simpson (Cartwright correction) */
+       IONO_QUAD_TRAPEZOID = 2 };
+
+/* ---- context ------------------------------------------------------------------------------ */
+int iono_ctx_create(int device_id, iono_ctx **out);
+int iono_ctx_destroy(iono_ctx *ctx);
+const char *iono_last_error(iono_ctx *ctx);              /* ctx may be NULL: last global error */
+int iono_ctx_set_stream(iono_ctx *ctx, void *hip_stream);/* NULL -> the ctx's own stream */
+int iono_ctx_synchronize(iono_ctx *ctx);
+int iono_version(void);
+
+/* ---- grid: TriCubic(xvec,yvec,zvec,M) container (geometry/tri_cubic.py:13-59) ---------------- */
+/* axes are strictly increasing, may be non-uniform; M (host, float64, nx*ny*nz) may be NULL to
+ * allocate only.  storage = IONO_F64 | IONO_F32. */
+int iono_grid_set(iono_ctx *ctx, const double *xvec, int nx, const double *yvec, int ny,
+                  const double *zvec, int nz, const double *M, int storage);
+int iono_grid_set_values(iono_ctx *ctx, const double *M);           /* TriCubic.M setter (:49-59); NaN/Inf -> IONO_ERR_NONFINITE */
+int iono_grid_get_values(iono_ctx *ctx, double *M_out);
+int iono_grid_set_values_dev(iono_ctx *ctx, const double *M_dev);   /* float64 device source, converted to the storage type */
+/* M = scale * exp(m) at the NODES: ne = K_ne exp(m)/TECU (inversion/forward_equation.py:41-43),
+ * ne = K exp(mu) (inversion/iterative_newton.py:104-106) */
+int iono_grid_set_exp(iono_ctx *ctx, const double *m_host, double scale);
+int iono_grid_set_exp_dev(iono_ctx *ctx, const double *m_dev, double scale);
+void *iono_grid_values_ptr(iono_ctx *ctx);                          /* device pointer of the stored values */
+
+/* ---- TriCubic.interp / .extrapolate (geometry/tri_cubic.py:69-75) --------------------------- */
+int iono_interp(iono_ctx *ctx, const double *x, const double *y, const double *z, int64_t n,
+                int interp_kind, int extrapolate, double *out);
+
+/* ---- ray geometry: cast_ray / Fermat.integrate_ray (geometry/calc_rays.py:61-96,
+ *      inversion/fermat.py:150-174).  rays_out[R][4][Ns] = x,y,z,s ----------------------------- */
+int iono_trace_straight(iono_ctx *ctx, const double *origins, const double *directions, int64_t R,
+                        double tmax, int Ns, double *rays_out);
+/* grid must hold ne [m^-3].  bend = 0 reproduces the shipped "curved" mode (grad n forced to 0,
+ * fermat.py:54-55: straight x,y,z and s = int n/pz dz); bend = 1 integrates the true equations
+ * (notebooks/FermatClass.ipynb c0:60-96) with fixed-step RK4, `substeps` steps per output sample. */
+int iono_trace_fermat(iono_ctx *ctx, const double *origins, const double *directions, int64_t R,
+                      double tmax, int Ns, double frequency, int bend, int interp_kind, int substeps,
+                      double *rays_out);
+
+/* ---- forward: tec[r] = simps(interp(M; x,y,z), s) (inversion/forward_equation.py:13-33) ------ */
+/* samples generated in-kernel on straight z-parametrised rays (never materialises rays[R,4,Ns]) */
+int iono_forward_tec_straight(iono_ctx *ctx, const double *origins, const double *directions,
+                              int64_t R, double tmax, int Ns, int interp_kind, int quad_rule,
+                              double *tec_out);
+/* explicit samples rays[R][4][Ns], exactly the reference's argument */
+int iono_forward_tec_rays(iono_ctx *ctx, const double *rays, int64_t R, int Ns, int interp_kind,
+                          int quad_rule, double *tec_out);
+/* dtec = tec - tec[i0] over [Na][Nt*Nd] (inversion/forward_equation.py:50) */
+int iono_subtract_reference(iono_ctx *ctx, double *tec_inout, int Na, int64_t NtNd, int i0);
+/* phase observable g[Na][Nt][Nd][Nf] (inversion/iterative_newton.py:86-127); grid holds ne = K exp(mu) */
+int iono_forward_phase_rays(iono_ctx *ctx, const double *rays, int Na, int Nt, int Nd, int Ns,
+                            const double *freqs, int Nf, const double *clock /*[Na][Nt]*/,
+                            const double *const_ /*[Na]*/, int i0, int quad_rule, double *g_out);
+
+/* ---- adjoint (exact transpose of the forward; SURVEY.md section 8a row A7') ------------------- */
+/* grad[v] (+)= sum_r w[r] sum_k c_{r,k} W_{k,v}; if scale_by_grid, grad[v] *= M[v] afterwards
+ * (gradient w.r.t. the log-model, cf. inversion/gradient.py:19).  grad_out: float64[nx*ny*nz]. */
+int iono_adjoint_straight(iono_ctx *ctx, const double *origins, const double *directions,
+                          const double *w, int64_t R, double tmax, int Ns, int quad_rule,
+                          int scale_by_grid, double *grad_out);
+int iono_adjoint_rays(iono_ctx *ctx, const double *rays, const double *w, int64_t R, int Ns,
+                      int quad_rule, int scale_by_grid, double *grad_out);
+
+/* ---- device-pointer (asynchronous) variants used by the inversion loop, bench.py and the
+ *      multi-GPU driver.  Out-of-grid samples set a sticky device flag read by iono_check_oob. ---- */
+int iono_forward_tec_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
+                                  int64_t R, double tmax, int Ns, int interp_kind, int quad_rule,
+                                  double *tec_dev);
+int iono_forward_tec_rays_dev(iono_ctx *ctx, const double *rays_dev, int64_t R, int Ns,
+                              int interp_kind, int quad_rule, double *tec_dev);
+/* accumulates INTO grad_dev (caller zeroes it); accum_dtype IONO_F64 | IONO_F32 selects the
+ * element type of grad_dev and of the atomics */
+int iono_adjoint_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
+                              const double *w_dev, int64_t R, double tmax, int Ns, int quad_rule,
+                              void *grad_dev, int accum_dtype);
+int iono_adjoint_rays_dev(iono_ctx *ctx, const double *rays_dev, const double *w_dev, int64_t R,
+                          int Ns, int quad_rule, void *grad_dev, int accum_dtype);
+/* fused residual -> differential weights -> back-projection for layout [Na][Nt*Nd]:
+ *   dd = (tec[a,p] - tec[i0,p] - dobs[a,p]) / (CdCt[a,p] + 1e-15)      (inversion/gradient.py:77-81)
+ *   w[a,p] = dd[a,p] - [a == i0] sum_a' dd[a',p]                        (transpose of the i0 differencing)
+ * then the adjoint of the straight-ray forward, in ONE launch. */
+int iono_adjoint_residual_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
+                                       const double *tec_dev, const double *dobs_dev, const double *cdct_dev,
+                                       int Na, int64_t NtNd, int i0, double tmax, int Ns, int quad_rule,
+                                       void *grad_dev, int accum_dtype);
+int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);
+int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,286 @@
+"""ctypes binding of libionotomo_hip.so (include/ionotomo_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or no GPU is visible every
+compute entry point raises.  (``oracle/`` holds a CPU restatement, but that is test
+infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libionotomo_hip.so")
+
+OK, ERR_OOB, ERR_NONFINITE, ERR_SHAPE, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
+F64, F32 = 0, 1
+INTERP_TRILINEAR, INTERP_TRICUBIC = 0, 1
+QUAD_SIMPSON_AVG, QUAD_SIMPSON_SCIPY, QUAD_TRAPEZOID = 0, 1, 2
+
+_INTERP = {"linear": 0, "trilinear": 0, 0: 0, "cubic": 1, "tricubic": 1, 1: 1}
+_QUAD = {"avg": 0, "simpson": 0, "simps": 0, 0: 0, "scipy": 1, "cartwright": 1, 1: 1, "trapz": 2, "trapezoid": 2, 2: 2}
+_STORAGE = {"f64": 0, "float64": 0, np.float64: 0, 0: 0, "f32": 1, "float32": 1, np.float32: 1, 1: 1}
+
+
+def interp_kind(k):
+    return _INTERP[k]
+
+
+def quad_rule(q):
+    return _QUAD[q]
+
+
+def storage_code(s):
+    return _STORAGE[s]
+
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+_P, _I, _L, _D, _V = c_double_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
+
+# name -> argument types after the leading ctx pointer (None = no ctx argument)
+_SIGNATURES = {
+    "iono_ctx_destroy": [],
+    "iono_ctx_set_stream": [_V],
+    "iono_ctx_synchronize": [],
+    "iono_grid_set": [_P, _I, _P, _I, _P, _I, _P, _I],
+    "iono_grid_set_values": [_P],
+    "iono_grid_get_values": [_P],
+    "iono_grid_set_values_dev": [_V],
+    "iono_grid_set_exp": [_P, _D],
+    "iono_grid_set_exp_dev": [_V, _D],
+    "iono_interp": [_P, _P, _P, _L, _I, _I, _P],
+    "iono_trace_straight": [_P, _P, _L, _D, _I, _P],
+    "iono_trace_fermat": [_P, _P, _L, _D, _I, _D, _I, _I, _I, _P],
+    "iono_forward_tec_straight": [_P, _P, _L, _D, _I, _I, _I, _P],
+    "iono_forward_tec_rays": [_P, _L, _I, _I, _I, _P],
+    "iono_subtract_reference": [_P, _I, _L, _I],
+    "iono_forward_phase_rays": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P],
+    "iono_adjoint_straight": [_P, _P, _P, _L, _D, _I, _I, _I, _P],
+    "iono_adjoint_rays": [_P, _P, _L, _I, _I, _I, _P],
+    "iono_forward_tec_straight_dev": [_V, _V, _L, _D, _I, _I, _I, _V],
+    "iono_forward_tec_rays_dev": [_V, _L, _I, _I, _I, _V],
+    "iono_adjoint_straight_dev": [_V, _V, _V, _L, _D, _I, _I, _V, _I],
+    "iono_adjoint_rays_dev": [_V, _V, _L, _I, _I, _V, _I],
+    "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _V, _I],
+    "iono_subtract_reference_dev": [_V, _I, _L, _I],
+    "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
+}
+EXPORTED = sorted(list(_SIGNATURES) + ["iono_ctx_create", "iono_last_error", "iono_version", "iono_grid_values_ptr"])
+
+_lib = None
+
+
+def load():
+    """dlopen the library (once).  Raises if it has not been built -- by design."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "ionotomo_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.iono_ctx_create.argtypes = [_I, ctypes.POINTER(_V)]
+    lib.iono_ctx_create.restype = _I
+    lib.iono_last_error.argtypes = [_V]
+    lib.iono_last_error.restype = ctypes.c_char_p
+    lib.iono_version.argtypes = []
+    lib.iono_version.restype = _I
+    lib.iono_grid_values_ptr.argtypes = [_V]
+    lib.iono_grid_values_ptr.restype = _V
+    for name, args in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes = [_V] + args
+        fn.restype = _I
+    _lib = lib
+    return lib
+
+
+def _dp(a):
+    """float64 C-contiguous host array -> double*"""
+    return a.ctypes.data_as(c_double_p)
+
+
+def as_f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class Context(object):
+    """One GPU context (``iono_ctx``).  Create after fork; not thread-safe."""
+
+    def __init__(self, device=0):
+        self._lib = load()
+        h = _V()
+        rc = self._lib.iono_ctx_create(int(device), ctypes.byref(h))
+        if rc != OK:
+            raise RuntimeError("iono_ctx_create failed: %s" % self._lib.iono_last_error(None).decode())
+        self._h = h
+        self.device = int(device)
+        self.pid = os.getpid()
+        self.grid_shape = None
+        self.storage = None
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self.pid == os.getpid():
+            self._lib.iono_ctx_destroy(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- error mapping: mirrors what the reference raises --------------------------
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self._lib.iono_last_error(self._h).decode()
+        if rc == ERR_OOB:
+            raise ValueError(msg)                 # scipy RGI bounds_error=True
+        if rc == ERR_NONFINITE:
+            raise AssertionError(msg)             # geometry/tri_cubic.py:51
+        if rc in (ERR_SHAPE, ERR_ARG):
+            raise ValueError(msg)
+        raise RuntimeError(msg)
+
+    def call(self, name, *args):
+        self._check(getattr(self._lib, name)(self._h, *args))
+
+    # -- grid ------------------------------------------------------------------------------------
+    def set_grid(self, xvec, yvec, zvec, M=None, storage="f64"):
+        xv, yv, zv = as_f64(xvec).ravel(), as_f64(yvec).ravel(), as_f64(zvec).ravel()
+        Mp = None
+        if M is not None:
+            M = as_f64(M)
+            if M.size != xv.size * yv.size * zv.size:
+                raise ValueError("M has %d values, grid has %d nodes" % (M.size, xv.size * yv.size * zv.size))
+            Mp = _dp(M)
+        self.call("iono_grid_set", _dp(xv), xv.size, _dp(yv), yv.size, _dp(zv), zv.size, Mp, storage_code(storage))
+        self.grid_shape = (xv.size, yv.size, zv.size)
+        self.storage = storage_code(storage)
+
+    def set_values(self, M):
+        M = as_f64(M)
+        self._need(M.size)
+        self.call("iono_grid_set_values", _dp(M))
+
+    def set_values_exp(self, m, scale):
+        m = as_f64(m)
+        self._need(m.size)
+        self.call("iono_grid_set_exp", _dp(m), float(scale))
+
+    def get_values(self):
+        out = np.empty(self.grid_shape, dtype=np.float64)
+        self.call("iono_grid_get_values", _dp(out))
+        return out
+
+    def _need(self, size):
+        if self.grid_shape is None:
+            raise ValueError("no grid set")
+        if size != int(np.prod(self.grid_shape)):
+            raise ValueError("expected %d grid values, got %d" % (int(np.prod(self.grid_shape)), size))
+
+    def values_ptr(self):
+        return self._lib.iono_grid_values_ptr(self._h)
+
+    def set_stream(self, stream_ptr):
+        self.call("iono_ctx_set_stream", _V(stream_ptr))
+
+    def synchronize(self):
+        self.call("iono_ctx_synchronize")
+
+    def check_oob(self):
+        v = ctypes.c_int(0)
+        self.call("iono_check_oob", ctypes.byref(v))
+        return bool(v.value)
+
+    # -- host-pointer numerics -----------------------------------------------------------------------
+    def interp(self, x, y, z, kind="linear", extrapolate=False):
+        shp = np.shape(x)
+        x, y, z = as_f64(x).ravel(), as_f64(y).ravel(), as_f64(z).ravel()
+        if not (x.size == y.size == z.size):
+            raise ValueError("x, y, z must have equal shapes")
+        out = np.empty(x.size, dtype=np.float64)
+        self.call("iono_interp", _dp(x), _dp(y), _dp(z), x.size, interp_kind(kind), int(bool(extrapolate)), _dp(out))
+        return out.reshape(shp)
+
+    def trace_straight(self, origins, directions, tmax, Ns):
+        o, d, R = _rays_in(origins, directions)
+        out = np.empty((R, 4, int(Ns)), dtype=np.float64)
+        self.call("iono_trace_straight", _dp(o), _dp(d), R, float(tmax), int(Ns), _dp(out))
+        return out
+
+    def trace_fermat(self, origins, directions, tmax, Ns, frequency, bend=True, kind="cubic", substeps=4):
+        o, d, R = _rays_in(origins, directions)
+        out = np.empty((R, 4, int(Ns)), dtype=np.float64)
+        self.call("iono_trace_fermat", _dp(o), _dp(d), R, float(tmax), int(Ns), float(frequency), int(bool(bend)),
+                  interp_kind(kind), int(substeps), _dp(out))
+        return out
+
+    def forward_tec_straight(self, origins, directions, tmax, Ns, kind="linear", rule="avg"):
+        o, d, R = _rays_in(origins, directions)
+        out = np.empty(R, dtype=np.float64)
+        self.call("iono_forward_tec_straight", _dp(o), _dp(d), R, float(tmax), int(Ns), interp_kind(kind),
+                  quad_rule(rule), _dp(out))
+        return out
+
+    def forward_tec_rays(self, rays, kind="linear", rule="avg"):
+        rays = as_f64(rays)
+        Ns = rays.shape[-1]
+        if rays.ndim < 2 or rays.shape[-2] != 4:
+            raise ValueError("rays must have shape [..., 4, Ns]")
+        R = int(np.prod(rays.shape[:-2], dtype=np.int64))
+        out = np.empty(R, dtype=np.float64)
+        self.call("iono_forward_tec_rays", _dp(rays), R, int(Ns), interp_kind(kind), quad_rule(rule), _dp(out))
+        return out.reshape(rays.shape[:-2])
+
+    def forward_phase_rays(self, rays, freqs, clock, const, i0, rule="avg"):
+        rays = as_f64(rays)
+        Na, Nt, Nd, four, Ns = rays.shape
+        freqs, clock, const = as_f64(freqs), as_f64(clock), as_f64(const)
+        if clock.shape != (Na, Nt) or const.shape != (Na,):
+            raise ValueError("clock must be [Na,Nt] and const [Na]")
+        out = np.empty((Na, Nt, Nd, freqs.size), dtype=np.float64)
+        self.call("iono_forward_phase_rays", _dp(rays), Na, Nt, Nd, Ns, _dp(freqs), freqs.size, _dp(clock), _dp(const),
+                  int(i0), quad_rule(rule), _dp(out))
+        return out
+
+    def adjoint_straight(self, origins, directions, w, tmax, Ns, rule="avg", scale_by_grid=False):
+        o, d, R = _rays_in(origins, directions)
+        w = as_f64(w).ravel()
+        if w.size != R:
+            raise ValueError("one weight per ray expected")
+        out = np.empty(self.grid_shape, dtype=np.float64)
+        self.call("iono_adjoint_straight", _dp(o), _dp(d), _dp(w), R, float(tmax), int(Ns), quad_rule(rule),
+                  int(bool(scale_by_grid)), _dp(out))
+        return out
+
+    def adjoint_rays(self, rays, w, rule="avg", scale_by_grid=False):
+        rays = as_f64(rays)
+        Ns = rays.shape[-1]
+        R = int(np.prod(rays.shape[:-2], dtype=np.int64))
+        w = as_f64(w).ravel()
+        if w.size != R:
+            raise ValueError("one weight per ray expected")
+        out = np.empty(self.grid_shape, dtype=np.float64)
+        self.call("iono_adjoint_rays", _dp(rays), _dp(w), R, int(Ns), quad_rule(rule), int(bool(scale_by_grid)), _dp(out))
+        return out
+
+
+def _rays_in(origins, directions):
+    o, d = as_f64(origins), as_f64(directions)
+    if o.shape != d.shape or o.shape[-1] != 3:
+        raise ValueError("origins and directions must both have shape [..., 3]")
+    return o, d, int(np.prod(o.shape[:-1], dtype=np.int64))
+
+
+_default = None
+
+
+def default_context():
+    """Process-wide context on device LOCAL_RANK (or 0); re-created after fork."""
+    global _default
+    if _default is None or _default.pid != os.getpid():
+        _default = Context(int(os.environ.get("IONOTOMO_DEVICE", os.environ.get("LOCAL_RANK", "0"))))
+    return _default

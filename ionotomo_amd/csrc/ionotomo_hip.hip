@@ -1,0 +1,1364 @@
+// ionotomo_hip.hip -- MI355X (gfx950 / CDNA4) ray-integral engine behind include/ionotomo_hip.h.
+//
+// Hot path of Joshuaalbert/IonoTomo, rebuilt for 64-wide wavefronts:
+//   forward : one wavefront per ray, lanes = samples along the ray.  Rays are z-parametrised and
+//             the grid is C-ordered with z fastest, so the 64 lanes of a wave read z-contiguous
+//             runs of the four (i,j) corner columns -> coalesced HBM/L2 reads; the per-ray
+//             quadrature (Simpson) is a weighted wave-level reduction (DPP shuffles).
+//   adjoint : the same traversal scattering  w_r c_k W_kv  with hardware float atomics; lanes
+//             of a wave hit z-contiguous addresses (well-shaped atomic wave-instructions).
+//   tracer  : the Fermat ODE is sequential in z, so there lanes = rays (fixed-step RK4).
+// The path is gather/bandwidth bound (about 1 flop per byte): no MFMA anywhere.
+//
+// Reference citations (file:line) are relative to /root/reference/src/ionotomo/.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../include/ionotomo_hip.h"
+
+#define IONO_VERSION 100
+#define PLASMA_A (8.980 * 8.980)             // inversion/fermat.py:42
+#define SPEED_OF_LIGHT 299792458.0           // inversion/iterative_newton.py:15
+
+namespace {
+
+thread_local std::string g_last_error;
+
+// ------------------------------------------------------------------------------------------------
+// device-side grid description
+// ------------------------------------------------------------------------------------------------
+struct GridView {
+    const double *axes;   // xvec | yvec | zvec concatenated (device)
+    const void *M;        // nx*ny*nz values, float64 or float32
+    int nx, ny, nz;
+    double inv_h[3];      // 1/(mean spacing) per axis: first guess of the cell index
+    int uniform[3];       // axis is (numerically) uniform -> guess + fix-up; else binary search
+};
+
+struct Axes {             // axis tables staged in LDS
+    const double *x, *y, *z;
+    int nx, ny, nz;
+};
+
+__device__ __forceinline__ Axes stage_axes(const GridView &g, double *lds) {
+    const int n = g.nx + g.ny + g.nz;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = g.axes[t];
+    __syncthreads();
+    Axes a;
+    a.x = lds;
+    a.y = lds + g.nx;
+    a.z = lds + g.nx + g.ny;
+    a.nx = g.nx;
+    a.ny = g.ny;
+    a.nz = g.nz;
+    return a;
+}
+
+// scipy RegularGridInterpolator._find_indices: i = clip(searchsorted(g, x) - 1, 0, n-2), i.e.
+// g[i] < x <= g[i+1] inside the grid (tomography/interpolation.py:166-196 spells it out).
+__device__ __forceinline__ int find_cell(const double *g, int n, double x, double inv_h, int uniform) {
+    int i;
+    if (uniform) {
+        double f = (x - g[0]) * inv_h;
+        f = fmin(fmax(f, 0.0), (double)(n - 2));
+        i = (int)f;
+    } else {
+        int lo = 0, hi = n - 1;
+        while (hi - lo > 1) {
+            int mid = (lo + hi) >> 1;
+            if (g[mid] < x) lo = mid; else hi = mid;
+        }
+        i = lo;
+    }
+    while (i > 0 && !(g[i] < x)) --i;
+    while (i < n - 2 && g[i + 1] < x) ++i;
+    return i;
+}
+
+__device__ __forceinline__ bool outside(const double *g, int n, double x) {
+    return !(x >= g[0] && x <= g[n - 1]);     // NaN is outside, like scipy
+}
+
+// ---- trilinear (geometry/tri_cubic.py:69-70 -> scipy RGI 'linear') -----------------------------
+template <typename GT>
+__device__ __forceinline__ double trilinear_at(const GridView &g, const Axes &ax, double x, double y, double z) {
+    const int i = find_cell(ax.x, ax.nx, x, g.inv_h[0], g.uniform[0]);
+    const int j = find_cell(ax.y, ax.ny, y, g.inv_h[1], g.uniform[1]);
+    const int k = find_cell(ax.z, ax.nz, z, g.inv_h[2], g.uniform[2]);
+    const double tx = (x - ax.x[i]) / (ax.x[i + 1] - ax.x[i]);
+    const double ty = (y - ax.y[j]) / (ax.y[j + 1] - ax.y[j]);
+    const double tz = (z - ax.z[k]) / (ax.z[k + 1] - ax.z[k]);
+    const GT *p = (const GT *)g.M + ((size_t)i * g.ny + j) * g.nz + k;
+    const size_t sj = g.nz, si = (size_t)g.ny * g.nz;
+    const double c000 = p[0], c001 = p[1];
+    const double c010 = p[sj], c011 = p[sj + 1];
+    const double c100 = p[si], c101 = p[si + 1];
+    const double c110 = p[si + sj], c111 = p[si + sj + 1];
+    const double c00 = c000 + tz * (c001 - c000);
+    const double c01 = c010 + tz * (c011 - c010);
+    const double c10 = c100 + tz * (c101 - c100);
+    const double c11 = c110 + tz * (c111 - c110);
+    const double c0 = c00 + ty * (c01 - c00);
+    const double c1 = c10 + ty * (c11 - c10);
+    return c0 + tx * (c1 - c0);
+}
+
+// value and analytic gradient of the trilinear cell polynomial (double grid only; tracer)
+__device__ __forceinline__ void trilinear_grad_at(const GridView &g, const double *M, double x, double y, double z,
+                                                  double &f, double &fx, double &fy, double &fz) {
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    const int i = find_cell(gx, g.nx, x, g.inv_h[0], g.uniform[0]);
+    const int j = find_cell(gy, g.ny, y, g.inv_h[1], g.uniform[1]);
+    const int k = find_cell(gz, g.nz, z, g.inv_h[2], g.uniform[2]);
+    const double hx = gx[i + 1] - gx[i], hy = gy[j + 1] - gy[j], hz = gz[k + 1] - gz[k];
+    const double tx = (x - gx[i]) / hx, ty = (y - gy[j]) / hy, tz = (z - gz[k]) / hz;
+    const double *p = M + ((size_t)i * g.ny + j) * g.nz + k;
+    const size_t sj = g.nz, si = (size_t)g.ny * g.nz;
+    const double wx[2] = {1 - tx, tx}, wy[2] = {1 - ty, ty}, wz[2] = {1 - tz, tz};
+    const double sg[2] = {-1.0, 1.0};
+    f = fx = fy = fz = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const double v = p[a * si + b * sj + c];
+                f += v * wx[a] * wy[b] * wz[c];
+                fx += v * sg[a] * wy[b] * wz[c];
+                fy += v * wx[a] * sg[b] * wz[c];
+                fz += v * wx[a] * wy[b] * sg[c];
+            }
+    fx /= hx;
+    fy /= hy;
+    fz /= hz;
+}
+
+// ---- tricubic: Lekien-Marsden with 4th-order central-difference derivative data --------------
+// (notebooks/TricubicInterpolation.ipynb c0:138-1257).  With finite-difference slopes (mixed
+// ones formed by the same 1-D stencil along each axis) the interpolant is the tensor product of
+// 1-D cubic Hermite splines whose slopes are (f[i-2] - 8 f[i-1] + 8 f[i+1] - f[i+2]) /
+// (6 (x[i+1] - x[i-1])): 6 taps per axis, support i-2 .. i+3.  Slopes are scaled to cell units
+// (df/du = h df/dx), which Lekien-Marsden requires; see oracle.tricubic_axis_weights.
+__device__ __forceinline__ int cubic_axis(const double *g, int n, double x, double inv_h, int uniform,
+                                          double w[6], double dw[6], bool want_d) {
+    int i = find_cell(g, n, x, inv_h, uniform);
+    i = min(max(i, 2), n - 4);
+    const double h = g[i + 1] - g[i];
+    const double t = (x - g[i]) / h;
+    const double t2 = t * t, t3 = t2 * t;
+    const double b0 = 2 * t3 - 3 * t2 + 1, b1 = -2 * t3 + 3 * t2, b2 = t3 - 2 * t2 + t, b3 = t3 - t2;
+    const double c0 = h / (6.0 * (g[i + 1] - g[i - 1]));
+    const double c1 = h / (6.0 * (g[i + 2] - g[i]));
+    w[0] = b2 * c0;
+    w[1] = -8.0 * b2 * c0 + b3 * c1;
+    w[2] = b0 - 8.0 * b3 * c1;
+    w[3] = b1 + 8.0 * b2 * c0;
+    w[4] = -b2 * c0 + 8.0 * b3 * c1;
+    w[5] = -b3 * c1;
+    if (want_d) {
+        const double d0 = (6 * t2 - 6 * t) / h, d1 = (-6 * t2 + 6 * t) / h;
+        const double d2 = (3 * t2 - 4 * t + 1) / h, d3 = (3 * t2 - 2 * t) / h;
+        dw[0] = d2 * c0;
+        dw[1] = -8.0 * d2 * c0 + d3 * c1;
+        dw[2] = d0 - 8.0 * d3 * c1;
+        dw[3] = d1 + 8.0 * d2 * c0;
+        dw[4] = -d2 * c0 + 8.0 * d3 * c1;
+        dw[5] = -d3 * c1;
+    }
+    return i;
+}
+
+template <typename GT, bool GRAD>
+__device__ __forceinline__ void tricubic_eval(const GridView &g, const double *gx, const double *gy, const double *gz,
+                                              double x, double y, double z, double &f, double &fx, double &fy, double &fz) {
+    double wx[6], wy[6], wz[6], dx[6], dy[6], dz[6];
+    const int i = cubic_axis(gx, g.nx, x, g.inv_h[0], g.uniform[0], wx, dx, GRAD);
+    const int j = cubic_axis(gy, g.ny, y, g.inv_h[1], g.uniform[1], wy, dy, GRAD);
+    const int k = cubic_axis(gz, g.nz, z, g.inv_h[2], g.uniform[2], wz, dz, GRAD);
+    const GT *base = (const GT *)g.M + ((size_t)(i - 2) * g.ny + (j - 2)) * g.nz + (k - 2);
+    f = fx = fy = fz = 0.0;
+    for (int a = 0; a < 6; ++a) {
+        double fa = 0.0, fya = 0.0, fza = 0.0;
+        for (int b = 0; b < 6; ++b) {
+            const GT *p = base + ((size_t)a * g.ny + b) * g.nz;
+            double s = 0.0, sz = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double v = p[c];
+                s += v * wz[c];
+                if (GRAD) sz += v * dz[c];
+            }
+            fa += s * wy[b];
+            if (GRAD) {
+                fya += s * dy[b];
+                fza += sz * wy[b];
+            }
+        }
+        f += fa * wx[a];
+        if (GRAD) {
+            fx += fa * dx[a];
+            fy += fya * wx[a];
+            fz += fza * wx[a];
+        }
+    }
+}
+
+template <typename GT, int KIND>
+__device__ __forceinline__ double sample_at(const GridView &g, const Axes &ax, double x, double y, double z) {
+    if (KIND == IONO_INTERP_TRILINEAR) return trilinear_at<GT>(g, ax, x, y, z);
+    double f, fx, fy, fz;
+    tricubic_eval<GT, false>(g, ax.x, ax.y, ax.z, x, y, z, f, fx, fy, fz);
+    return f;
+}
+
+template <int KIND>
+__device__ __forceinline__ bool sample_outside(const Axes &ax, double x, double y, double z) {
+    if (KIND == IONO_INTERP_TRILINEAR)
+        return outside(ax.x, ax.nx, x) || outside(ax.y, ax.ny, y) || outside(ax.z, ax.nz, z);
+    // tricubic needs the 6-node stencil: valid for g[2] <= x <= g[n-3]
+    return !(x >= ax.x[2] && x <= ax.x[ax.nx - 3]) || !(y >= ax.y[2] && y <= ax.y[ax.ny - 3]) ||
+           !(z >= ax.z[2] && z <= ax.z[ax.nz - 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// quadrature weights on explicit abscissae s[0..N) (tomography/integrate.py:50-74,130-153;
+// scipy.integrate.simpson for the Cartwright even-N rule)
+// ------------------------------------------------------------------------------------------------
+// composite Simpson weight of sample k within the odd-length sub-range [a, b]
+__device__ __forceinline__ double basic_simpson_weight(const double *s, int a, int b, int k) {
+    if (k < a || k > b || b - a < 2) return 0.0;
+    const int p = k - a;
+    double w = 0.0;
+    if (p & 1) {
+        const double h0 = s[k] - s[k - 1], h1 = s[k + 1] - s[k], hs = h0 + h1;
+        w = hs / 6.0 * (hs * hs / (h0 * h1));
+    } else {
+        if (k > a) {
+            const double h0 = s[k - 1] - s[k - 2], h1 = s[k] - s[k - 1], hs = h0 + h1;
+            w += hs / 6.0 * (2.0 - h0 / h1);
+        }
+        if (k < b) {
+            const double h0 = s[k + 1] - s[k], h1 = s[k + 2] - s[k + 1], hs = h0 + h1;
+            w += hs / 6.0 * (2.0 - h1 / h0);
+        }
+    }
+    return w;
+}
+
+__device__ __forceinline__ double quad_weight(const double *s, int N, int k, int rule) {
+    if (rule == IONO_QUAD_TRAPEZOID || N == 2) {
+        double w = 0.0;
+        if (k > 0) w += 0.5 * (s[k] - s[k - 1]);
+        if (k < N - 1) w += 0.5 * (s[k + 1] - s[k]);
+        return w;
+    }
+    if (N & 1) return basic_simpson_weight(s, 0, N - 1, k);
+    if (rule == IONO_QUAD_SIMPSON_AVG) {
+        double wa = basic_simpson_weight(s, 0, N - 2, k);
+        if (k >= N - 2) wa += 0.5 * (s[N - 1] - s[N - 2]);
+        double wb = basic_simpson_weight(s, 1, N - 1, k);
+        if (k <= 1) wb += 0.5 * (s[1] - s[0]);
+        return 0.5 * (wa + wb);
+    }
+    double w = basic_simpson_weight(s, 0, N - 2, k);
+    const double h0 = s[N - 2] - s[N - 3], h1 = s[N - 1] - s[N - 2];
+    if (k == N - 1) w += (2 * h1 * h1 + 3 * h0 * h1) / (6 * (h0 + h1));
+    if (k == N - 2) w += (h1 * h1 + 3 * h0 * h1) / (6 * h0);
+    if (k == N - 3) w -= h1 * h1 * h1 / (6 * h0 * (h0 + h1));
+    return w;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// rays are dealt so that each XCD (blocks b, b+8, ... share one) walks a contiguous range of
+// rays: neighbouring rays (same antenna / neighbouring directions) share grid columns, which then
+// stay in that XCD's private L2.  Pure speed heuristic; correctness never depends on placement.
+struct RayWalk {
+    int64_t r, end, stride;
+};
+__device__ __forceinline__ RayWalk ray_walk(int64_t R) {
+    const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    RayWalk w;
+    if ((gridDim.x & 7) == 0 && R >= 64 * 8) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+        const int64_t per = (R + 7) / 8;
+        const int64_t lo = per * xcd;
+        w.end = min(R, lo + per);
+        w.r = lo + (int64_t)slot * wpb + wid;
+        w.stride = (int64_t)nslot * wpb;
+    } else {
+        w.r = (int64_t)blockIdx.x * wpb + wid;
+        w.end = R;
+        w.stride = (int64_t)gridDim.x * wpb;
+    }
+    return w;
+}
+
+struct StraightRay {
+    double ox, oy, oz, sx, sy, L, h, step, pz;
+};
+// straight z-parametrised ray: z = linspace(z0, tmax, N), x = x0 + px/pz (z - z0), s = (z - z0)/pz
+// (inversion/fermat.py:64-72,150-174 with n = 1; == tomography/model.py:27-35)
+__device__ __forceinline__ StraightRay load_straight(const double *origins, const double *dirs, int64_t r,
+                                                     double tmax, int Ns) {
+    StraightRay q;
+    q.ox = origins[3 * r];
+    q.oy = origins[3 * r + 1];
+    q.oz = origins[3 * r + 2];
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    const double px = dx / nrm, py = dy / nrm, pz = dz / nrm;
+    q.sx = px / pz;
+    q.sy = py / pz;
+    q.L = tmax - q.oz;
+    q.step = 1.0 / (double)(Ns - 1);
+    q.h = q.L * q.step / pz;      // uniform spacing of s
+    q.pz = pz;
+    return q;
+}
+__device__ __forceinline__ void straight_point(const StraightRay &q, int k, int Ns, double &x, double &y, double &z) {
+    const double frac = (k == Ns - 1) ? 1.0 : (double)k * q.step;
+    const double dz = q.L * frac;
+    x = q.ox + q.sx * dz;
+    y = q.oy + q.sy * dz;
+    z = q.oz + dz;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward kernels
+// ------------------------------------------------------------------------------------------------
+template <typename GT, int KIND>
+__global__ __launch_bounds__(256) void k_forward_straight(GridView g, const double *__restrict__ origins,
+                                                          const double *__restrict__ dirs, int64_t R, double tmax, int Ns,
+                                                          const double *__restrict__ unitw, double *__restrict__ tec,
+                                                          int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+        double acc = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            double x, y, z;
+            straight_point(q, k, Ns, x, y, z);
+            if (sample_outside<KIND>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            acc += unitw[k] * sample_at<GT, KIND>(g, ax, x, y, z);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) tec[w.r] = acc * q.h;
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+template <typename GT, int KIND>
+__global__ __launch_bounds__(256) void k_forward_rays(GridView g, const double *__restrict__ rays, int64_t R, int Ns,
+                                                      int rule, double *__restrict__ tec, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
+        double acc = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            const double x = rx[k], y = ry[k], z = rz[k];
+            if (sample_outside<KIND>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            acc += quad_weight(rs, Ns, k, rule) * sample_at<GT, KIND>(g, ax, x, y, z);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) tec[w.r] = acc;
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// phase observable, per-frequency integrals of 1 - sqrt(1 - ne/n_p) (inversion/iterative_newton.py:108-119)
+template <typename GT, int MAXF>
+__global__ __launch_bounds__(256) void k_forward_phase_rays(GridView g, const double *__restrict__ rays, int64_t R, int Ns,
+                                                            int rule, const double *__restrict__ inv_np, int nf, int ldf,
+                                                            double *__restrict__ phi, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    double inp[MAXF];
+#pragma unroll
+    for (int l = 0; l < MAXF; ++l) inp[l] = l < nf ? inv_np[l] : 0.0;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
+        double acc[MAXF];
+#pragma unroll
+        for (int l = 0; l < MAXF; ++l) acc[l] = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            const double x = rx[k], y = ry[k], z = rz[k];
+            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            const double ne = trilinear_at<GT>(g, ax, x, y, z);
+            const double c = quad_weight(rs, Ns, k, rule);
+#pragma unroll
+            for (int l = 0; l < MAXF; ++l) acc[l] += c * (1.0 - sqrt(1.0 - ne * inp[l]));
+        }
+#pragma unroll
+        for (int l = 0; l < MAXF; ++l) {
+            const double v = wave_sum(acc[l]);
+            if (lane == 0 && l < nf) phi[(size_t)w.r * ldf + l] = v;
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// g = const_i + 2 pi nu clock_ij - (phi - phi[i0]) 2 pi nu / c   (inversion/iterative_newton.py:107-123)
+__global__ void k_phase_finish(const double *__restrict__ phi, const double *__restrict__ freqs,
+                               const double *__restrict__ clock, const double *__restrict__ cst, int Na, int Nt, int Nd,
+                               int Nf, int i0, double *__restrict__ gout) {
+    const int64_t n = (int64_t)Na * Nt * Nd * Nf;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int l = idx % Nf;
+        const int64_t r = idx / Nf;
+        const int64_t td = r % ((int64_t)Nt * Nd);
+        const int a = r / ((int64_t)Nt * Nd);
+        const int t = td / Nd;
+        const double a_ = 2.0 * M_PI * freqs[l];
+        const double ph = (phi[r * Nf + l] - phi[((int64_t)i0 * Nt * Nd + td) * Nf + l]) * (a_ / SPEED_OF_LIGHT);
+        gout[idx] = cst[a] + a_ * clock[(int64_t)a * Nt + t] - ph;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// adjoint kernels: exact transpose of trilinear + quadrature (SURVEY section 8a, A7')
+// ------------------------------------------------------------------------------------------------
+template <typename AT>
+__device__ __forceinline__ void scatter_trilinear(const GridView &g, const Axes &ax, AT *__restrict__ G, double x, double y,
+                                                  double z, double c) {
+    const int i = find_cell(ax.x, ax.nx, x, g.inv_h[0], g.uniform[0]);
+    const int j = find_cell(ax.y, ax.ny, y, g.inv_h[1], g.uniform[1]);
+    const int k = find_cell(ax.z, ax.nz, z, g.inv_h[2], g.uniform[2]);
+    const double tx = (x - ax.x[i]) / (ax.x[i + 1] - ax.x[i]);
+    const double ty = (y - ax.y[j]) / (ax.y[j + 1] - ax.y[j]);
+    const double tz = (z - ax.z[k]) / (ax.z[k + 1] - ax.z[k]);
+    AT *p = G + ((size_t)i * g.ny + j) * g.nz + k;
+    const size_t sj = g.nz, si = (size_t)g.ny * g.nz;
+    const double w0 = c * (1 - tx), w1 = c * tx;
+    const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
+    atomicAdd(p, (AT)(w00 * (1 - tz)));
+    atomicAdd(p + 1, (AT)(w00 * tz));
+    atomicAdd(p + sj, (AT)(w01 * (1 - tz)));
+    atomicAdd(p + sj + 1, (AT)(w01 * tz));
+    atomicAdd(p + si, (AT)(w10 * (1 - tz)));
+    atomicAdd(p + si + 1, (AT)(w10 * tz));
+    atomicAdd(p + si + sj, (AT)(w11 * (1 - tz)));
+    atomicAdd(p + si + sj + 1, (AT)(w11 * tz));
+}
+
+// MODE 0: weights given (w[R]);  MODE 1: fused residual -> differential weights for layout
+// [Na][NtNd]: dd = (tec - tec[i0] - dobs)/(CdCt + 1e-15) (inversion/gradient.py:77-81),
+// w = dd - [a == i0] sum_a' dd[a']  (transpose of "tec - tec[i0]", forward_equation.py:50)
+template <typename AT, int MODE>
+__global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const double *__restrict__ origins,
+                                                          const double *__restrict__ dirs, const double *__restrict__ wray,
+                                                          const double *__restrict__ tec, const double *__restrict__ dobs,
+                                                          const double *__restrict__ cdct, int Na, int64_t NtNd, int i0,
+                                                          int64_t R, double tmax, int Ns, const double *__restrict__ unitw,
+                                                          AT *__restrict__ G, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        double wr;
+        if (MODE == 0) {
+            wr = wray[w.r];
+        } else {
+            const int a = (int)(w.r / NtNd);
+            const int64_t p = w.r % NtNd;
+            const double tref = tec[(int64_t)i0 * NtNd + p];
+            wr = (tec[w.r] - tref - dobs[w.r]) / (cdct[w.r] + 1e-15);
+            if (a == i0) {
+                double s = 0.0;
+                for (int a2 = lane; a2 < Na; a2 += 64) {
+                    const int64_t r2 = (int64_t)a2 * NtNd + p;
+                    s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
+                }
+                wr -= wave_sum(s);
+            }
+        }
+        if (wr == 0.0) continue;
+        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+        const double scale = wr * q.h;
+        for (int k = lane; k < Ns; k += 64) {
+            double x, y, z;
+            straight_point(q, k, Ns, x, y, z);
+            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            scatter_trilinear<AT>(g, ax, G, x, y, z, scale * unitw[k]);
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void k_adjoint_rays(GridView g, const double *__restrict__ rays,
+                                                      const double *__restrict__ wray, int64_t R, int Ns, int rule,
+                                                      AT *__restrict__ G, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
+        const double wr = wray[w.r];
+        if (wr == 0.0) continue;
+        for (int k = lane; k < Ns; k += 64) {
+            const double x = rx[k], y = ry[k], z = rz[k];
+            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            scatter_trilinear<AT>(g, ax, G, x, y, z, wr * quad_weight(rs, Ns, k, rule));
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise / geometry kernels
+// ------------------------------------------------------------------------------------------------
+template <typename GT>
+__global__ void k_set_values(const double *__restrict__ src, GT *__restrict__ dst, int64_t n, int do_exp, double scale,
+                             int *nonfinite) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = src[i];
+        if (do_exp) v = exp(v) * scale;
+        if (!isfinite(v)) bad = true;
+        dst[i] = (GT)v;
+    }
+    if (bad) atomicOr(nonfinite, 1);
+}
+
+template <typename GT>
+__global__ void k_get_values(const GT *__restrict__ src, double *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (double)src[i];
+}
+
+// n = sqrt(1 - 8.980^2 ne / nu^2) at the nodes (inversion/fermat.py:36-46)
+template <typename GT>
+__global__ void k_ne_to_n(const GT *__restrict__ ne, double *__restrict__ nM, int64_t n, double freq) {
+    const double A = -PLASMA_A / (freq * freq);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        nM[i] = sqrt(1.0 + (double)ne[i] * A);
+}
+
+template <typename AT, typename GT>
+__global__ void k_scale_by_grid(AT *__restrict__ G, const GT *__restrict__ M, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        G[i] = (AT)((double)G[i] * (double)M[i]);
+}
+
+__global__ void k_subtract_reference(double *__restrict__ tec, int Na, int64_t NtNd, int i0) {
+    // rows other than i0 first (they read row i0), row i0 is zeroed by a second launch
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)Na * NtNd;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int a = idx / NtNd;
+        if (a != i0) tec[idx] -= tec[(int64_t)i0 * NtNd + idx % NtNd];
+    }
+}
+__global__ void k_zero(double *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
+template <typename GT, int KIND, bool EXTRAP>
+__global__ void k_interp_points(GridView g, const double *__restrict__ x, const double *__restrict__ y,
+                                const double *__restrict__ z, int64_t n, double *__restrict__ out, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    bool oob = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double px = x[i], py = y[i], pz = z[i];
+        if (!EXTRAP && sample_outside<KIND>(ax, px, py, pz)) {
+            oob = true;
+            out[i] = nan("");
+            continue;
+        }
+        out[i] = sample_at<GT, KIND>(g, ax, px, py, pz);
+    }
+    if (oob) atomicOr(oob_flag, 1);
+}
+
+__global__ void k_trace_straight(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
+                                 int Ns, double *__restrict__ rays) {
+    const int64_t n = R * Ns;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / Ns;
+        const int k = idx % Ns;
+        const StraightRay q = load_straight(origins, dirs, r, tmax, Ns);
+        double x, y, z;
+        straight_point(q, k, Ns, x, y, z);
+        double *o = rays + (size_t)r * 4 * Ns;
+        o[k] = x;
+        o[Ns + k] = y;
+        o[2 * Ns + k] = z;
+        const double frac = (k == Ns - 1) ? 1.0 : (double)k * q.step;
+        o[3 * Ns + k] = q.L * frac / q.pz;     // s = (z - z0)/pz
+    }
+}
+
+// Fermat ray ODE in z (inversion/fermat.py:64-72; notebooks/FermatClass.ipynb c0:76-84):
+//   s' = n/pz, p' = grad(n) n/pz, x' = px/pz, y' = py/pz, z' = 1.   Lanes = rays, RK4.
+struct FState {
+    double px, py, pz, x, y, z, s;
+};
+template <int KIND, bool BEND>
+__device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u) {
+    double n, nx, ny, nz;
+    if (KIND == IONO_INTERP_TRILINEAR) {
+        trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
+    } else {
+        GridView gn = g;
+        gn.M = nM;
+        tricubic_eval<double, true>(gn, g.axes, g.axes + g.nx, g.axes + g.nx + g.ny, u.x, u.y, u.z, n, nx, ny, nz);
+    }
+    if (!BEND) nx = ny = nz = 0.0;
+    const double f = n / u.pz;
+    FState d;
+    d.px = nx * f;
+    d.py = ny * f;
+    d.pz = nz * f;
+    d.x = u.px / u.pz;
+    d.y = u.py / u.pz;
+    d.z = 1.0;
+    d.s = f;
+    return d;
+}
+__device__ __forceinline__ FState axpy(const FState &u, double a, const FState &d) {
+    FState r;
+    r.px = u.px + a * d.px;
+    r.py = u.py + a * d.py;
+    r.pz = u.pz + a * d.pz;
+    r.x = u.x + a * d.x;
+    r.y = u.y + a * d.y;
+    r.z = u.z + a * d.z;
+    r.s = u.s + a * d.s;
+    return r;
+}
+template <int KIND, bool BEND>
+__global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *__restrict__ nM,
+                                                     const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                     int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
+                                                     int *oob_flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm;
+    u.py = dy / nrm;
+    u.pz = dz / nrm;
+    u.x = origins[3 * r];
+    u.y = origins[3 * r + 1];
+    u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    double *o = rays + (size_t)r * 4 * Ns;
+    o[0] = u.x;
+    o[Ns] = u.y;
+    o[2 * Ns] = u.z;
+    o[3 * Ns] = u.s;
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    bool oob = false;
+    for (int k = 1; k < Ns; ++k) {
+        for (int sub = 0; sub < substeps; ++sub) {
+            const FState k1 = fermat_rhs<KIND, BEND>(g, nM, u);
+            const FState k2 = fermat_rhs<KIND, BEND>(g, nM, axpy(u, 0.5 * h, k1));
+            const FState k3 = fermat_rhs<KIND, BEND>(g, nM, axpy(u, 0.5 * h, k2));
+            const FState k4 = fermat_rhs<KIND, BEND>(g, nM, axpy(u, h, k3));
+            FState sum = axpy(axpy(axpy(k1, 2.0, k2), 2.0, k3), 1.0, k4);
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
+        o[k] = u.x;
+        o[Ns + k] = u.y;
+        o[2 * Ns + k] = u.z;
+        o[3 * Ns + k] = u.s;
+    }
+    if (oob) atomicOr(oob_flag, 1);
+}
+
+}  // namespace
+
+// ================================================================================================
+// host side
+// ================================================================================================
+struct iono_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    int nx = 0, ny = 0, nz = 0, storage = IONO_F64;
+    double *d_axes = nullptr;
+    void *d_M = nullptr;
+    double inv_h[3] = {0, 0, 0};
+    int uniform[3] = {0, 0, 0};
+    int *d_flags = nullptr;          // [0] out-of-bounds, [1] non-finite
+    double *d_unitw = nullptr;       // cached unit-spacing quadrature weights
+    int unitw_n = 0, unitw_rule = -1;
+    std::string err;
+    int num_cus = 256;
+};
+
+namespace {
+
+int fail(iono_ctx *c, int code, const std::string &msg) {
+    g_last_error = msg;
+    if (c) c->err = msg;
+    return code;
+}
+#define HIP_TRY(c, expr)                                                                         \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(c, IONO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+struct DevBuf {   // scoped device allocation for the host-pointer entry points
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+GridView view(const iono_ctx *c) {
+    GridView g;
+    g.axes = c->d_axes;
+    g.M = c->d_M;
+    g.nx = c->nx;
+    g.ny = c->ny;
+    g.nz = c->nz;
+    for (int a = 0; a < 3; ++a) {
+        g.inv_h[a] = c->inv_h[a];
+        g.uniform[a] = c->uniform[a];
+    }
+    return g;
+}
+size_t lds_bytes(const iono_ctx *c) { return sizeof(double) * (size_t)(c->nx + c->ny + c->nz); }
+int64_t ncells(const iono_ctx *c) { return (int64_t)c->nx * c->ny * c->nz; }
+
+int need_grid(iono_ctx *c) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (!c->d_M) return fail(c, IONO_ERR_ARG, "no grid set (call iono_grid_set first)");
+    return IONO_OK;
+}
+
+int ray_grid_blocks(const iono_ctx *c, int64_t R) {
+    // one wave per ray, 4 waves per block; cap at 8 blocks per CU and grid-stride the rest
+    int64_t b = (R + 3) / 4;
+    const int64_t cap = (int64_t)c->num_cus * 8;
+    if (b > cap) b = cap;
+    if (b >= 8) b = (b + 7) / 8 * 8;      // multiple of 8 so the XCD-aware walk applies
+    return (int)(b < 1 ? 1 : b);
+}
+int ew_blocks(const iono_ctx *c, int64_t n) {
+    int64_t b = (n + 255) / 256;
+    const int64_t cap = (int64_t)c->num_cus * 8;
+    return (int)(b > cap ? cap : (b < 1 ? 1 : b));
+}
+
+// unit-spacing quadrature weights (h = 1): straight rays sample s uniformly, so the integral is
+// h * sum(unitw * y).  Same formulas as quad_weight() above, evaluated once on the host.
+void host_unit_weights(int N, int rule, std::vector<double> &w) {
+    w.assign(N, 0.0);
+    auto basic = [&](int a, int b, double f) {
+        for (int k = a; k + 2 <= b; k += 2) {
+            w[k] += f / 3.0;
+            w[k + 1] += f * 4.0 / 3.0;
+            w[k + 2] += f / 3.0;
+        }
+    };
+    if (rule == IONO_QUAD_TRAPEZOID || N == 2) {
+        for (int k = 0; k + 1 < N; ++k) {
+            w[k] += 0.5;
+            w[k + 1] += 0.5;
+        }
+    } else if (N & 1) {
+        basic(0, N - 1, 1.0);
+    } else if (rule == IONO_QUAD_SIMPSON_AVG) {
+        basic(0, N - 2, 0.5);
+        w[N - 1] += 0.25;
+        w[N - 2] += 0.25;
+        basic(1, N - 1, 0.5);
+        w[0] += 0.25;
+        w[1] += 0.25;
+    } else {
+        basic(0, N - 2, 1.0);
+        w[N - 1] += 5.0 / 12.0;
+        w[N - 2] += 4.0 / 6.0;
+        w[N - 3] -= 1.0 / 12.0;
+    }
+}
+
+int ensure_unitw(iono_ctx *c, int Ns, int rule) {
+    if (c->d_unitw && c->unitw_n == Ns && c->unitw_rule == rule) return IONO_OK;
+    std::vector<double> w;
+    host_unit_weights(Ns, rule, w);
+    if (c->d_unitw) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipFree(c->d_unitw));
+        c->d_unitw = nullptr;
+    }
+    HIP_TRY(c, hipMalloc((void **)&c->d_unitw, sizeof(double) * Ns));
+    HIP_TRY(c, hipMemcpy(c->d_unitw, w.data(), sizeof(double) * Ns, hipMemcpyHostToDevice));
+    c->unitw_n = Ns;
+    c->unitw_rule = rule;
+    return IONO_OK;
+}
+
+int check_common(iono_ctx *c, int64_t R, int Ns, int kind, int rule) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    if (R < 0 || Ns < 2) return fail(c, IONO_ERR_SHAPE, "need R >= 0 and Ns >= 2");
+    if (kind != IONO_INTERP_TRILINEAR && kind != IONO_INTERP_TRICUBIC) return fail(c, IONO_ERR_ARG, "bad interp_kind");
+    if (rule < 0 || rule > 2) return fail(c, IONO_ERR_ARG, "bad quad_rule");
+    if (kind == IONO_INTERP_TRICUBIC && (c->nx < 6 || c->ny < 6 || c->nz < 6))
+        return fail(c, IONO_ERR_SHAPE, "tricubic needs at least 6 nodes per axis");
+    return IONO_OK;
+}
+
+int read_flag(iono_ctx *c, int which, int *out) {
+    int v[2] = {0, 0};
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(v, c->d_flags, sizeof(v), hipMemcpyDeviceToHost));
+    *out = v[which];
+    if (v[which]) {
+        v[which] = 0;
+        HIP_TRY(c, hipMemcpy(c->d_flags, v, sizeof(v), hipMemcpyHostToDevice));
+    }
+    return IONO_OK;
+}
+
+int finish_host_call(iono_ctx *c, const char *what) {
+    int oob = 0;
+    int rc = read_flag(c, 0, &oob);
+    if (rc) return rc;
+    if (oob) return fail(c, IONO_ERR_OOB, std::string(what) + ": One of the requested xi is out of bounds");
+    return IONO_OK;
+}
+
+template <typename F> int dispatch_storage(iono_ctx *c, F f) {
+    return c->storage == IONO_F64 ? f((double *)nullptr) : f((float *)nullptr);
+}
+
+}  // namespace
+
+extern "C" {
+
+int iono_version(void) { return IONO_VERSION; }
+
+const char *iono_last_error(iono_ctx *ctx) { return ctx ? ctx->err.c_str() : g_last_error.c_str(); }
+
+int iono_ctx_create(int device_id, iono_ctx **out) {
+    if (!out) return fail(nullptr, IONO_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(nullptr, IONO_ERR_HIP, "no HIP device visible: libionotomo_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(nullptr, IONO_ERR_ARG, "device_id out of range");
+    iono_ctx *c = new iono_ctx();
+    c->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flags, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 2 * sizeof(int));
+    if (e != hipSuccess) {
+        std::string m = std::string("iono_ctx_create: ") + hipGetErrorString(e);
+        delete c;
+        return fail(nullptr, IONO_ERR_HIP, m);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
+        c->num_cus = prop.multiProcessorCount;
+    c->stream = c->own_stream;
+    *out = c;
+    return IONO_OK;
+}
+
+int iono_ctx_destroy(iono_ctx *c) {
+    if (!c) return IONO_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->d_axes) (void)hipFree(c->d_axes);
+    if (c->d_M) (void)hipFree(c->d_M);
+    if (c->d_flags) (void)hipFree(c->d_flags);
+    if (c->d_unitw) (void)hipFree(c->d_unitw);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+    return IONO_OK;
+}
+
+int iono_ctx_set_stream(iono_ctx *c, void *s) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return IONO_OK;
+}
+
+int iono_ctx_synchronize(iono_ctx *c) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return IONO_OK;
+}
+
+// ---- grid ------------------------------------------------------------------------------------
+int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int ny, const double *zv, int nz,
+                  const double *M, int storage) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (!xv || !yv || !zv) return fail(c, IONO_ERR_ARG, "null axis");
+    if (nx < 2 || ny < 2 || nz < 2) return fail(c, IONO_ERR_SHAPE, "every axis needs at least 2 nodes");
+    if (storage != IONO_F64 && storage != IONO_F32) return fail(c, IONO_ERR_ARG, "bad storage type");
+    if ((size_t)(nx + ny + nz) * sizeof(double) > 96 * 1024) return fail(c, IONO_ERR_SHAPE, "axes do not fit the LDS budget");
+    const double *ax[3] = {xv, yv, zv};
+    const int n[3] = {nx, ny, nz};
+    for (int a = 0; a < 3; ++a) {
+        bool uni = true;
+        const double h = (ax[a][n[a] - 1] - ax[a][0]) / (n[a] - 1);
+        for (int i = 0; i + 1 < n[a]; ++i) {
+            const double d = ax[a][i + 1] - ax[a][i];
+            if (!(d > 0) || !std::isfinite(d)) return fail(c, IONO_ERR_ARG, "axes must be strictly increasing and finite");
+            if (std::fabs(d - h) > 1e-6 * h) uni = false;
+        }
+        c->uniform[a] = uni ? 1 : 0;
+        c->inv_h[a] = 1.0 / h;
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_axes) HIP_TRY(c, hipFree(c->d_axes));
+    if (c->d_M) HIP_TRY(c, hipFree(c->d_M));
+    c->d_axes = nullptr;
+    c->d_M = nullptr;
+    c->nx = nx;
+    c->ny = ny;
+    c->nz = nz;
+    c->storage = storage;
+    std::vector<double> cat;
+    cat.insert(cat.end(), xv, xv + nx);
+    cat.insert(cat.end(), yv, yv + ny);
+    cat.insert(cat.end(), zv, zv + nz);
+    HIP_TRY(c, hipMalloc((void **)&c->d_axes, cat.size() * sizeof(double)));
+    HIP_TRY(c, hipMemcpy(c->d_axes, cat.data(), cat.size() * sizeof(double), hipMemcpyHostToDevice));
+    const size_t esz = storage == IONO_F64 ? 8 : 4;
+    HIP_TRY(c, hipMalloc(&c->d_M, (size_t)ncells(c) * esz));
+    HIP_TRY(c, hipMemset(c->d_M, 0, (size_t)ncells(c) * esz));
+    if (M) return iono_grid_set_values(c, M);
+    return IONO_OK;
+}
+
+static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, double scale) {
+    const int64_t n = ncells(c);
+    int rc = dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+        hipLaunchKernelGGL((k_set_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, src_dev, (GT *)c->d_M, n,
+                           do_exp, scale, c->d_flags + 1);
+        return IONO_OK;
+    });
+    HIP_TRY(c, hipGetLastError());
+    return rc;
+}
+
+static int set_values_host_impl(iono_ctx *c, const double *M, int do_exp, double scale) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    if (!M) return fail(c, IONO_ERR_ARG, "null values");
+    DevBuf tmp;
+    HIP_TRY(c, tmp.alloc((size_t)ncells(c) * 8));
+    HIP_TRY(c, hipMemcpyAsync(tmp.p, M, (size_t)ncells(c) * 8, hipMemcpyHostToDevice, c->stream));
+    rc = set_values_dev_impl(c, tmp.as<double>(), do_exp, scale);
+    if (rc) return rc;
+    int bad = 0;
+    rc = read_flag(c, 1, &bad);
+    if (rc) return rc;
+    if (bad) return fail(c, IONO_ERR_NONFINITE, "grid values contain NaN or Inf");
+    return IONO_OK;
+}
+
+int iono_grid_set_values(iono_ctx *c, const double *M) { return set_values_host_impl(c, M, 0, 1.0); }
+int iono_grid_set_exp(iono_ctx *c, const double *m, double scale) { return set_values_host_impl(c, m, 1, scale); }
+int iono_grid_set_values_dev(iono_ctx *c, const double *M_dev) {
+    int rc = need_grid(c);
+    return rc ? rc : set_values_dev_impl(c, M_dev, 0, 1.0);
+}
+int iono_grid_set_exp_dev(iono_ctx *c, const double *m_dev, double scale) {
+    int rc = need_grid(c);
+    return rc ? rc : set_values_dev_impl(c, m_dev, 1, scale);
+}
+void *iono_grid_values_ptr(iono_ctx *c) { return c ? c->d_M : nullptr; }
+
+int iono_grid_get_values(iono_ctx *c, double *out) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    const int64_t n = ncells(c);
+    DevBuf tmp;
+    HIP_TRY(c, tmp.alloc((size_t)n * 8));
+    dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+        hipLaunchKernelGGL((k_get_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M,
+                           tmp.as<double>(), n);
+        return IONO_OK;
+    });
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, tmp.p, (size_t)n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return IONO_OK;
+}
+
+// ---- interp at points --------------------------------------------------------------------------
+int iono_interp(iono_ctx *c, const double *x, const double *y, const double *z, int64_t n, int kind, int extrapolate,
+                double *out) {
+    int rc = check_common(c, n, 2, kind, 0);
+    if (rc) return rc;
+    if (n == 0) return IONO_OK;
+    DevBuf b;
+    HIP_TRY(c, b.alloc((size_t)n * 8 * 4));
+    double *dx = b.as<double>(), *dy = dx + n, *dz = dy + n, *dout = dz + n;
+    HIP_TRY(c, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dy, y, n * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dz, z, n * 8, hipMemcpyHostToDevice, c->stream));
+    const GridView g = view(c);
+    const dim3 grid(ew_blocks(c, n)), block(256);
+    const size_t lds = lds_bytes(c);
+    dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+#define LAUNCH_INTERP(K, E) \
+    hipLaunchKernelGGL((k_interp_points<GT, K, E>), grid, block, lds, c->stream, g, dx, dy, dz, n, dout, c->d_flags)
+        if (kind == IONO_INTERP_TRILINEAR) {
+            if (extrapolate) LAUNCH_INTERP(IONO_INTERP_TRILINEAR, true); else LAUNCH_INTERP(IONO_INTERP_TRILINEAR, false);
+        } else {
+            if (extrapolate) LAUNCH_INTERP(IONO_INTERP_TRICUBIC, true); else LAUNCH_INTERP(IONO_INTERP_TRICUBIC, false);
+        }
+#undef LAUNCH_INTERP
+        return IONO_OK;
+    });
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(out, dout, n * 8, hipMemcpyDeviceToHost, c->stream));
+    return finish_host_call(c, "iono_interp");
+}
+
+// ---- forward (device pointers) ---------------------------------------------------------------
+int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, int kind,
+                                  int rule, double *tec) {
+    int rc = check_common(c, R, Ns, kind, rule);
+    if (rc) return rc;
+    if (R == 0) return IONO_OK;
+    rc = ensure_unitw(c, Ns, rule);
+    if (rc) return rc;
+    const GridView g = view(c);
+    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    const size_t lds = lds_bytes(c);
+    dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+        if (kind == IONO_INTERP_TRILINEAR)
+            hipLaunchKernelGGL((k_forward_straight<GT, IONO_INTERP_TRILINEAR>), grid, block, lds, c->stream, g, o, d, R, tmax,
+                               Ns, c->d_unitw, tec, c->d_flags);
+        else
+            hipLaunchKernelGGL((k_forward_straight<GT, IONO_INTERP_TRICUBIC>), grid, block, lds, c->stream, g, o, d, R, tmax,
+                               Ns, c->d_unitw, tec, c->d_flags);
+        return IONO_OK;
+    });
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_forward_tec_rays_dev(iono_ctx *c, const double *rays, int64_t R, int Ns, int kind, int rule, double *tec) {
+    int rc = check_common(c, R, Ns, kind, rule);
+    if (rc) return rc;
+    if (R == 0) return IONO_OK;
+    const GridView g = view(c);
+    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    const size_t lds = lds_bytes(c);
+    dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+        if (kind == IONO_INTERP_TRILINEAR)
+            hipLaunchKernelGGL((k_forward_rays<GT, IONO_INTERP_TRILINEAR>), grid, block, lds, c->stream, g, rays, R, Ns, rule,
+                               tec, c->d_flags);
+        else
+            hipLaunchKernelGGL((k_forward_rays<GT, IONO_INTERP_TRICUBIC>), grid, block, lds, c->stream, g, rays, R, Ns, rule,
+                               tec, c->d_flags);
+        return IONO_OK;
+    });
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_subtract_reference_dev(iono_ctx *c, double *tec, int Na, int64_t NtNd, int i0) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "reference antenna index out of range");
+    hipLaunchKernelGGL(k_subtract_reference, dim3(ew_blocks(c, (int64_t)Na * NtNd)), dim3(256), 0, c->stream, tec, Na, NtNd, i0);
+    hipLaunchKernelGGL(k_zero, dim3(ew_blocks(c, NtNd)), dim3(256), 0, c->stream, tec + (int64_t)i0 * NtNd, NtNd);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+// ---- adjoint (device pointers) ----------------------------------------------------------------
+static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const double *d, const double *w,
+                                   const double *tec, const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0,
+                                   int64_t R, double tmax, int Ns, int rule, void *grad, int accum) {
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    if (rc) return rc;
+    if (accum != IONO_F64 && accum != IONO_F32) return fail(c, IONO_ERR_ARG, "bad accum_dtype");
+    if (R == 0) return IONO_OK;
+    rc = ensure_unitw(c, Ns, rule);
+    if (rc) return rc;
+    const GridView g = view(c);
+    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    const size_t lds = lds_bytes(c);
+#define LAUNCH_ADJ(AT, MODE)                                                                                          \
+    hipLaunchKernelGGL((k_adjoint_straight<AT, MODE>), grid, block, lds, c->stream, g, o, d, w, tec, dobs, cdct, Na, \
+                       NtNd, i0, R, tmax, Ns, c->d_unitw, (AT *)grad, c->d_flags)
+    if (accum == IONO_F64) {
+        if (mode == 0) LAUNCH_ADJ(double, 0); else LAUNCH_ADJ(double, 1);
+    } else {
+        if (mode == 0) LAUNCH_ADJ(float, 0); else LAUNCH_ADJ(float, 1);
+    }
+#undef LAUNCH_ADJ
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_adjoint_straight_dev(iono_ctx *c, const double *o, const double *d, const double *w, int64_t R, double tmax, int Ns,
+                              int rule, void *grad, int accum) {
+    return adjoint_straight_launch(c, 0, o, d, w, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, rule, grad, accum);
+}
+
+int iono_adjoint_residual_straight_dev(iono_ctx *c, const double *o, const double *d, const double *tec, const double *dobs,
+                                       const double *cdct, int Na, int64_t NtNd, int i0, double tmax, int Ns, int rule,
+                                       void *grad, int accum) {
+    if (Na < 1 || NtNd < 0 || i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "bad [Na][NtNd]/i0");
+    return adjoint_straight_launch(c, 1, o, d, nullptr, tec, dobs, cdct, Na, NtNd, i0, (int64_t)Na * NtNd, tmax, Ns, rule,
+                                   grad, accum);
+}
+
+int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int rule, void *grad,
+                          int accum) {
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    if (rc) return rc;
+    if (accum != IONO_F64 && accum != IONO_F32) return fail(c, IONO_ERR_ARG, "bad accum_dtype");
+    if (R == 0) return IONO_OK;
+    const GridView g = view(c);
+    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    const size_t lds = lds_bytes(c);
+    if (accum == IONO_F64)
+        hipLaunchKernelGGL((k_adjoint_rays<double>), grid, block, lds, c->stream, g, rays, w, R, Ns, rule, (double *)grad,
+                           c->d_flags);
+    else
+        hipLaunchKernelGGL((k_adjoint_rays<float>), grid, block, lds, c->stream, g, rays, w, R, Ns, rule, (float *)grad,
+                           c->d_flags);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_check_oob(iono_ctx *c, int *oob) {
+    if (!c || !oob) return fail(c, IONO_ERR_ARG, "null argument");
+    return read_flag(c, 0, oob);
+}
+
+// ---- host-pointer wrappers --------------------------------------------------------------------
+int iono_forward_tec_straight(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, int kind, int rule,
+                              double *tec) {
+    int rc = check_common(c, R, Ns, kind, rule);
+    if (rc) return rc;
+    if (R == 0) return IONO_OK;
+    DevBuf b;
+    HIP_TRY(c, b.alloc((size_t)R * 8 * 7));
+    double *dO = b.as<double>(), *dD = dO + 3 * R, *dT = dD + 3 * R;
+    HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
+    rc = iono_forward_tec_straight_dev(c, dO, dD, R, tmax, Ns, kind, rule, dT);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(tec, dT, R * 8, hipMemcpyDeviceToHost, c->stream));
+    return finish_host_call(c, "iono_forward_tec_straight");
+}
+
+int iono_forward_tec_rays(iono_ctx *c, const double *rays, int64_t R, int Ns, int kind, int rule, double *tec) {
+    int rc = check_common(c, R, Ns, kind, rule);
+    if (rc) return rc;
+    if (R == 0) return IONO_OK;
+    DevBuf b;
+    HIP_TRY(c, b.alloc((size_t)R * 8 * (4 * (size_t)Ns + 1)));
+    double *dR = b.as<double>(), *dT = dR + (size_t)R * 4 * Ns;
+    HIP_TRY(c, hipMemcpyAsync(dR, rays, (size_t)R * 4 * Ns * 8, hipMemcpyHostToDevice, c->stream));
+    rc = iono_forward_tec_rays_dev(c, dR, R, Ns, kind, rule, dT);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(tec, dT, R * 8, hipMemcpyDeviceToHost, c->stream));
+    return finish_host_call(c, "iono_forward_tec_rays");
+}
+
+int iono_subtract_reference(iono_ctx *c, double *tec, int Na, int64_t NtNd, int i0) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    const int64_t n = (int64_t)Na * NtNd;
+    DevBuf b;
+    HIP_TRY(c, b.alloc((size_t)n * 8));
+    HIP_TRY(c, hipMemcpyAsync(b.p, tec, n * 8, hipMemcpyHostToDevice, c->stream));
+    int rc = iono_subtract_reference_dev(c, b.as<double>(), Na, NtNd, i0);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(tec, b.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return IONO_OK;
+}
+
+int iono_forward_phase_rays(iono_ctx *c, const double *rays, int Na, int Nt, int Nd, int Ns, const double *freqs, int Nf,
+                            const double *clock, const double *cst, int i0, int rule, double *gout) {
+    const int64_t R = (int64_t)Na * Nt * Nd;
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    if (rc) return rc;
+    if (Nf < 1 || i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "bad Nf / i0");
+    if (R == 0) return IONO_OK;
+    constexpr int MAXF = 8;
+    DevBuf b;
+    const size_t nr = (size_t)R * 4 * Ns, nphi = (size_t)R * Nf;
+    HIP_TRY(c, b.alloc(8 * (nr + 2 * nphi + 2 * (size_t)Nf + (size_t)Na * Nt + Na)));
+    double *dR = b.as<double>(), *dPhi = dR + nr, *dG = dPhi + nphi, *dF = dG + nphi, *dInv = dF + Nf, *dClock = dInv + Nf,
+           *dConst = dClock + (size_t)Na * Nt;
+    std::vector<double> inv(Nf);
+    for (int l = 0; l < Nf; ++l) inv[l] = 1.0 / (1.2404e-2 * freqs[l] * freqs[l]);     // iterative_newton.py:112
+    HIP_TRY(c, hipMemcpyAsync(dR, rays, nr * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dF, freqs, Nf * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dInv, inv.data(), Nf * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dClock, clock, (size_t)Na * Nt * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dConst, cst, (size_t)Na * 8, hipMemcpyHostToDevice, c->stream));
+    const GridView g = view(c);
+    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    for (int f0 = 0; f0 < Nf; f0 += MAXF) {
+        const int nf = std::min(MAXF, Nf - f0);
+        dispatch_storage(c, [&](auto *tag) {
+            using GT = std::remove_pointer_t<decltype(tag)>;
+            hipLaunchKernelGGL((k_forward_phase_rays<GT, MAXF>), grid, block, lds_bytes(c), c->stream, g, dR, R, Ns, rule,
+                               dInv + f0, nf, Nf, dPhi + f0, c->d_flags);
+            return IONO_OK;
+        });
+    }
+    hipLaunchKernelGGL(k_phase_finish, dim3(ew_blocks(c, (int64_t)nphi)), dim3(256), 0, c->stream, dPhi, dF, dClock, dConst, Na,
+                       Nt, Nd, Nf, i0, dG);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(gout, dG, nphi * 8, hipMemcpyDeviceToHost, c->stream));
+    return finish_host_call(c, "iono_forward_phase_rays");
+}
+
+static int adjoint_host_finish(iono_ctx *c, double *dG, int scale_by_grid, double *grad_out, const char *what) {
+    const int64_t n = ncells(c);
+    if (scale_by_grid)
+        dispatch_storage(c, [&](auto *tag) {
+            using GT = std::remove_pointer_t<decltype(tag)>;
+            hipLaunchKernelGGL((k_scale_by_grid<double, GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, dG,
+                               (const GT *)c->d_M, n);
+            return IONO_OK;
+        });
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(grad_out, dG, n * 8, hipMemcpyDeviceToHost, c->stream));
+    return finish_host_call(c, what);
+}
+
+int iono_adjoint_straight(iono_ctx *c, const double *o, const double *d, const double *w, int64_t R, double tmax, int Ns,
+                          int rule, int scale_by_grid, double *grad_out) {
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    if (rc) return rc;
+    const int64_t n = ncells(c);
+    DevBuf b;
+    HIP_TRY(c, b.alloc(8 * ((size_t)R * 7 + (size_t)n)));
+    double *dO = b.as<double>(), *dD = dO + 3 * R, *dW = dD + 3 * R, *dG = dW + R;
+    HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dW, w, R * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dG, 0, n * 8, c->stream));
+    rc = iono_adjoint_straight_dev(c, dO, dD, dW, R, tmax, Ns, rule, dG, IONO_F64);
+    if (rc) return rc;
+    return adjoint_host_finish(c, dG, scale_by_grid, grad_out, "iono_adjoint_straight");
+}
+
+int iono_adjoint_rays(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int rule, int scale_by_grid,
+                      double *grad_out) {
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    if (rc) return rc;
+    const int64_t n = ncells(c);
+    DevBuf b;
+    const size_t nr = (size_t)R * 4 * Ns;
+    HIP_TRY(c, b.alloc(8 * (nr + (size_t)R + (size_t)n)));
+    double *dR = b.as<double>(), *dW = dR + nr, *dG = dW + R;
+    HIP_TRY(c, hipMemcpyAsync(dR, rays, nr * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dW, w, R * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dG, 0, n * 8, c->stream));
+    rc = iono_adjoint_rays_dev(c, dR, dW, R, Ns, rule, dG, IONO_F64);
+    if (rc) return rc;
+    return adjoint_host_finish(c, dG, scale_by_grid, grad_out, "iono_adjoint_rays");
+}
+
+// ---- ray geometry ------------------------------------------------------------------------------
+int iono_trace_straight(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, double *rays_out) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (R < 0 || Ns < 2) return fail(c, IONO_ERR_SHAPE, "need R >= 0 and Ns >= 2");
+    if (R == 0) return IONO_OK;
+    DevBuf b;
+    const size_t nr = (size_t)R * 4 * Ns;
+    HIP_TRY(c, b.alloc(8 * (nr + 6 * (size_t)R)));
+    double *dR = b.as<double>(), *dO = dR + nr, *dD = dO + 3 * R;
+    HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_trace_straight, dim3(ew_blocks(c, R * Ns)), dim3(256), 0, c->stream, dO, dD, R, tmax, Ns, dR);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(rays_out, dR, nr * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return IONO_OK;
+}
+
+int iono_trace_fermat(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, double frequency, int bend,
+                      int kind, int substeps, double *rays_out) {
+    int rc = check_common(c, R, Ns, kind, 0);
+    if (rc) return rc;
+    if (substeps < 1 || !(frequency > 0)) return fail(c, IONO_ERR_ARG, "need substeps >= 1 and frequency > 0");
+    if (R == 0) return IONO_OK;
+    const int64_t n = ncells(c);
+    DevBuf b;
+    const size_t nr = (size_t)R * 4 * Ns;
+    HIP_TRY(c, b.alloc(8 * (nr + 6 * (size_t)R + (size_t)n)));
+    double *dR = b.as<double>(), *dO = dR + nr, *dD = dO + 3 * R, *dN = dD + 3 * R;
+    HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
+    dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+        hipLaunchKernelGGL((k_ne_to_n<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M, dN, n, frequency);
+        return IONO_OK;
+    });
+    const GridView g = view(c);
+    const dim3 grid((unsigned)((R + 63) / 64)), block(64);
+#define LAUNCH_F(K, B) \
+    hipLaunchKernelGGL((k_trace_fermat<K, B>), grid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags)
+    if (kind == IONO_INTERP_TRILINEAR) {
+        if (bend) LAUNCH_F(IONO_INTERP_TRILINEAR, true); else LAUNCH_F(IONO_INTERP_TRILINEAR, false);
+    } else {
+        if (bend) LAUNCH_F(IONO_INTERP_TRICUBIC, true); else LAUNCH_F(IONO_INTERP_TRICUBIC, false);
+    }
+#undef LAUNCH_F
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(rays_out, dR, nr * 8, hipMemcpyDeviceToHost, c->stream));
+    return finish_host_call(c, "iono_trace_fermat");
+}
+
+}  // extern "C"

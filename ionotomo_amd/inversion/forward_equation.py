@@ -1,0 +1,41 @@
+"""dTEC forward model -- drop-in for ionotomo.inversion.forward_equation (inversion/forward_equation.py:13-67).
+
+``forward_equation(rays, K_ne, m_tci, i0)``: ne = K_ne exp(m)/TECU at the nodes, TEC = Simpson
+integral of the interpolated ne along every ray, dTEC = TEC - TEC[i0].  One GPU launch per call
+(exp at nodes) + one (all rays) + one (reference-antenna subtraction) instead of the reference's
+per-ray Python loop.
+
+``quad`` pins the quadrature rule (SURVEY.md surprise 3): 'avg' = reference-era
+``scipy.integrate.simps`` default (even='avg'); 'scipy' = scipy >= 1.11 ``simpson``.  For odd
+sample counts all Simpson variants coincide.
+"""
+import numpy as np
+
+from .. import _lib
+
+TECU = 1e13    # inversion/forward_equation.py:12
+
+
+def do_forward_equation(rays, ne_tci, quad="avg"):
+    """tec[N1,N2] for rays[N1,N2,4,Ns] through ``ne_tci`` as it stands (forward_equation.py:13-33)."""
+    ctx = ne_tci.bind()
+    return ctx.forward_tec_rays(rays, kind=ne_tci.kind, rule=quad)
+
+
+def forward_equation(rays, K_ne, m_tci, i0, quad="avg"):
+    """dtec[Na,Nt,Nd] using reference antenna ``i0`` (forward_equation.py:36-51)."""
+    rays = np.asarray(rays, dtype=np.float64)
+    Na, Nt, Nd, _, Ns = rays.shape
+    ctx = _lib.default_context()
+    ctx.set_grid(m_tci.xvec, m_tci.yvec, m_tci.zvec, None, storage=m_tci.storage)
+    ctx.set_values_exp(m_tci.M, K_ne / TECU)
+    tec = ctx.forward_tec_rays(rays, kind=m_tci.kind, rule=quad)
+    tec = np.ascontiguousarray(tec.reshape(Na, Nt * Nd))
+    ctx.call("iono_subtract_reference", _lib._dp(tec), Na, Nt * Nd, int(i0))
+    return tec.reshape(Na, Nt, Nd)
+
+
+def forward_equation_dask(rays, K_ne, m_tci, i0, quad="avg"):
+    """The reference's dask-multiprocessing variant computes the same numbers
+    (tests/test_forward_equation.py:27 asserts exact equality); one GPU needs no task split."""
+    return forward_equation(rays, K_ne, m_tci, i0, quad=quad)

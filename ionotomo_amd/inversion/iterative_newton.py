@@ -1,0 +1,37 @@
+"""Phase forward model + objective -- the hot-path part of ionotomo.inversion.iterative_newton
+(inversion/iterative_newton.py:17-55,86-127).
+
+NOTE on parity: the reference's ``forward_equation`` here passes 4-D coordinate arrays to
+``TriCubic.interp``, whose ``np.reshape(rgi(np.array([x,y,z]).T), np.shape(x))``
+(geometry/tri_cubic.py:70) returns the values in transposed order for ndim > 1 -- every sample
+lands on the wrong ray.  This build implements the evidently intended semantics (sample k of ray
+(a,t,d) stays with that ray).  tests/test_oracle_golden.py pins every other term of the formula
+against the reference's actual output by emulating that permutation in the oracle.
+"""
+import numpy as np
+
+from .. import _lib
+
+TECU = 1e13
+speedoflight = 299792458.
+
+
+def forward_equation(model, tci, rays, freqs, K=1e11, i0=0, quad="avg"):
+    """g[Na,Nt,Nd,Nf] = const_i + 2 pi nu clock_ij - (2 pi nu / c) [int (1-n) ds - ref]
+    (inversion/iterative_newton.py:86-127).  Like the reference it leaves ``tci.M = K exp(mu)``."""
+    rays = np.asarray(rays, dtype=np.float64)
+    mu, clock, const = model
+    ne = np.exp(mu)
+    ne *= K
+    tci.M = ne                                   # reference side effect (:106)
+    ctx = tci.bind()
+    return ctx.forward_phase_rays(rays, freqs, clock, const, i0, rule=quad)
+
+
+def neg_log_like(g, dobs, CdCt, covariance=None, model=None, model_prior=None, tci=None, full=False):
+    """S = 1/2 sum (dobs - g)^2 / CdCt (inversion/iterative_newton.py:17-38).  The ``full=True`` prior
+    terms need the reference's Covariance object (out of scope)."""
+    if full:
+        raise NotImplementedError("prior terms need ionosphere.covariance.Covariance (outside the hot path)")
+    dd = dobs - g
+    return float(np.sum(dd * dd / CdCt) / 2.)
