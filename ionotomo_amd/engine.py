@@ -1,0 +1,105 @@
+"""Device-resident driver of the ray-integral kernels: everything stays in HBM.
+
+The reference API (``forward_equation(rays, K_ne, m_tci, i0)`` ...) hands over host numpy arrays,
+so every facade call pays PCIe for the grid and the rays.  The inversion loop, bench.py and the
+multi-GPU driver instead keep origins / directions / model / data as torch CUDA tensors and call
+the ``*_dev`` C-ABI entry points with raw device pointers on torch's current stream.  torch is
+used for device memory, streams and torch.distributed only -- all numerics are the HIP kernels.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+TECU = 1e13
+
+
+def _ptr(t):
+    return _lib._V(t.data_ptr())
+
+
+class RayEngine(object):
+    """One GPU, one grid, straight z-parametrised rays generated in-kernel (rays[R,4,Ns] is never
+    materialised: at config 4 it would be 5.1 GB)."""
+
+    def __init__(self, device=0, storage="f64", interp="linear", quad="avg"):
+        if not torch.cuda.is_available():
+            raise RuntimeError("RayEngine needs a GPU (no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        torch.cuda.set_device(self.device)
+        self.ctx = _lib.Context(device)
+        self.storage = storage
+        self.kind = _lib.interp_kind(interp)
+        self.rule = _lib.quad_rule(quad)
+        self.shape = None
+        self._bound_stream = None
+
+    def _sync_stream(self):
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != self._bound_stream:
+            self.ctx.set_stream(s)
+            self._bound_stream = s
+
+    def tensor(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(self.device)
+
+    # -- grid ------------------------------------------------------------------------------------
+    def set_grid(self, xvec, yvec, zvec, M=None):
+        self.ctx.set_grid(xvec, yvec, zvec, M, storage=self.storage)
+        self.shape = self.ctx.grid_shape
+        self.ncells = int(np.prod(self.shape))
+
+    def set_values(self, M_t):
+        """grid values <- float64 device tensor"""
+        self._sync_stream()
+        assert M_t.is_cuda and M_t.dtype == torch.float64 and M_t.numel() == self.ncells and M_t.is_contiguous()
+        self.ctx.call("iono_grid_set_values_dev", _ptr(M_t))
+
+    def set_log_model(self, m_t, scale):
+        """grid values <- scale * exp(m) at the nodes (inversion/forward_equation.py:41-43)"""
+        self._sync_stream()
+        assert m_t.is_cuda and m_t.dtype == torch.float64 and m_t.numel() == self.ncells and m_t.is_contiguous()
+        self.ctx.call("iono_grid_set_exp_dev", _ptr(m_t), float(scale))
+
+    # -- hot path ----------------------------------------------------------------------------------
+    def forward(self, origins_t, dirs_t, tmax, Ns, out=None):
+        """tec[R] for straight rays; origins/dirs are [R,3] float64 device tensors."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        if out is None:
+            out = torch.empty(R, dtype=torch.float64, device=self.device)
+        self.ctx.call("iono_forward_tec_straight_dev", _ptr(origins_t), _ptr(dirs_t), R, float(tmax), int(Ns), self.kind,
+                      self.rule, _ptr(out))
+        return out
+
+    def adjoint(self, origins_t, dirs_t, w_t, tmax, Ns, out=None, accum=torch.float64):
+        """out[nx,ny,nz] += G^T w  (out is zeroed when allocated here)."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        if out is None:
+            out = torch.zeros(self.shape, dtype=accum, device=self.device)
+        self.ctx.call("iono_adjoint_straight_dev", _ptr(origins_t), _ptr(dirs_t), _ptr(w_t), R, float(tmax), int(Ns),
+                      self.rule, _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+        return out
+
+    def adjoint_residual(self, origins_t, dirs_t, tec_t, dobs_t, cdct_t, Na, i0, tmax, Ns, out=None,
+                         accum=torch.float64):
+        """One launch: dd = (tec - tec[i0] - dobs)/(CdCt + 1e-15) -> differential weights -> G^T.
+        Ray layout [Na][NtNd]."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        assert R % Na == 0
+        if out is None:
+            out = torch.zeros(self.shape, dtype=accum, device=self.device)
+        self.ctx.call("iono_adjoint_residual_straight_dev", _ptr(origins_t), _ptr(dirs_t), _ptr(tec_t), _ptr(dobs_t),
+                      _ptr(cdct_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.rule, _ptr(out),
+                      _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+        return out
+
+    def subtract_reference(self, tec_t, Na, i0):
+        self._sync_stream()
+        self.ctx.call("iono_subtract_reference_dev", _ptr(tec_t), int(Na), tec_t.numel() // Na, int(i0))
+        return tec_t
+
+    def check_oob(self):
+        return self.ctx.check_oob()

@@ -78,7 +78,7 @@ def matern52_field(xvec, yvec, zvec, sigma, corr, seed):
     S = np.sqrt(S)
     rs = np.random.RandomState(seed)
     Z = rs.normal(size=S.shape) + 1j * rs.normal(size=S.shape)
-    B = np.fft.ifftn(S * Z, (nx, ny, nz)).real * (sx * nx) * (sy * ny) * (sz * nz)
+    B = np.fft.ifftn(S * Z, (nx, ny, nz), axes=(0, 1, 2)).real * (sx * nx) * (sy * ny) * (sz * nz)
     B[::2, :, :] *= -1
     B[:, ::2, :] *= -1
     B[:, :, ::2] *= -1
