@@ -128,6 +128,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--main-only", action="store_true",
+                    help="only the timed headline launches (clean rocprofv3 --stats averages); implies --no-cpu")
     args = ap.parse_args()
 
     import torch
@@ -163,6 +165,13 @@ def main():
     tec_gpu = tec_t.cpu().numpy()
 
     extra = {}
+    if args.main_only:
+        if rank == 0:
+            print(json.dumps({"metric": "ray-integrals/sec through 256^3 ne grid", "value": value, "n_gpus": world,
+                              "steps": args.steps, "kernel_ms": kern * 1e3, "main_only": True}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     # ---- adjoint + one full iteration (forward, fused residual adjoint, all-reduce of the update)
     rng = np.random.default_rng(2 + rank)
     dobs_t = eng.tensor(tec_gpu.reshape(NA, -1) - tec_gpu.reshape(NA, -1)[0] + rng.normal(size=(NA, R // NA)) * 1e-3)

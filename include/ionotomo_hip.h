@@ -54,7 +54,10 @@ enum { IONO_QUAD_SIMPSON_AVG = 0,                        /* odd N composite Simp
 int iono_ctx_create(int device_id, iono_ctx **out);
 int iono_ctx_destroy(iono_ctx *ctx);
 const char *iono_last_error(iono_ctx *ctx);              /* ctx may be NULL: last global error */
-int iono_ctx_set_stream(iono_ctx *ctx, void *hip_stream);/* NULL -> the ctx's own stream */
+/* every launch goes to the handle given, used as is: NULL is HIP's null (legacy default) stream,
+ * which is what torch.cuda.current_stream() is unless the caller switched streams */
+int iono_ctx_set_stream(iono_ctx *ctx, void *hip_stream);
+int iono_ctx_use_own_stream(iono_ctx *ctx);              /* back to the ctx's private non-blocking stream (the default) */
 int iono_ctx_synchronize(iono_ctx *ctx);
 int iono_version(void);
 

@@ -41,6 +41,7 @@ _P, _I, _L, _D, _V = c_double_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, 
 _SIGNATURES = {
     "iono_ctx_destroy": [],
     "iono_ctx_set_stream": [_V],
+    "iono_ctx_use_own_stream": [],
     "iono_ctx_synchronize": [],
     "iono_grid_set": [_P, _I, _P, _I, _P, _I, _P, _I],
     "iono_grid_set_values": [_P],

@@ -918,7 +918,14 @@ int iono_ctx_destroy(iono_ctx *c) {
 int iono_ctx_set_stream(iono_ctx *c, void *s) {
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->stream = s ? (hipStream_t)s : c->own_stream;
+    c->stream = (hipStream_t)s;
+    return IONO_OK;
+}
+
+int iono_ctx_use_own_stream(iono_ctx *c) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = c->own_stream;
     return IONO_OK;
 }
 

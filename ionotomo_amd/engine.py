@@ -32,7 +32,7 @@ class RayEngine(object):
         self.kind = _lib.interp_kind(interp)
         self.rule = _lib.quad_rule(quad)
         self.shape = None
-        self._bound_stream = None
+        self._bound_stream = -1
 
     def _sync_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
