@@ -1,0 +1,103 @@
+"""Ray sharding over GPUs: one process per GPU, rays split by (time, direction) pair, grid replicated.
+
+The reference's only "reduction across workers" is ``da.sum(da.stack([...]))`` over per-direction
+dask tasks that each return a full [nx,ny,nz] gradient (inversion/gradient.py:52-54); its forward
+splits rays by antenna or direction with no exchange (inversion/forward_equation.py:60-67).
+Here:
+
+* rays are laid out [Na][P] with P = Nt*Nd (time,direction) pairs; rank r owns a contiguous block
+  of pairs and ALL Na antennas of each pair, so the reference-antenna differencing
+  ``tec - tec[i0]`` (forward_equation.py:50) never leaves the GPU;
+* forward: no collective;
+* adjoint: every rank back-projects its rays into a full-size partial gradient, then ONE
+  ``all_reduce(sum)`` (RCCL over xGMI with the nccl backend; gloo in the CPU tests);
+* scalars (objective, step lengths): all_reduce of a few doubles.
+
+``engine`` is any object with ``forward(origins, dirs, tmax, Ns) -> tec`` and
+``adjoint_residual(...)/adjoint(...)`` over torch tensors: ``ionotomo_amd.engine.RayEngine`` in
+production; the tests drive the same code with a CPU stand-in over gloo.
+"""
+import torch
+import torch.distributed as dist
+
+
+def pair_block(n_pairs, world, rank):
+    """Contiguous, balanced block [lo, hi) of the P (time,direction) pairs for ``rank``."""
+    base, rem = divmod(n_pairs, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def world_info():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(), dist.get_rank()
+    return 1, 0
+
+
+def all_reduce_sum_(t):
+    """In-place sum over ranks (no-op on one rank)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+class ShardedRays(object):
+    """This rank's slice of a [Na][P] ray bundle (+ optional data), resident on the engine's device."""
+
+    def __init__(self, engine, origins, directions, tmax, Ns, dobs=None, cdct=None, i0=0):
+        """origins/directions: [Na,P,3] (numpy or tensor, FULL problem); dobs/cdct: [Na,P]."""
+        self.engine = engine
+        self.world, self.rank = world_info()
+        o = torch.as_tensor(origins, dtype=torch.float64)
+        d = torch.as_tensor(directions, dtype=torch.float64)
+        self.Na, self.P = o.shape[0], o.shape[1]
+        self.lo, self.hi = pair_block(self.P, self.world, self.rank)
+        dev = engine.device
+        self.origins = o[:, self.lo:self.hi].reshape(-1, 3).contiguous().to(dev)
+        self.dirs = d[:, self.lo:self.hi].reshape(-1, 3).contiguous().to(dev)
+        self.tmax, self.Ns, self.i0 = float(tmax), int(Ns), int(i0)
+        self.P_local = self.hi - self.lo
+        self.R_local = self.Na * self.P_local
+        self.dobs = None if dobs is None else self.slice(dobs)
+        self.cdct = None if cdct is None else self.slice(cdct)
+
+    def slice(self, full):
+        """[Na,P] (full problem) -> this rank's [Na*P_local] device vector."""
+        t = torch.as_tensor(full, dtype=torch.float64)
+        return t[:, self.lo:self.hi].reshape(-1).contiguous().to(self.engine.device)
+
+    # -- operators ---------------------------------------------------------------------------------
+    def forward_tec(self):
+        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns)
+
+    def forward(self):
+        """differential TEC of the current grid values, local rays: A x = G x - (G x)[i0]."""
+        tec = self.forward_tec().view(self.Na, self.P_local)
+        return (tec - tec[self.i0:self.i0 + 1]).reshape(-1)
+
+    def adjoint(self, y):
+        """A^T y summed over all ranks: differential weights, back-projection, all-reduce."""
+        w = y.view(self.Na, self.P_local).clone()
+        w[self.i0] -= y.view(self.Na, self.P_local).sum(dim=0)
+        g = self.engine.adjoint(self.origins, self.dirs, w.reshape(-1), self.tmax, self.Ns)
+        return all_reduce_sum_(g)
+
+    def gradient_from_tec(self, tec):
+        """Fused residual -> weights -> back-projection (one launch) + all-reduce:
+        G^T diff((tec - tec[i0] - dobs)/(CdCt + 1e-15))."""
+        g = self.engine.adjoint_residual(self.origins, self.dirs, tec, self.dobs, self.cdct, self.Na, self.i0,
+                                         self.tmax, self.Ns)
+        return all_reduce_sum_(g)
+
+    def dot_rays(self, a, b):
+        """<a, b> over ALL rays (local dot + scalar all-reduce)."""
+        return float(all_reduce_sum_(torch.dot(a, b).reshape(1))[0])
+
+    def gather_rays(self, local):
+        """[Na*P_local] on every rank -> [Na,P] on every rank (host), for reporting/tests."""
+        loc = local.view(self.Na, self.P_local).cpu()
+        if self.world == 1:
+            return loc
+        parts = [None] * self.world
+        dist.all_gather_object(parts, loc)
+        return torch.cat(parts, dim=1)

@@ -1,0 +1,122 @@
+"""Tomographic inversion drivers on top of the two hot kernels (forward, adjoint).
+
+The reference has no solver literally called SIRT or CG; the pieces it does
+have, and which are reused here, are
+  * the objective  S = 1/2 sum (g - dobs)^2 / CdCt           (inversion/iterative_newton.py:32-38,
+                                                              inversion/line_search.py:48-49: + 1e-15)
+  * the stopping rule: at least 5 iterations; stop when the relative decrease <= factr*eps
+    (factr = 1e7), or max|dm| <= pgtol = 1e-2, or iter >= 20   (iterative_newton.py:959-962,993)
+  * the linearised exact line search eps = sum(Gdm dd/Cd) / sum(Gdm^2/Cd)   (:542-554)
+  * SIRT's row/column-sum normalisation L = diag(sum_v G), C = diag(sum_r G)
+                                                              (geometry/oct_trees/Inversion.py:559,564)
+  * steepest descent  m <- m - eps (C_m G^T C_d^-1 r + m - m_prior)       (Inversion.py:533)
+Every iteration is one forward launch + one adjoint launch (+ one all-reduce of the
+back-projected update when rays are sharded over GPUs) + grid-sized vector updates.
+
+``problem`` is a ``parallel.ShardedRays``; grid-sized vectors are torch tensors on its device and
+are identical on every rank (they only ever change by all-reduced quantities).
+"""
+import torch
+
+FACTR, PGTOL, EPS = 1e7, 1e-2, 2.220446049250313e-16
+
+
+def objective(problem, resid):
+    """S = 1/2 sum r^2/(CdCt + 1e-15) over all rays."""
+    return 0.5 * problem.dot_rays(resid, resid / (problem.cdct + 1e-15))
+
+
+def _set_x(problem, x):
+    problem.engine.set_values(x.reshape(-1))
+
+
+def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None):
+    """x_{k+1} = x_k + relax * C A^T L (d - A x_k),  A = differenced ray operator.
+    L, C from row / column sums of |A| bounded by the un-differenced sums (keeps rho <= 1)."""
+    eng = problem.engine
+    x = x0.clone()
+    ones = torch.ones(eng.shape, dtype=torch.float64, device=eng.device)
+    _set_x(problem, ones)
+    rows = problem.forward_tec().view(problem.Na, problem.P_local)          # path lengths
+    L = 1.0 / (rows + rows[problem.i0:problem.i0 + 1]).reshape(-1)
+    wcol = torch.ones(problem.Na, problem.P_local, dtype=torch.float64, device=eng.device)
+    wcol[problem.i0] += problem.Na
+    col = parallel_adjoint_raw(problem, wcol.reshape(-1))
+    C = torch.where(col > 0, 1.0 / col, torch.zeros_like(col))
+    hist = []
+    for k in range(n_iter):
+        _set_x(problem, x)
+        r = problem.dobs - problem.forward()
+        hist.append(objective(problem, r))
+        if callback:
+            callback(k, x, hist[-1])
+        x += relax * C * problem.adjoint(L * r)
+        if nonneg:
+            x.clamp_(min=0)
+    return x, hist
+
+
+def parallel_adjoint_raw(problem, w):
+    """G^T w (no differencing), summed over ranks."""
+    from .parallel import all_reduce_sum_
+    return all_reduce_sum_(problem.engine.adjoint(problem.origins, problem.dirs, w, problem.tmax, problem.Ns))
+
+
+def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
+    """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2 + damp/2 ||x||^2,  W = 1/(CdCt + 1e-15)."""
+    x = x0.clone()
+    Wh = torch.rsqrt(problem.cdct + 1e-15)
+    _set_x(problem, x)
+    r = Wh * (problem.dobs - problem.forward())
+    s = problem.adjoint(Wh * r) - damp * x
+    p = s.clone()
+    gamma = float(torch.dot(s.reshape(-1), s.reshape(-1)))
+    hist = []
+    for k in range(n_iter):
+        hist.append(0.5 * problem.dot_rays(r, r))
+        if callback:
+            callback(k, x, hist[-1])
+        _set_x(problem, p)
+        q = Wh * problem.forward()
+        alpha = gamma / (problem.dot_rays(q, q) + damp * float(torch.dot(p.reshape(-1), p.reshape(-1))))
+        x += alpha * p
+        r -= alpha * q
+        s = problem.adjoint(Wh * r) - damp * x
+        gnew = float(torch.dot(s.reshape(-1), s.reshape(-1)))
+        p = s + (gnew / gamma) * p
+        gamma = gnew
+    return x, hist
+
+
+def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=0.0, max_iter=20, min_iter=5,
+                               callback=None):
+    """Nonlinear inversion in the log-model m (ne = K_scale exp(m) at the nodes) with the
+    reference's objective, update, line search and stopping rule (module docstring)."""
+    eng = problem.engine
+    m = m0.clone()
+    hist = []
+    for k in range(max_iter):
+        eng.set_log_model(m.reshape(-1), K_scale)
+        tec = problem.forward_tec()
+        t2 = tec.view(problem.Na, problem.P_local)
+        resid = (t2 - t2[problem.i0:problem.i0 + 1]).reshape(-1) - problem.dobs
+        S = objective(problem, resid)
+        hist.append(S)
+        if callback:
+            callback(k, m, S)
+        if k >= min_iter and len(hist) > 1 and (hist[-2] - S) <= FACTR * EPS * max(abs(hist[-2]), abs(S), 1.0):
+            break
+        ne = K_scale * torch.exp(m)
+        dm = problem.gradient_from_tec(tec) * ne                  # d S / d m  (exp at nodes => node-wise product)
+        if m_prior is not None and prior_weight > 0:
+            dm = dm + prior_weight * (m - m_prior)
+        # linearised exact line search along -dm: d(A ne)/d eps = -A (ne * dm)
+        _set_x(problem, ne * dm)
+        Gdm = problem.forward()
+        Wt = 1.0 / (problem.cdct + 1e-15)
+        eps = problem.dot_rays(Gdm, resid * Wt) / max(problem.dot_rays(Gdm, Gdm * Wt), 1e-300)
+        step = eps * dm
+        m -= step
+        if k >= min_iter and float(step.abs().max()) <= PGTOL:
+            break
+    return m, hist

@@ -1,0 +1,132 @@
+"""Device-resident engine, fused residual adjoint, solvers and size-independent properties at
+BASELINE sizes.  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from ionotomo_amd import parallel, solvers, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def make_engine(w, storage="f64"):
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0, storage=storage)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    return eng
+
+
+def test_engine_forward_adjoint_vs_oracle(O):
+    w = syn.make_workload("cfg1")
+    eng = make_engine(w)
+    eng.set_log_model(eng.tensor(w["m"]), w["K_ne"] / 1e13)
+    o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+    tec = eng.forward(o, d, w["tmax"], w["Ns"]).cpu().numpy()
+    rays = O.straight_rays(w["origins"], w["directions"], w["tmax"], w["Ns"])
+    ref = O.forward_tec(rays, w["xvec"], w["yvec"], w["zvec"], O.ne_from_log_model(w["m"], w["K_ne"]))
+    assert np.max(np.abs(tec - ref.ravel()) / np.abs(ref.ravel())) < 1e-12
+    assert not eng.check_oob()
+    y = np.random.default_rng(0).normal(size=ref.shape)
+    g = eng.adjoint(o, d, eng.tensor(y.ravel()), w["tmax"], w["Ns"]).cpu().numpy()
+    gref = O.adjoint_tec(rays, w["xvec"], w["yvec"], w["zvec"], y)
+    assert np.max(np.abs(g - gref)) < 1e-11 * np.max(np.abs(gref))
+    g32 = eng.adjoint(o, d, eng.tensor(y.ravel()), w["tmax"], w["Ns"], accum=torch.float32).cpu().numpy()
+    assert np.max(np.abs(g32 - gref)) < 1e-5 * np.max(np.abs(gref))          # f32 atomics (SURVEY 8d gate)
+    # out-of-grid rays set the sticky flag instead of faulting
+    eng.forward(o, d, w["zvec"][-1] + 100.0, w["Ns"])
+    assert eng.check_oob() and not eng.check_oob()
+
+
+def test_fused_residual_adjoint_equals_separate_steps(O):
+    w = syn.make_workload(antennas="example", na=6, nd=5, nt=3, n=20)
+    na, P = 6, 15
+    o = w["origins"].reshape(na, P, 3)
+    d = w["directions"].reshape(na, P, 3)
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    rng = np.random.default_rng(4)
+    dobs = rng.normal(size=(na, P)) * 0.1
+    cdct = rng.uniform(0.5, 2.0, size=(na, P))
+    for i0 in (0, 3, 5):
+        prob = parallel.ShardedRays(eng, o, d, w["tmax"], 21, dobs=dobs, cdct=cdct, i0=i0)
+        tec = prob.forward_tec()
+        fused = prob.gradient_from_tec(tec).cpu().numpy()
+        t = tec.cpu().numpy().reshape(na, P)
+        dd = (t - t[i0] - dobs) / (cdct + 1e-15)
+        rays = O.straight_rays(o, d, w["tmax"], 21)
+        ref = O.adjoint_tec(rays, w["xvec"], w["yvec"], w["zvec"], O.differential_weights(dd, i0))
+        assert np.max(np.abs(fused - ref)) < 1e-11 * np.max(np.abs(ref))
+        sep = prob.adjoint(eng.tensor(dd.ravel())).cpu().numpy()
+        assert np.max(np.abs(sep - ref)) < 1e-11 * np.max(np.abs(ref))
+
+
+def test_solvers_on_gpu_match_dense_restatement():
+    from oracle import oracle as Or, solvers as OS
+    from problems import small_problem
+    pb = small_problem()
+    w = pb["w"]
+    rays = Or.straight_rays(pb["o"], pb["d"], pb["tmax"], pb["Ns"])
+    G, A = OS.dense_operator(rays, w["xvec"], w["yvec"], w["zvec"], pb["i0"])
+    d = A @ pb["x_true"].ravel() + pb["rng"].normal(size=A.shape[0]) * 1e-3
+    cd = np.full(A.shape[0], 1e-6)
+    eng = make_engine(w)
+    prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d.reshape(pb["na"], pb["P"]),
+                                cdct=cd.reshape(pb["na"], pb["P"]), i0=pb["i0"])
+    x0 = eng.tensor(pb["x0"])
+    xs, hs = solvers.sirt(prob, x0, n_iter=10)
+    xr, hr = OS.sirt(G, A, d, cd, pb["x0"].ravel(), pb["na"], pb["P"], pb["i0"], 10)
+    assert np.allclose(hs, hr, rtol=1e-9) and np.allclose(xs.cpu().numpy().ravel(), xr, rtol=1e-9, atol=1e-12)
+    xc, hc = solvers.cgls(prob, x0, n_iter=10)
+    xr, hr = OS.cgls(A, d, cd, pb["x0"].ravel(), 10)
+    assert np.allclose(hc, hr, rtol=1e-6) and np.allclose(xc.cpu().numpy().ravel(), xr, rtol=1e-5, atol=1e-9)
+    K = float(np.median(pb["x0"]))
+    mm, hm = solvers.steepest_descent_log_model(prob, eng.tensor(np.log(pb["x0"] / K)), K, max_iter=8)
+    mr, hr = OS.steepest_descent_log_model(A, d, cd, np.log(pb["x0"] / K).ravel(), K, max_iter=8)
+    assert len(hm) == len(hr) and np.allclose(hm, hr, rtol=1e-7)
+    assert np.allclose(mm.cpu().numpy().ravel(), mr, rtol=1e-6, atol=1e-9)
+
+
+def test_full_size_properties_256_cubed():
+    """BASELINE full size (256^3 grid, Ns = 257, 62 x 42 x 8 rays): size-independent properties
+    instead of the (slow) oracle -- linearity, exactness on a linear field, dot-product test."""
+    import bench
+    w = bench.build_workload(0)
+    sel = np.arange(62 * 100 * 42).reshape(62, 100, 42)[:, :8, :].ravel()
+    eng = make_engine(w)
+    o, d = eng.tensor(w["origins"][sel]), eng.tensor(w["directions"][sel])
+    X, Y, Z = np.meshgrid(w["xvec"], w["yvec"], w["zvec"], indexing="ij")
+    # (1) a field linear in x,y,z is reproduced exactly by trilinear interpolation and Simpson:
+    #     TEC = path length * field at the ray midpoint
+    lin = 2.0 + 0.01 * X - 0.02 * Y + 0.003 * Z
+    eng.set_values(eng.tensor(lin))
+    tec = eng.forward(o, d, 1000.0, 257).cpu().numpy()
+    oo, dd = w["origins"][sel], w["directions"][sel]
+    p = dd / np.linalg.norm(dd, axis=1, keepdims=True)
+    L = (1000.0 - oo[:, 2]) / p[:, 2]
+    mid = oo + p * (L / 2)[:, None]
+    exact = L * (2.0 + 0.01 * mid[:, 0] - 0.02 * mid[:, 1] + 0.003 * mid[:, 2])
+    assert np.max(np.abs(tec - exact) / np.abs(exact)) < 1e-12
+    # (2) linearity in the grid values
+    rng = np.random.default_rng(0)
+    a, b = rng.uniform(0.5, 1.5, size=lin.shape), rng.uniform(0.5, 1.5, size=lin.shape)
+    eng.set_values(eng.tensor(a))
+    ta = eng.forward(o, d, 1000.0, 257).clone()
+    eng.set_values(eng.tensor(b))
+    tb = eng.forward(o, d, 1000.0, 257).clone()
+    eng.set_values(eng.tensor(2.0 * a - 3.0 * b))
+    tc = eng.forward(o, d, 1000.0, 257)
+    assert float((tc - (2.0 * ta - 3.0 * tb)).abs().max()) < 1e-10 * float(ta.abs().max())
+    # (3) <G x, y> == <x, G^T y>
+    y = eng.tensor(rng.normal(size=sel.size))
+    eng.set_values(eng.tensor(a))
+    Gx = eng.forward(o, d, 1000.0, 257)
+    Gty = eng.adjoint(o, d, y, 1000.0, 257)
+    lhs, rhs = float(torch.dot(Gx, y)), float(torch.dot(eng.tensor(a).reshape(-1), Gty.reshape(-1)))
+    assert abs(lhs - rhs) < 1e-10 * float(Gx.norm()) * float(y.norm())
+    assert not eng.check_oob()

@@ -1,0 +1,66 @@
+"""parallel.py + solvers.py (product host logic) driven by the CPU stand-in engine, against the
+dense-matrix restatement in oracle/solvers.py.  CPU only."""
+import numpy as np
+import torch
+
+from ionotomo_amd import parallel, solvers
+from oracle import oracle as O
+from oracle import solvers as OS
+from cpu_engine import OracleEngine
+from problems import small_problem
+
+
+def setup():
+    pb = small_problem()
+    w = pb["w"]
+    rays = O.straight_rays(pb["o"], pb["d"], pb["tmax"], pb["Ns"])
+    G, A = OS.dense_operator(rays, w["xvec"], w["yvec"], w["zvec"], pb["i0"])
+    d = A @ pb["x_true"].ravel() + pb["rng"].normal(size=A.shape[0]) * 1e-3
+    cd = np.full(A.shape[0], 1e-6)
+    eng = OracleEngine(w["xvec"], w["yvec"], w["zvec"])
+    prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d.reshape(pb["na"], pb["P"]),
+                                cdct=cd.reshape(pb["na"], pb["P"]), i0=pb["i0"])
+    return pb, G, A, d, cd, prob
+
+
+def test_pair_block_partitions_evenly():
+    for P in (1, 7, 10, 4200):
+        for world in (1, 2, 3, 8):
+            blocks = [parallel.pair_block(P, world, r) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == P
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b[1] - b[0] for b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_forward_adjoint_match_dense_operator():
+    pb, G, A, d, cd, prob = setup()
+    x = torch.from_numpy(pb["x_true"].copy())
+    prob.engine.set_values(x)
+    assert np.allclose(prob.forward().numpy(), A @ pb["x_true"].ravel(), rtol=1e-12, atol=1e-14)
+    y = torch.from_numpy(pb["rng"].normal(size=A.shape[0]))
+    assert np.allclose(prob.adjoint(y).numpy().ravel(), A.T @ y.numpy(), rtol=1e-11, atol=1e-13)
+    tec = prob.forward_tec()
+    g = prob.gradient_from_tec(tec).numpy().ravel()
+    ref = A.T @ ((A @ pb["x_true"].ravel() - d) / (cd + 1e-15))
+    assert np.allclose(g, ref, rtol=1e-10, atol=1e-8 * np.abs(ref).max())
+
+
+def test_sirt_cgls_sd_match_dense_restatement():
+    pb, G, A, d, cd, prob = setup()
+    x0 = torch.from_numpy(pb["x0"].copy())
+    xs, hs = solvers.sirt(prob, x0, n_iter=8)
+    xr, hr = OS.sirt(G, A, d, cd, pb["x0"].ravel(), pb["na"], pb["P"], pb["i0"], 8)
+    assert np.allclose(hs, hr, rtol=1e-9) and np.allclose(xs.numpy().ravel(), xr, rtol=1e-9, atol=1e-12)
+    assert hs[-1] < hs[0]
+    xc, hc = solvers.cgls(prob, x0, n_iter=8)
+    xr, hr = OS.cgls(A, d, cd, pb["x0"].ravel(), 8)
+    assert np.allclose(hc, hr, rtol=1e-7) and np.allclose(xc.numpy().ravel(), xr, rtol=1e-6, atol=1e-9)
+    assert hc[-1] < 0.5 * hc[0]
+    K = float(np.median(pb["x0"]))
+    m0 = torch.from_numpy(np.log(pb["x0"] / K))                 # start at the prior, like the reference
+    mm, hm = solvers.steepest_descent_log_model(prob, m0, K, max_iter=8)
+    mr, hr = OS.steepest_descent_log_model(A, d, cd, np.log(pb["x0"] / K).ravel(), K, max_iter=8)
+    assert len(hm) == len(hr) and np.allclose(hm, hr, rtol=1e-8)
+    assert np.allclose(mm.numpy().ravel(), mr, rtol=1e-7, atol=1e-10)
+    assert hm[-1] < hm[0]
