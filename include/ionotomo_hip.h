@@ -116,9 +116,12 @@ int iono_adjoint_rays(iono_ctx *ctx, const double *rays, const double *w, int64_
 
 /* ---- device-pointer (asynchronous) variants used by the inversion loop, bench.py and the
  *      multi-GPU driver.  Out-of-grid samples set a sticky device flag read by iono_check_oob. ---- */
+/* order_dev (nullable): int32 permutation of 0..R-1 giving the order in which rays are WALKED
+ * (results still land in tec_dev[ray]); sort rays so that neighbours in the walk are neighbours in
+ * space and the grid lines they share stay in L1/L2.  Speed only. */
 int iono_forward_tec_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
-                                  int64_t R, double tmax, int Ns, int interp_kind, int quad_rule,
-                                  double *tec_dev);
+                                  const int *order_dev, int64_t R, double tmax, int Ns, int interp_kind,
+                                  int quad_rule, double *tec_dev);
 int iono_forward_tec_rays_dev(iono_ctx *ctx, const double *rays_dev, int64_t R, int Ns,
                               int interp_kind, int quad_rule, double *tec_dev);
 /* accumulates INTO grad_dev (caller zeroes it); accum_dtype IONO_F64 | IONO_F32 selects the

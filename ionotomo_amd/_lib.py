@@ -58,7 +58,7 @@ _SIGNATURES = {
     "iono_forward_phase_rays": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P],
     "iono_adjoint_straight": [_P, _P, _P, _L, _D, _I, _I, _I, _P],
     "iono_adjoint_rays": [_P, _P, _L, _I, _I, _I, _P],
-    "iono_forward_tec_straight_dev": [_V, _V, _L, _D, _I, _I, _I, _V],
+    "iono_forward_tec_straight_dev": [_V, _V, _V, _L, _D, _I, _I, _I, _V],
     "iono_forward_tec_rays_dev": [_V, _L, _I, _I, _I, _V],
     "iono_adjoint_straight_dev": [_V, _V, _V, _L, _D, _I, _I, _V, _I],
     "iono_adjoint_rays_dev": [_V, _V, _L, _I, _I, _V, _I],

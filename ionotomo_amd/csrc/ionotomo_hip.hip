@@ -16,6 +16,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <type_traits>
@@ -40,6 +41,7 @@ struct GridView {
     int nx, ny, nz;
     double inv_h[3];      // 1/(mean spacing) per axis: first guess of the cell index
     int uniform[3];       // axis is (numerically) uniform -> guess + fix-up; else binary search
+    double g0[3], glast[3];   // first / last node per axis (host copies)
 };
 
 struct Axes {             // axis tables staged in LDS
@@ -362,6 +364,284 @@ __global__ __launch_bounds__(256) void k_forward_straight(GridView g, const doub
         }
         acc = wave_sum(acc);
         if (lane == 0) tec[w.r] = acc * q.h;
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- fast path (trilinear, numerically uniform axes, grid < 4 GB): the instruction diet ---------
+// The general kernel above is issue-bound, not memory-bound (float32 storage buys nothing): three
+// f64 divisions, per-sample bounds tests and looped cell fix-ups dominate.  Here: reciprocal cell
+// widths are tabulated in LDS beside the axes (t = (x - g[i]) * inv[i]), the cell guess
+// floor((x - g0)/h) is verified against the table with one compare pair (the exact searchsorted
+// rule runs only for lanes whose guess is off, i.e. samples within rounding of a node), the
+// bounds test is done once per ray on its two end points (a straight segment in a convex box),
+// and addressing is 32-bit.
+struct FastAxes {
+    const double *g[3];
+    const double *inv[3];
+    double g0[3];
+};
+
+__device__ __forceinline__ FastAxes stage_axes_fast(const GridView &g, double *lds) {
+    const int n = g.nx + g.ny + g.nz;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = g.axes[t];
+    __syncthreads();
+    for (int t = threadIdx.x; t < n - 1; t += blockDim.x) lds[n + t] = 1.0 / (lds[t + 1] - lds[t]);
+    __syncthreads();
+    FastAxes a;
+    a.g[0] = lds;
+    a.g[1] = lds + g.nx;
+    a.g[2] = lds + g.nx + g.ny;
+    a.inv[0] = lds + n;
+    a.inv[1] = lds + n + g.nx;
+    a.inv[2] = lds + n + g.nx + g.ny;
+    for (int d = 0; d < 3; ++d) a.g0[d] = a.g[d][0];
+    return a;
+}
+
+__device__ __forceinline__ void cell_fast(const double *g, const double *inv, int n, double g0, double ih, double x, int &i,
+                                          double &t) {
+    double f = (x - g0) * ih;
+    f = fmin(fmax(f, 0.0), (double)(n - 2));
+    i = (int)f;
+    double a = g[i];
+    const double b = g[i + 1];
+    if (__builtin_expect(!((a < x) & (x <= b)), 0)) {      // guess off by one, or x on the clipped edge
+        while (i > 0 && !(g[i] < x)) --i;
+        while (i < n - 2 && g[i + 1] < x) ++i;
+        a = g[i];
+    }
+    t = (x - a) * inv[i];
+}
+
+template <typename GT>
+__device__ __forceinline__ double trilinear_fast(const GridView &g, const FastAxes &ax, double x, double y, double z) {
+    int i, j, k;
+    double tx, ty, tz;
+    cell_fast(ax.g[0], ax.inv[0], g.nx, ax.g0[0], g.inv_h[0], x, i, tx);
+    cell_fast(ax.g[1], ax.inv[1], g.ny, ax.g0[1], g.inv_h[1], y, j, ty);
+    cell_fast(ax.g[2], ax.inv[2], g.nz, ax.g0[2], g.inv_h[2], z, k, tz);
+    const unsigned sj = (unsigned)g.nz, si = (unsigned)g.ny * (unsigned)g.nz;
+    const unsigned off = ((unsigned)i * (unsigned)g.ny + (unsigned)j) * sj + (unsigned)k;
+    const GT *p = (const GT *)g.M + off;
+    const double c000 = p[0], c001 = p[1];
+    const double c010 = p[sj], c011 = p[sj + 1];
+    const double c100 = p[si], c101 = p[si + 1];
+    const double c110 = p[si + sj], c111 = p[si + sj + 1];
+    const double c00 = c000 + tz * (c001 - c000);
+    const double c01 = c010 + tz * (c011 - c010);
+    const double c10 = c100 + tz * (c101 - c100);
+    const double c11 = c110 + tz * (c111 - c110);
+    const double c0 = c00 + ty * (c01 - c00);
+    const double c1 = c10 + ty * (c11 - c10);
+    return c0 + tx * (c1 - c0);
+}
+
+__device__ __forceinline__ bool ray_leaves_grid(const FastAxes &ax, const GridView &g, const StraightRay &q) {
+    const double xe = q.ox + q.sx * q.L, ye = q.oy + q.sy * q.L, ze = q.oz + q.L;
+    return outside(ax.g[0], g.nx, q.ox) || outside(ax.g[0], g.nx, xe) || outside(ax.g[1], g.ny, q.oy) ||
+           outside(ax.g[1], g.ny, ye) || outside(ax.g[2], g.nz, q.oz) || outside(ax.g[2], g.nz, ze);
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void k_forward_straight_fast(GridView g, const double *__restrict__ origins,
+                                                               const double *__restrict__ dirs, int64_t R, double tmax, int Ns,
+                                                               const double *__restrict__ unitw, double *__restrict__ tec,
+                                                               int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const FastAxes ax = stage_axes_fast(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+        if (ray_leaves_grid(ax, g, q)) {
+            oob = true;
+            if (lane == 0) tec[w.r] = nan("");
+            continue;
+        }
+        double acc = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            double x, y, z;
+            straight_point(q, k, Ns, x, y, z);
+            acc += unitw[k] * trilinear_fast<GT>(g, ax, x, y, z);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) tec[w.r] = acc * q.h;
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- v2 fast path: "ideal uniform" grid coordinates ------------------------------------------------
+// Taken when every axis equals g0 + i*h to within 2.5e-13 h (what np.linspace produces; checked on
+// the host), so a sample's grid coordinate is ONE fma per axis, f = f0 + k*df, its cell is
+// (int)f and its weight fract(f): no axis tables, no divisions in the loop.  Per-ray work that is
+// wave-uniform in the kernels above (normalisation, slopes, bounds test on the two end points,
+// the <= 8 tail samples when Ns is not a multiple of 64) is done LANE-PARALLEL for a group of up
+// to 16 rays (lane = ray) and broadcast with v_readlane; the Simpson sum is a DPP row_shr /
+// row_bcast reduction (no LDS round trips); the weight table lives in LDS.  `order` (optional)
+// is a permutation of the rays: callers sort rays so that neighbours in the walk are neighbours in
+// space, which turns L2 traffic into L1 hits.
+#define U_MAXG 16
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+// sum over the 64 lanes; the total is returned wave-uniform (read from lane 63)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add<0x111, 0xf>(v);    // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);    // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);    // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);    // row_shr:8   -> lane 15 of each row holds the row total
+    v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_lane(double v, int src) {     // src must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+struct URay {            // a straight ray in ideal grid coordinates: f(k) = f0 + k * df per axis
+    double fx0, dfx, fy0, dfy, fz0, dfz, h;
+    bool valid;
+};
+__device__ __forceinline__ URay load_uray(const GridView &g, const double *origins, const double *dirs, int64_t r, double tmax,
+                                          int Ns) {
+    const double ox = origins[3 * r], oy = origins[3 * r + 1], oz = origins[3 * r + 2];
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    const double px = dx / nrm, py = dy / nrm, pz = dz / nrm;
+    const double sx = px / pz, sy = py / pz;
+    const double L = tmax - oz;
+    const double Lstep = L * (1.0 / (double)(Ns - 1));
+    URay u;
+    u.h = Lstep / pz;
+    u.fx0 = (ox - g.g0[0]) * g.inv_h[0];
+    u.fy0 = (oy - g.g0[1]) * g.inv_h[1];
+    u.fz0 = (oz - g.g0[2]) * g.inv_h[2];
+    u.dfx = sx * Lstep * g.inv_h[0];
+    u.dfy = sy * Lstep * g.inv_h[1];
+    u.dfz = Lstep * g.inv_h[2];
+    const double xe = ox + sx * L, ye = oy + sy * L, ze = oz + L;
+    u.valid = (ox >= g.g0[0]) & (ox <= g.glast[0]) & (xe >= g.g0[0]) & (xe <= g.glast[0]) & (oy >= g.g0[1]) &
+              (oy <= g.glast[1]) & (ye >= g.g0[1]) & (ye <= g.glast[1]) & (oz >= g.g0[2]) & (oz <= g.glast[2]) &
+              (ze >= g.g0[2]) & (ze <= g.glast[2]);
+    return u;
+}
+
+// The grid allocation is padded by one plane + one row + 2 zero elements (iono_grid_set), so a
+// sample sitting exactly on the top face of an axis (cell index n-1, weight 0 on the far corner)
+// may read the far corner without a clamp: it is multiplied by 0.
+template <typename GT>
+__device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const GT *__restrict__ b01,
+                                              const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz, double fx,
+                                              double fy, double fz) {
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    const double tx = fx - (double)i, ty = fy - (double)j, tz = fz - (double)k;
+    const unsigned boff = (((unsigned)i * (unsigned)ny + (unsigned)j) * (unsigned)nz + (unsigned)k) * (unsigned)sizeof(GT);
+    const GT *p00 = (const GT *)((const char *)b00 + boff), *p01 = (const GT *)((const char *)b01 + boff);
+    const GT *p10 = (const GT *)((const char *)b10 + boff), *p11 = (const GT *)((const char *)b11 + boff);
+    const double c000 = p00[0], c001 = p00[1];
+    const double c010 = p01[0], c011 = p01[1];
+    const double c100 = p10[0], c101 = p10[1];
+    const double c110 = p11[0], c111 = p11[1];
+    const double c00 = c000 + tz * (c001 - c000);
+    const double c01 = c010 + tz * (c011 - c010);
+    const double c10 = c100 + tz * (c101 - c100);
+    const double c11 = c110 + tz * (c111 - c110);
+    const double c0 = c00 + ty * (c01 - c00);
+    const double c1 = c10 + ty * (c11 - c10);
+    return c0 + tx * (c1 - c0);
+}
+
+// groups of G consecutive walk positions per wave; XCD b%8 takes a contiguous eighth of the groups
+struct GroupWalk {
+    int64_t q, end, stride;     // in units of groups
+};
+__device__ __forceinline__ GroupWalk group_walk(int64_t ngroups) {
+    const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    GroupWalk w;
+    if ((gridDim.x & 7) == 0 && ngroups >= 64) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+        const int64_t per = (ngroups + 7) / 8;
+        const int64_t lo = per * xcd;
+        w.end = min(ngroups, lo + per);
+        w.q = lo + (int64_t)slot * wpb + wid;
+        w.stride = (int64_t)nslot * wpb;
+    } else {
+        w.q = (int64_t)blockIdx.x * wpb + wid;
+        w.end = ngroups;
+        w.stride = (int64_t)gridDim.x * wpb;
+    }
+    return w;
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void k_forward_straight_u(GridView g, const double *__restrict__ origins,
+                                                            const double *__restrict__ dirs, const int *__restrict__ order,
+                                                            int64_t R, double tmax, int Ns, int G,
+                                                            const double *__restrict__ unitw, double *__restrict__ tec,
+                                                            int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double wlds[];
+    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nfull = Ns >> 6, ntail0 = nfull << 6;        // samples [ntail0, Ns) are the tail
+    const bool tail_by_lane = (Ns - ntail0) <= 8;          // else: one more (masked) wave iteration
+    const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
+    const int64_t ngroups = (R + G - 1) / G;
+    bool oob = false;
+    for (GroupWalk w = group_walk(ngroups); w.q < w.end; w.q += w.stride) {
+        const int64_t q0 = w.q * G;
+        const int cnt = (int)min((int64_t)G, R - q0);
+        // ---- lane-parallel set-up: lane l owns ray q0 + l ------------------------------------------
+        URay u = {};
+        int64_t r = 0;
+        double tail = 0.0;
+        if (lane < cnt) {
+            r = order ? (int64_t)order[q0 + lane] : q0 + lane;
+            u = load_uray(g, origins, dirs, r, tmax, Ns);
+            if (u.valid && tail_by_lane) {
+                for (int k = ntail0; k < Ns; ++k) {
+                    const double kd = (double)k;
+                    tail += wlds[k] * trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fma(kd, u.dfx, u.fx0),
+                                                       fma(kd, u.dfy, u.fy0), fma(kd, u.dfz, u.fz0));
+                }
+            }
+            if (!u.valid) oob = true;
+        }
+        // ---- one ray at a time, lanes = samples ----------------------------------------------------
+        double res = 0.0;
+        const double dlane = (double)lane;
+        for (int gi = 0; gi < cnt; ++gi) {
+            const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
+            if (!ok) continue;
+            const double dfx = bcast_lane(u.dfx, gi), dfy = bcast_lane(u.dfy, gi), dfz = bcast_lane(u.dfz, gi);
+            double fx = fma(dlane, dfx, bcast_lane(u.fx0, gi));
+            double fy = fma(dlane, dfy, bcast_lane(u.fy0, gi));
+            double fz = fma(dlane, dfz, bcast_lane(u.fz0, gi));
+            const double sx64 = 64.0 * dfx, sy64 = 64.0 * dfy, sz64 = 64.0 * dfz;
+            double acc = 0.0;
+            const double *wp = wlds + lane;
+            for (int it = 0; it < nfull; ++it) {
+                acc = fma(wp[it << 6], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
+                fx += sx64;
+                fy += sy64;
+                fz += sz64;
+            }
+            if (!tail_by_lane && lane + ntail0 < Ns)
+                acc = fma(wp[ntail0], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
+            const double total = wave_sum_dpp(acc);
+            if (lane == gi) res = total;
+        }
+        if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
     }
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
@@ -725,6 +1005,9 @@ struct iono_ctx {
     int unitw_n = 0, unitw_rule = -1;
     std::string err;
     int num_cus = 256;
+    int force_general = 0;           // testing/ablation: 1 = general kernels only, 2 = no "ideal uniform" kernels
+    int ideal = 0;                   // every axis is g0 + i*h to within 2.5e-13 h (np.linspace)
+    double g0[3] = {0, 0, 0}, glast[3] = {0, 0, 0};
 };
 
 namespace {
@@ -758,11 +1041,30 @@ GridView view(const iono_ctx *c) {
     for (int a = 0; a < 3; ++a) {
         g.inv_h[a] = c->inv_h[a];
         g.uniform[a] = c->uniform[a];
+        g.g0[a] = c->g0[a];
+        g.glast[a] = c->glast[a];
     }
     return g;
 }
 size_t lds_bytes(const iono_ctx *c) { return sizeof(double) * (size_t)(c->nx + c->ny + c->nz); }
 int64_t ncells(const iono_ctx *c) { return (int64_t)c->nx * c->ny * c->nz; }
+// fast kernels: all three axes uniform (cell guess off by at most one), 32-bit element offsets
+bool fast_path_ok(const iono_ctx *c) {
+    return c->uniform[0] && c->uniform[1] && c->uniform[2] && ncells(c) < ((int64_t)1 << 31) && c->force_general != 1;
+}
+bool ideal_path_ok(const iono_ctx *c) { return fast_path_ok(c) && c->ideal && c->force_general == 0; }
+// rays per wave group for the v2 kernels: enough groups to fill the chip, at most U_MAXG
+int group_size(const iono_ctx *c, int64_t R) {
+    int64_t G = R / ((int64_t)c->num_cus * 32);
+    return (int)(G < 1 ? 1 : (G > U_MAXG ? U_MAXG : G));
+}
+int group_grid_blocks(const iono_ctx *c, int64_t R, int G) {
+    int64_t b = ((R + G - 1) / G + 3) / 4;
+    const int64_t cap = (int64_t)c->num_cus * 8;
+    if (b > cap) b = cap;
+    if (b >= 8) b = (b + 7) / 8 * 8;
+    return (int)(b < 1 ? 1 : b);
+}
 
 int need_grid(iono_ctx *c) {
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
@@ -898,6 +1200,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0)
         c->num_cus = prop.multiProcessorCount;
     c->stream = c->own_stream;
+    if (const char *e = getenv("IONOTOMO_FORCE_GENERAL")) c->force_general = atoi(e);
     *out = c;
     return IONO_OK;
 }
@@ -945,6 +1248,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     if ((size_t)(nx + ny + nz) * sizeof(double) > 96 * 1024) return fail(c, IONO_ERR_SHAPE, "axes do not fit the LDS budget");
     const double *ax[3] = {xv, yv, zv};
     const int n[3] = {nx, ny, nz};
+    bool ideal = true;
     for (int a = 0; a < 3; ++a) {
         bool uni = true;
         const double h = (ax[a][n[a] - 1] - ax[a][0]) / (n[a] - 1);
@@ -955,7 +1259,12 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
         }
         c->uniform[a] = uni ? 1 : 0;
         c->inv_h[a] = 1.0 / h;
+        c->g0[a] = ax[a][0];
+        c->glast[a] = ax[a][n[a] - 1];
+        for (int i = 0; i < n[a]; ++i)
+            if (std::fabs(ax[a][i] - (ax[a][0] + i * h)) > 2.5e-13 * h) ideal = false;
     }
+    c->ideal = ideal ? 1 : 0;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_axes) HIP_TRY(c, hipFree(c->d_axes));
@@ -973,8 +1282,10 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     HIP_TRY(c, hipMalloc((void **)&c->d_axes, cat.size() * sizeof(double)));
     HIP_TRY(c, hipMemcpy(c->d_axes, cat.data(), cat.size() * sizeof(double), hipMemcpyHostToDevice));
     const size_t esz = storage == IONO_F64 ? 8 : 4;
-    HIP_TRY(c, hipMalloc(&c->d_M, (size_t)ncells(c) * esz));
-    HIP_TRY(c, hipMemset(c->d_M, 0, (size_t)ncells(c) * esz));
+    // + one plane + one row + 2 zero elements: see trilinear_u (unclamped far-corner reads, weight 0)
+    const size_t padded = (size_t)ncells(c) + (size_t)ny * nz + nz + 2;
+    HIP_TRY(c, hipMalloc(&c->d_M, padded * esz));
+    HIP_TRY(c, hipMemset(c->d_M, 0, padded * esz));
     if (M) return iono_grid_set_values(c, M);
     return IONO_OK;
 }
@@ -1070,8 +1381,8 @@ int iono_interp(iono_ctx *c, const double *x, const double *y, const double *z, 
 }
 
 // ---- forward (device pointers) ---------------------------------------------------------------
-int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, int kind,
-                                  int rule, double *tec) {
+int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, int64_t R, double tmax,
+                                  int Ns, int kind, int rule, double *tec) {
     int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (R == 0) return IONO_OK;
@@ -1082,7 +1393,16 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
     const size_t lds = lds_bytes(c);
     dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        if (kind == IONO_INTERP_TRILINEAR)
+        if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c)) {
+            const int G = group_size(c, R);
+            hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(group_grid_blocks(c, R, G)), block, sizeof(double) * Ns,
+                               c->stream, g, o, d, order, R, tmax, Ns, G, c->d_unitw, tec, c->d_flags);
+        } else if (order) {
+            rc = fail(c, IONO_ERR_ARG, "ray `order` is only supported on the uniform-grid trilinear path");
+        } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))
+            hipLaunchKernelGGL((k_forward_straight_fast<GT>), grid, block, 2 * lds, c->stream, g, o, d, R, tmax, Ns,
+                               c->d_unitw, tec, c->d_flags);
+        else if (kind == IONO_INTERP_TRILINEAR)
             hipLaunchKernelGGL((k_forward_straight<GT, IONO_INTERP_TRILINEAR>), grid, block, lds, c->stream, g, o, d, R, tmax,
                                Ns, c->d_unitw, tec, c->d_flags);
         else
@@ -1091,7 +1411,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
         return IONO_OK;
     });
     HIP_TRY(c, hipGetLastError());
-    return IONO_OK;
+    return rc;
 }
 
 int iono_forward_tec_rays_dev(iono_ctx *c, const double *rays, int64_t R, int Ns, int kind, int rule, double *tec) {
@@ -1198,7 +1518,7 @@ int iono_forward_tec_straight(iono_ctx *c, const double *o, const double *d, int
     double *dO = b.as<double>(), *dD = dO + 3 * R, *dT = dD + 3 * R;
     HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
-    rc = iono_forward_tec_straight_dev(c, dO, dD, R, tmax, Ns, kind, rule, dT);
+    rc = iono_forward_tec_straight_dev(c, dO, dD, nullptr, R, tmax, Ns, kind, rule, dT);
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(tec, dT, R * 8, hipMemcpyDeviceToHost, c->stream));
     return finish_host_call(c, "iono_forward_tec_straight");

@@ -62,15 +62,32 @@ class RayEngine(object):
         self.ctx.call("iono_grid_set_exp_dev", _ptr(m_t), float(scale))
 
     # -- hot path ----------------------------------------------------------------------------------
-    def forward(self, origins_t, dirs_t, tmax, Ns, out=None):
-        """tec[R] for straight rays; origins/dirs are [R,3] float64 device tensors."""
+    def forward(self, origins_t, dirs_t, tmax, Ns, out=None, order=None):
+        """tec[R] for straight rays; origins/dirs are [R,3] float64 device tensors.  ``order``: optional
+        int32 device permutation -- the order in which rays are walked (see ``locality_order``)."""
         self._sync_stream()
         R = origins_t.shape[0]
         if out is None:
             out = torch.empty(R, dtype=torch.float64, device=self.device)
-        self.ctx.call("iono_forward_tec_straight_dev", _ptr(origins_t), _ptr(dirs_t), R, float(tmax), int(Ns), self.kind,
-                      self.rule, _ptr(out))
+        op = _lib._V(0) if order is None else _ptr(order)
+        self.ctx.call("iono_forward_tec_straight_dev", _ptr(origins_t), _ptr(dirs_t), op, R, float(tmax), int(Ns),
+                      self.kind, self.rule, _ptr(out))
         return out
+
+    @staticmethod
+    def locality_order(origins_t, dirs_t, tmax, cell=1.0):
+        """Permutation that walks rays whose paths nearly coincide one after another: sort by the
+        quantised (x, y) of the ray's far end, then of its origin.  Host-side plumbing (torch sort),
+        not part of the numerics; any permutation gives identical results."""
+        o, d = origins_t, dirs_t
+        L = (tmax - o[:, 2]) / d[:, 2]
+        end = o[:, :2] + d[:, :2] * L[:, None]
+        key = torch.stack([torch.floor(o[:, 0] / cell), torch.floor(o[:, 1] / cell), torch.floor(end[:, 0] / cell),
+                           torch.floor(end[:, 1] / cell)], dim=1).to(torch.int64)
+        key = key - key.min(dim=0).values
+        span = key.max(dim=0).values + 1
+        flat = ((key[:, 0] * span[1] + key[:, 1]) * span[2] + key[:, 2]) * span[3] + key[:, 3]
+        return torch.argsort(flat, stable=True).to(torch.int32).contiguous()
 
     def adjoint(self, origins_t, dirs_t, w_t, tmax, Ns, out=None, accum=torch.float64):
         """out[nx,ny,nz] += G^T w  (out is zeroed when allocated here)."""
