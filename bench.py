@@ -157,10 +157,10 @@ def main():
 
     # walk order: rays whose paths nearly coincide run back to back (geometry only, computed once,
     # reused by every launch of an inversion; results are independent of it)
-    order_t = eng.locality_order(o_t, d_t, TMAX, cell=float(w["xvec"][1] - w["xvec"][0])) if args.order else None
+    order_t = eng.locality_order(o_t, d_t, TMAX) if args.order else None
 
     def fwd():
-        eng.forward(o_t, d_t, TMAX, NS, out=tec_t, order=order_t)
+        eng.forward(o_t, d_t, TMAX, NS, out=tec_t)          # the forward gains nothing from the order (measured)
 
     wall, kern = time_steps(fwd, args.steps, args.warmup, torch, dist, world)
     assert not eng.check_oob(), "rays left the grid"
@@ -185,7 +185,7 @@ def main():
 
     def adj():
         grad_t.zero_()
-        eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t)
+        eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t, order=order_t)
 
     def iteration():
         fwd()
@@ -200,14 +200,17 @@ def main():
     extra["adjoint_ms"] = akern * 1e3
     extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
     if order_t is not None:
-        wn, kn = time_steps(lambda: eng.forward(o_t, d_t, TMAX, NS, out=tec_t), k2, 1, torch, dist, world)
-        extra["unordered_walk_ray_integrals_per_s"] = world * R * k2 / wn
+        def adj_unordered():
+            grad_t.zero_()
+            eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t)
+        wn, kn = time_steps(adj_unordered, k2, 1, torch, dist, world)
+        extra["adjoint_unordered_walk_ms"] = kn * 1e3
     # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
     eng32 = RayEngine(local, storage="f32")
     eng32.set_grid(w["xvec"], w["yvec"], w["zvec"])
     eng32.set_log_model(m_t, w["K_ne"] / 1e13)
     tec32 = torch.empty_like(tec_t)
-    w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=order_t), k2, 1, torch, dist, world)
+    w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32), k2, 1, torch, dist, world)
     extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
     extra["f32_grid_roofline_frac"] = R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9 / HBM_PEAK_GBS
     extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())

@@ -118,17 +118,20 @@ int iono_adjoint_rays(iono_ctx *ctx, const double *rays, const double *w, int64_
  *      multi-GPU driver.  Out-of-grid samples set a sticky device flag read by iono_check_oob. ---- */
 /* order_dev (nullable): int32 permutation of 0..R-1 giving the order in which rays are WALKED
  * (results still land in tec_dev[ray]); sort rays so that neighbours in the walk are neighbours in
- * space and the grid lines they share stay in L1/L2.  Speed only. */
+ * space and the grid lines they share stay in L1/L2.  Speed only; kernels for non-uniform grids
+ * and the tricubic ignore it. */
 int iono_forward_tec_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
                                   const int *order_dev, int64_t R, double tmax, int Ns, int interp_kind,
                                   int quad_rule, double *tec_dev);
 int iono_forward_tec_rays_dev(iono_ctx *ctx, const double *rays_dev, int64_t R, int Ns,
                               int interp_kind, int quad_rule, double *tec_dev);
 /* accumulates INTO grad_dev (caller zeroes it); accum_dtype IONO_F64 | IONO_F32 selects the
- * element type of grad_dev and of the atomics */
+ * element type of grad_dev and of the atomics.  order_dev (nullable) as for the forward: on uniform
+ * grids the adjoint pre-reduces bundles of 64 consecutive rays of the walk in LDS, so an order that
+ * puts spatially neighbouring rays next to each other cuts global atomics by an order of magnitude. */
 int iono_adjoint_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
-                              const double *w_dev, int64_t R, double tmax, int Ns, int quad_rule,
-                              void *grad_dev, int accum_dtype);
+                              const int *order_dev, const double *w_dev, int64_t R, double tmax, int Ns,
+                              int quad_rule, void *grad_dev, int accum_dtype);
 int iono_adjoint_rays_dev(iono_ctx *ctx, const double *rays_dev, const double *w_dev, int64_t R,
                           int Ns, int quad_rule, void *grad_dev, int accum_dtype);
 /* fused residual -> differential weights -> back-projection for layout [Na][Nt*Nd]:
@@ -136,7 +139,7 @@ int iono_adjoint_rays_dev(iono_ctx *ctx, const double *rays_dev, const double *w
  *   w[a,p] = dd[a,p] - [a == i0] sum_a' dd[a',p]                        (transpose of the i0 differencing)
  * then the adjoint of the straight-ray forward, in ONE launch. */
 int iono_adjoint_residual_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
-                                       const double *tec_dev, const double *dobs_dev, const double *cdct_dev,
+                                       const int *order_dev, const double *tec_dev, const double *dobs_dev, const double *cdct_dev,
                                        int Na, int64_t NtNd, int i0, double tmax, int Ns, int quad_rule,
                                        void *grad_dev, int accum_dtype);
 int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);

@@ -60,9 +60,9 @@ _SIGNATURES = {
     "iono_adjoint_rays": [_P, _P, _L, _I, _I, _I, _P],
     "iono_forward_tec_straight_dev": [_V, _V, _V, _L, _D, _I, _I, _I, _V],
     "iono_forward_tec_rays_dev": [_V, _L, _I, _I, _I, _V],
-    "iono_adjoint_straight_dev": [_V, _V, _V, _L, _D, _I, _I, _V, _I],
+    "iono_adjoint_straight_dev": [_V, _V, _V, _V, _L, _D, _I, _I, _V, _I],
     "iono_adjoint_rays_dev": [_V, _V, _L, _I, _I, _V, _I],
-    "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _V, _I],
+    "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _V, _I],
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
 }

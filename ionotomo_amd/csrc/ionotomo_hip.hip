@@ -540,53 +540,96 @@ __device__ __forceinline__ URay load_uray(const GridView &g, const double *origi
 // sample sitting exactly on the top face of an axis (cell index n-1, weight 0 on the far corner)
 // may read the far corner without a clamp: it is multiplied by 0.
 template <typename GT>
-__device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const GT *__restrict__ b01,
-                                              const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz, double fx,
-                                              double fy, double fz) {
+struct Corners {
+    GT c000, c001, c010, c011, c100, c101, c110, c111;
+    double tx, ty, tz;
+};
+template <typename GT>
+__device__ __forceinline__ Corners<GT> load_corners(const GT *__restrict__ b00, const GT *__restrict__ b01,
+                                                    const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz,
+                                                    double fx, double fy, double fz) {
     const int i = (int)fx, j = (int)fy, k = (int)fz;
-    const double tx = fx - (double)i, ty = fy - (double)j, tz = fz - (double)k;
+    Corners<GT> c;
+    c.tx = fx - (double)i;
+    c.ty = fy - (double)j;
+    c.tz = fz - (double)k;
     const unsigned boff = (((unsigned)i * (unsigned)ny + (unsigned)j) * (unsigned)nz + (unsigned)k) * (unsigned)sizeof(GT);
     const GT *p00 = (const GT *)((const char *)b00 + boff), *p01 = (const GT *)((const char *)b01 + boff);
     const GT *p10 = (const GT *)((const char *)b10 + boff), *p11 = (const GT *)((const char *)b11 + boff);
-    const double c000 = p00[0], c001 = p00[1];
-    const double c010 = p01[0], c011 = p01[1];
-    const double c100 = p10[0], c101 = p10[1];
-    const double c110 = p11[0], c111 = p11[1];
-    const double c00 = c000 + tz * (c001 - c000);
-    const double c01 = c010 + tz * (c011 - c010);
-    const double c10 = c100 + tz * (c101 - c100);
-    const double c11 = c110 + tz * (c111 - c110);
-    const double c0 = c00 + ty * (c01 - c00);
-    const double c1 = c10 + ty * (c11 - c10);
-    return c0 + tx * (c1 - c0);
+    c.c000 = p00[0];
+    c.c001 = p00[1];
+    c.c010 = p01[0];
+    c.c011 = p01[1];
+    c.c100 = p10[0];
+    c.c101 = p10[1];
+    c.c110 = p11[0];
+    c.c111 = p11[1];
+    return c;
+}
+template <typename GT>
+__device__ __forceinline__ double lerp_corners(const Corners<GT> &c) {
+    const double c000 = c.c000, c010 = c.c010, c100 = c.c100, c110 = c.c110;
+    const double c00 = c000 + c.tz * ((double)c.c001 - c000);
+    const double c01 = c010 + c.tz * ((double)c.c011 - c010);
+    const double c10 = c100 + c.tz * ((double)c.c101 - c100);
+    const double c11 = c110 + c.tz * ((double)c.c111 - c110);
+    const double c0 = c00 + c.ty * (c01 - c00);
+    const double c1 = c10 + c.ty * (c11 - c10);
+    return c0 + c.tx * (c1 - c0);
+}
+// The grid allocation is padded by one plane + one row + 2 zero elements (iono_grid_set), so a
+// sample sitting exactly on the top face of an axis (cell index n-1, weight 0 on the far corner)
+// may read the far corner without a clamp: it is multiplied by 0.
+template <typename GT>
+__device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const GT *__restrict__ b01,
+                                              const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz, double fx,
+                                              double fy, double fz) {
+    return lerp_corners<GT>(load_corners<GT>(b00, b01, b10, b11, ny, nz, fx, fy, fz));
 }
 
-// groups of G consecutive walk positions per wave; XCD b%8 takes a contiguous eighth of the groups
-struct GroupWalk {
-    int64_t q, end, stride;     // in units of groups
+// Every wave owns one contiguous, balanced chunk of the walk (floor or ceil of R / #waves rays) and
+// goes through it in groups of up to U_MAXG rays; waves are numbered XCD-major (blocks b, b+8, ...
+// share an XCD), so each XCD's L2 sees one contiguous eighth of the rays.  The grid is sized to
+// what is resident at once, so there is no second, under-occupied round of workgroups.
+struct Chunk {
+    int64_t lo, hi, stride;     // walk positions lo, lo+stride, ... < hi
 };
-__device__ __forceinline__ GroupWalk group_walk(int64_t ngroups) {
+// mode 0: one contiguous chunk per wave.  mode 1: one contiguous chunk per WORKGROUP, its 4 waves
+// interleaved (wave w takes lo+w, lo+w+4, ...): with a locality-sorted `order` the waves of a
+// workgroup then read (nearly) the same grid lines at the same time and share them in L1.
+// bit 1 of mode (value 2): scatter consecutive chunks over workgroups with an odd multiplier so
+// that neighbouring CUs do not hammer the same L2 lines at the same moment.
+__device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
     const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
-    GroupWalk w;
-    if ((gridDim.x & 7) == 0 && ngroups >= 64) {
+    int64_t bidx;
+    if ((gridDim.x & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-        const int64_t per = (ngroups + 7) / 8;
-        const int64_t lo = per * xcd;
-        w.end = min(ngroups, lo + per);
-        w.q = lo + (int64_t)slot * wpb + wid;
-        w.stride = (int64_t)nslot * wpb;
+        bidx = (int64_t)xcd * nslot + slot;
     } else {
-        w.q = (int64_t)blockIdx.x * wpb + wid;
-        w.end = ngroups;
-        w.stride = (int64_t)gridDim.x * wpb;
+        bidx = blockIdx.x;
     }
-    return w;
+    if (mode & 2) bidx = (bidx * 2654435761LL) % gridDim.x == bidx ? bidx : (bidx * 40503LL + 17) % gridDim.x;
+    Chunk c;
+    if (mode & 1) {
+        const int64_t nb = gridDim.x, base = R / nb, rem = R % nb;
+        const int64_t lo = bidx * base + min(bidx, rem);
+        c.hi = lo + base + (bidx < rem ? 1 : 0);
+        c.lo = lo + wid;
+        c.stride = wpb;
+    } else {
+        const int64_t widx = bidx * wpb + wid, nw = (int64_t)gridDim.x * wpb;
+        const int64_t base = R / nw, rem = R % nw;
+        c.lo = widx * base + min(widx, rem);
+        c.hi = c.lo + base + (widx < rem ? 1 : 0);
+        c.stride = 1;
+    }
+    return c;
 }
 
 template <typename GT>
 __global__ __launch_bounds__(256) void k_forward_straight_u(GridView g, const double *__restrict__ origins,
                                                             const double *__restrict__ dirs, const int *__restrict__ order,
-                                                            int64_t R, double tmax, int Ns, int G,
+                                                            int64_t R, double tmax, int Ns, int walk_mode,
                                                             const double *__restrict__ unitw, double *__restrict__ tec,
                                                             int *oob_flag) {
     extern __shared__ __attribute__((aligned(16))) double wlds[];
@@ -596,17 +639,19 @@ __global__ __launch_bounds__(256) void k_forward_straight_u(GridView g, const do
     const int nfull = Ns >> 6, ntail0 = nfull << 6;        // samples [ntail0, Ns) are the tail
     const bool tail_by_lane = (Ns - ntail0) <= 8;          // else: one more (masked) wave iteration
     const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
-    const int64_t ngroups = (R + G - 1) / G;
+    const Chunk ch = wave_chunk(R, walk_mode);
+    const double dlane = (double)lane;
+    const double *wp = wlds + lane;
     bool oob = false;
-    for (GroupWalk w = group_walk(ngroups); w.q < w.end; w.q += w.stride) {
-        const int64_t q0 = w.q * G;
-        const int cnt = (int)min((int64_t)G, R - q0);
+    for (int64_t q0 = ch.lo; q0 < ch.hi; q0 += U_MAXG * ch.stride) {
+        const int cnt = (int)min((int64_t)U_MAXG, (ch.hi - q0 + ch.stride - 1) / ch.stride);
         // ---- lane-parallel set-up: lane l owns ray q0 + l ------------------------------------------
         URay u = {};
         int64_t r = 0;
         double tail = 0.0;
         if (lane < cnt) {
-            r = order ? (int64_t)order[q0 + lane] : q0 + lane;
+            const int64_t q = q0 + lane * ch.stride;
+            r = order ? (int64_t)order[q] : q;
             u = load_uray(g, origins, dirs, r, tmax, Ns);
             if (u.valid && tail_by_lane) {
                 for (int k = ntail0; k < Ns; ++k) {
@@ -619,7 +664,6 @@ __global__ __launch_bounds__(256) void k_forward_straight_u(GridView g, const do
         }
         // ---- one ray at a time, lanes = samples ----------------------------------------------------
         double res = 0.0;
-        const double dlane = (double)lane;
         for (int gi = 0; gi < cnt; ++gi) {
             const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
             if (!ok) continue;
@@ -629,7 +673,8 @@ __global__ __launch_bounds__(256) void k_forward_straight_u(GridView g, const do
             double fz = fma(dlane, dfz, bcast_lane(u.fz0, gi));
             const double sx64 = 64.0 * dfx, sy64 = 64.0 * dfy, sz64 = 64.0 * dfz;
             double acc = 0.0;
-            const double *wp = wlds + lane;
+            // (a software-pipelined version of this loop -- next iteration's loads in flight during the
+            //  interpolation -- measured 15 % SLOWER: +26 VGPRs cost more occupancy than the overlap won)
             for (int it = 0; it < nfull; ++it) {
                 acc = fma(wp[it << 6], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
                 fx += sx64;
@@ -795,6 +840,193 @@ __global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const doub
             scatter_trilinear<AT>(g, ax, G, x, y, z, scale * unitw[k]);
         }
     }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- privatised adjoint (ideal-uniform grids) --------------------------------------------------------
+// Plain atomics run at ~0.3 TB/s here: every ray of a station crosses the same low-altitude cells,
+// and rays of neighbouring stations / consecutive timesteps nearly coincide all the way up, so the
+// same addresses are hit thousands of times.  This kernel pre-reduces in LDS.  A workgroup takes a
+// BUNDLE of 64 consecutive rays of the walk (callers order the walk so that consecutive rays are
+// neighbours in space).  Per slab of 64 samples it keeps a SHEARED tile in LDS: for each of T_TK z
+// levels an 8 x 8 window of nodes whose origin follows the bundle's reference ray (its first valid
+// ray) at that level.  Contributions falling inside the tile are LDS float atomics (lanes =
+// consecutive z levels -> consecutive LDS words, conflict-free); anything outside goes straight to
+// global atomics, so the result never depends on how good the ordering is.  After the slab the
+// tile's non-zero nodes are flushed with ONE global atomic each.
+#define T_WIN 8
+#define T_TK 72
+#define T_TKP 73
+
+template <typename AT>
+__device__ __forceinline__ void tile_or_global_add(AT *tile, AT *__restrict__ G, const int *I0, const int *J0, int m, int i, int j,
+                                                   int kk, int ny, int nz, double w00, double w01, double w10, double w11) {
+    // the four (i..i+1, j..j+1) nodes of z level kk (tile level m); tile if the 2x2 patch is inside the window
+    bool in = (m >= 0) & (m < T_TK);
+    int a = 0, b = 0;
+    if (in) {
+        a = i - I0[m];
+        b = j - J0[m];
+        in = (a >= 0) & (a + 1 < T_WIN) & (b >= 0) & (b + 1 < T_WIN);
+    }
+    if (in) {
+        AT *t = tile + (a * T_WIN + b) * T_TKP + m;
+        atomicAdd(t, (AT)w00);
+        atomicAdd(t + T_TKP, (AT)w01);
+        atomicAdd(t + T_WIN * T_TKP, (AT)w10);
+        atomicAdd(t + (T_WIN + 1) * T_TKP, (AT)w11);
+    } else {
+        AT *p = G + ((size_t)i * ny + j) * nz + kk;
+        atomicAdd(p, (AT)w00);
+        atomicAdd(p + nz, (AT)w01);
+        atomicAdd(p + (size_t)ny * nz, (AT)w10);
+        atomicAdd(p + (size_t)ny * nz + nz, (AT)w11);
+    }
+}
+
+template <typename AT>
+__device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
+                                                     int kz0, double fx, double fy, double fz, double c) {
+    const int i = min((int)fx, g.nx - 2), j = min((int)fy, g.ny - 2), k = min((int)fz, g.nz - 2);
+    const double tx = fx - (double)i, ty = fy - (double)j, tz = fz - (double)k;
+    const double w0 = c * (1 - tx), w1 = c * tx;
+    const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
+    const int m = k - kz0;
+    tile_or_global_add<AT>(tile, G, I0, J0, m, i, j, k, g.ny, g.nz, w00 * (1 - tz), w01 * (1 - tz), w10 * (1 - tz), w11 * (1 - tz));
+    tile_or_global_add<AT>(tile, G, I0, J0, m + 1, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz);
+}
+
+// residual -> differential weight of ray r = (a, p) in layout [Na][NtNd] (see k_adjoint_straight MODE 1)
+__device__ __forceinline__ double residual_weight(const double *__restrict__ tec, const double *__restrict__ dobs,
+                                                  const double *__restrict__ cdct, int Na, int64_t NtNd, int i0, int64_t r) {
+    const int a = (int)(r / NtNd);
+    const int64_t p = r % NtNd;
+    const double tref = tec[(int64_t)i0 * NtNd + p];
+    double wr = (tec[r] - tref - dobs[r]) / (cdct[r] + 1e-15);
+    if (a == i0) {
+        double s = 0.0;
+        for (int a2 = 0; a2 < Na; ++a2) {
+            const int64_t r2 = (int64_t)a2 * NtNd + p;
+            s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
+        }
+        wr -= s;
+    }
+    return wr;
+}
+
+template <typename AT, int MODE>
+__global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
+                                                               const double *__restrict__ dirs, const int *__restrict__ order,
+                                                               const double *__restrict__ wray, const double *__restrict__ tec,
+                                                               const double *__restrict__ dobs, const double *__restrict__ cdct,
+                                                               int Na, int64_t NtNd, int i0, int64_t R, double tmax, int Ns,
+                                                               const double *__restrict__ unitw, AT *__restrict__ G,
+                                                               int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *wlds = (double *)smem;                                   // [Ns] quadrature weights
+    double *ref = wlds + ((Ns + 1) & ~1);                            // [4 waves][8] reference-ray candidates
+    AT *tile = (AT *)(ref + 32);                                     // [T_WIN*T_WIN][T_TKP]
+    int *I0 = (int *)(tile + T_WIN * T_WIN * T_TKP);                 // [T_TK] window origins per z level
+    int *J0 = I0 + T_TK;
+    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
+    for (int t = threadIdx.x; t < T_WIN * T_WIN * T_TKP; t += blockDim.x) tile[t] = (AT)0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nfull = Ns >> 6, ntail0 = nfull << 6;
+    const bool tail_by_lane = (Ns - ntail0) <= 8;
+    const int nslab = tail_by_lane ? nfull : nfull + 1;
+    // contiguous balanced range of the walk per workgroup (XCD-major), 64 rays (4 waves x 16) at a time
+    int64_t bidx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bidx = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t base = R / gridDim.x, rem = R % gridDim.x;
+    const int64_t lo = bidx * base + min(bidx, rem), hi = lo + base + (bidx < rem ? 1 : 0);
+    const double dlane = (double)lane;
+    bool oob = false;
+    __syncthreads();
+    for (int64_t q0 = lo; q0 < hi; q0 += 64) {
+        // ---- lane-parallel set-up: wave w, lane l < 16 owns walk position q0 + 16 w + l -----------------
+        const int64_t qw = q0 + 16 * wid;
+        const int cnt = (int)max((int64_t)0, min((int64_t)16, hi - qw));
+        URay u = {};
+        double scale = 0.0;
+        if (lane < cnt) {
+            const int64_t q = qw + lane;
+            const int64_t r = order ? (int64_t)order[q] : q;
+            u = load_uray(g, origins, dirs, r, tmax, Ns);
+            const double wr = MODE == 0 ? wray[r] : residual_weight(tec, dobs, cdct, Na, NtNd, i0, r);
+            if (u.valid) scale = wr * u.h; else oob = true;
+            if (scale != 0.0 && tail_by_lane) {           // the <= 8 tail samples: straight to global memory
+                for (int k = ntail0; k < Ns; ++k) {
+                    const double kd = (double)k;
+                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, -(1 << 28), fma(kd, u.dfx, u.fx0), fma(kd, u.dfy, u.fy0),
+                                             fma(kd, u.dfz, u.fz0), scale * wlds[k]);
+                }
+            }
+        }
+        // ---- reference ray of the bundle = first ray with non-zero weight --------------------------------
+        const unsigned long long live = __ballot(scale != 0.0);
+        if (lane == 0) ref[8 * wid + 7] = live ? 1.0 : 0.0;
+        if (live) {
+            const int src = __ffsll((long long)live) - 1;
+            if (lane == 0) {
+                ref[8 * wid + 0] = 0;
+            }
+            const double a0 = bcast_lane(u.fx0, src), a1 = bcast_lane(u.dfx, src), a2 = bcast_lane(u.fy0, src);
+            const double a3 = bcast_lane(u.dfy, src), a4 = bcast_lane(u.fz0, src), a5 = bcast_lane(u.dfz, src);
+            if (lane == 0) {
+                ref[8 * wid + 0] = a0;
+                ref[8 * wid + 1] = a1;
+                ref[8 * wid + 2] = a2;
+                ref[8 * wid + 3] = a3;
+                ref[8 * wid + 4] = a4;
+                ref[8 * wid + 5] = a5;
+            }
+        }
+        __syncthreads();
+        int rw = -1;
+        for (int w2 = 3; w2 >= 0; --w2)
+            if (ref[8 * w2 + 7] != 0.0) rw = w2;
+        if (rw < 0) {            // nothing to do in this bundle (block-uniform)
+            __syncthreads();
+            continue;
+        }
+        const double rfx0 = ref[8 * rw], rdfx = ref[8 * rw + 1], rfy0 = ref[8 * rw + 2], rdfy = ref[8 * rw + 3];
+        const double rfz0 = ref[8 * rw + 4], rdfz = ref[8 * rw + 5];
+        for (int it = 0; it < nslab; ++it) {
+            const int k0 = it << 6;
+            const int kz0 = max((int)fma((double)k0, rdfz, rfz0) - 1, 0);
+            if (threadIdx.x < T_TK) {     // window origin per z level: follow the reference ray
+                const double kk = ((double)(kz0 + (int)threadIdx.x) - rfz0) / rdfz;      // (real) sample index at that level
+                I0[threadIdx.x] = (int)floor(fma(kk, rdfx, rfx0)) - (T_WIN / 2 - 1);
+                J0[threadIdx.x] = (int)floor(fma(kk, rdfy, rfy0)) - (T_WIN / 2 - 1);
+            }
+            __syncthreads();
+            for (int gi = 0; gi < cnt; ++gi) {
+                const double sc = bcast_lane(scale, gi);
+                if (sc == 0.0) continue;
+                const int k = k0 + lane;
+                if (k < Ns && (tail_by_lane ? k < ntail0 : true)) {
+                    const double kd = (double)k;
+                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(u.dfx, gi), bcast_lane(u.fx0, gi)),
+                                             fma(kd, bcast_lane(u.dfy, gi), bcast_lane(u.fy0, gi)),
+                                             fma(kd, bcast_lane(u.dfz, gi), bcast_lane(u.fz0, gi)), sc * wlds[k]);
+                }
+            }
+            __syncthreads();
+            // ---- flush + re-zero: one global atomic per touched node -------------------------------------
+            for (int e = threadIdx.x; e < T_WIN * T_WIN * T_TKP; e += blockDim.x) {
+                const AT v = tile[e];
+                if (v != (AT)0) {
+                    tile[e] = (AT)0;
+                    const int cell = e / T_TKP, m = e - cell * T_TKP;
+                    const int gi_ = I0[m] + cell / T_WIN, gj_ = J0[m] + cell % T_WIN, gk_ = kz0 + m;
+                    if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz)
+                        atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    (void)dlane;
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
@@ -1006,6 +1238,9 @@ struct iono_ctx {
     std::string err;
     int num_cus = 256;
     int force_general = 0;           // testing/ablation: 1 = general kernels only, 2 = no "ideal uniform" kernels
+    int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
+    int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
+    int walk_mode = 0;               // env IONOTOMO_WALK (see wave_chunk)
     int ideal = 0;                   // every axis is g0 + i*h to within 2.5e-13 h (np.linspace)
     double g0[3] = {0, 0, 0}, glast[3] = {0, 0, 0};
 };
@@ -1053,16 +1288,20 @@ bool fast_path_ok(const iono_ctx *c) {
     return c->uniform[0] && c->uniform[1] && c->uniform[2] && ncells(c) < ((int64_t)1 << 31) && c->force_general != 1;
 }
 bool ideal_path_ok(const iono_ctx *c) { return fast_path_ok(c) && c->ideal && c->force_general == 0; }
-// rays per wave group for the v2 kernels: enough groups to fill the chip, at most U_MAXG
-int group_size(const iono_ctx *c, int64_t R) {
-    int64_t G = R / ((int64_t)c->num_cus * 32);
-    return (int)(G < 1 ? 1 : (G > U_MAXG ? U_MAXG : G));
+// v2 kernels: grid = what is resident at once (blocks per CU from the occupancy query, cached per
+// kernel), but no more waves than rays
+template <typename K>
+int resident_blocks(iono_ctx *c, K kernel, size_t lds) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    if (per_cu > 8) per_cu = 8;
+    if (c->blocks_per_cu_override > 0) per_cu = c->blocks_per_cu_override;
+    return per_cu * c->num_cus;
 }
-int group_grid_blocks(const iono_ctx *c, int64_t R, int G) {
-    int64_t b = ((R + G - 1) / G + 3) / 4;
-    const int64_t cap = (int64_t)c->num_cus * 8;
-    if (b > cap) b = cap;
-    if (b >= 8) b = (b + 7) / 8 * 8;
+int chunk_grid_blocks(int resident, int64_t R) {
+    int64_t b = (R + 3) / 4;                 // at least one ray per wave
+    if (b > resident) b = resident;
+    if (b >= 8) b = b / 8 * 8;               // multiple of 8: XCD-major wave numbering
     return (int)(b < 1 ? 1 : b);
 }
 
@@ -1201,6 +1440,9 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
         c->num_cus = prop.multiProcessorCount;
     c->stream = c->own_stream;
     if (const char *e = getenv("IONOTOMO_FORCE_GENERAL")) c->force_general = atoi(e);
+    if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
+    if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
+    if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e);
     *out = c;
     return IONO_OK;
 }
@@ -1394,12 +1636,11 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
     dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
         if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c)) {
-            const int G = group_size(c, R);
-            hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(group_grid_blocks(c, R, G)), block, sizeof(double) * Ns,
-                               c->stream, g, o, d, order, R, tmax, Ns, G, c->d_unitw, tec, c->d_flags);
-        } else if (order) {
-            rc = fail(c, IONO_ERR_ARG, "ray `order` is only supported on the uniform-grid trilinear path");
-        } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))
+            const size_t wl = sizeof(double) * Ns;
+            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
+            hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
+                               c->walk_mode, c->d_unitw, tec, c->d_flags);
+        } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))      // (`order` is a speed hint: ignored here)
             hipLaunchKernelGGL((k_forward_straight_fast<GT>), grid, block, 2 * lds, c->stream, g, o, d, R, tmax, Ns,
                                c->d_unitw, tec, c->d_flags);
         else if (kind == IONO_INTERP_TRILINEAR)
@@ -1445,7 +1686,7 @@ int iono_subtract_reference_dev(iono_ctx *c, double *tec, int Na, int64_t NtNd, 
 }
 
 // ---- adjoint (device pointers) ----------------------------------------------------------------
-static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const double *d, const double *w,
+static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const double *d, const int *order, const double *w,
                                    const double *tec, const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0,
                                    int64_t R, double tmax, int Ns, int rule, void *grad, int accum) {
     int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
@@ -1455,7 +1696,30 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
     rc = ensure_unitw(c, Ns, rule);
     if (rc) return rc;
     const GridView g = view(c);
-    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    const dim3 block(256);
+    if (ideal_path_ok(c) && c->variant != 2) {
+        const size_t esz = accum == IONO_F64 ? 8 : 4;
+        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + 32 * sizeof(double) +
+                          esz * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
+#define LAUNCH_ADJT(AT, MODE)                                                                                              \
+    do {                                                                                                                   \
+        int nb = resident_blocks(c, k_adjoint_straight_tile<AT, MODE>, tl);                                                \
+        const int64_t nbund = (R + 63) / 64;                                                                               \
+        if (nb > nbund) nb = (int)nbund;                                                                                   \
+        if (nb >= 8) nb = nb / 8 * 8;                                                                                      \
+        hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE>), dim3(nb), block, tl, c->stream, g, o, d, order, w, tec,   \
+                           dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->d_unitw, (AT *)grad, c->d_flags);                     \
+    } while (0)
+        if (accum == IONO_F64) {
+            if (mode == 0) LAUNCH_ADJT(double, 0); else LAUNCH_ADJT(double, 1);
+        } else {
+            if (mode == 0) LAUNCH_ADJT(float, 0); else LAUNCH_ADJT(float, 1);
+        }
+#undef LAUNCH_ADJT
+        HIP_TRY(c, hipGetLastError());
+        return IONO_OK;
+    }
+    const dim3 grid(ray_grid_blocks(c, R));
     const size_t lds = lds_bytes(c);
 #define LAUNCH_ADJ(AT, MODE)                                                                                          \
     hipLaunchKernelGGL((k_adjoint_straight<AT, MODE>), grid, block, lds, c->stream, g, o, d, w, tec, dobs, cdct, Na, \
@@ -1470,17 +1734,17 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
     return IONO_OK;
 }
 
-int iono_adjoint_straight_dev(iono_ctx *c, const double *o, const double *d, const double *w, int64_t R, double tmax, int Ns,
-                              int rule, void *grad, int accum) {
-    return adjoint_straight_launch(c, 0, o, d, w, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, rule, grad, accum);
+int iono_adjoint_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, const double *w, int64_t R,
+                              double tmax, int Ns, int rule, void *grad, int accum) {
+    return adjoint_straight_launch(c, 0, o, d, order, w, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, rule, grad, accum);
 }
 
-int iono_adjoint_residual_straight_dev(iono_ctx *c, const double *o, const double *d, const double *tec, const double *dobs,
-                                       const double *cdct, int Na, int64_t NtNd, int i0, double tmax, int Ns, int rule,
-                                       void *grad, int accum) {
+int iono_adjoint_residual_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, const double *tec,
+                                       const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0, double tmax, int Ns,
+                                       int rule, void *grad, int accum) {
     if (Na < 1 || NtNd < 0 || i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "bad [Na][NtNd]/i0");
-    return adjoint_straight_launch(c, 1, o, d, nullptr, tec, dobs, cdct, Na, NtNd, i0, (int64_t)Na * NtNd, tmax, Ns, rule,
-                                   grad, accum);
+    return adjoint_straight_launch(c, 1, o, d, order, nullptr, tec, dobs, cdct, Na, NtNd, i0, (int64_t)Na * NtNd, tmax, Ns,
+                                   rule, grad, accum);
 }
 
 int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int rule, void *grad,
@@ -1615,7 +1879,7 @@ int iono_adjoint_straight(iono_ctx *c, const double *o, const double *d, const d
     HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dW, w, R * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(dG, 0, n * 8, c->stream));
-    rc = iono_adjoint_straight_dev(c, dO, dD, dW, R, tmax, Ns, rule, dG, IONO_F64);
+    rc = iono_adjoint_straight_dev(c, dO, dD, nullptr, dW, R, tmax, Ns, rule, dG, IONO_F64);
     if (rc) return rc;
     return adjoint_host_finish(c, dG, scale_by_grid, grad_out, "iono_adjoint_straight");
 }

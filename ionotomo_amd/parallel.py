@@ -60,6 +60,9 @@ class ShardedRays(object):
         self.R_local = self.Na * self.P_local
         self.dobs = None if dobs is None else self.slice(dobs)
         self.cdct = None if cdct is None else self.slice(cdct)
+        # walk order for the kernels (speed only): spatial neighbours next to each other
+        self.order = engine.locality_order(self.origins, self.dirs, self.tmax) if (
+            hasattr(engine, "locality_order") and self.R_local > 0) else None
 
     def slice(self, full):
         """[Na,P] (full problem) -> this rank's [Na*P_local] device vector."""
@@ -68,7 +71,7 @@ class ShardedRays(object):
 
     # -- operators ---------------------------------------------------------------------------------
     def forward_tec(self):
-        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns)
+        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns, order=self.order)
 
     def forward(self):
         """differential TEC of the current grid values, local rays: A x = G x - (G x)[i0]."""
@@ -79,14 +82,14 @@ class ShardedRays(object):
         """A^T y summed over all ranks: differential weights, back-projection, all-reduce."""
         w = y.view(self.Na, self.P_local).clone()
         w[self.i0] -= y.view(self.Na, self.P_local).sum(dim=0)
-        g = self.engine.adjoint(self.origins, self.dirs, w.reshape(-1), self.tmax, self.Ns)
+        g = self.engine.adjoint(self.origins, self.dirs, w.reshape(-1), self.tmax, self.Ns, order=self.order)
         return all_reduce_sum_(g)
 
     def gradient_from_tec(self, tec):
         """Fused residual -> weights -> back-projection (one launch) + all-reduce:
         G^T diff((tec - tec[i0] - dobs)/(CdCt + 1e-15))."""
         g = self.engine.adjoint_residual(self.origins, self.dirs, tec, self.dobs, self.cdct, self.Na, self.i0,
-                                         self.tmax, self.Ns)
+                                         self.tmax, self.Ns, order=self.order)
         return all_reduce_sum_(g)
 
     def dot_rays(self, a, b):

@@ -42,7 +42,8 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None):
     wcol = torch.ones(problem.Na, problem.P_local, dtype=torch.float64, device=eng.device)
     wcol[problem.i0] += problem.Na
     col = parallel_adjoint_raw(problem, wcol.reshape(-1))
-    C = torch.where(col > 0, 1.0 / col, torch.zeros_like(col))
+    # nodes with (numerically) no ray coverage are left alone: 1/col would turn rounding noise into updates
+    C = torch.where(col > 1e-9 * col.max(), 1.0 / col, torch.zeros_like(col))
     hist = []
     for k in range(n_iter):
         _set_x(problem, x)
@@ -59,7 +60,8 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None):
 def parallel_adjoint_raw(problem, w):
     """G^T w (no differencing), summed over ranks."""
     from .parallel import all_reduce_sum_
-    return all_reduce_sum_(problem.engine.adjoint(problem.origins, problem.dirs, w, problem.tmax, problem.Ns))
+    return all_reduce_sum_(problem.engine.adjoint(problem.origins, problem.dirs, w, problem.tmax, problem.Ns,
+                                                  order=problem.order))
 
 
 def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):

@@ -36,7 +36,8 @@ def sirt(G, A, d, cd, x0, Na, P, i0, n_iter, relax=1.0):
     wcol = np.ones((Na, P))
     wcol[i0] += Na
     col = G.T @ wcol.ravel()
-    C = np.where(col > 0, 1.0 / np.where(col > 0, col, 1.0), 0.0)
+    live = col > 1e-9 * col.max()
+    C = np.where(live, 1.0 / np.where(live, col, 1.0), 0.0)
     hist = []
     for _ in range(n_iter):
         r = d - A @ x

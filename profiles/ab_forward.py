@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of forward-kernel variants in ONE process (guide rule 24).
+    python profiles/ab_forward.py "VARIANT=0" "VARIANT=1" "VARIANT=0,BLOCKS_PER_CU=4" ...
+Each spec sets IONOTOMO_<KEY> env vars before creating its own context/engine."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from ionotomo_amd.engine import RayEngine  # noqa: E402
+
+specs = sys.argv[1:] or ["VARIANT=0", "VARIANT=1"]
+w = bench.build_workload(0)
+R = w["origins"].shape[0]
+engines = []
+for spec in specs:
+    kv = dict(x.split("=") for x in spec.split(",") if x)
+    for k in list(os.environ):
+        if k.startswith("IONOTOMO_"):
+            del os.environ[k]
+    storage = kv.pop("STORAGE", "f64")
+    use_order = kv.pop("ORDER", "0") == "1"
+    for k, v in kv.items():
+        os.environ["IONOTOMO_" + k] = v
+    e = RayEngine(0, storage=storage)
+    e.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    e.set_log_model(e.tensor(w["m"]), w["K_ne"] / 1e13)
+    engines.append((spec, e, use_order))
+o_t, d_t = engines[0][1].tensor(w["origins"]), engines[0][1].tensor(w["directions"])
+order = engines[0][1].locality_order(o_t, d_t, bench.TMAX)
+out = torch.empty(R, dtype=torch.float64, device="cuda")
+times = {s: [] for s, _, _ in engines}
+ref = None
+for rnd in range(7):
+    for spec, e, uo in engines:
+        for _ in range(2):
+            e.forward(o_t, d_t, bench.TMAX, bench.NS, out=out, order=order if uo else None)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(10):
+            e.forward(o_t, d_t, bench.TMAX, bench.NS, out=out, order=order if uo else None)
+        b.record()
+        torch.cuda.synchronize()
+        times[spec].append(a.elapsed_time(b) / 10)
+        if ref is None:
+            ref = out.clone()
+        elif "f32" not in spec:
+            assert float((out - ref).abs().max() / ref.abs().max()) < 1e-12, spec
+for spec in times:
+    t = np.array(times[spec])
+    print("%-40s median %.4f ms  min %.4f ms  -> %.3e rays/s" % (spec, np.median(t), t.min(), R / np.median(t) * 1e3), flush=True)

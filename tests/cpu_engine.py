@@ -24,15 +24,15 @@ class OracleEngine(object):
     def set_log_model(self, m_t, scale):
         self.M = scale * np.exp(m_t.detach().cpu().numpy().reshape(self.shape))
 
-    def forward(self, o, d, tmax, Ns, out=None):
+    def forward(self, o, d, tmax, Ns, out=None, order=None):
         tec = OC.forward_tec_straight(self.xv, self.yv, self.zv, self.M, o.numpy(), d.numpy(), tmax, Ns, 2)
         return torch.from_numpy(tec.reshape(-1))
 
-    def adjoint(self, o, d, w, tmax, Ns, out=None, accum=None):
+    def adjoint(self, o, d, w, tmax, Ns, out=None, accum=None, order=None):
         g = OC.adjoint_straight(self.xv, self.yv, self.zv, o.numpy(), d.numpy(), w.numpy(), tmax, Ns)
         return torch.from_numpy(g)
 
-    def adjoint_residual(self, o, d, tec, dobs, cdct, Na, i0, tmax, Ns, out=None, accum=None):
+    def adjoint_residual(self, o, d, tec, dobs, cdct, Na, i0, tmax, Ns, out=None, accum=None, order=None):
         t2 = tec.view(Na, -1)
         dd = ((t2 - t2[i0:i0 + 1]).reshape(-1) - dobs) / (cdct + 1e-15)
         w = torch.from_numpy(O.differential_weights(dd.view(Na, -1).numpy(), i0)).reshape(-1)

@@ -81,7 +81,8 @@ def test_solvers_on_gpu_match_dense_restatement():
     x0 = eng.tensor(pb["x0"])
     xs, hs = solvers.sirt(prob, x0, n_iter=10)
     xr, hr = OS.sirt(G, A, d, cd, pb["x0"].ravel(), pb["na"], pb["P"], pb["i0"], 10)
-    assert np.allclose(hs, hr, rtol=1e-9) and np.allclose(xs.cpu().numpy().ravel(), xr, rtol=1e-9, atol=1e-12)
+    assert np.allclose(hs, hr, rtol=1e-9)
+    assert np.max(np.abs(xs.cpu().numpy().ravel() - xr)) < 1e-9 * np.max(np.abs(xr))    # relative to the iterate's scale
     xc, hc = solvers.cgls(prob, x0, n_iter=10)
     xr, hr = OS.cgls(A, d, cd, pb["x0"].ravel(), 10)
     # CG amplifies rounding differences between the two forward implementations (1e-14 vs 1e-16):
@@ -92,7 +93,7 @@ def test_solvers_on_gpu_match_dense_restatement():
     mm, hm = solvers.steepest_descent_log_model(prob, eng.tensor(np.log(pb["x0"] / K)), K, max_iter=8)
     mr, hr = OS.steepest_descent_log_model(A, d, cd, np.log(pb["x0"] / K).ravel(), K, max_iter=8)
     assert len(hm) == len(hr) and np.allclose(hm, hr, rtol=1e-7)
-    assert np.allclose(mm.cpu().numpy().ravel(), mr, rtol=1e-6, atol=1e-9)
+    assert np.max(np.abs(mm.cpu().numpy().ravel() - mr)) < 1e-7 * np.max(np.abs(mr))
 
 
 def test_full_size_properties_256_cubed():
