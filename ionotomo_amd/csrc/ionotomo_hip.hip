@@ -860,7 +860,8 @@ __global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const doub
 
 template <typename AT>
 __device__ __forceinline__ void tile_or_global_add(AT *tile, AT *__restrict__ G, const int *I0, const int *J0, int m, int i, int j,
-                                                   int kk, int ny, int nz, double w00, double w01, double w10, double w11) {
+                                                   int kk, int ny, int nz, double w00, double w01, double w10, double w11,
+                                                   int dbg = 0) {
     // the four (i..i+1, j..j+1) nodes of z level kk (tile level m); tile if the 2x2 patch is inside the window
     bool in = (m >= 0) & (m < T_TK);
     int a = 0, b = 0;
@@ -875,7 +876,7 @@ __device__ __forceinline__ void tile_or_global_add(AT *tile, AT *__restrict__ G,
         atomicAdd(t + T_TKP, (AT)w01);
         atomicAdd(t + T_WIN * T_TKP, (AT)w10);
         atomicAdd(t + (T_WIN + 1) * T_TKP, (AT)w11);
-    } else {
+    } else if (!(dbg & 4)) {
         AT *p = G + ((size_t)i * ny + j) * nz + kk;
         atomicAdd(p, (AT)w00);
         atomicAdd(p + nz, (AT)w01);
@@ -886,14 +887,14 @@ __device__ __forceinline__ void tile_or_global_add(AT *tile, AT *__restrict__ G,
 
 template <typename AT>
 __device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
-                                                     int kz0, double fx, double fy, double fz, double c) {
+                                                     int kz0, double fx, double fy, double fz, double c, int dbg = 0) {
     const int i = min((int)fx, g.nx - 2), j = min((int)fy, g.ny - 2), k = min((int)fz, g.nz - 2);
     const double tx = fx - (double)i, ty = fy - (double)j, tz = fz - (double)k;
     const double w0 = c * (1 - tx), w1 = c * tx;
     const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
     const int m = k - kz0;
-    tile_or_global_add<AT>(tile, G, I0, J0, m, i, j, k, g.ny, g.nz, w00 * (1 - tz), w01 * (1 - tz), w10 * (1 - tz), w11 * (1 - tz));
-    tile_or_global_add<AT>(tile, G, I0, J0, m + 1, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz);
+    tile_or_global_add<AT>(tile, G, I0, J0, m, i, j, k, g.ny, g.nz, w00 * (1 - tz), w01 * (1 - tz), w10 * (1 - tz), w11 * (1 - tz), dbg);
+    tile_or_global_add<AT>(tile, G, I0, J0, m + 1, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz, dbg);
 }
 
 // residual -> differential weight of ray r = (a, p) in layout [Na][NtNd] (see k_adjoint_straight MODE 1)
@@ -914,18 +915,60 @@ __device__ __forceinline__ double residual_weight(const double *__restrict__ tec
     return wr;
 }
 
+// min / max over the 64 lanes (wave-uniform result), same DPP ladder as wave_sum_dpp
+template <int CTRL, int ROW_MASK, bool IS_MAX>
+__device__ __forceinline__ double dpp_minmax(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const double o = __hiloint2double(hi2, lo2);
+    return IS_MAX ? fmax(v, o) : fmin(v, o);
+}
+template <bool IS_MAX>
+__device__ __forceinline__ double wave_minmax_dpp(double v) {
+    v = dpp_minmax<0x111, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x112, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x114, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x118, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x142, 0xa, IS_MAX>(v);
+    v = dpp_minmax<0x143, 0xc, IS_MAX>(v);
+    return bcast_lane(v, 63);
+}
+
+struct AdjRay {
+    URay u;
+    double scale;
+};
+// lane-parallel load of `q` rays per wave starting at walk position qw (lanes >= cnt idle)
+template <int MODE>
+__device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *origins, const double *dirs, const int *order,
+                                               const double *wray, const double *tec, const double *dobs, const double *cdct,
+                                               int Na, int64_t NtNd, int i0, int64_t q, bool active, double tmax, int Ns,
+                                               bool &oob) {
+    AdjRay a;
+    a.u = URay{};
+    a.scale = 0.0;
+    if (active) {
+        const int64_t r = order ? (int64_t)order[q] : q;
+        a.u = load_uray(g, origins, dirs, r, tmax, Ns);
+        const double wr = MODE == 0 ? wray[r] : residual_weight(tec, dobs, cdct, Na, NtNd, i0, r);
+        if (a.u.valid) a.scale = wr * a.u.h; else oob = true;
+    }
+    return a;
+}
+
 template <typename AT, int MODE>
 __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
                                                                const double *__restrict__ dirs, const int *__restrict__ order,
                                                                const double *__restrict__ wray, const double *__restrict__ tec,
                                                                const double *__restrict__ dobs, const double *__restrict__ cdct,
                                                                int Na, int64_t NtNd, int i0, int64_t R, double tmax, int Ns,
-                                                               const double *__restrict__ unitw, AT *__restrict__ G,
+                                                               int dbg, const double *__restrict__ unitw, AT *__restrict__ G,
                                                                int *oob_flag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
-    double *ref = wlds + ((Ns + 1) & ~1);                            // [4 waves][8] reference-ray candidates
-    AT *tile = (AT *)(ref + 32);                                     // [T_WIN*T_WIN][T_TKP]
+    double *ref = wlds + ((Ns + 1) & ~1);                            // [4 waves][16] per-wave sums and bounding boxes
+    AT *tile = (AT *)(ref + 64);                                     // [T_WIN*T_WIN][T_TKP]
     int *I0 = (int *)(tile + T_WIN * T_WIN * T_TKP);                 // [T_TK] window origins per z level
     int *J0 = I0 + T_TK;
     for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
@@ -934,63 +977,88 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
     const int nfull = Ns >> 6, ntail0 = nfull << 6;
     const bool tail_by_lane = (Ns - ntail0) <= 8;
     const int nslab = tail_by_lane ? nfull : nfull + 1;
-    // contiguous balanced range of the walk per workgroup (XCD-major), 64 rays (4 waves x 16) at a time
+    const double klast = (double)(Ns - 1);
+    // contiguous balanced range of the walk per workgroup (XCD-major)
     int64_t bidx = blockIdx.x;
     if ((gridDim.x & 7) == 0) bidx = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int64_t base = R / gridDim.x, rem = R % gridDim.x;
     const int64_t lo = bidx * base + min(bidx, rem), hi = lo + base + (bidx < rem ? 1 : 0);
-    const double dlane = (double)lane;
+    const double BIG = 1e300;
     bool oob = false;
     __syncthreads();
-    for (int64_t q0 = lo; q0 < hi; q0 += 64) {
-        // ---- lane-parallel set-up: wave w, lane l < 16 owns walk position q0 + 16 w + l -----------------
-        const int64_t qw = q0 + 16 * wid;
-        const int cnt = (int)max((int64_t)0, min((int64_t)16, hi - qw));
-        URay u = {};
-        double scale = 0.0;
-        if (lane < cnt) {
-            const int64_t q = qw + lane;
-            const int64_t r = order ? (int64_t)order[q] : q;
-            u = load_uray(g, origins, dirs, r, tmax, Ns);
-            const double wr = MODE == 0 ? wray[r] : residual_weight(tec, dobs, cdct, Na, NtNd, i0, r);
-            if (u.valid) scale = wr * u.h; else oob = true;
-            if (scale != 0.0 && tail_by_lane) {           // the <= 8 tail samples: straight to global memory
-                for (int k = ntail0; k < Ns; ++k) {
-                    const double kd = (double)k;
-                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, -(1 << 28), fma(kd, u.dfx, u.fx0), fma(kd, u.dfy, u.fy0),
-                                             fma(kd, u.dfz, u.fz0), scale * wlds[k]);
-                }
+    for (int64_t q0 = lo; q0 < hi;) {
+        // ---- candidate bundle: up to 64 rays, wave w lanes 0..15 own walk positions q0 + 16 w + l ----------
+        int q = 16;                                     // rays per wave
+        int64_t qw = q0 + (int64_t)q * wid;
+        int cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
+        AdjRay a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
+                                      Ns, oob);
+        int c = 64;
+        for (int round = 0; round < 2; ++round) {
+            // per-wave sums (for the mean ray) and bounding boxes at the bottom / top of the rays
+            const bool lv = a.scale != 0.0;
+            const double live = lv ? 1.0 : 0.0;
+            const double xe = fma(klast, a.u.dfx, a.u.fx0), ye = fma(klast, a.u.dfy, a.u.fy0);
+            const double s0 = wave_sum_dpp(live * a.u.fx0), s1 = wave_sum_dpp(live * a.u.dfx), s2 = wave_sum_dpp(live * a.u.fy0);
+            const double s3 = wave_sum_dpp(live * a.u.dfy), s4 = wave_sum_dpp(live * a.u.fz0), s5 = wave_sum_dpp(live * a.u.dfz);
+            const double s7 = wave_sum_dpp(live);
+            double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
+            if (round == 0) {
+                b0 = wave_minmax_dpp<false>(lv ? a.u.fx0 : BIG);
+                b1 = wave_minmax_dpp<true>(lv ? a.u.fx0 : -BIG);
+                b2 = wave_minmax_dpp<false>(lv ? a.u.fy0 : BIG);
+                b3 = wave_minmax_dpp<true>(lv ? a.u.fy0 : -BIG);
+                b4 = wave_minmax_dpp<false>(lv ? xe : BIG);
+                b5 = wave_minmax_dpp<true>(lv ? xe : -BIG);
+                b6 = wave_minmax_dpp<false>(lv ? ye : BIG);
+                b7 = wave_minmax_dpp<true>(lv ? ye : -BIG);
+            }
+            if (lane == 0) {
+                double *rp = ref + 16 * wid;
+                rp[0] = s0, rp[1] = s1, rp[2] = s2, rp[3] = s3, rp[4] = s4, rp[5] = s5, rp[7] = s7;
+                if (round == 0) rp[8] = b0, rp[9] = b1, rp[10] = b2, rp[11] = b3, rp[12] = b4, rp[13] = b5, rp[14] = b6, rp[15] = b7;
+            }
+            __syncthreads();
+            if (round == 1) break;
+            // largest c in {64, 32, 16} whose rays stay within the tile window at both ends (block-uniform)
+            const double lim = (double)(T_WIN - 3);
+            double m0 = BIG, M0 = -BIG, m1 = BIG, M1 = -BIG, m2 = BIG, M2 = -BIG, m3 = BIG, M3 = -BIG;
+            int fit = 0;
+            for (int w2 = 0; w2 < 4; ++w2) {
+                const double *rp = ref + 16 * w2;
+                m0 = fmin(m0, rp[8]), M0 = fmax(M0, rp[9]), m1 = fmin(m1, rp[10]), M1 = fmax(M1, rp[11]);
+                m2 = fmin(m2, rp[12]), M2 = fmax(M2, rp[13]), m3 = fmin(m3, rp[14]), M3 = fmax(M3, rp[15]);
+                const bool ok = (M0 - m0 <= lim) & (M1 - m1 <= lim) & (M2 - m2 <= lim) & (M3 - m3 <= lim);
+                if (ok && (w2 == 0 || w2 == 1 || w2 == 3)) fit = w2 + 1;      // 1, 2 or 4 waves' worth of rays
+            }
+            c = fit == 4 ? 64 : (fit == 2 ? 32 : 16);
+            if (c == 64) break;
+            // spread too wide: shrink the bundle and re-deal its rays evenly over the four waves
+            __syncthreads();
+            q = c >> 2;
+            qw = q0 + (int64_t)q * wid;
+            cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
+            a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax, Ns,
+                                   oob);
+        }
+        q0 += c;
+        if (a.scale != 0.0 && tail_by_lane) {               // the <= 8 tail samples: straight to global memory
+            for (int k = ntail0; k < Ns; ++k) {
+                const double kd = (double)k;
+                scatter_sample_tiled<AT>(g, tile, G, I0, J0, -(1 << 28), fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
+                                         fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k]);
             }
         }
-        // ---- reference ray of the bundle = first ray with non-zero weight --------------------------------
-        const unsigned long long live = __ballot(scale != 0.0);
-        if (lane == 0) ref[8 * wid + 7] = live ? 1.0 : 0.0;
-        if (live) {
-            const int src = __ffsll((long long)live) - 1;
-            if (lane == 0) {
-                ref[8 * wid + 0] = 0;
-            }
-            const double a0 = bcast_lane(u.fx0, src), a1 = bcast_lane(u.dfx, src), a2 = bcast_lane(u.fy0, src);
-            const double a3 = bcast_lane(u.dfy, src), a4 = bcast_lane(u.fz0, src), a5 = bcast_lane(u.dfz, src);
-            if (lane == 0) {
-                ref[8 * wid + 0] = a0;
-                ref[8 * wid + 1] = a1;
-                ref[8 * wid + 2] = a2;
-                ref[8 * wid + 3] = a3;
-                ref[8 * wid + 4] = a4;
-                ref[8 * wid + 5] = a5;
-            }
-        }
-        __syncthreads();
-        int rw = -1;
-        for (int w2 = 3; w2 >= 0; --w2)
-            if (ref[8 * w2 + 7] != 0.0) rw = w2;
-        if (rw < 0) {            // nothing to do in this bundle (block-uniform)
+        const double nlive = ref[7] + ref[23] + ref[39] + ref[55];
+        if (nlive == 0.0) {            // nothing to do in this bundle (block-uniform)
             __syncthreads();
             continue;
         }
-        const double rfx0 = ref[8 * rw], rdfx = ref[8 * rw + 1], rfy0 = ref[8 * rw + 2], rdfy = ref[8 * rw + 3];
-        const double rfz0 = ref[8 * rw + 4], rdfz = ref[8 * rw + 5];
+        // reference ray = mean of the bundle's weighted rays; the tile windows are centred on it
+        const double inl = 1.0 / nlive;
+        const double rfx0 = (ref[0] + ref[16] + ref[32] + ref[48]) * inl, rdfx = (ref[1] + ref[17] + ref[33] + ref[49]) * inl;
+        const double rfy0 = (ref[2] + ref[18] + ref[34] + ref[50]) * inl, rdfy = (ref[3] + ref[19] + ref[35] + ref[51]) * inl;
+        const double rfz0 = (ref[4] + ref[20] + ref[36] + ref[52]) * inl, rdfz = (ref[5] + ref[21] + ref[37] + ref[53]) * inl;
         for (int it = 0; it < nslab; ++it) {
             const int k0 = it << 6;
             const int kz0 = max((int)fma((double)k0, rdfz, rfz0) - 1, 0);
@@ -1001,14 +1069,14 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
             }
             __syncthreads();
             for (int gi = 0; gi < cnt; ++gi) {
-                const double sc = bcast_lane(scale, gi);
+                const double sc = bcast_lane(a.scale, gi);
                 if (sc == 0.0) continue;
                 const int k = k0 + lane;
                 if (k < Ns && (tail_by_lane ? k < ntail0 : true)) {
                     const double kd = (double)k;
-                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(u.dfx, gi), bcast_lane(u.fx0, gi)),
-                                             fma(kd, bcast_lane(u.dfy, gi), bcast_lane(u.fy0, gi)),
-                                             fma(kd, bcast_lane(u.dfz, gi), bcast_lane(u.fz0, gi)), sc * wlds[k]);
+                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
+                                             fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
+                                             fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi)), sc * wlds[k], dbg);
                 }
             }
             __syncthreads();
@@ -1019,14 +1087,13 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
                     tile[e] = (AT)0;
                     const int cell = e / T_TKP, m = e - cell * T_TKP;
                     const int gi_ = I0[m] + cell / T_WIN, gj_ = J0[m] + cell % T_WIN, gk_ = kz0 + m;
-                    if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz)
+                    if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz && !(dbg & 8))
                         atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, v);
                 }
             }
             __syncthreads();
         }
     }
-    (void)dlane;
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
@@ -1699,7 +1766,7 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
     const dim3 block(256);
     if (ideal_path_ok(c) && c->variant != 2) {
         const size_t esz = accum == IONO_F64 ? 8 : 4;
-        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + 32 * sizeof(double) +
+        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + 64 * sizeof(double) +
                           esz * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
 #define LAUNCH_ADJT(AT, MODE)                                                                                              \
     do {                                                                                                                   \
@@ -1708,7 +1775,7 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
         if (nb > nbund) nb = (int)nbund;                                                                                   \
         if (nb >= 8) nb = nb / 8 * 8;                                                                                      \
         hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE>), dim3(nb), block, tl, c->stream, g, o, d, order, w, tec,   \
-                           dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->d_unitw, (AT *)grad, c->d_flags);                     \
+                           dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->walk_mode, c->d_unitw, (AT *)grad, c->d_flags);        \
     } while (0)
         if (accum == IONO_F64) {
             if (mode == 0) LAUNCH_ADJT(double, 0); else LAUNCH_ADJT(double, 1);

@@ -75,22 +75,23 @@ class RayEngine(object):
         return out
 
     @staticmethod
-    def locality_order(origins_t, dirs_t, tmax, cell=2.0):
-        """Permutation that walks rays whose paths nearly coincide one after another: sort by the
-        quantised (x, y) of the ray's origin, then of its far end, then by the exact far end.  The
-        adjoint pre-reduces bundles of 64 consecutive rays of the walk in LDS, so this cuts its
-        global atomics by an order of magnitude.  Host-side plumbing (torch sort), not part of the
-        numerics: any permutation gives the same results (up to atomic summation order)."""
+    def locality_order(origins_t, dirs_t, tmax, cell=0.5, bits=15):
+        """Permutation that walks rays whose paths nearly coincide one after another: 4-D Morton
+        (Z-order) code of the quantised origin (x, y) and far-end (x, y) of each ray, so that any 64
+        consecutive rays of the walk form a compact bundle all the way up.  The adjoint pre-reduces
+        such bundles in LDS, which cuts its global atomics by an order of magnitude.  Host-side
+        plumbing (torch integer ops + sort), not part of the numerics: any permutation gives the
+        same results (up to atomic summation order)."""
         o, d = origins_t, dirs_t
         L = (tmax - o[:, 2]) / d[:, 2]
         end = o[:, :2] + d[:, :2] * L[:, None]
-        key = torch.stack([torch.floor(o[:, 0] / cell), torch.floor(o[:, 1] / cell), torch.floor(end[:, 0] / (2 * cell)),
-                           torch.floor(end[:, 1] / (2 * cell))], dim=1).to(torch.int64)
-        key = key - key.min(dim=0).values
-        span = key.max(dim=0).values + 1
-        flat = ((key[:, 0] * span[1] + key[:, 1]) * span[2] + key[:, 2]) * span[3] + key[:, 3]
-        fine = torch.argsort(end[:, 0], stable=True)                       # tie-break inside a key cell
-        return fine[torch.argsort(flat[fine], stable=True)].to(torch.int32).contiguous()
+        coords = torch.stack([o[:, 0], o[:, 1], end[:, 0], end[:, 1]], dim=1)
+        q = torch.floor((coords - coords.min(dim=0).values) / cell).to(torch.int64).clamp_(0, (1 << bits) - 1)
+        code = torch.zeros(q.shape[0], dtype=torch.int64, device=q.device)
+        for b in range(bits):
+            for dim in range(4):
+                code |= ((q[:, dim] >> b) & 1) << (4 * b + dim)
+        return torch.argsort(code, stable=True).to(torch.int32).contiguous()
 
     def adjoint(self, origins_t, dirs_t, w_t, tmax, Ns, out=None, accum=torch.float64, order=None):
         """out[nx,ny,nz] += G^T w  (out is zeroed when allocated here)."""

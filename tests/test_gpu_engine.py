@@ -134,3 +134,41 @@ def test_full_size_properties_256_cubed():
     lhs, rhs = float(torch.dot(Gx, y)), float(torch.dot(eng.tensor(a).reshape(-1), Gty.reshape(-1)))
     assert abs(lhs - rhs) < 1e-10 * float(Gx.norm()) * float(y.norm())
     assert not eng.check_oob()
+
+
+def test_tiled_adjoint_cfg2_ordered_and_unordered(O):
+    """config 2 geometry (62 LOFAR stations x 42 directions, 128^3): the LDS-privatised adjoint must
+    give the same back-projection whatever the walk order (in-tile and out-of-tile contributions,
+    bundles of coincident and of scattered rays), in float64 and float32 accumulation."""
+    from oracle import oracle_c as OC
+    w = syn.make_workload(antennas="lofar", na=62, nd=42, nt=3, n=128)
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    oo, dd = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    o, d = eng.tensor(oo), eng.tensor(dd)
+    rng = np.random.default_rng(11)
+    y = rng.normal(size=oo.shape[0])
+    y[rng.integers(0, y.size, 200)] = 0.0                      # zero-weight rays are skipped
+    ref = OC.adjoint_straight(w["xvec"], w["yvec"], w["zvec"], oo, dd, y, w["tmax"], 129)
+    scale = np.max(np.abs(ref))
+    yt = eng.tensor(y)
+    order = eng.locality_order(o, d, w["tmax"])
+    assert sorted(order.cpu().numpy().tolist()) == list(range(oo.shape[0]))
+    rev = torch.flip(order, dims=[0]).contiguous()
+    perm = eng.tensor(rng.permutation(oo.shape[0])).to(torch.int32)
+    for od in (None, order, rev, perm):
+        g = eng.adjoint(o, d, yt, w["tmax"], 129, order=od).cpu().numpy()
+        assert np.max(np.abs(g - ref)) < 1e-11 * scale
+        tec = eng.forward(o, d, w["tmax"], 129, order=od).cpu().numpy()
+        assert np.all(np.isfinite(tec))
+    g32 = eng.adjoint(o, d, yt, w["tmax"], 129, order=order, accum=torch.float32).cpu().numpy()
+    assert np.max(np.abs(g32 - ref)) < 2e-5 * scale
+    # even sample count (Ns = 128: no tail) and a tail longer than 8 samples (Ns = 140: masked slab)
+    for Ns in (128, 140):
+        ref2 = OC.adjoint_straight(w["xvec"], w["yvec"], w["zvec"], oo[:500], dd[:500], y[:500], w["tmax"], Ns)
+        g2 = eng.adjoint(o[:500].contiguous(), d[:500].contiguous(), yt[:500].contiguous(), w["tmax"], Ns).cpu().numpy()
+        assert np.max(np.abs(g2 - ref2)) < 1e-11 * np.max(np.abs(ref2))
+        t2 = eng.forward(o[:500].contiguous(), d[:500].contiguous(), w["tmax"], Ns).cpu().numpy()
+        r2 = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], w["ne"] / 1e13, oo[:500], dd[:500], w["tmax"], Ns)
+        assert np.max(np.abs(t2 - r2) / np.abs(r2)) < 1e-12
+    assert not eng.check_oob()
