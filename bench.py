@@ -89,7 +89,7 @@ def time_steps(fn, steps, warmup, torch, dist, world):
     wall = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)        # MAX over ranks
         wall = float(t.item())
     kern = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
     return wall, kern
@@ -141,9 +141,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # one process per GPU; IONO_BENCH_BACKEND=gloo + several ranks on one card is only for rehearsing the
+    # multi-rank control flow on a 1-GPU box
+    backend = os.environ.get("IONO_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
 
     from ionotomo_amd.engine import RayEngine
     w = build_workload(rank)

@@ -143,6 +143,12 @@ int iono_adjoint_residual_straight_dev(iono_ctx *ctx, const double *origins_dev,
                                        int Na, int64_t NtNd, int i0, double tmax, int Ns, int quad_rule,
                                        void *grad_dev, int accum_dtype);
 int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);
+/* Fermat tracer with device buffers (rays_dev[R][4][Ns]); the refractive-index nodes are cached in the
+ * ctx and rebuilt when the grid values or the frequency change.  Feed rays_dev to
+ * iono_forward_tec_rays_dev for the curved-ray TEC (BASELINE config 3) without leaving the GPU. */
+int iono_trace_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R,
+                          double tmax, int Ns, double frequency, int bend, int interp_kind, int substeps,
+                          double *rays_dev);
 int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
 
 #ifdef __cplusplus

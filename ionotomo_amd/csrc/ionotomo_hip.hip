@@ -1270,11 +1270,15 @@ __global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *_
     bool oob = false;
     for (int k = 1; k < Ns; ++k) {
         for (int sub = 0; sub < substeps; ++sub) {
-            const FState k1 = fermat_rhs<KIND, BEND>(g, nM, u);
-            const FState k2 = fermat_rhs<KIND, BEND>(g, nM, axpy(u, 0.5 * h, k1));
-            const FState k3 = fermat_rhs<KIND, BEND>(g, nM, axpy(u, 0.5 * h, k2));
-            const FState k4 = fermat_rhs<KIND, BEND>(g, nM, axpy(u, h, k3));
-            FState sum = axpy(axpy(axpy(k1, 2.0, k2), 2.0, k3), 1.0, k4);
+            // classic RK4 with the four stages as a loop (one copy of the right-hand side: four inlined
+            // tricubic evaluations need > 512 VGPRs and spill): sum = k1 + 2 k2 + 2 k3 + k4
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs<KIND, BEND>(g, nM, axpy(u, ca, kprev));
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
             u = axpy(u, h / 6.0, sum);
         }
         oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
@@ -1305,6 +1309,8 @@ struct iono_ctx {
     std::string err;
     int num_cus = 256;
     int force_general = 0;           // testing/ablation: 1 = general kernels only, 2 = no "ideal uniform" kernels
+    double *d_nM = nullptr;          // refractive-index nodes for the tracer (device-pointer entry), lazily built
+    double nM_freq = -1.0;           // frequency d_nM was built for; < 0 = stale
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     int walk_mode = 0;               // env IONOTOMO_WALK (see wave_chunk)
@@ -1522,6 +1528,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_M) (void)hipFree(c->d_M);
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_unitw) (void)hipFree(c->d_unitw);
+    if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return IONO_OK;
@@ -1578,8 +1585,11 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->d_axes) HIP_TRY(c, hipFree(c->d_axes));
     if (c->d_M) HIP_TRY(c, hipFree(c->d_M));
+    if (c->d_nM) HIP_TRY(c, hipFree(c->d_nM));
     c->d_axes = nullptr;
     c->d_M = nullptr;
+    c->d_nM = nullptr;
+    c->nM_freq = -1.0;
     c->nx = nx;
     c->ny = ny;
     c->nz = nz;
@@ -1601,6 +1611,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
 
 static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, double scale) {
     const int64_t n = ncells(c);
+    c->nM_freq = -1.0;
     int rc = dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
         hipLaunchKernelGGL((k_set_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, src_dev, (GT *)c->d_M, n,
@@ -1986,26 +1997,26 @@ int iono_trace_straight(iono_ctx *c, const double *o, const double *d, int64_t R
     return IONO_OK;
 }
 
-int iono_trace_fermat(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, double frequency, int bend,
-                      int kind, int substeps, double *rays_out) {
+int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64_t R, double tmax, int Ns, double frequency,
+                          int bend, int kind, int substeps, double *dR) {
     int rc = check_common(c, R, Ns, kind, 0);
     if (rc) return rc;
     if (substeps < 1 || !(frequency > 0)) return fail(c, IONO_ERR_ARG, "need substeps >= 1 and frequency > 0");
     if (R == 0) return IONO_OK;
     const int64_t n = ncells(c);
-    DevBuf b;
-    const size_t nr = (size_t)R * 4 * Ns;
-    HIP_TRY(c, b.alloc(8 * (nr + 6 * (size_t)R + (size_t)n)));
-    double *dR = b.as<double>(), *dO = dR + nr, *dD = dO + 3 * R, *dN = dD + 3 * R;
-    HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
-    dispatch_storage(c, [&](auto *tag) {
-        using GT = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL((k_ne_to_n<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M, dN, n, frequency);
-        return IONO_OK;
-    });
+    if (!c->d_nM) HIP_TRY(c, hipMalloc((void **)&c->d_nM, (size_t)n * 8));
+    if (c->nM_freq != frequency) {       // n = sqrt(1 - 8.98^2 ne / nu^2) at the nodes, rebuilt when ne or nu changed
+        dispatch_storage(c, [&](auto *tag) {
+            using GT = std::remove_pointer_t<decltype(tag)>;
+            hipLaunchKernelGGL((k_ne_to_n<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M, c->d_nM, n,
+                               frequency);
+            return IONO_OK;
+        });
+        c->nM_freq = frequency;
+    }
     const GridView g = view(c);
     const dim3 grid((unsigned)((R + 63) / 64)), block(64);
+    double *dN = c->d_nM;
 #define LAUNCH_F(K, B) \
     hipLaunchKernelGGL((k_trace_fermat<K, B>), grid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags)
     if (kind == IONO_INTERP_TRILINEAR) {
@@ -2015,6 +2026,22 @@ int iono_trace_fermat(iono_ctx *c, const double *o, const double *d, int64_t R, 
     }
 #undef LAUNCH_F
     HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_trace_fermat(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, double frequency, int bend,
+                      int kind, int substeps, double *rays_out) {
+    int rc = check_common(c, R, Ns, kind, 0);
+    if (rc) return rc;
+    if (R == 0) return IONO_OK;
+    DevBuf b;
+    const size_t nr = (size_t)R * 4 * Ns;
+    HIP_TRY(c, b.alloc(8 * (nr + 6 * (size_t)R)));
+    double *dR = b.as<double>(), *dO = dR + nr, *dD = dO + 3 * R;
+    HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
+    rc = iono_trace_fermat_dev(c, dO, dD, R, tmax, Ns, frequency, bend, kind, substeps, dR);
+    if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(rays_out, dR, nr * 8, hipMemcpyDeviceToHost, c->stream));
     return finish_host_call(c, "iono_trace_fermat");
 }

@@ -119,6 +119,26 @@ class RayEngine(object):
                       _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 
+    def trace_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=True, kind="cubic", substeps=4, out=None):
+        """rays[R,4,Ns] (x,y,z,s) of the Fermat ray ODE, on the device; the grid must hold ne [m^-3]."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        if out is None:
+            out = torch.empty((R, 4, int(Ns)), dtype=torch.float64, device=self.device)
+        self.ctx.call("iono_trace_fermat_dev", _ptr(origins_t), _ptr(dirs_t), R, float(tmax), int(Ns), float(frequency),
+                      int(bool(bend)), _lib.interp_kind(kind), int(substeps), _ptr(out))
+        return out
+
+    def forward_rays(self, rays_t, out=None, kind=None):
+        """tec[R] along explicit samples rays[R,4,Ns] (device), non-uniform Simpson in-kernel."""
+        self._sync_stream()
+        R, _, Ns = rays_t.shape
+        if out is None:
+            out = torch.empty(R, dtype=torch.float64, device=self.device)
+        self.ctx.call("iono_forward_tec_rays_dev", _ptr(rays_t), R, int(Ns), self.kind if kind is None else _lib.interp_kind(kind),
+                      self.rule, _ptr(out))
+        return out
+
     def subtract_reference(self, tec_t, Na, i0):
         self._sync_stream()
         self.ctx.call("iono_subtract_reference_dev", _ptr(tec_t), int(Na), tec_t.numel() // Na, int(i0))

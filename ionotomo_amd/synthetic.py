@@ -197,14 +197,14 @@ CONFIGS = {
 
 
 def make_workload(name=None, antennas="lofar", na=62, nd=42, nt=1, n=128, tmax=1000.0,
-                  seed=1234, turbulent=True):
+                  seed=1234, turbulent=True, margin_cells=4):
     """Everything the forward model needs, as plain numpy float64 arrays."""
     if name is not None:
         antennas, na, nd, nt, n = CONFIGS[name]
     ants = lofar_enu_km()[:na] if antennas == "lofar" else example_antennas_km(na, 0)
     dirs = rotate_about_pole(facet_directions(nd, 4.0, 1), nt)
     origins, directions = ray_bundle(ants, dirs)
-    xvec, yvec, zvec = domain_for(origins, directions, n, tmax)
+    xvec, yvec, zvec = domain_for(origins, directions, n, tmax, margin_cells)
     ne = ne_model(xvec, yvec, zvec, seed=seed, turbulent=turbulent)
     K_ne = float(np.median(ne))
     return dict(xvec=xvec, yvec=yvec, zvec=zvec, ne=ne, K_ne=K_ne, m=np.log(ne / K_ne),

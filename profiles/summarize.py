@@ -47,3 +47,18 @@ if summary:
     out = os.path.join(P, "%s_pmc_summary.json" % tag)
     json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out)
+
+# HBM traffic of the headline forward launch for bench.py's roofline.traffic: FETCH_SIZE / WRITE_SIZE are in
+# KiB; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> doubled
+# (MI355X_MICROARCH.md, HBM section).  Only the full-batch launches (largest grid) are used.
+fwd = [(k, v) for k, v in summary.items() if k.startswith("k_forward_straight_u<double>")]
+if fwd:
+    k, v = max(fwd, key=lambda kv: int(kv[0].split("grid=")[1]))
+    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+        traffic = 2.0 * v["FETCH_SIZE"]["mean"] * 1024 + v["WRITE_SIZE"]["mean"] * 1024
+        out = os.path.join(P, "pmc_forward.json")
+        json.dump({"rays_per_launch": 260400, "samples_per_ray": 257, "hbm_bytes_per_launch": traffic,
+                   "fetch_size_kib": v["FETCH_SIZE"]["mean"], "write_size_kib": v["WRITE_SIZE"]["mean"],
+                   "kernel": k, "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
+                                          "FETCH_SIZE doubled per the gfx950 correction)" % tag}, open(out, "w"), indent=1)
+        print("wrote", out)

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Timings of the BASELINE.json configs other than the bench line (these are parity-test cases, not
+bench lines; this script records how fast they run on one MI355X).  Prints one JSON object.
+
+cfg2  62 x 42 x 1, 128^3, trilinear and tricubic forward (Ns = 129)
+cfg3  same geometry, Fermat curved-ray tracer (true bending, tricubic n) + TEC along the traced rays
+cfg5  50 CGLS and 50 SIRT iterations (forward + adjoint each) on the 256^3 grid with this GPU's share
+      of config 4 (62 x 42 x 100 rays), synthetic data from a perturbed model; objective history
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from ionotomo_amd import parallel, solvers, synthetic as syn  # noqa: E402
+from ionotomo_amd.engine import RayEngine  # noqa: E402
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+out = {}
+# ---------------------------------------------------------------- cfg2 / cfg3
+w = syn.make_workload("cfg2")
+R = w["origins"].reshape(-1, 3).shape[0]
+for kind in ("linear", "cubic"):
+    eng = RayEngine(0, interp=kind)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+    ms = timeit(lambda: eng.forward(o, d, w["tmax"], w["Ns"]), 50, 5)
+    out["cfg2_%s_forward_us" % kind] = ms * 1e3
+    out["cfg2_%s_ray_integrals_per_s" % kind] = R / ms * 1e3
+# cfg3: same rays, grid with a wider margin (this synthetic, strongly turbulent ionosphere bends 120 MHz
+# rays by kilometres; rays leaving the grid raise, exactly like the reference's bounds_error=True)
+w = syn.make_workload("cfg2", margin_cells=16)
+eng = RayEngine(0, interp="linear")
+eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+eng.set_values(eng.tensor(w["ne"]))                      # ne [m^-3] for the tracer
+o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+rays = torch.empty((R, 4, w["Ns"]), dtype=torch.float64, device="cuda")
+for kind, sub in (("cubic", 4), ("linear", 4)):
+    ms = timeit(lambda: eng.trace_fermat(o, d, w["tmax"], w["Ns"], 120e6, bend=True, kind=kind, substeps=sub, out=rays), 10, 2)
+    out["cfg3_fermat_trace_%s_ms" % kind] = ms
+    out["cfg3_fermat_%s_rays_per_s" % kind] = R / ms * 1e3
+ms = timeit(lambda: eng.forward_rays(rays), 50, 5)
+out["cfg3_tec_along_traced_rays_us"] = ms * 1e3
+eng.trace_fermat(o, d, w["tmax"], w["Ns"], 120e6, bend=True, kind="cubic", substeps=4, out=rays)
+straight = eng.forward(o, d, w["tmax"], w["Ns"])
+curved = eng.forward_rays(rays)
+out["cfg3_max_lateral_bending_km"] = float((rays[:, 0, -1] - (o[:, 0] + d[:, 0] / d[:, 2] * (w["tmax"] - o[:, 2]))).abs().max())
+out["cfg3_max_rel_tec_change_from_bending_120MHz"] = float(((curved - straight).abs() / straight.abs()).max())
+assert not eng.check_oob()
+
+# ---------------------------------------------------------------- cfg5 (one GPU's share)
+wb = bench.build_workload(0)
+eng = RayEngine(0)
+eng.set_grid(wb["xvec"], wb["yvec"], wb["zvec"])
+na, P = bench.NA, bench.NT * bench.ND
+oo = wb["origins"].reshape(na, P, 3)
+dd = wb["directions"].reshape(na, P, 3)
+x0 = np.exp(wb["m"]) * (wb["K_ne"] / 1e13)                               # prior model (TECU/km)
+rng = np.random.default_rng(3)
+X, Y, Z = np.meshgrid(wb["xvec"], wb["yvec"], wb["zvec"], indexing="ij")
+blob = 1.0 + 0.3 * np.exp(-((X - 5) ** 2 + (Y + 8) ** 2) / 15.0 ** 2 - ((Z - 300) / 80.0) ** 2)
+x_true = x0 * blob
+prob = parallel.ShardedRays(eng, oo, dd, bench.TMAX, bench.NS, dobs=np.zeros((na, P)), cdct=np.full((na, P), 1e-6), i0=0)
+eng.set_values(eng.tensor(x_true))
+prob.dobs = prob.forward() + eng.tensor(rng.normal(size=na * P) * 1e-3)
+for name, fn in (("cgls", lambda: solvers.cgls(prob, eng.tensor(x0), n_iter=50)),
+                 ("sirt", lambda: solvers.sirt(prob, eng.tensor(x0), n_iter=50))):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    x, hist = fn()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    err0 = float(np.linalg.norm(x0 - x_true) / np.linalg.norm(x_true - x0 + 1e-300))
+    err = float((x - eng.tensor(x_true)).norm() / (eng.tensor(x0) - eng.tensor(x_true)).norm())
+    out["cfg5_%s_50_iterations_s" % name] = dt
+    out["cfg5_%s_ms_per_iteration" % name] = dt / 50 * 1e3
+    out["cfg5_%s_objective_first_last" % name] = [hist[0], hist[-1]]
+    out["cfg5_%s_model_error_vs_prior_error" % name] = err
+print(json.dumps(out, indent=1))
