@@ -172,3 +172,42 @@ def test_tiled_adjoint_cfg2_ordered_and_unordered(O):
         r2 = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], w["ne"] / 1e13, oo[:500], dd[:500], w["tmax"], Ns)
         assert np.max(np.abs(t2 - r2) / np.abs(r2)) < 1e-12
     assert not eng.check_oob()
+
+
+def test_edge_geometry_on_grid_faces_and_tiny_batches(O):
+    """Samples exactly on the outer faces of the grid (cell index n-1, weight 0 on the far corner: the
+    forward's unclamped read relies on the padded allocation), rays along a node line, R smaller than
+    one wave group, Ns below 64, and zero-length batches."""
+    from oracle import oracle_c as OC
+    n = 24
+    xv = np.linspace(-10.0, 13.0, n)
+    yv = np.linspace(-7.0, 16.0, n)
+    zv = np.linspace(0.0, 46.0, n)
+    rng = np.random.default_rng(5)
+    M = rng.uniform(1.0, 2.0, size=(n, n, n))
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0)
+    eng.set_grid(xv, yv, zv)
+    eng.set_values(eng.tensor(M))
+    oo = np.array([[xv[-1], yv[-1], zv[0]],        # runs up the far corner edge, ends on the top corner node
+                   [xv[0], yv[0], zv[0]],          # near corner edge
+                   [xv[3], yv[5], zv[0]],          # exactly along a node line
+                   [xv[-1] - 4.0, yv[-1], zv[0]],  # ends exactly on the x = max face
+                   [1.234, 2.345, 0.5]])
+    dd = np.array([[0, 0, 1.0], [0, 0, 1.0], [0, 0, 2.0], [4.0, 0, zv[-1]], [0.05, -0.03, 1.0]])
+    for Ns in (2, 5, 24, 47, 64, 65, 130):
+        ref = OC.forward_tec_straight(xv, yv, zv, M, oo, dd, zv[-1], Ns)
+        tec = eng.forward(eng.tensor(oo), eng.tensor(dd), zv[-1], Ns).cpu().numpy()
+        assert np.max(np.abs(tec - ref) / np.abs(ref)) < 1e-12, Ns
+        y = rng.normal(size=len(oo))
+        g = eng.adjoint(eng.tensor(oo), eng.tensor(dd), eng.tensor(y), zv[-1], Ns).cpu().numpy()
+        gref = OC.adjoint_straight(xv, yv, zv, oo, dd, y, zv[-1], Ns)
+        assert np.max(np.abs(g - gref)) < 1e-12 * np.max(np.abs(gref)), Ns
+    assert not eng.check_oob()
+    empty = eng.forward(eng.tensor(np.zeros((0, 3))), eng.tensor(np.zeros((0, 3))), 10.0, 9)
+    assert empty.shape == (0,)
+    # one ray pokes out of the top: flagged, its TEC is NaN, the others are untouched
+    tec = eng.forward(eng.tensor(oo), eng.tensor(dd), zv[-1] + 1.0, 33).cpu().numpy()
+    assert eng.check_oob() and np.all(np.isnan(tec))
+    tec = eng.forward(eng.tensor(oo), eng.tensor(dd * [1, 1, 1]), zv[-1] - 1.0, 33).cpu().numpy()
+    assert not eng.check_oob() and np.all(np.isfinite(tec))
