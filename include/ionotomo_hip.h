@@ -151,6 +151,15 @@ int iono_trace_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double
                           double *rays_dev);
 int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
 
+/* ---- model-covariance smoothing C_m: Covariance.smooth =
+ *      scipy.ndimage.convolve(phi, c_stencil, mode='nearest') (ionosphere/covariance.py:46-63,383-385) with the
+ *      reference's separable stencil c[a][b][c] = kx[a] ky[b] kz[c], each of length 2h+1 (host arrays).  Arrays
+ *      have the grid's shape; in/out/work (device variant) must be distinct buffers. ---------------------------- */
+int iono_smooth_separable(iono_ctx *ctx, const double *in, double *out, const double *kx, const double *ky,
+                          const double *kz, int h);
+int iono_smooth_separable_dev(iono_ctx *ctx, const double *in_dev, double *out_dev, double *work_dev,
+                              const double *kx, const double *ky, const double *kz, int h);
+
 #ifdef __cplusplus
 }
 #endif

@@ -66,6 +66,8 @@ _SIGNATURES = {
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
+    "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],
+    "iono_smooth_separable_dev": [_V, _V, _V, _P, _P, _P, _I],
 }
 EXPORTED = sorted(list(_SIGNATURES) + ["iono_ctx_create", "iono_last_error", "iono_version", "iono_grid_values_ptr"])
 
@@ -258,6 +260,14 @@ class Context(object):
                   int(bool(scale_by_grid)), _dp(out))
         return out
 
+    def smooth_separable(self, phi, kx, ky, kz):
+        phi = as_f64(phi)
+        self._need(phi.size)
+        kx, ky, kz, h = _smooth_args(kx, ky, kz)
+        out = np.empty(self.grid_shape, dtype=np.float64)
+        self.call("iono_smooth_separable", _dp(phi), _dp(out), _dp(kx), _dp(ky), _dp(kz), h)
+        return out
+
     def adjoint_rays(self, rays, w, rule="avg", scale_by_grid=False):
         rays = as_f64(rays)
         Ns = rays.shape[-1]
@@ -268,6 +278,13 @@ class Context(object):
         out = np.empty(self.grid_shape, dtype=np.float64)
         self.call("iono_adjoint_rays", _dp(rays), _dp(w), R, int(Ns), quad_rule(rule), int(bool(scale_by_grid)), _dp(out))
         return out
+
+
+def _smooth_args(kx, ky, kz):
+    kx, ky, kz = as_f64(kx).ravel(), as_f64(ky).ravel(), as_f64(kz).ravel()
+    if not (kx.size == ky.size == kz.size) or kx.size % 2 != 1:
+        raise ValueError("the three 1-D kernels must have the same odd length")
+    return kx, ky, kz, kx.size // 2
 
 
 def _rays_in(origins, directions):

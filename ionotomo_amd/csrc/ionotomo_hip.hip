@@ -13,6 +13,7 @@
 // Reference citations (file:line) are relative to /root/reference/src/ionotomo/.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -1169,6 +1170,84 @@ __global__ void k_zero(double *__restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
 }
 
+// C_m smoothing: Covariance.smooth = scipy.ndimage.convolve(phi, c_stencil, mode='nearest')
+// (ionosphere/covariance.py:46-63,383-385).  The reference's stencil is the product of three 1-D
+// exponential kernels, so the (2h+1)^3 convolution is three 1-D passes with edge replication.
+// Lanes run along z (contiguous) in every pass; taps along x / y are whole coalesced rows.
+#define CONV_T 32          // outputs along the filtered axis per workgroup (x / y passes)
+// x / y pass: a workgroup owns 64 consecutive z (lanes) x CONV_T outputs along the axis for one value
+// of the third index; the CONV_T + 2h input rows (edge rows replicated) are staged in LDS once, then
+// every thread produces CONV_T/4 outputs from LDS (2h+1 taps each).  Global loads per output:
+// (CONV_T + 2h) / CONV_T, all coalesced 512-B rows.
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_conv_xy(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int nz,
+                                                 const double *__restrict__ w, int h) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *wl = sm;                      // [2h+1]
+    double *tile = sm + ((2 * h + 2) & ~1);    // [CONV_T + 2h][64]
+    const int m = 2 * h + 1, rows = CONV_T + 2 * h;
+    for (int t = threadIdx.x; t < m; t += blockDim.x) wl[t] = w[t];
+    const int na = AXIS == 0 ? nx : ny;               // filtered axis
+    const int no = AXIS == 0 ? ny : nx;               // the other non-z axis
+    const int64_t sa = AXIS == 0 ? (int64_t)ny * nz : nz, so = AXIS == 0 ? nz : (int64_t)ny * nz;
+    const int zt = (nz + 63) / 64, at = (na + CONV_T - 1) / CONV_T;
+    const int64_t ntile = (int64_t)zt * at * no;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int64_t tid = blockIdx.x; tid < ntile; tid += gridDim.x) {
+        const int z0 = (int)(tid % zt) * 64;
+        const int a0 = (int)((tid / zt) % at) * CONV_T;
+        const int o = (int)(tid / ((int64_t)zt * at));
+        const int k = z0 + lane;
+        __syncthreads();
+        if (k < nz) {
+            const double *base = in + (int64_t)o * so + k;
+            for (int r = grp; r < rows; r += 4) {
+                const int a = min(max(a0 + r - h, 0), na - 1);
+                tile[r * 64 + lane] = base[(int64_t)a * sa];
+            }
+        }
+        __syncthreads();
+        if (k < nz) {
+            for (int q = grp; q < CONV_T; q += 4) {
+                if (a0 + q >= na) break;
+                double acc = 0.0;
+                const double *tp = tile + q * 64 + lane;
+                for (int t = 0; t < m; ++t) acc += wl[m - 1 - t] * tp[t * 64];
+                out[(int64_t)o * so + (int64_t)(a0 + q) * sa + k] = acc;
+            }
+        }
+    }
+}
+
+// z pass: each wave owns 64 consecutive z of one (i, j) row; the 64 + 2h inputs go through LDS
+__global__ __launch_bounds__(256) void k_conv_z(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int nz,
+                                                const double *__restrict__ w, int h) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *wl = sm;
+    const int m = 2 * h + 1, span = 64 + 2 * h;
+    double *tile = sm + ((2 * h + 2) & ~1) + (threadIdx.x >> 6) * span;     // per wave
+    for (int t = threadIdx.x; t < m; t += blockDim.x) wl[t] = w[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int zt = (nz + 63) / 64;
+    const int64_t nseg = (int64_t)nx * ny * zt;
+    for (int64_t sid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sid < nseg; sid += (int64_t)gridDim.x * 4) {
+        const int z0 = (int)(sid % zt) * 64;
+        const double *row = in + (sid / zt) * nz;
+        for (int t = lane; t < span; t += 64) tile[t] = row[min(max(z0 + t - h, 0), nz - 1)];
+        // same-wave LDS write -> read: the wave executes in lockstep, a waitcnt is all that is needed
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int k = z0 + lane;
+        if (k < nz) {
+            double acc = 0.0;
+            for (int t = 0; t < m; ++t) acc += wl[m - 1 - t] * tile[lane + t];
+            out[(sid / zt) * nz + k] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 template <typename GT, int KIND, bool EXTRAP>
 __global__ void k_interp_points(GridView g, const double *__restrict__ x, const double *__restrict__ y,
                                 const double *__restrict__ z, int64_t n, double *__restrict__ out, int *oob_flag) {
@@ -1309,6 +1388,8 @@ struct iono_ctx {
     std::string err;
     int num_cus = 256;
     int force_general = 0;           // testing/ablation: 1 = general kernels only, 2 = no "ideal uniform" kernels
+    double *d_kern = nullptr;        // 3 x (2h+1) smoothing kernels
+    int kern_cap = 0;
     double *d_nM = nullptr;          // refractive-index nodes for the tracer (device-pointer entry), lazily built
     double nM_freq = -1.0;           // frequency d_nM was built for; < 0 = stale
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
@@ -1529,6 +1610,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_unitw) (void)hipFree(c->d_unitw);
     if (c->d_nM) (void)hipFree(c->d_nM);
+    if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return IONO_OK;
@@ -1977,6 +2059,57 @@ int iono_adjoint_rays(iono_ctx *c, const double *rays, const double *w, int64_t 
     rc = iono_adjoint_rays_dev(c, dR, dW, R, Ns, rule, dG, IONO_F64);
     if (rc) return rc;
     return adjoint_host_finish(c, dG, scale_by_grid, grad_out, "iono_adjoint_rays");
+}
+
+// ---- C_m smoothing ------------------------------------------------------------------------------------
+int iono_smooth_separable_dev(iono_ctx *c, const double *in_dev, double *out_dev, double *work_dev, const double *kx,
+                              const double *ky, const double *kz, int h) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    if (h < 0 || h > 512 || !kx || !ky || !kz) return fail(c, IONO_ERR_ARG, "bad smoothing kernel");
+    if (in_dev == out_dev || in_dev == work_dev || out_dev == work_dev) return fail(c, IONO_ERR_ARG, "in/out/work must differ");
+    const int m = 2 * h + 1;
+    if (c->kern_cap < 3 * m) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_kern) HIP_TRY(c, hipFree(c->d_kern));
+        c->d_kern = nullptr;
+        HIP_TRY(c, hipMalloc((void **)&c->d_kern, sizeof(double) * 3 * m));
+        c->kern_cap = 3 * m;
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_kern, kx, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_kern + m, ky, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_kern + 2 * m, kz, sizeof(double) * m, hipMemcpyHostToDevice, c->stream));
+    const dim3 block(256);
+    const size_t wpad = sizeof(double) * ((2 * h + 2) & ~1);
+    const size_t lds_xy = wpad + sizeof(double) * 64 * (CONV_T + 2 * h), lds_z = wpad + sizeof(double) * 4 * (64 + 2 * h);
+    if (lds_xy > 150 * 1024) return fail(c, IONO_ERR_ARG, "smoothing stencil too wide for the LDS tile");
+    const int zt = (c->nz + 63) / 64;
+    auto tiles = [&](int na, int no) { return (int64_t)zt * ((na + CONV_T - 1) / CONV_T) * no; };
+    auto nblk = [&](int64_t work) { return dim3((unsigned)std::min<int64_t>(work, (int64_t)c->num_cus * 16)); };
+    hipLaunchKernelGGL((k_conv_xy<0>), nblk(tiles(c->nx, c->ny)), block, lds_xy, c->stream, in_dev, out_dev, c->nx, c->ny, c->nz,
+                       c->d_kern, h);
+    hipLaunchKernelGGL((k_conv_xy<1>), nblk(tiles(c->ny, c->nx)), block, lds_xy, c->stream, out_dev, work_dev, c->nx, c->ny, c->nz,
+                       c->d_kern + m, h);
+    hipLaunchKernelGGL(k_conv_z, nblk(((int64_t)c->nx * c->ny * zt + 3) / 4), block, lds_z, c->stream, work_dev, out_dev, c->nx,
+                       c->ny, c->nz, c->d_kern + 2 * m, h);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_smooth_separable(iono_ctx *c, const double *in, double *out, const double *kx, const double *ky, const double *kz,
+                          int h) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    const int64_t n = ncells(c);
+    DevBuf b;
+    HIP_TRY(c, b.alloc((size_t)n * 8 * 3));
+    double *dI = b.as<double>(), *dO = dI + n, *dW = dO + n;
+    HIP_TRY(c, hipMemcpyAsync(dI, in, n * 8, hipMemcpyHostToDevice, c->stream));
+    rc = iono_smooth_separable_dev(c, dI, dO, dW, kx, ky, kz, h);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(out, dO, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return IONO_OK;
 }
 
 // ---- ray geometry ------------------------------------------------------------------------------

@@ -139,6 +139,15 @@ class RayEngine(object):
                       self.rule, _ptr(out))
         return out
 
+    def smooth(self, phi_t, kx, ky, kz, out=None, work=None):
+        """C_m phi with the separable stencil kx x ky x kz (host arrays, odd length), on the device."""
+        self._sync_stream()
+        kx, ky, kz, h = _lib._smooth_args(kx, ky, kz)
+        out = torch.empty_like(phi_t) if out is None else out
+        work = torch.empty_like(phi_t) if work is None else work
+        self.ctx.call("iono_smooth_separable_dev", _ptr(phi_t), _ptr(out), _ptr(work), _lib._dp(kx), _lib._dp(ky), _lib._dp(kz), h)
+        return out
+
     def subtract_reference(self, tec_t, Na, i0):
         self._sync_stream()
         self.ctx.call("iono_subtract_reference_dev", _ptr(tec_t), int(Na), tec_t.numel() // Na, int(i0))

@@ -21,6 +21,12 @@ import torch
 FACTR, PGTOL, EPS = 1e7, 1e-2, 2.220446049250313e-16
 
 
+def smooth_grid(eng, v, covariance):
+    """C_m v on the engine's device (engines without a smoothing kernel -- the CPU test stand-in -- may
+    provide ``smooth`` too)."""
+    return eng.smooth(v.contiguous(), covariance.kx, covariance.ky, covariance.kz)
+
+
 def objective(problem, resid):
     """S = 1/2 sum r^2/(CdCt + 1e-15) over all rays."""
     return 0.5 * problem.dot_rays(resid, resid / (problem.cdct + 1e-15))
@@ -91,9 +97,12 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
 
 
 def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=0.0, max_iter=20, min_iter=5,
-                               callback=None):
+                               callback=None, covariance=None):
     """Nonlinear inversion in the log-model m (ne = K_scale exp(m) at the nodes) with the
-    reference's objective, update, line search and stopping rule (module docstring)."""
+    reference's objective, update, line search and stopping rule (module docstring).
+    ``covariance``: an ``ionosphere.covariance.Covariance``; the data gradient is then pre-multiplied
+    by C_m (its separable smoothing stencil), giving the reference's regularised direction
+    C_m G^T C_d^-1 r (+ m - m_prior)."""
     eng = problem.engine
     m = m0.clone()
     hist = []
@@ -110,6 +119,8 @@ def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=
             break
         ne = K_scale * torch.exp(m)
         dm = problem.gradient_from_tec(tec) * ne                  # d S / d m  (exp at nodes => node-wise product)
+        if covariance is not None:
+            dm = smooth_grid(eng, dm, covariance)
         if m_prior is not None and prior_weight > 0:
             dm = dm + prior_weight * (m - m_prior)
         # linearised exact line search along -dm: d(A ne)/d eps = -A (ne * dm)

@@ -73,7 +73,7 @@ def import_reference():
     mods = {}
     for m in ["geometry.tri_cubic", "geometry.slab_method", "geometry.ray_dirac", "inversion.fermat",
               "geometry.calc_rays", "inversion.forward_equation", "inversion.gradient",
-              "inversion.iterative_newton", "ionosphere.simulation"]:
+              "inversion.iterative_newton", "ionosphere.simulation", "ionosphere.covariance"]:
         mods[m] = importlib.import_module("ionotomo." + m)
     return mods
 
@@ -252,6 +252,18 @@ def main():
                         cells=np.array(cells), coeffs=np.array(coeffs), pts=np.array(pts),
                         ucells=np.array([(2, 2, 2), (3, 4, 5), (5, 3, 2)]), ucoeffs=np.array(ucoef),
                         meta=meta())
+    # ---- 10. Covariance.smooth: C_m applied with the numerical stencil (ionosphere/covariance.py:46-63,383-385)
+    rng = np.random.default_rng(21)
+    cases = {}
+    for tag, (dx, dy, dz, shape) in {"a": (5.0, 6.0, 7.0, (12, 11, 13)), "b": (9.0, 4.0, 12.0, (7, 16, 9))}.items():
+        C = R["ionosphere.covariance"].Covariance(dx=dx, dy=dy, dz=dz)
+        phi = rng.normal(size=shape)
+        cases["phi_" + tag] = phi
+        cases["out_" + tag] = C.smooth(phi)
+        cases["d_" + tag] = np.array([dx, dy, dz])
+        cases["m_" + tag] = C.c_stencil.shape[0]
+        cases["stencil_" + tag] = C.c_stencil
+    np.savez_compressed(os.path.join(OUT, "covariance_smooth.npz"), meta=meta(), **cases)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

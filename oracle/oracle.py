@@ -479,3 +479,30 @@ def n_field_tricubic(xvec, yvec, zvec, nM):
     def field(x, y, z):
         return tricubic(xvec, yvec, zvec, nM, x, y, z, grad=True)
     return field
+
+
+# --------------------------------------------------------------------------- C_m smoothing (section 8f #3)
+def covariance_stencil_half_width(dx, dy, dz, l=20.0):
+    """Half width h of the (2h+1)^3 stencil ionosphere/covariance.py:46-63 settles on: start at m = 5
+    and grow by 2 while the corner value / centre value of the kernel exceeds 0.05.  The default kernel
+    is the product of three exponential (Matern p = 0) factors exp(-|r_axis| / l)
+    (ionosphere/covariance.py:22; utils/gaussian_process.py:440-467 with p = 0, sigma = 1)."""
+    h = 2
+    while np.exp(-h * (dx + dy + dz) / l) > 0.05:
+        h += 1
+    return h
+
+
+def exp_kernel_1d(d, h, l=20.0):
+    return np.exp(-np.abs(np.arange(-h, h + 1) * d) / l)
+
+
+def smooth(phi, dx, dy, dz, l=20.0):
+    """Covariance.smooth (ionosphere/covariance.py:383-385): scipy.ndimage.convolve(phi, c_stencil,
+    mode='nearest').  The stencil is separable, so this is three 1-D convolutions with edge
+    replication."""
+    from scipy.ndimage import convolve1d
+    h = covariance_stencil_half_width(dx, dy, dz, l)
+    out = convolve1d(phi, exp_kernel_1d(dx, h, l), axis=0, mode='nearest')
+    out = convolve1d(out, exp_kernel_1d(dy, h, l), axis=1, mode='nearest')
+    return convolve1d(out, exp_kernel_1d(dz, h, l), axis=2, mode='nearest')

@@ -67,7 +67,7 @@ def cgls(A, d, cd, x0, n_iter, damp=0.0):
     return x, hist
 
 
-def steepest_descent_log_model(A, d, cd, m0, K_scale, max_iter=20, min_iter=5):
+def steepest_descent_log_model(A, d, cd, m0, K_scale, max_iter=20, min_iter=5, smooth=None):
     m = m0.copy()
     hist = []
     Wt = 1.0 / (cd + 1e-15)
@@ -79,6 +79,8 @@ def steepest_descent_log_model(A, d, cd, m0, K_scale, max_iter=20, min_iter=5):
         if k >= min_iter and len(hist) > 1 and (hist[-2] - S) <= FACTR * EPS * max(abs(hist[-2]), abs(S), 1.0):
             break
         dm = (A.T @ (resid * Wt)) * ne
+        if smooth is not None:
+            dm = smooth(dm)
         Gdm = A @ (ne * dm)
         eps = np.sum(Gdm * resid * Wt) / max(np.sum(Gdm * Gdm * Wt), 1e-300)
         step = eps * dm

@@ -37,3 +37,10 @@ class OracleEngine(object):
         dd = ((t2 - t2[i0:i0 + 1]).reshape(-1) - dobs) / (cdct + 1e-15)
         w = torch.from_numpy(O.differential_weights(dd.view(Na, -1).numpy(), i0)).reshape(-1)
         return self.adjoint(o, d, w, tmax, Ns)
+
+    def smooth(self, v, kx, ky, kz, out=None, work=None):
+        from scipy.ndimage import convolve1d
+        a = v.numpy().reshape(self.shape)
+        for ax, k in enumerate((kx, ky, kz)):
+            a = convolve1d(a, np.asarray(k), axis=ax, mode='nearest')
+        return torch.from_numpy(a.copy())

@@ -94,6 +94,15 @@ def test_solvers_on_gpu_match_dense_restatement():
     mr, hr = OS.steepest_descent_log_model(A, d, cd, np.log(pb["x0"] / K).ravel(), K, max_iter=8)
     assert len(hm) == len(hr) and np.allclose(hm, hr, rtol=1e-7)
     assert np.max(np.abs(mm.cpu().numpy().ravel() - mr)) < 1e-7 * np.max(np.abs(mr))
+    # the same with the C_m-smoothed direction
+    from ionotomo_amd.ionosphere.covariance import Covariance
+    cov = Covariance(dx=w["xvec"][1] - w["xvec"][0], dy=w["yvec"][1] - w["yvec"][0], dz=w["zvec"][1] - w["zvec"][0], l=40.0)
+    shape = pb["x0"].shape
+    ms, hs2 = solvers.steepest_descent_log_model(prob, eng.tensor(np.log(pb["x0"] / K)), K, max_iter=6, covariance=cov)
+    mr2, hr2 = OS.steepest_descent_log_model(A, d, cd, np.log(pb["x0"] / K).ravel(), K, max_iter=6,
+                                             smooth=lambda v: Or.smooth(v.reshape(shape), cov.dx, cov.dy, cov.dz, l=40.0).ravel())
+    assert len(hs2) == len(hr2) and np.allclose(hs2, hr2, rtol=1e-7)
+    assert np.max(np.abs(ms.cpu().numpy().ravel() - mr2)) < 1e-7 * np.max(np.abs(mr2))
 
 
 def test_full_size_properties_256_cubed():

@@ -312,3 +312,21 @@ def test_calc_rays_facade_shapes(golden):
     assert np.max(np.abs(rays65 - g["rays65"])) < 1e-9
     x, y, z, s = it.Fermat(tci).integrate_ray(w["origins"][1, 0, 2], w["directions"][1, 0, 2], 1000.0, N=65)
     assert np.max(np.abs(x - g["rays65"][1, 0, 2, 0])) < 1e-9 and np.max(np.abs(s - g["rays65"][1, 0, 2, 3])) < 1e-9
+
+
+# --------------------------------------------------------------------------- C_m smoothing
+def test_covariance_smooth_matches_reference_golden(golden, O):
+    from ionotomo_amd.ionosphere.covariance import Covariance
+    g = golden("covariance_smooth")
+    for tag in ("a", "b"):
+        dx, dy, dz = g["d_" + tag]
+        C = Covariance(dx=dx, dy=dy, dz=dz)
+        assert C.c_stencil.shape == g["stencil_" + tag].shape
+        assert np.max(np.abs(C.c_stencil - g["stencil_" + tag])) < 1e-15
+        out = C.smooth(g["phi_" + tag])
+        assert np.max(np.abs(out - g["out_" + tag])) < 1e-12 * np.max(np.abs(g["out_" + tag]))
+    # stencil wider than the array (every tap clamps), 2-node-thick axis, z longer than one 64-lane segment
+    rng = np.random.default_rng(0)
+    phi = rng.normal(size=(3, 2, 70))
+    C = Covariance(dx=1.0, dy=1.0, dz=1.0)
+    assert np.max(np.abs(C.smooth(phi) - O.smooth(phi, 1.0, 1.0, 1.0))) < 1e-11 * np.max(np.abs(phi)) * C.c_stencil.sum()

@@ -254,3 +254,15 @@ def test_tricubic_cell_units_reproduces_the_notebooks_own_test_function():
     bad = O.tricubic(xv, xv, xv, M, *p, cell_units=False)
     assert np.max(np.abs(good - f(*p))) < 2e-3
     assert np.max(np.abs(bad - f(*p))) > 10 * np.max(np.abs(good - f(*p)))
+
+
+def test_covariance_smooth_matches_reference(golden):
+    g = golden("covariance_smooth")
+    for tag in ("a", "b"):
+        dx, dy, dz = g["d_" + tag]
+        h = O.covariance_stencil_half_width(dx, dy, dz)
+        assert 2 * h + 1 == int(g["m_" + tag])
+        k3 = (O.exp_kernel_1d(dx, h)[:, None, None] * O.exp_kernel_1d(dy, h)[None, :, None] * O.exp_kernel_1d(dz, h)[None, None, :])
+        assert np.max(np.abs(k3 - g["stencil_" + tag])) < 1e-15
+        out = O.smooth(g["phi_" + tag], dx, dy, dz)
+        assert np.max(np.abs(out - g["out_" + tag])) < 1e-12 * np.max(np.abs(g["out_" + tag]))
