@@ -241,7 +241,10 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel": "k_forward_straight_u<double>", "kernel_ms": kern * 1e3,
-                     "algorithmic_bytes_per_ray": bytes_ray},
+                     "algorithmic_bytes_per_ray": bytes_ray,
+                     "note": "achieved = ALGORITHMIC bytes (Ns*8 corners*8 B + 56 per ray, no credit for reuse) / kernel "
+                             "time; it can exceed the HBM peak because the 128 MiB grid is served from L2 / Infinity "
+                             "Cache -- `traffic` is the PMC-measured HBM-side bytes per launch"},
         "extra": extra,
     }
     pmc = os.path.join(ROOT, "profiles", "pmc_forward.json")

@@ -9,13 +9,13 @@ import os
 
 import numpy as np
 
-from ..synthetic import itrs_to_enu_km, read_array_table
+from ..synthetic import itrs_to_enu_km, read_array_table, read_station_enu_csv
 
 _ARRAYS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "arrays")
 
 
 class RadioArray(object):
-    lofar_array = os.path.join(_ARRAYS, 'lofar.hba.antenna.cfg')
+    lofar_array = os.path.join(_ARRAYS, 'lofar_hba_stations.csv')
 
     def __init__(self, array_file=None, antenna_pos=None, name=None, msFile=None, num_antennas=0, earth_locs=None,
                  frequency=120e6, **kwargs):
@@ -30,7 +30,10 @@ class RadioArray(object):
     def load_array_file(self, array_file):
         """Whitespace table ``X Y Z diameter label`` in ITRS metres, ``#`` comments
         (astro/radio_array.py:28-45)."""
-        xyz, diam, labels = read_array_table(array_file)
+        if str(array_file).endswith(".csv"):
+            xyz, diam, labels = read_station_enu_csv(array_file)     # ENU-offset station table shipped here
+        else:
+            xyz, diam, labels = read_array_table(array_file)         # the reference's X Y Z diam label format
         self.locs = xyz
         self.diameters = diam
         self.labels = labels

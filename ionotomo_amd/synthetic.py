@@ -24,7 +24,7 @@ import numpy as np
 from scipy.special import gamma
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LOFAR_HBA_CFG = os.path.join(_HERE, "astro", "arrays", "lofar.hba.antenna.cfg")
+LOFAR_HBA_CSV = os.path.join(_HERE, "astro", "arrays", "lofar_hba_stations.csv")
 
 EARTH_ROT_RATE = 7.2921e-5  # rad / s
 TIME_CADENCE = 8.0  # s
@@ -121,9 +121,38 @@ def read_array_table(path):
     return np.array(xyz), (None if np.all(np.isnan(diam)) else diam), np.array(labels)
 
 
+def enu_rotation(lon, lat):
+    """Rows (east, north, up) in ITRS axes at geodetic longitude / latitude (radians)."""
+    sl, cl, so, co = np.sin(lat), np.cos(lat), np.sin(lon), np.cos(lon)
+    return np.array([[-so, co, 0.0], [-sl * co, -sl * so, cl], [cl * co, cl * so, sl]])
+
+
+def read_station_enu_csv(path):
+    """Station table stored as East/North/Up offsets (metres) from a reference ITRS point given in the
+    header (``# ref_itrs_m = X Y Z`` and ``# ref_lon_lat_rad = lon lat``).  Returns
+    (itrs_xyz[N,3] metres, diameters[N], labels[N])."""
+    ref, lonlat, rows = None, None, []
+    with open(path) as fh:
+        for line in fh:
+            line = line.strip()
+            if line.startswith("#"):
+                if "ref_itrs_m" in line:
+                    ref = np.array([float(t) for t in line.split("=")[1].split()])
+                if "ref_lon_lat_rad" in line:
+                    lonlat = [float(t) for t in line.split("=")[1].split()]
+                continue
+            if not line or line.startswith("station"):
+                continue
+            rows.append(line.split(","))
+    enu = np.array([[float(r[1]), float(r[2]), float(r[3])] for r in rows])
+    xyz = ref + enu @ enu_rotation(*lonlat)
+    return xyz, np.array([float(r[4]) for r in rows]), np.array([r[0] for r in rows])
+
+
 def lofar_enu_km():
-    """The 62 LOFAR-HBA stations as ENU km about their centroid."""
-    xyz, _, _ = read_array_table(LOFAR_HBA_CFG)
+    """The 62 LOFAR-HBA stations (``astro/arrays/lofar.hba.antenna.cfg`` in the reference) as ENU km about
+    their centroid."""
+    xyz, _, _ = read_station_enu_csv(LOFAR_HBA_CSV)
     return itrs_to_enu_km(xyz)
 
 

@@ -23,7 +23,7 @@ for spec in specs:
         if k.startswith("IONOTOMO_"):
             del os.environ[k]
     storage = kv.pop("STORAGE", "f64")
-    use_order = kv.pop("ORDER", "0") == "1"
+    use_order = int(kv.pop("ORDER", "0"))
     for k, v in kv.items():
         os.environ["IONOTOMO_" + k] = v
     e = RayEngine(0, storage=storage)
@@ -31,19 +31,23 @@ for spec in specs:
     e.set_log_model(e.tensor(w["m"]), w["K_ne"] / 1e13)
     engines.append((spec, e, use_order))
 o_t, d_t = engines[0][1].tensor(w["origins"]), engines[0][1].tensor(w["directions"])
-order = engines[0][1].locality_order(o_t, d_t, bench.TMAX)
+order1 = engines[0][1].locality_order(o_t, d_t, bench.TMAX)
+# ORDER=2: (antenna, direction, time) -- consecutive rays are the same line of sight 8 s apart
+idx = torch.arange(R, device="cuda").reshape(bench.NA, bench.NT, bench.ND)
+order2 = idx.permute(0, 2, 1).reshape(-1).to(torch.int32).contiguous()
+orders = {0: None, 1: order1, 2: order2}
 out = torch.empty(R, dtype=torch.float64, device="cuda")
 times = {s: [] for s, _, _ in engines}
 ref = None
 for rnd in range(7):
     for spec, e, uo in engines:
         for _ in range(2):
-            e.forward(o_t, d_t, bench.TMAX, bench.NS, out=out, order=order if uo else None)
+            e.forward(o_t, d_t, bench.TMAX, bench.NS, out=out, order=orders[uo])
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         a.record()
         for _ in range(10):
-            e.forward(o_t, d_t, bench.TMAX, bench.NS, out=out, order=order if uo else None)
+            e.forward(o_t, d_t, bench.TMAX, bench.NS, out=out, order=orders[uo])
         b.record()
         torch.cuda.synchronize()
         times[spec].append(a.elapsed_time(b) / 10)
