@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- ray-integrals/s through a 256^3 ne grid (BASELINE.json metric) on N MI355X GPUs.
 
-    python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 1 --steps 100 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -125,8 +125,8 @@ def cpu_baseline(w, tec_gpu):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-order", dest="order", action="store_false", help="walk rays in [Na][Nt][Nd] memory order")
     ap.add_argument("--main-only", action="store_true",
@@ -200,7 +200,7 @@ def main():
         if world > 1:
             dist.all_reduce(grad_t)
 
-    k2 = max(3, args.steps // 4)
+    k2 = max(3, min(25, args.steps // 4))
     awall, akern = time_steps(adj, k2, 1, torch, dist, world)
     iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
     extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall

@@ -68,6 +68,20 @@ out["cfg3_max_lateral_bending_km"] = float((rays[:, 0, -1] - (o[:, 0] + d[:, 0] 
 out["cfg3_max_rel_tec_change_from_bending_120MHz"] = float(((curved - straight).abs() / straight.abs()).max())
 assert not eng.check_oob()
 
+# ---------------------------------------------------------------- PCIe-inclusive facade call (host numpy in/out)
+import ionotomo_amd as it  # noqa: E402
+w2 = syn.make_workload("cfg2")
+rays_h = it.calc_rays(w2["origins"][:, 0, 0, :], w2["directions"][0], [0.0], None, None, None,
+                      it.TriCubic(w2["xvec"], w2["yvec"], w2["zvec"], w2["ne"]), 120e6, True, w2["tmax"], w2["Ns"])
+m_tci = it.TriCubic(w2["xvec"], w2["yvec"], w2["zvec"], w2["m"])
+it.forward_equation(rays_h, w2["K_ne"], m_tci, 0)
+t0 = time.perf_counter()
+for _ in range(5):
+    it.forward_equation(rays_h, w2["K_ne"], m_tci, 0)
+dt = (time.perf_counter() - t0) / 5
+out["cfg2_facade_forward_equation_ms_pcie_inclusive"] = dt * 1e3
+out["cfg2_facade_ray_integrals_per_s_pcie_inclusive"] = rays_h.shape[0] * rays_h.shape[2] / dt
+
 # ---------------------------------------------------------------- cfg5 (one GPU's share)
 wb = bench.build_workload(0)
 eng = RayEngine(0)
