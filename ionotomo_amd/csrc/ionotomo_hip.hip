@@ -1369,6 +1369,120 @@ __global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *_
     if (oob) atomicOr(oob_flag, 1);
 }
 
+// ---- cooperative tricubic tracer: 8 lanes per ray -------------------------------------------------------
+// With lanes = rays a 2,604-ray config is 41 waves, each lane serially gathering 216 nodes per RK4
+// stage.  Here a ray is shared by 8 consecutive lanes: lane `sub` (< 6) owns x-tap `a = sub` and
+// contracts its 6 x 6 (y, z) plane (z taps are 6 contiguous doubles per load group); the four partial
+// results (n, nx, ny, nz) are summed over the 8 lanes with three DPP steps (quad_perm xor 1, xor 2,
+// row_half_mirror).  Every lane keeps the full ray state, so no broadcast is needed.
+template <int CTRL>
+__device__ __forceinline__ double dpp_xadd(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double sum8(double v) {
+    v = dpp_xadd<0xB1>(v);      // quad_perm:[1,0,3,2]
+    v = dpp_xadd<0x4E>(v);      // quad_perm:[2,3,0,1]
+    return dpp_xadd<0x141>(v);  // row_half_mirror: lane i <-> 7 - i within each group of 8
+}
+__device__ __forceinline__ void pick_tap(const double w[6], const double dw[6], int a, double &wa, double &da) {
+    wa = a == 0 ? w[0] : a == 1 ? w[1] : a == 2 ? w[2] : a == 3 ? w[3] : a == 4 ? w[4] : a == 5 ? w[5] : 0.0;
+    da = a == 0 ? dw[0] : a == 1 ? dw[1] : a == 2 ? dw[2] : a == 3 ? dw[3] : a == 4 ? dw[4] : a == 5 ? dw[5] : 0.0;
+}
+template <bool BEND>
+__device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const double *__restrict__ nM, const FState &u, int sub) {
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    double wx[6], wy[6], wz[6], dx[6], dy[6], dz[6];
+    const int i = cubic_axis(gx, g.nx, u.x, g.inv_h[0], g.uniform[0], wx, dx, true);
+    const int j = cubic_axis(gy, g.ny, u.y, g.inv_h[1], g.uniform[1], wy, dy, true);
+    const int k = cubic_axis(gz, g.nz, u.z, g.inv_h[2], g.uniform[2], wz, dz, true);
+    double wxa, dxa;
+    pick_tap(wx, dx, sub, wxa, dxa);
+    const int a = min(sub, 5);
+    const double *base = nM + ((size_t)(i - 2 + a) * g.ny + (j - 2)) * g.nz + (k - 2);
+    double fa = 0.0, fya = 0.0, fza = 0.0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const double *p = base + (size_t)b * g.nz;
+        double sv = 0.0, sz = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double v = p[c];
+            sv += v * wz[c];
+            sz += v * dz[c];
+        }
+        fa += sv * wy[b];
+        fya += sv * dy[b];
+        fza += sz * wy[b];
+    }
+    const double n = sum8(fa * wxa);
+    double nx = sum8(fa * dxa), ny = sum8(fya * wxa), nz = sum8(fza * wxa);
+    if (!BEND) nx = ny = nz = 0.0;
+    const double f = n / u.pz;
+    FState d;
+    d.px = nx * f;
+    d.py = ny * f;
+    d.pz = nz * f;
+    d.x = u.px / u.pz;
+    d.y = u.py / u.pz;
+    d.z = 1.0;
+    d.s = f;
+    return d;
+}
+template <bool BEND>
+__global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const double *__restrict__ nM,
+                                                          const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                          int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
+                                                          int *oob_flag) {
+    const int sub = threadIdx.x & 7;
+    int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+    const bool live = r < R;
+    if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm;
+    u.py = dy / nrm;
+    u.pz = dz / nrm;
+    u.x = origins[3 * r];
+    u.y = origins[3 * r + 1];
+    u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    double *o = rays + (size_t)r * 4 * Ns;
+    const bool writer = live && sub == 0;
+    if (writer) {
+        o[0] = u.x;
+        o[Ns] = u.y;
+        o[2 * Ns] = u.z;
+        o[3 * Ns] = u.s;
+    }
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    bool oob = false;
+    for (int k = 1; k < Ns; ++k) {
+        for (int s2 = 0; s2 < substeps; ++s2) {
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs_coop<BEND>(g, nM, axpy(u, ca, kprev), sub);
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
+        if (writer) {
+            o[k] = u.x;
+            o[Ns + k] = u.y;
+            o[2 * Ns + k] = u.z;
+            o[3 * Ns + k] = u.s;
+        }
+    }
+    if (oob && writer) atomicOr(oob_flag, 1);
+}
+
 }  // namespace
 
 // ================================================================================================
@@ -2154,8 +2268,16 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
     hipLaunchKernelGGL((k_trace_fermat<K, B>), grid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags)
     if (kind == IONO_INTERP_TRILINEAR) {
         if (bend) LAUNCH_F(IONO_INTERP_TRILINEAR, true); else LAUNCH_F(IONO_INTERP_TRILINEAR, false);
-    } else {
+    } else if (c->variant == 3) {           // lanes = rays (kept for A/B)
         if (bend) LAUNCH_F(IONO_INTERP_TRICUBIC, true); else LAUNCH_F(IONO_INTERP_TRICUBIC, false);
+    } else {                                // 8 lanes per ray
+        const dim3 cgrid((unsigned)((R + 7) / 8));
+        if (bend)
+            hipLaunchKernelGGL((k_trace_fermat_coop<true>), cgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR,
+                               c->d_flags);
+        else
+            hipLaunchKernelGGL((k_trace_fermat_coop<false>), cgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR,
+                               c->d_flags);
     }
 #undef LAUNCH_F
     HIP_TRY(c, hipGetLastError());

@@ -99,6 +99,8 @@ eng.set_values(eng.tensor(x_true))
 prob.dobs = prob.forward() + eng.tensor(rng.normal(size=na * P) * 1e-3)
 for name, fn in (("cgls", lambda: solvers.cgls(prob, eng.tensor(x0), n_iter=50)),
                  ("sirt", lambda: solvers.sirt(prob, eng.tensor(x0), n_iter=50))):
+    fn3 = {"cgls": lambda: solvers.cgls(prob, eng.tensor(x0), n_iter=3), "sirt": lambda: solvers.sirt(prob, eng.tensor(x0), n_iter=3)}
+    fn3[name]()                                   # warm-up (allocator, caches)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     x, hist = fn()

@@ -143,6 +143,19 @@ def test_full_size_properties_256_cubed():
     lhs, rhs = float(torch.dot(Gx, y)), float(torch.dot(eng.tensor(a).reshape(-1), Gty.reshape(-1)))
     assert abs(lhs - rhs) < 1e-10 * float(Gx.norm()) * float(y.norm())
     assert not eng.check_oob()
+    # (4) the FULL per-GPU batch (260,400 rays): a random sample of rays against the C oracle, and the
+    #     adjoint of the full batch against the oracle adjoint of a thinned batch is covered by (3)
+    from oracle import oracle_c as OC
+    eng.set_log_model(eng.tensor(w["m"]), w["K_ne"] / 1e13)
+    of, df = eng.tensor(w["origins"]), eng.tensor(w["directions"])
+    order = eng.locality_order(of, df, 1000.0)
+    tec_full = eng.forward(of, df, 1000.0, 257).cpu().numpy()
+    tec_ord = eng.forward(of, df, 1000.0, 257, order=order).cpu().numpy()
+    assert np.array_equal(tec_full, tec_ord)                      # the walk order never changes a ray's TEC
+    pick = rng.choice(w["origins"].shape[0], 600, replace=False)
+    ne = np.exp(w["m"]) * (w["K_ne"] / 1e13)
+    ref = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], ne, w["origins"][pick], w["directions"][pick], 1000.0, 257)
+    assert np.max(np.abs(tec_full[pick] - ref) / np.abs(ref)) < 1e-12
 
 
 def test_tiled_adjoint_cfg2_ordered_and_unordered(O):
