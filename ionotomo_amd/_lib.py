@@ -123,6 +123,7 @@ class Context(object):
         self.pid = os.getpid()
         self.grid_shape = None
         self.storage = None
+        self._axes = (None, None, None)
 
     def close(self):
         if getattr(self, "_h", None) is not None and self.pid == os.getpid():
@@ -160,9 +161,16 @@ class Context(object):
             if M.size != xv.size * yv.size * zv.size:
                 raise ValueError("M has %d values, grid has %d nodes" % (M.size, xv.size * yv.size * zv.size))
             Mp = _dp(M)
+        same = (self.grid_shape == (xv.size, yv.size, zv.size) and self.storage == storage_code(storage)
+                and all(np.array_equal(a, b) for a, b in zip(self._axes, (xv, yv, zv))))
+        if same:                      # same axes: keep the device allocation, refresh the values only
+            if Mp is not None:
+                self.call("iono_grid_set_values", Mp)
+            return
         self.call("iono_grid_set", _dp(xv), xv.size, _dp(yv), yv.size, _dp(zv), zv.size, Mp, storage_code(storage))
         self.grid_shape = (xv.size, yv.size, zv.size)
         self.storage = storage_code(storage)
+        self._axes = (xv.copy(), yv.copy(), zv.copy())
 
     def set_values(self, M):
         M = as_f64(M)

@@ -1502,6 +1502,8 @@ struct iono_ctx {
     std::string err;
     int num_cus = 256;
     int force_general = 0;           // testing/ablation: 1 = general kernels only, 2 = no "ideal uniform" kernels
+    void *d_work = nullptr;          // workspace of the host-pointer entry points (grow-only)
+    size_t work_cap = 0;
     double *d_kern = nullptr;        // 3 x (2h+1) smoothing kernels
     int kern_cap = 0;
     double *d_nM = nullptr;          // refractive-index nodes for the tracer (device-pointer entry), lazily built
@@ -1527,10 +1529,14 @@ int fail(iono_ctx *c, int code, const std::string &msg) {
             return fail(c, IONO_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
     } while (0)
 
-struct DevBuf {   // scoped device allocation for the host-pointer entry points
+// Device workspace of the host-pointer entry points: one grow-only buffer per ctx instead of a
+// hipMalloc/hipFree pair per call (those cost more than the kernels at config-2 sizes).  Host entry
+// points are synchronous and a ctx is single-threaded, so the buffer is free again when they return.
+struct DevBuf {
+    iono_ctx *c;
     void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 8); }
+    explicit DevBuf(iono_ctx *ctx) : c(ctx) {}
+    hipError_t alloc(size_t bytes);
     template <typename T> T *as() { return (T *)p; }
 };
 
@@ -1549,6 +1555,22 @@ GridView view(const iono_ctx *c) {
     }
     return g;
 }
+hipError_t DevBuf::alloc(size_t bytes) {
+    if (bytes > c->work_cap) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return e;
+        if (c->d_work) (void)hipFree(c->d_work);
+        c->d_work = nullptr;
+        c->work_cap = 0;
+        const size_t cap = bytes + bytes / 4 + 4096;
+        e = hipMalloc(&c->d_work, cap);
+        if (e != hipSuccess) return e;
+        c->work_cap = cap;
+    }
+    p = c->d_work;
+    return hipSuccess;
+}
+
 size_t lds_bytes(const iono_ctx *c) { return sizeof(double) * (size_t)(c->nx + c->ny + c->nz); }
 int64_t ncells(const iono_ctx *c) { return (int64_t)c->nx * c->ny * c->nz; }
 // fast kernels: all three axes uniform (cell guess off by at most one), 32-bit element offsets
@@ -1725,6 +1747,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_unitw) (void)hipFree(c->d_unitw);
     if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->d_kern) (void)hipFree(c->d_kern);
+    if (c->d_work) (void)hipFree(c->d_work);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return IONO_OK;
@@ -1822,7 +1845,7 @@ static int set_values_host_impl(iono_ctx *c, const double *M, int do_exp, double
     int rc = need_grid(c);
     if (rc) return rc;
     if (!M) return fail(c, IONO_ERR_ARG, "null values");
-    DevBuf tmp;
+    DevBuf tmp(c);
     HIP_TRY(c, tmp.alloc((size_t)ncells(c) * 8));
     HIP_TRY(c, hipMemcpyAsync(tmp.p, M, (size_t)ncells(c) * 8, hipMemcpyHostToDevice, c->stream));
     rc = set_values_dev_impl(c, tmp.as<double>(), do_exp, scale);
@@ -1850,7 +1873,7 @@ int iono_grid_get_values(iono_ctx *c, double *out) {
     int rc = need_grid(c);
     if (rc) return rc;
     const int64_t n = ncells(c);
-    DevBuf tmp;
+    DevBuf tmp(c);
     HIP_TRY(c, tmp.alloc((size_t)n * 8));
     dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
@@ -1870,7 +1893,7 @@ int iono_interp(iono_ctx *c, const double *x, const double *y, const double *z, 
     int rc = check_common(c, n, 2, kind, 0);
     if (rc) return rc;
     if (n == 0) return IONO_OK;
-    DevBuf b;
+    DevBuf b(c);
     HIP_TRY(c, b.alloc((size_t)n * 8 * 4));
     double *dx = b.as<double>(), *dy = dx + n, *dz = dy + n, *dout = dz + n;
     HIP_TRY(c, hipMemcpyAsync(dx, x, n * 8, hipMemcpyHostToDevice, c->stream));
@@ -2051,7 +2074,7 @@ int iono_forward_tec_straight(iono_ctx *c, const double *o, const double *d, int
     int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (R == 0) return IONO_OK;
-    DevBuf b;
+    DevBuf b(c);
     HIP_TRY(c, b.alloc((size_t)R * 8 * 7));
     double *dO = b.as<double>(), *dD = dO + 3 * R, *dT = dD + 3 * R;
     HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
@@ -2066,7 +2089,7 @@ int iono_forward_tec_rays(iono_ctx *c, const double *rays, int64_t R, int Ns, in
     int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (R == 0) return IONO_OK;
-    DevBuf b;
+    DevBuf b(c);
     HIP_TRY(c, b.alloc((size_t)R * 8 * (4 * (size_t)Ns + 1)));
     double *dR = b.as<double>(), *dT = dR + (size_t)R * 4 * Ns;
     HIP_TRY(c, hipMemcpyAsync(dR, rays, (size_t)R * 4 * Ns * 8, hipMemcpyHostToDevice, c->stream));
@@ -2079,7 +2102,7 @@ int iono_forward_tec_rays(iono_ctx *c, const double *rays, int64_t R, int Ns, in
 int iono_subtract_reference(iono_ctx *c, double *tec, int Na, int64_t NtNd, int i0) {
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
     const int64_t n = (int64_t)Na * NtNd;
-    DevBuf b;
+    DevBuf b(c);
     HIP_TRY(c, b.alloc((size_t)n * 8));
     HIP_TRY(c, hipMemcpyAsync(b.p, tec, n * 8, hipMemcpyHostToDevice, c->stream));
     int rc = iono_subtract_reference_dev(c, b.as<double>(), Na, NtNd, i0);
@@ -2097,7 +2120,7 @@ int iono_forward_phase_rays(iono_ctx *c, const double *rays, int Na, int Nt, int
     if (Nf < 1 || i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "bad Nf / i0");
     if (R == 0) return IONO_OK;
     constexpr int MAXF = 8;
-    DevBuf b;
+    DevBuf b(c);
     const size_t nr = (size_t)R * 4 * Ns, nphi = (size_t)R * Nf;
     HIP_TRY(c, b.alloc(8 * (nr + 2 * nphi + 2 * (size_t)Nf + (size_t)Na * Nt + Na)));
     double *dR = b.as<double>(), *dPhi = dR + nr, *dG = dPhi + nphi, *dF = dG + nphi, *dInv = dF + Nf, *dClock = dInv + Nf,
@@ -2146,7 +2169,7 @@ int iono_adjoint_straight(iono_ctx *c, const double *o, const double *d, const d
     int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
     if (rc) return rc;
     const int64_t n = ncells(c);
-    DevBuf b;
+    DevBuf b(c);
     HIP_TRY(c, b.alloc(8 * ((size_t)R * 7 + (size_t)n)));
     double *dO = b.as<double>(), *dD = dO + 3 * R, *dW = dD + 3 * R, *dG = dW + R;
     HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
@@ -2163,7 +2186,7 @@ int iono_adjoint_rays(iono_ctx *c, const double *rays, const double *w, int64_t 
     int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
     if (rc) return rc;
     const int64_t n = ncells(c);
-    DevBuf b;
+    DevBuf b(c);
     const size_t nr = (size_t)R * 4 * Ns;
     HIP_TRY(c, b.alloc(8 * (nr + (size_t)R + (size_t)n)));
     double *dR = b.as<double>(), *dW = dR + nr, *dG = dW + R;
@@ -2215,7 +2238,7 @@ int iono_smooth_separable(iono_ctx *c, const double *in, double *out, const doub
     int rc = need_grid(c);
     if (rc) return rc;
     const int64_t n = ncells(c);
-    DevBuf b;
+    DevBuf b(c);
     HIP_TRY(c, b.alloc((size_t)n * 8 * 3));
     double *dI = b.as<double>(), *dO = dI + n, *dW = dO + n;
     HIP_TRY(c, hipMemcpyAsync(dI, in, n * 8, hipMemcpyHostToDevice, c->stream));
@@ -2231,7 +2254,7 @@ int iono_trace_straight(iono_ctx *c, const double *o, const double *d, int64_t R
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
     if (R < 0 || Ns < 2) return fail(c, IONO_ERR_SHAPE, "need R >= 0 and Ns >= 2");
     if (R == 0) return IONO_OK;
-    DevBuf b;
+    DevBuf b(c);
     const size_t nr = (size_t)R * 4 * Ns;
     HIP_TRY(c, b.alloc(8 * (nr + 6 * (size_t)R)));
     double *dR = b.as<double>(), *dO = dR + nr, *dD = dO + 3 * R;
@@ -2289,7 +2312,7 @@ int iono_trace_fermat(iono_ctx *c, const double *o, const double *d, int64_t R, 
     int rc = check_common(c, R, Ns, kind, 0);
     if (rc) return rc;
     if (R == 0) return IONO_OK;
-    DevBuf b;
+    DevBuf b(c);
     const size_t nr = (size_t)R * 4 * Ns;
     HIP_TRY(c, b.alloc(8 * (nr + 6 * (size_t)R)));
     double *dR = b.as<double>(), *dO = dR + nr, *dD = dO + 3 * R;
