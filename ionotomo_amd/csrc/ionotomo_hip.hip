@@ -603,7 +603,7 @@ struct Chunk {
 __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
     const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
     int64_t bidx;
-    if ((gridDim.x & 7) == 0) {
+    if ((gridDim.x & 7) == 0 && !(mode & 4)) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
         bidx = (int64_t)xcd * nslot + slot;
     } else {
