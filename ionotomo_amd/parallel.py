@@ -94,7 +94,12 @@ class ShardedRays(object):
 
     def dot_rays(self, a, b):
         """<a, b> over ALL rays (local dot + scalar all-reduce)."""
-        return float(all_reduce_sum_(torch.dot(a, b).reshape(1))[0])
+        return float(self.dot_rays_t(a, b))
+
+    def dot_rays_t(self, a, b):
+        """Same, as a 0-dim tensor that stays on the device (no host synchronisation: the solvers keep
+        their step lengths on the GPU so the CPU can queue launches ahead of the kernels)."""
+        return all_reduce_sum_(torch.dot(a, b).reshape(1))[0]
 
     def gather_rays(self, local):
         """[Na*P_local] on every rank -> [Na,P] on every rank (host), for reporting/tests."""

@@ -51,16 +51,17 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None):
     # nodes with (numerically) no ray coverage are left alone: 1/col would turn rounding noise into updates
     C = torch.where(col > 1e-9 * col.max(), 1.0 / col, torch.zeros_like(col))
     hist = []
+    Wt = 1.0 / (problem.cdct + 1e-15)
     for k in range(n_iter):
         _set_x(problem, x)
         r = problem.dobs - problem.forward()
-        hist.append(objective(problem, r))
+        hist.append(0.5 * problem.dot_rays_t(r, r * Wt))        # stays on the device (see cgls)
         if callback:
-            callback(k, x, hist[-1])
+            callback(k, x, float(hist[-1]))
         x += relax * C * problem.adjoint(L * r)
         if nonneg:
             x.clamp_(min=0)
-    return x, hist
+    return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
 
 
 def parallel_adjoint_raw(problem, w):
@@ -71,29 +72,31 @@ def parallel_adjoint_raw(problem, w):
 
 
 def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
-    """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2 + damp/2 ||x||^2,  W = 1/(CdCt + 1e-15)."""
+    """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2 + damp/2 ||x||^2,  W = 1/(CdCt + 1e-15).
+    All scalars (alpha, beta, objective) stay on the device; the history is read back once at the
+    end, so an iteration never waits for the host (``callback`` forces a read-back per iteration)."""
     x = x0.clone()
     Wh = torch.rsqrt(problem.cdct + 1e-15)
     _set_x(problem, x)
     r = Wh * (problem.dobs - problem.forward())
     s = problem.adjoint(Wh * r) - damp * x
     p = s.clone()
-    gamma = float(torch.dot(s.reshape(-1), s.reshape(-1)))
+    gamma = torch.dot(s.reshape(-1), s.reshape(-1))
     hist = []
     for k in range(n_iter):
-        hist.append(0.5 * problem.dot_rays(r, r))
+        hist.append(0.5 * problem.dot_rays_t(r, r))
         if callback:
-            callback(k, x, hist[-1])
+            callback(k, x, float(hist[-1]))
         _set_x(problem, p)
         q = Wh * problem.forward()
-        alpha = gamma / (problem.dot_rays(q, q) + damp * float(torch.dot(p.reshape(-1), p.reshape(-1))))
+        alpha = gamma / (problem.dot_rays_t(q, q) + damp * torch.dot(p.reshape(-1), p.reshape(-1)))
         x += alpha * p
         r -= alpha * q
         s = problem.adjoint(Wh * r) - damp * x
-        gnew = float(torch.dot(s.reshape(-1), s.reshape(-1)))
+        gnew = torch.dot(s.reshape(-1), s.reshape(-1))
         p = s + (gnew / gamma) * p
         gamma = gnew
-    return x, hist
+    return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
 
 
 def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=0.0, max_iter=20, min_iter=5,
