@@ -38,16 +38,24 @@ def model_frame_bundle(antennas, patches, times=None):
 
 def calc_rays(antennas, patches, times, array_center, fixtime, phase, ne_tci, frequency, straight_line_approx, tmax,
               N=None, **fermat_kwargs):
-    """Same signature as geometry/calc_rays.py:109.  ``antennas``/``patches`` are model-frame arrays
-    (see module docstring); ``array_center``, ``fixtime``, ``phase`` are accepted for signature
-    compatibility and unused for pre-transformed inputs."""
+    """Same signature as geometry/calc_rays.py:109.  Two input conventions:
+    * ``array_center is None``: ``antennas``/``patches`` are model-frame arrays (module docstring);
+    * ``array_center`` (ITRS [3] m) and ``phase`` ((ra, dec) rad) given: ``antennas`` are ITRS [Na,3] m,
+      ``patches`` (ra, dec) [Nd,2] rad, ``times`` UTC unix seconds -- transformed to the Pointing frame
+      per observation time as the reference does (plain arrays instead of astropy objects)."""
     if N is None:
         N = ne_tci.nz
     if hasattr(antennas, "transform_to") or hasattr(patches, "transform_to"):
         raise NotImplementedError(
             "astropy coordinate objects are not transformed here (astropy is not part of this build); pass "
             "model-frame arrays: antennas [Na,3] km, patches [Nd,3] or [Nt,Nd,3] direction vectors")
-    origins, directions = model_frame_bundle(antennas, patches, times)
+    if array_center is not None and phase is not None:
+        # ITRS antennas [Na,3] m, (ra, dec) patches [Nd,2] rad, UTC unix times, centre ITRS [3] m,
+        # phase centre (ra, dec): the reference's Pointing-frame set-up without astropy (astro/frames.py)
+        from ..astro.frames import model_frame_bundle_from_sky
+        origins, directions = model_frame_bundle_from_sky(antennas, patches, times, array_center, phase, fixtime)
+    else:
+        origins, directions = model_frame_bundle(antennas, patches, times)
     fermat = Fermat(ne_tci=ne_tci, frequency=frequency, type='z', straight_line_approx=straight_line_approx,
                     **fermat_kwargs)
     return cast_ray((origins, directions), fermat, tmax, N)

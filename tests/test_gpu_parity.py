@@ -330,3 +330,21 @@ def test_covariance_smooth_matches_reference_golden(golden, O):
     phi = rng.normal(size=(3, 2, 70))
     C = Covariance(dx=1.0, dy=1.0, dz=1.0)
     assert np.max(np.abs(C.smooth(phi) - O.smooth(phi, 1.0, 1.0, 1.0))) < 1e-11 * np.max(np.abs(phi)) * C.c_stencil.sum()
+
+
+def test_calc_rays_from_sky_coordinates():
+    import ionotomo_amd as it
+    from ionotomo_amd.astro import frames
+    ra_ = it.RadioArray(array_file=it.RadioArray.lofar_array)
+    lon, lat, _ = frames.geodetic_from_itrs(ra_.get_center())
+    t0 = 1.7e9
+    phase = (frames.gmst_rad(t0) + lon, lat)
+    pat = np.stack([phase[0] + np.array([0.0, 0.01, -0.02]), phase[1] + np.array([0.0, 0.015, 0.01])], -1)
+    o, d = frames.model_frame_bundle_from_sky(ra_.get_antenna_locs()[:6], pat, [t0], ra_.get_center(), phase)
+    xv, yv, zv = frames.determine_inversion_domain(20.0, o[:, 0, 0, :], d[0, 0], 1000.0, padding=3)
+    tci = it.TriCubic(xv, yv, zv, np.ones((len(xv), len(yv), len(zv))))
+    rays = it.calc_rays(ra_.get_antenna_locs()[:6], pat, [t0], ra_.get_center(), t0, phase, tci, 120e6, True, 1000.0, 33)
+    assert rays.shape == (6, 1, 3, 4, 33)
+    assert np.allclose(rays[:, 0, :, 2, -1], 1000.0) and np.allclose(rays[:, 0, :, :3, 0], o[:, 0, :, :])
+    tec = it.do_forward_equation(rays[:, 0], tci)                   # unit field: TEC = path length
+    assert np.allclose(tec, rays[:, 0, :, 3, -1], rtol=1e-12)
