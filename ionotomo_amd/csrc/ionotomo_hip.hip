@@ -1582,8 +1582,16 @@ bool ideal_path_ok(const iono_ctx *c) { return fast_path_ok(c) && c->ideal && c-
 // kernel), but no more waves than rays
 template <typename K>
 int resident_blocks(iono_ctx *c, K kernel, size_t lds) {
+    // the occupancy query costs a few microseconds: remember the answer per (kernel, LDS size)
+    static thread_local std::vector<std::pair<std::pair<const void *, size_t>, int>> cache;
+    const std::pair<const void *, size_t> key((const void *)kernel, lds);
     int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+    for (auto &e : cache)
+        if (e.first == key) per_cu = e.second;
+    if (per_cu == 0) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, lds) != hipSuccess || per_cu < 1) per_cu = 4;
+        cache.push_back({key, per_cu});
+    }
     if (per_cu > 8) per_cu = 8;
     if (c->blocks_per_cu_override > 0) per_cu = c->blocks_per_cu_override;
     return per_cu * c->num_cus;
