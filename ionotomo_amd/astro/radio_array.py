@@ -16,6 +16,8 @@ _ARRAYS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "arrays")
 
 class RadioArray(object):
     lofar_array = os.path.join(_ARRAYS, 'lofar_hba_stations.csv')
+    lofar_cycle0_array = os.path.join(_ARRAYS, 'lofar_cycle0_hba_stations.csv')
+    gmrt_array = os.path.join(_ARRAYS, 'gmrt_stations.csv')
 
     def __init__(self, array_file=None, antenna_pos=None, name=None, msFile=None, num_antennas=0, earth_locs=None,
                  frequency=120e6, **kwargs):
@@ -35,6 +37,8 @@ class RadioArray(object):
         else:
             xyz, diam, labels = read_array_table(array_file)         # the reference's X Y Z diam label format
         self.locs = xyz
+        if diam is not None and np.all(np.asarray(diam) < 0):
+            diam = None                                # table without dish diameters (GMRT)
         self.diameters = diam
         self.labels = labels
         self.Nantenna = int(xyz.shape[0])

@@ -79,5 +79,7 @@ def test_radio_array_lofar():
     enu = ra.enu_km()
     assert enu.shape == (62, 3) and abs(enu.mean(0)).max() < 1e-6 and np.abs(enu[:, 2]).max() < 1.0
     assert ra.get_antenna_idx("CS002HBA1") == 3
+    assert it.RadioArray(array_file=it.RadioArray.gmrt_array).Nantenna == 32
+    assert it.RadioArray(array_file=it.RadioArray.lofar_cycle0_array).Nantenna == 47
     ex = it.generate_example_radio_array(Nant=7, seed=1)
     assert ex.Nantenna == 7
