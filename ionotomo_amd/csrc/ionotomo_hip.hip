@@ -595,11 +595,10 @@ __device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const 
 struct Chunk {
     int64_t lo, hi, stride;     // walk positions lo, lo+stride, ... < hi
 };
-// mode 0: one contiguous chunk per wave.  mode 1: one contiguous chunk per WORKGROUP, its 4 waves
-// interleaved (wave w takes lo+w, lo+w+4, ...): with a locality-sorted `order` the waves of a
-// workgroup then read (nearly) the same grid lines at the same time and share them in L1.
-// bit 1 of mode (value 2): scatter consecutive chunks over workgroups with an odd multiplier so
-// that neighbouring CUs do not hammer the same L2 lines at the same moment.
+// mode 0 (default): one contiguous chunk per wave.  mode bit 0: one contiguous chunk per WORKGROUP, its
+// 4 waves interleaved (wave w takes lo+w, lo+w+4, ...).  mode bit 2: plain block order instead of
+// XCD-major.  Both alternatives measured slower or equal on the bench workload; kept for A/B runs
+// (env IONOTOMO_WALK).
 __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
     const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
     int64_t bidx;
@@ -609,7 +608,6 @@ __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
     } else {
         bidx = blockIdx.x;
     }
-    if (mode & 2) bidx = (bidx * 2654435761LL) % gridDim.x == bidx ? bidx : (bidx * 40503LL + 17) % gridDim.x;
     Chunk c;
     if (mode & 1) {
         const int64_t nb = gridDim.x, base = R / nb, rem = R % nb;
@@ -1578,6 +1576,8 @@ bool fast_path_ok(const iono_ctx *c) {
     return c->uniform[0] && c->uniform[1] && c->uniform[2] && ncells(c) < ((int64_t)1 << 31) && c->force_general != 1;
 }
 bool ideal_path_ok(const iono_ctx *c) { return fast_path_ok(c) && c->ideal && c->force_general == 0; }
+// the v2 kernels keep the Ns quadrature weights in LDS
+bool ideal_path_ok(const iono_ctx *c, int Ns) { return ideal_path_ok(c) && Ns <= 4096; }
 // v2 kernels: grid = what is resident at once (blocks per CU from the occupancy query, cached per
 // kernel), but no more waves than rays
 template <typename K>
@@ -1940,7 +1940,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
     const size_t lds = lds_bytes(c);
     dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c)) {
+        if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
             hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
@@ -2002,7 +2002,7 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
     if (rc) return rc;
     const GridView g = view(c);
     const dim3 block(256);
-    if (ideal_path_ok(c) && c->variant != 2) {
+    if (ideal_path_ok(c, Ns) && c->variant != 2) {
         const size_t esz = accum == IONO_F64 ? 8 : 4;
         const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + 64 * sizeof(double) +
                           esz * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;

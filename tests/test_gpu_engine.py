@@ -233,3 +233,20 @@ def test_edge_geometry_on_grid_faces_and_tiny_batches(O):
     assert eng.check_oob() and np.all(np.isnan(tec))
     tec = eng.forward(eng.tensor(oo), eng.tensor(dd * [1, 1, 1]), zv[-1] - 1.0, 33).cpu().numpy()
     assert not eng.check_oob() and np.all(np.isfinite(tec))
+
+
+def test_very_long_rays_fall_back_to_the_table_kernels():
+    """Ns above the LDS weight-table limit of the v2 kernels (4096) takes the table-uniform kernels."""
+    from oracle import oracle_c as OC
+    w = syn.make_workload("cfg1")
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    oo, dd = w["origins"].reshape(-1, 3)[:5], w["directions"].reshape(-1, 3)[:5]
+    for Ns in (4096, 4097, 6001):
+        ref = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], w["ne"] / 1e13, oo, dd, w["tmax"], Ns)
+        tec = eng.forward(eng.tensor(oo), eng.tensor(dd), w["tmax"], Ns).cpu().numpy()
+        assert np.max(np.abs(tec - ref) / np.abs(ref)) < 1e-12
+        y = np.arange(1.0, 6.0)
+        g = eng.adjoint(eng.tensor(oo), eng.tensor(dd), eng.tensor(y), w["tmax"], Ns).cpu().numpy()
+        gref = OC.adjoint_straight(w["xvec"], w["yvec"], w["zvec"], oo, dd, y, w["tmax"], Ns)
+        assert np.max(np.abs(g - gref)) < 1e-11 * np.max(np.abs(gref))
