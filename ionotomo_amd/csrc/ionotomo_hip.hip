@@ -1002,7 +1002,7 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
             const double s3 = wave_sum_dpp(live * a.u.dfy), s4 = wave_sum_dpp(live * a.u.fz0), s5 = wave_sum_dpp(live * a.u.dfz);
             const double s7 = wave_sum_dpp(live);
             double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
-            if (round == 0) {
+            {
                 b0 = wave_minmax_dpp<false>(lv ? a.u.fx0 : BIG);
                 b1 = wave_minmax_dpp<true>(lv ? a.u.fx0 : -BIG);
                 b2 = wave_minmax_dpp<false>(lv ? a.u.fy0 : BIG);
@@ -1015,7 +1015,7 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
             if (lane == 0) {
                 double *rp = ref + 16 * wid;
                 rp[0] = s0, rp[1] = s1, rp[2] = s2, rp[3] = s3, rp[4] = s4, rp[5] = s5, rp[7] = s7;
-                if (round == 0) rp[8] = b0, rp[9] = b1, rp[10] = b2, rp[11] = b3, rp[12] = b4, rp[13] = b5, rp[14] = b6, rp[15] = b7;
+                rp[8] = b0, rp[9] = b1, rp[10] = b2, rp[11] = b3, rp[12] = b4, rp[13] = b5, rp[14] = b6, rp[15] = b7;
             }
             __syncthreads();
             if (round == 1) break;
@@ -1053,10 +1053,17 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
             __syncthreads();
             continue;
         }
-        // reference ray = mean of the bundle's weighted rays; the tile windows are centred on it
+        // reference line of the bundle: through the centres of its bounding boxes at the bottom and at the
+        // top (a bundle that passed the spread test then lies entirely inside the windows); z from the mean
         const double inl = 1.0 / nlive;
-        const double rfx0 = (ref[0] + ref[16] + ref[32] + ref[48]) * inl, rdfx = (ref[1] + ref[17] + ref[33] + ref[49]) * inl;
-        const double rfy0 = (ref[2] + ref[18] + ref[34] + ref[50]) * inl, rdfy = (ref[3] + ref[19] + ref[35] + ref[51]) * inl;
+        double bx0 = BIG, bx1 = -BIG, by0 = BIG, by1 = -BIG, tx0 = BIG, tx1 = -BIG, ty0 = BIG, ty1 = -BIG;
+        for (int w2 = 0; w2 < 4; ++w2) {
+            const double *rp = ref + 16 * w2;
+            bx0 = fmin(bx0, rp[8]), bx1 = fmax(bx1, rp[9]), by0 = fmin(by0, rp[10]), by1 = fmax(by1, rp[11]);
+            tx0 = fmin(tx0, rp[12]), tx1 = fmax(tx1, rp[13]), ty0 = fmin(ty0, rp[14]), ty1 = fmax(ty1, rp[15]);
+        }
+        const double rfx0 = 0.5 * (bx0 + bx1), rdfx = (0.5 * (tx0 + tx1) - rfx0) / klast;
+        const double rfy0 = 0.5 * (by0 + by1), rdfy = (0.5 * (ty0 + ty1) - rfy0) / klast;
         const double rfz0 = (ref[4] + ref[20] + ref[36] + ref[52]) * inl, rdfz = (ref[5] + ref[21] + ref[37] + ref[53]) * inl;
         for (int it = 0; it < nslab; ++it) {
             const int k0 = it << 6;
