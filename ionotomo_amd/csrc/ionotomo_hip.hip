@@ -998,9 +998,7 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
             const bool lv = a.scale != 0.0;
             const double live = lv ? 1.0 : 0.0;
             const double xe = fma(klast, a.u.dfx, a.u.fx0), ye = fma(klast, a.u.dfy, a.u.fy0);
-            const double s0 = wave_sum_dpp(live * a.u.fx0), s1 = wave_sum_dpp(live * a.u.dfx), s2 = wave_sum_dpp(live * a.u.fy0);
-            const double s3 = wave_sum_dpp(live * a.u.dfy), s4 = wave_sum_dpp(live * a.u.fz0), s5 = wave_sum_dpp(live * a.u.dfz);
-            const double s7 = wave_sum_dpp(live);
+            const double s4 = wave_sum_dpp(live * a.u.fz0), s5 = wave_sum_dpp(live * a.u.dfz), s7 = wave_sum_dpp(live);
             double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
             {
                 b0 = wave_minmax_dpp<false>(lv ? a.u.fx0 : BIG);
@@ -1014,7 +1012,7 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
             }
             if (lane == 0) {
                 double *rp = ref + 16 * wid;
-                rp[0] = s0, rp[1] = s1, rp[2] = s2, rp[3] = s3, rp[4] = s4, rp[5] = s5, rp[7] = s7;
+                rp[4] = s4, rp[5] = s5, rp[7] = s7;
                 rp[8] = b0, rp[9] = b1, rp[10] = b2, rp[11] = b3, rp[12] = b4, rp[13] = b5, rp[14] = b6, rp[15] = b7;
             }
             __syncthreads();

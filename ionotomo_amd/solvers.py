@@ -77,9 +77,14 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
     end, so an iteration never waits for the host (``callback`` forces a read-back per iteration)."""
     x = x0.clone()
     Wh = torch.rsqrt(problem.cdct + 1e-15)
+
+    def normal_residual(r_):                    # A^T W^(1/2) r - damp x   (grid-sized; one fused pass when damp = 0)
+        s_ = problem.adjoint(Wh * r_)
+        return s_.sub_(x, alpha=damp) if damp != 0.0 else s_
+
     _set_x(problem, x)
     r = Wh * (problem.dobs - problem.forward())
-    s = problem.adjoint(Wh * r) - damp * x
+    s = normal_residual(r)
     p = s.clone()
     gamma = torch.dot(s.reshape(-1), s.reshape(-1))
     hist = []
@@ -89,12 +94,13 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
             callback(k, x, float(hist[-1]))
         _set_x(problem, p)
         q = Wh * problem.forward()
-        alpha = gamma / (problem.dot_rays_t(q, q) + damp * torch.dot(p.reshape(-1), p.reshape(-1)))
-        x += alpha * p
-        r -= alpha * q
-        s = problem.adjoint(Wh * r) - damp * x
+        qq = problem.dot_rays_t(q, q)
+        alpha = gamma / (qq + damp * torch.dot(p.reshape(-1), p.reshape(-1)) if damp != 0.0 else qq)
+        x.addcmul_(p, alpha)                     # x += alpha p   (alpha is a 0-dim device tensor)
+        r.addcmul_(q, -alpha)
+        s = normal_residual(r)
         gnew = torch.dot(s.reshape(-1), s.reshape(-1))
-        p = s + (gnew / gamma) * p
+        p.mul_(gnew / gamma).add_(s)             # p = s + beta p, in place
         gamma = gnew
     return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
 
