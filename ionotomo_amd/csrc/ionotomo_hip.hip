@@ -956,8 +956,8 @@ __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *
     return a;
 }
 
-template <typename AT, int MODE>
-__global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
+template <typename AT, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
                                                                const double *__restrict__ dirs, const int *__restrict__ order,
                                                                const double *__restrict__ wray, const double *__restrict__ tec,
                                                                const double *__restrict__ dobs, const double *__restrict__ cdct,
@@ -966,8 +966,8 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
                                                                int *oob_flag) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
-    double *ref = wlds + ((Ns + 1) & ~1);                            // [4 waves][16] per-wave sums and bounding boxes
-    AT *tile = (AT *)(ref + 64);                                     // [T_WIN*T_WIN][T_TKP]
+    double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][16] per-wave sums and bounding boxes
+    AT *tile = (AT *)(ref + 16 * NW);                                     // [T_WIN*T_WIN][T_TKP]
     int *I0 = (int *)(tile + T_WIN * T_WIN * T_TKP);                 // [T_TK] window origins per z level
     int *J0 = I0 + T_TK;
     for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
@@ -992,7 +992,7 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
         int cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
         AdjRay a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
                                       Ns, oob);
-        int c = 64;
+        int c = 16 * NW;
         for (int round = 0; round < 2; ++round) {
             // per-wave sums (for the mean ray) and bounding boxes at the bottom / top of the rays
             const bool lv = a.scale != 0.0;
@@ -1021,18 +1021,18 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
             const double lim = (double)(T_WIN - 3);
             double m0 = BIG, M0 = -BIG, m1 = BIG, M1 = -BIG, m2 = BIG, M2 = -BIG, m3 = BIG, M3 = -BIG;
             int fit = 0;
-            for (int w2 = 0; w2 < 4; ++w2) {
+            for (int w2 = 0; w2 < NW; ++w2) {
                 const double *rp = ref + 16 * w2;
                 m0 = fmin(m0, rp[8]), M0 = fmax(M0, rp[9]), m1 = fmin(m1, rp[10]), M1 = fmax(M1, rp[11]);
                 m2 = fmin(m2, rp[12]), M2 = fmax(M2, rp[13]), m3 = fmin(m3, rp[14]), M3 = fmax(M3, rp[15]);
                 const bool ok = (M0 - m0 <= lim) & (M1 - m1 <= lim) & (M2 - m2 <= lim) & (M3 - m3 <= lim);
-                if (ok && (w2 == 0 || w2 == 1 || w2 == 3)) fit = w2 + 1;      // 1, 2 or 4 waves' worth of rays
+                if (ok && ((w2 + 1) & w2) == 0) fit = w2 + 1;           // 1, 2, 4 (, 8) waves' worth of rays
             }
-            c = fit == 4 ? 64 : (fit == 2 ? 32 : 16);
-            if (c == 64) break;
+            c = 16 * max(fit, 1);
+            if (c == 16 * NW) break;
             // spread too wide: shrink the bundle and re-deal its rays evenly over the four waves
             __syncthreads();
-            q = c >> 2;
+            q = c / NW;
             qw = q0 + (int64_t)q * wid;
             cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
             a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax, Ns,
@@ -1046,7 +1046,8 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
                                          fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k]);
             }
         }
-        const double nlive = ref[7] + ref[23] + ref[39] + ref[55];
+        double nlive = 0.0, sz0 = 0.0, sdz = 0.0;
+        for (int w2 = 0; w2 < NW; ++w2) nlive += ref[16 * w2 + 7], sz0 += ref[16 * w2 + 4], sdz += ref[16 * w2 + 5];
         if (nlive == 0.0) {            // nothing to do in this bundle (block-uniform)
             __syncthreads();
             continue;
@@ -1055,14 +1056,14 @@ __global__ __launch_bounds__(256) void k_adjoint_straight_tile(GridView g, const
         // top (a bundle that passed the spread test then lies entirely inside the windows); z from the mean
         const double inl = 1.0 / nlive;
         double bx0 = BIG, bx1 = -BIG, by0 = BIG, by1 = -BIG, tx0 = BIG, tx1 = -BIG, ty0 = BIG, ty1 = -BIG;
-        for (int w2 = 0; w2 < 4; ++w2) {
+        for (int w2 = 0; w2 < NW; ++w2) {
             const double *rp = ref + 16 * w2;
             bx0 = fmin(bx0, rp[8]), bx1 = fmax(bx1, rp[9]), by0 = fmin(by0, rp[10]), by1 = fmax(by1, rp[11]);
             tx0 = fmin(tx0, rp[12]), tx1 = fmax(tx1, rp[13]), ty0 = fmin(ty0, rp[14]), ty1 = fmax(ty1, rp[15]);
         }
         const double rfx0 = 0.5 * (bx0 + bx1), rdfx = (0.5 * (tx0 + tx1) - rfx0) / klast;
         const double rfy0 = 0.5 * (by0 + by1), rdfy = (0.5 * (ty0 + ty1) - rfy0) / klast;
-        const double rfz0 = (ref[4] + ref[20] + ref[36] + ref[52]) * inl, rdfz = (ref[5] + ref[21] + ref[37] + ref[53]) * inl;
+        const double rfz0 = sz0 * inl, rdfz = sdz * inl;
         for (int it = 0; it < nslab; ++it) {
             const int k0 = it << 6;
             const int kz0 = max((int)fma((double)k0, rdfz, rfz0) - 1, 0);
@@ -2009,22 +2010,30 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
     const dim3 block(256);
     if (ideal_path_ok(c, Ns) && c->variant != 2) {
         const size_t esz = accum == IONO_F64 ? 8 : 4;
-        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + 64 * sizeof(double) +
+        constexpr int NWv = 4;    // waves per workgroup (8 waves sharing one tile, bundles of 128: measured 8 % slower)
+        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + 16 * NWv * sizeof(double) +
                           esz * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
-#define LAUNCH_ADJT(AT, MODE)                                                                                              \
+#define LAUNCH_ADJT(AT, MODE, NW)                                                                                          \
     do {                                                                                                                   \
-        int nb = resident_blocks(c, k_adjoint_straight_tile<AT, MODE>, tl);                                                \
-        const int64_t nbund = (R + 63) / 64;                                                                               \
+        int per_cu = 0;                                                                                                    \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_adjoint_straight_tile<AT, MODE, NW>, 64 * NW, tl) !=   \
+                hipSuccess || per_cu < 1)                                                                                  \
+            per_cu = 1;                                                                                                    \
+        int nb = per_cu * c->num_cus;                                                                                      \
+        const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);                                                               \
         if (nb > nbund) nb = (int)nbund;                                                                                   \
         if (nb >= 8) nb = nb / 8 * 8;                                                                                      \
-        hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE>), dim3(nb), block, tl, c->stream, g, o, d, order, w, tec,   \
-                           dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->walk_mode, c->d_unitw, (AT *)grad, c->d_flags);        \
+        hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE, NW>), dim3(nb), dim3(64 * NW), tl, c->stream, g, o, d,      \
+                           order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->walk_mode, c->d_unitw, (AT *)grad,     \
+                           c->d_flags);                                                                                    \
     } while (0)
+#define LAUNCH_ADJT_NW(AT, MODE) LAUNCH_ADJT(AT, MODE, NWv)
         if (accum == IONO_F64) {
-            if (mode == 0) LAUNCH_ADJT(double, 0); else LAUNCH_ADJT(double, 1);
+            if (mode == 0) LAUNCH_ADJT_NW(double, 0); else LAUNCH_ADJT_NW(double, 1);
         } else {
-            if (mode == 0) LAUNCH_ADJT(float, 0); else LAUNCH_ADJT(float, 1);
+            if (mode == 0) LAUNCH_ADJT_NW(float, 0); else LAUNCH_ADJT_NW(float, 1);
         }
+#undef LAUNCH_ADJT_NW
 #undef LAUNCH_ADJT
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
