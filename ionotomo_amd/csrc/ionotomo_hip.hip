@@ -480,8 +480,8 @@ __global__ __launch_bounds__(256) void k_forward_straight_fast(GridView g, const
 // the <= 8 tail samples when Ns is not a multiple of 64) is done LANE-PARALLEL for a group of up
 // to 16 rays (lane = ray) and broadcast with v_readlane; the Simpson sum is a DPP row_shr /
 // row_bcast reduction (no LDS round trips); the weight table lives in LDS.  `order` (optional)
-// is a permutation of the rays: callers sort rays so that neighbours in the walk are neighbours in
-// space, which turns L2 traffic into L1 hits.
+// is a permutation of the rays giving the walk order (it matters for the adjoint's LDS
+// pre-reduction; for this kernel it measured neutral).
 #define U_MAXG 16
 
 template <int CTRL, int ROW_MASK>
@@ -578,9 +578,6 @@ __device__ __forceinline__ double lerp_corners(const Corners<GT> &c) {
     const double c1 = c10 + c.ty * (c11 - c10);
     return c0 + c.tx * (c1 - c0);
 }
-// The grid allocation is padded by one plane + one row + 2 zero elements (iono_grid_set), so a
-// sample sitting exactly on the top face of an axis (cell index n-1, weight 0 on the far corner)
-// may read the far corner without a clamp: it is multiplied by 0.
 template <typename GT>
 __device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const GT *__restrict__ b01,
                                               const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz, double fx,
@@ -1579,7 +1576,9 @@ size_t lds_bytes(const iono_ctx *c) { return sizeof(double) * (size_t)(c->nx + c
 int64_t ncells(const iono_ctx *c) { return (int64_t)c->nx * c->ny * c->nz; }
 // fast kernels: all three axes uniform (cell guess off by at most one), 32-bit element offsets
 bool fast_path_ok(const iono_ctx *c) {
-    return c->uniform[0] && c->uniform[1] && c->uniform[2] && ncells(c) < ((int64_t)1 << 31) && c->force_general != 1;
+    // 32-bit BYTE offsets (SGPR base + VGPR offset addressing), padded far-corner reads included
+    const uint64_t bytes = ((uint64_t)ncells(c) + (uint64_t)c->ny * c->nz + c->nz + 2) * (c->storage == IONO_F64 ? 8 : 4);
+    return c->uniform[0] && c->uniform[1] && c->uniform[2] && bytes < ((uint64_t)1 << 32) && c->force_general != 1;
 }
 bool ideal_path_ok(const iono_ctx *c) { return fast_path_ok(c) && c->ideal && c->force_general == 0; }
 // the v2 kernels keep the Ns quadrature weights in LDS
@@ -1612,6 +1611,9 @@ int chunk_grid_blocks(int resident, int64_t R) {
 int need_grid(iono_ctx *c) {
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
     if (!c->d_M) return fail(c, IONO_ERR_ARG, "no grid set (call iono_grid_set first)");
+    // every allocation / launch below belongs to the ctx's GPU (one process per GPU is the model, but a
+    // caller whose current device differs must not end up allocating on the wrong card)
+    HIP_TRY(c, hipSetDevice(c->device));
     return IONO_OK;
 }
 
