@@ -1,0 +1,367 @@
+// adjoint (back-projection) kernels: plain atomics and the LDS-privatised tile kernel
+#ifndef IONO_ADJOINT_KERNELS_H
+#define IONO_ADJOINT_KERNELS_H
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// adjoint kernels: exact transpose of trilinear + quadrature (SURVEY section 8a, A7')
+// ------------------------------------------------------------------------------------------------
+template <typename AT>
+__device__ __forceinline__ void scatter_trilinear(const GridView &g, const Axes &ax, AT *__restrict__ G, double x, double y,
+                                                  double z, double c) {
+    const int i = find_cell(ax.x, ax.nx, x, g.inv_h[0], g.uniform[0]);
+    const int j = find_cell(ax.y, ax.ny, y, g.inv_h[1], g.uniform[1]);
+    const int k = find_cell(ax.z, ax.nz, z, g.inv_h[2], g.uniform[2]);
+    const double tx = (x - ax.x[i]) / (ax.x[i + 1] - ax.x[i]);
+    const double ty = (y - ax.y[j]) / (ax.y[j + 1] - ax.y[j]);
+    const double tz = (z - ax.z[k]) / (ax.z[k + 1] - ax.z[k]);
+    AT *p = G + ((size_t)i * g.ny + j) * g.nz + k;
+    const size_t sj = g.nz, si = (size_t)g.ny * g.nz;
+    const double w0 = c * (1 - tx), w1 = c * tx;
+    const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
+    atomicAdd(p, (AT)(w00 * (1 - tz)));
+    atomicAdd(p + 1, (AT)(w00 * tz));
+    atomicAdd(p + sj, (AT)(w01 * (1 - tz)));
+    atomicAdd(p + sj + 1, (AT)(w01 * tz));
+    atomicAdd(p + si, (AT)(w10 * (1 - tz)));
+    atomicAdd(p + si + 1, (AT)(w10 * tz));
+    atomicAdd(p + si + sj, (AT)(w11 * (1 - tz)));
+    atomicAdd(p + si + sj + 1, (AT)(w11 * tz));
+}
+
+// MODE 0: weights given (w[R]);  MODE 1: fused residual -> differential weights for layout
+// [Na][NtNd]: dd = (tec - tec[i0] - dobs)/(CdCt + 1e-15) (inversion/gradient.py:77-81),
+// w = dd - [a == i0] sum_a' dd[a']  (transpose of "tec - tec[i0]", forward_equation.py:50)
+template <typename AT, int MODE>
+__global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const double *__restrict__ origins,
+                                                          const double *__restrict__ dirs, const double *__restrict__ wray,
+                                                          const double *__restrict__ tec, const double *__restrict__ dobs,
+                                                          const double *__restrict__ cdct, int Na, int64_t NtNd, int i0,
+                                                          int64_t R, double tmax, int Ns, const double *__restrict__ unitw,
+                                                          AT *__restrict__ G, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        double wr;
+        if (MODE == 0) {
+            wr = wray[w.r];
+        } else {
+            const int a = (int)(w.r / NtNd);
+            const int64_t p = w.r % NtNd;
+            const double tref = tec[(int64_t)i0 * NtNd + p];
+            wr = (tec[w.r] - tref - dobs[w.r]) / (cdct[w.r] + 1e-15);
+            if (a == i0) {
+                double s = 0.0;
+                for (int a2 = lane; a2 < Na; a2 += 64) {
+                    const int64_t r2 = (int64_t)a2 * NtNd + p;
+                    s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
+                }
+                wr -= wave_sum(s);
+            }
+        }
+        if (wr == 0.0) continue;
+        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+        const double scale = wr * q.h;
+        for (int k = lane; k < Ns; k += 64) {
+            double x, y, z;
+            straight_point(q, k, Ns, x, y, z);
+            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            scatter_trilinear<AT>(g, ax, G, x, y, z, scale * unitw[k]);
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- privatised adjoint (ideal-uniform grids) --------------------------------------------------------
+// Plain atomics run at ~0.3 TB/s here: every ray of a station crosses the same low-altitude cells,
+// and rays of neighbouring stations / consecutive timesteps nearly coincide all the way up, so the
+// same addresses are hit thousands of times.  This kernel pre-reduces in LDS.  A workgroup takes a
+// BUNDLE of 64 consecutive rays of the walk (callers order the walk so that consecutive rays are
+// neighbours in space).  Per slab of 64 samples it keeps a SHEARED tile in LDS: for each of T_TK z
+// levels an 8 x 8 window of nodes whose origin follows the bundle's reference ray (its first valid
+// ray) at that level.  Contributions falling inside the tile are LDS float atomics (lanes =
+// consecutive z levels -> consecutive LDS words, conflict-free); anything outside goes straight to
+// global atomics, so the result never depends on how good the ordering is.  After the slab the
+// tile's non-zero nodes are flushed with ONE global atomic each.
+#define T_WIN 8
+#define T_TK 72
+#define T_TKP 73
+
+template <typename AT>
+__device__ __forceinline__ void tile_or_global_add(AT *tile, AT *__restrict__ G, const int *I0, const int *J0, int m, int i, int j,
+                                                   int kk, int ny, int nz, double w00, double w01, double w10, double w11,
+                                                   int dbg = 0) {
+    // the four (i..i+1, j..j+1) nodes of z level kk (tile level m); tile if the 2x2 patch is inside the window
+    bool in = (m >= 0) & (m < T_TK);
+    int a = 0, b = 0;
+    if (in) {
+        a = i - I0[m];
+        b = j - J0[m];
+        in = (a >= 0) & (a + 1 < T_WIN) & (b >= 0) & (b + 1 < T_WIN);
+    }
+    if (in) {
+        AT *t = tile + (a * T_WIN + b) * T_TKP + m;
+        atomicAdd(t, (AT)w00);
+        atomicAdd(t + T_TKP, (AT)w01);
+        atomicAdd(t + T_WIN * T_TKP, (AT)w10);
+        atomicAdd(t + (T_WIN + 1) * T_TKP, (AT)w11);
+    } else if (!(dbg & 4)) {
+        AT *p = G + ((size_t)i * ny + j) * nz + kk;
+        atomicAdd(p, (AT)w00);
+        atomicAdd(p + nz, (AT)w01);
+        atomicAdd(p + (size_t)ny * nz, (AT)w10);
+        atomicAdd(p + (size_t)ny * nz + nz, (AT)w11);
+    }
+}
+
+template <typename AT>
+__device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
+                                                     int kz0, double fx, double fy, double fz, double c, int dbg = 0) {
+    const int i = min((int)fx, g.nx - 2), j = min((int)fy, g.ny - 2), k = min((int)fz, g.nz - 2);
+    const double tx = fx - (double)i, ty = fy - (double)j, tz = fz - (double)k;
+    const double w0 = c * (1 - tx), w1 = c * tx;
+    const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
+    const int m = k - kz0;
+    tile_or_global_add<AT>(tile, G, I0, J0, m, i, j, k, g.ny, g.nz, w00 * (1 - tz), w01 * (1 - tz), w10 * (1 - tz), w11 * (1 - tz), dbg);
+    tile_or_global_add<AT>(tile, G, I0, J0, m + 1, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz, dbg);
+}
+
+// residual -> differential weight of ray r = (a, p) in layout [Na][NtNd] (see k_adjoint_straight MODE 1)
+__device__ __forceinline__ double residual_weight(const double *__restrict__ tec, const double *__restrict__ dobs,
+                                                  const double *__restrict__ cdct, int Na, int64_t NtNd, int i0, int64_t r) {
+    const int a = (int)(r / NtNd);
+    const int64_t p = r % NtNd;
+    const double tref = tec[(int64_t)i0 * NtNd + p];
+    double wr = (tec[r] - tref - dobs[r]) / (cdct[r] + 1e-15);
+    if (a == i0) {
+        double s = 0.0;
+        for (int a2 = 0; a2 < Na; ++a2) {
+            const int64_t r2 = (int64_t)a2 * NtNd + p;
+            s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
+        }
+        wr -= s;
+    }
+    return wr;
+}
+
+// min / max over the 64 lanes (wave-uniform result), same DPP ladder as wave_sum_dpp
+template <int CTRL, int ROW_MASK, bool IS_MAX>
+__device__ __forceinline__ double dpp_minmax(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const double o = __hiloint2double(hi2, lo2);
+    return IS_MAX ? fmax(v, o) : fmin(v, o);
+}
+template <bool IS_MAX>
+__device__ __forceinline__ double wave_minmax_dpp(double v) {
+    v = dpp_minmax<0x111, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x112, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x114, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x118, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x142, 0xa, IS_MAX>(v);
+    v = dpp_minmax<0x143, 0xc, IS_MAX>(v);
+    return bcast_lane(v, 63);
+}
+
+struct AdjRay {
+    URay u;
+    double scale;
+};
+// lane-parallel load of `q` rays per wave starting at walk position qw (lanes >= cnt idle)
+template <int MODE>
+__device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *origins, const double *dirs, const int *order,
+                                               const double *wray, const double *tec, const double *dobs, const double *cdct,
+                                               int Na, int64_t NtNd, int i0, int64_t q, bool active, double tmax, int Ns,
+                                               bool &oob) {
+    AdjRay a;
+    a.u = URay{};
+    a.scale = 0.0;
+    if (active) {
+        const int64_t r = order ? (int64_t)order[q] : q;
+        a.u = load_uray(g, origins, dirs, r, tmax, Ns);
+        const double wr = MODE == 0 ? wray[r] : residual_weight(tec, dobs, cdct, Na, NtNd, i0, r);
+        if (a.u.valid) a.scale = wr * a.u.h; else oob = true;
+    }
+    return a;
+}
+
+template <typename AT, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
+                                                               const double *__restrict__ dirs, const int *__restrict__ order,
+                                                               const double *__restrict__ wray, const double *__restrict__ tec,
+                                                               const double *__restrict__ dobs, const double *__restrict__ cdct,
+                                                               int Na, int64_t NtNd, int i0, int64_t R, double tmax, int Ns,
+                                                               int dbg, const double *__restrict__ unitw, AT *__restrict__ G,
+                                                               int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *wlds = (double *)smem;                                   // [Ns] quadrature weights
+    double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][16] per-wave sums and bounding boxes
+    AT *tile = (AT *)(ref + 16 * NW);                                     // [T_WIN*T_WIN][T_TKP]
+    int *I0 = (int *)(tile + T_WIN * T_WIN * T_TKP);                 // [T_TK] window origins per z level
+    int *J0 = I0 + T_TK;
+    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
+    for (int t = threadIdx.x; t < T_WIN * T_WIN * T_TKP; t += blockDim.x) tile[t] = (AT)0;
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int nfull = Ns >> 6, ntail0 = nfull << 6;
+    const bool tail_by_lane = (Ns - ntail0) <= 8;
+    const int nslab = tail_by_lane ? nfull : nfull + 1;
+    const double klast = (double)(Ns - 1);
+    // contiguous balanced range of the walk per workgroup (XCD-major)
+    int64_t bidx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bidx = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t base = R / gridDim.x, rem = R % gridDim.x;
+    const int64_t lo = bidx * base + min(bidx, rem), hi = lo + base + (bidx < rem ? 1 : 0);
+    const double BIG = 1e300;
+    bool oob = false;
+    __syncthreads();
+    for (int64_t q0 = lo; q0 < hi;) {
+        // ---- candidate bundle: up to 64 rays, wave w lanes 0..15 own walk positions q0 + 16 w + l ----------
+        int q = 16;                                     // rays per wave
+        int64_t qw = q0 + (int64_t)q * wid;
+        int cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
+        AdjRay a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
+                                      Ns, oob);
+        int c = 16 * NW;
+        for (int round = 0; round < 2; ++round) {
+            // per-wave sums (for the mean ray) and bounding boxes at the bottom / top of the rays
+            const bool lv = a.scale != 0.0;
+            const double live = lv ? 1.0 : 0.0;
+            const double xe = fma(klast, a.u.dfx, a.u.fx0), ye = fma(klast, a.u.dfy, a.u.fy0);
+            const double s4 = wave_sum_dpp(live * a.u.fz0), s5 = wave_sum_dpp(live * a.u.dfz), s7 = wave_sum_dpp(live);
+            double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
+            {
+                b0 = wave_minmax_dpp<false>(lv ? a.u.fx0 : BIG);
+                b1 = wave_minmax_dpp<true>(lv ? a.u.fx0 : -BIG);
+                b2 = wave_minmax_dpp<false>(lv ? a.u.fy0 : BIG);
+                b3 = wave_minmax_dpp<true>(lv ? a.u.fy0 : -BIG);
+                b4 = wave_minmax_dpp<false>(lv ? xe : BIG);
+                b5 = wave_minmax_dpp<true>(lv ? xe : -BIG);
+                b6 = wave_minmax_dpp<false>(lv ? ye : BIG);
+                b7 = wave_minmax_dpp<true>(lv ? ye : -BIG);
+            }
+            if (lane == 0) {
+                double *rp = ref + 16 * wid;
+                rp[4] = s4, rp[5] = s5, rp[7] = s7;
+                rp[8] = b0, rp[9] = b1, rp[10] = b2, rp[11] = b3, rp[12] = b4, rp[13] = b5, rp[14] = b6, rp[15] = b7;
+            }
+            __syncthreads();
+            if (round == 1) break;
+            // largest c in {64, 32, 16} whose rays stay within the tile window at both ends (block-uniform)
+            const double lim = (double)(T_WIN - 3);
+            double m0 = BIG, M0 = -BIG, m1 = BIG, M1 = -BIG, m2 = BIG, M2 = -BIG, m3 = BIG, M3 = -BIG;
+            int fit = 0;
+            for (int w2 = 0; w2 < NW; ++w2) {
+                const double *rp = ref + 16 * w2;
+                m0 = fmin(m0, rp[8]), M0 = fmax(M0, rp[9]), m1 = fmin(m1, rp[10]), M1 = fmax(M1, rp[11]);
+                m2 = fmin(m2, rp[12]), M2 = fmax(M2, rp[13]), m3 = fmin(m3, rp[14]), M3 = fmax(M3, rp[15]);
+                const bool ok = (M0 - m0 <= lim) & (M1 - m1 <= lim) & (M2 - m2 <= lim) & (M3 - m3 <= lim);
+                if (ok && ((w2 + 1) & w2) == 0) fit = w2 + 1;           // 1, 2, 4 (, 8) waves' worth of rays
+            }
+            c = 16 * max(fit, 1);
+            if (c == 16 * NW) break;
+            // spread too wide: shrink the bundle and re-deal its rays evenly over the four waves
+            __syncthreads();
+            q = c / NW;
+            qw = q0 + (int64_t)q * wid;
+            cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
+            a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax, Ns,
+                                   oob);
+        }
+        q0 += c;
+        if (a.scale != 0.0 && tail_by_lane) {               // the <= 8 tail samples: straight to global memory
+            for (int k = ntail0; k < Ns; ++k) {
+                const double kd = (double)k;
+                scatter_sample_tiled<AT>(g, tile, G, I0, J0, -(1 << 28), fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
+                                         fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k]);
+            }
+        }
+        double nlive = 0.0, sz0 = 0.0, sdz = 0.0;
+        for (int w2 = 0; w2 < NW; ++w2) nlive += ref[16 * w2 + 7], sz0 += ref[16 * w2 + 4], sdz += ref[16 * w2 + 5];
+        if (nlive == 0.0) {            // nothing to do in this bundle (block-uniform)
+            __syncthreads();
+            continue;
+        }
+        // reference line of the bundle: through the centres of its bounding boxes at the bottom and at the
+        // top (a bundle that passed the spread test then lies entirely inside the windows); z from the mean
+        const double inl = 1.0 / nlive;
+        double bx0 = BIG, bx1 = -BIG, by0 = BIG, by1 = -BIG, tx0 = BIG, tx1 = -BIG, ty0 = BIG, ty1 = -BIG;
+        for (int w2 = 0; w2 < NW; ++w2) {
+            const double *rp = ref + 16 * w2;
+            bx0 = fmin(bx0, rp[8]), bx1 = fmax(bx1, rp[9]), by0 = fmin(by0, rp[10]), by1 = fmax(by1, rp[11]);
+            tx0 = fmin(tx0, rp[12]), tx1 = fmax(tx1, rp[13]), ty0 = fmin(ty0, rp[14]), ty1 = fmax(ty1, rp[15]);
+        }
+        const double rfx0 = 0.5 * (bx0 + bx1), rdfx = (0.5 * (tx0 + tx1) - rfx0) / klast;
+        const double rfy0 = 0.5 * (by0 + by1), rdfy = (0.5 * (ty0 + ty1) - rfy0) / klast;
+        const double rfz0 = sz0 * inl, rdfz = sdz * inl;
+        for (int it = 0; it < nslab; ++it) {
+            const int k0 = it << 6;
+            const int kz0 = max((int)fma((double)k0, rdfz, rfz0) - 1, 0);
+            if (threadIdx.x < T_TK) {     // window origin per z level: follow the reference ray
+                const double kk = ((double)(kz0 + (int)threadIdx.x) - rfz0) / rdfz;      // (real) sample index at that level
+                I0[threadIdx.x] = (int)floor(fma(kk, rdfx, rfx0)) - (T_WIN / 2 - 1);
+                J0[threadIdx.x] = (int)floor(fma(kk, rdfy, rfy0)) - (T_WIN / 2 - 1);
+            }
+            __syncthreads();
+            for (int gi = 0; gi < cnt; ++gi) {
+                const double sc = bcast_lane(a.scale, gi);
+                if (sc == 0.0) continue;
+                const int k = k0 + lane;
+                if (k < Ns && (tail_by_lane ? k < ntail0 : true)) {
+                    const double kd = (double)k;
+                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
+                                             fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
+                                             fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi)), sc * wlds[k], dbg);
+                }
+            }
+            __syncthreads();
+            // ---- flush + re-zero: one global atomic per touched node -------------------------------------
+            for (int e = threadIdx.x; e < T_WIN * T_WIN * T_TKP; e += blockDim.x) {
+                const AT v = tile[e];
+                if (v != (AT)0) {
+                    tile[e] = (AT)0;
+                    const int cell = e / T_TKP, m = e - cell * T_TKP;
+                    const int gi_ = I0[m] + cell / T_WIN, gj_ = J0[m] + cell % T_WIN, gk_ = kz0 + m;
+                    if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz && !(dbg & 8))
+                        atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, v);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+template <typename AT>
+__global__ __launch_bounds__(256) void k_adjoint_rays(GridView g, const double *__restrict__ rays,
+                                                      const double *__restrict__ wray, int64_t R, int Ns, int rule,
+                                                      AT *__restrict__ G, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
+        const double wr = wray[w.r];
+        if (wr == 0.0) continue;
+        for (int k = lane; k < Ns; k += 64) {
+            const double x = rx[k], y = ry[k], z = rz[k];
+            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            scatter_trilinear<AT>(g, ax, G, x, y, z, wr * quad_weight(rs, Ns, k, rule));
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+}  // namespace
+
+#endif

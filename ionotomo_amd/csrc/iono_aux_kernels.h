@@ -1,0 +1,370 @@
+// elementwise kernels, C_m smoothing, point interpolation, straight / Fermat ray tracers
+#ifndef IONO_AUX_KERNELS_H
+#define IONO_AUX_KERNELS_H
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// small elementwise / geometry kernels
+// ------------------------------------------------------------------------------------------------
+template <typename GT>
+__global__ void k_set_values(const double *__restrict__ src, GT *__restrict__ dst, int64_t n, int do_exp, double scale,
+                             int *nonfinite) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v = src[i];
+        if (do_exp) v = exp(v) * scale;
+        if (!isfinite(v)) bad = true;
+        dst[i] = (GT)v;
+    }
+    if (bad) atomicOr(nonfinite, 1);
+}
+
+template <typename GT>
+__global__ void k_get_values(const GT *__restrict__ src, double *__restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = (double)src[i];
+}
+
+// n = sqrt(1 - 8.980^2 ne / nu^2) at the nodes (inversion/fermat.py:36-46)
+template <typename GT>
+__global__ void k_ne_to_n(const GT *__restrict__ ne, double *__restrict__ nM, int64_t n, double freq) {
+    const double A = -PLASMA_A / (freq * freq);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        nM[i] = sqrt(1.0 + (double)ne[i] * A);
+}
+
+template <typename AT, typename GT>
+__global__ void k_scale_by_grid(AT *__restrict__ G, const GT *__restrict__ M, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        G[i] = (AT)((double)G[i] * (double)M[i]);
+}
+
+__global__ void k_subtract_reference(double *__restrict__ tec, int Na, int64_t NtNd, int i0) {
+    // rows other than i0 first (they read row i0), row i0 is zeroed by a second launch
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)Na * NtNd;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int a = idx / NtNd;
+        if (a != i0) tec[idx] -= tec[(int64_t)i0 * NtNd + idx % NtNd];
+    }
+}
+__global__ void k_zero(double *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
+}
+
+// C_m smoothing: Covariance.smooth = scipy.ndimage.convolve(phi, c_stencil, mode='nearest')
+// (ionosphere/covariance.py:46-63,383-385).  The reference's stencil is the product of three 1-D
+// exponential kernels, so the (2h+1)^3 convolution is three 1-D passes with edge replication.
+// Lanes run along z (contiguous) in every pass; taps along x / y are whole coalesced rows.
+#define CONV_T 32          // outputs along the filtered axis per workgroup (x / y passes)
+// x / y pass: a workgroup owns 64 consecutive z (lanes) x CONV_T outputs along the axis for one value
+// of the third index; the CONV_T + 2h input rows (edge rows replicated) are staged in LDS once, then
+// every thread produces CONV_T/4 outputs from LDS (2h+1 taps each).  Global loads per output:
+// (CONV_T + 2h) / CONV_T, all coalesced 512-B rows.
+template <int AXIS>
+__global__ __launch_bounds__(256) void k_conv_xy(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int nz,
+                                                 const double *__restrict__ w, int h) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *wl = sm;                      // [2h+1]
+    double *tile = sm + ((2 * h + 2) & ~1);    // [CONV_T + 2h][64]
+    const int m = 2 * h + 1, rows = CONV_T + 2 * h;
+    for (int t = threadIdx.x; t < m; t += blockDim.x) wl[t] = w[t];
+    const int na = AXIS == 0 ? nx : ny;               // filtered axis
+    const int no = AXIS == 0 ? ny : nx;               // the other non-z axis
+    const int64_t sa = AXIS == 0 ? (int64_t)ny * nz : nz, so = AXIS == 0 ? nz : (int64_t)ny * nz;
+    const int zt = (nz + 63) / 64, at = (na + CONV_T - 1) / CONV_T;
+    const int64_t ntile = (int64_t)zt * at * no;
+    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    for (int64_t tid = blockIdx.x; tid < ntile; tid += gridDim.x) {
+        const int z0 = (int)(tid % zt) * 64;
+        const int a0 = (int)((tid / zt) % at) * CONV_T;
+        const int o = (int)(tid / ((int64_t)zt * at));
+        const int k = z0 + lane;
+        __syncthreads();
+        if (k < nz) {
+            const double *base = in + (int64_t)o * so + k;
+            for (int r = grp; r < rows; r += 4) {
+                const int a = min(max(a0 + r - h, 0), na - 1);
+                tile[r * 64 + lane] = base[(int64_t)a * sa];
+            }
+        }
+        __syncthreads();
+        if (k < nz) {
+            for (int q = grp; q < CONV_T; q += 4) {
+                if (a0 + q >= na) break;
+                double acc = 0.0;
+                const double *tp = tile + q * 64 + lane;
+                for (int t = 0; t < m; ++t) acc += wl[m - 1 - t] * tp[t * 64];
+                out[(int64_t)o * so + (int64_t)(a0 + q) * sa + k] = acc;
+            }
+        }
+    }
+}
+
+// z pass: each wave owns 64 consecutive z of one (i, j) row; the 64 + 2h inputs go through LDS
+__global__ __launch_bounds__(256) void k_conv_z(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int nz,
+                                                const double *__restrict__ w, int h) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double *wl = sm;
+    const int m = 2 * h + 1, span = 64 + 2 * h;
+    double *tile = sm + ((2 * h + 2) & ~1) + (threadIdx.x >> 6) * span;     // per wave
+    for (int t = threadIdx.x; t < m; t += blockDim.x) wl[t] = w[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int zt = (nz + 63) / 64;
+    const int64_t nseg = (int64_t)nx * ny * zt;
+    for (int64_t sid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sid < nseg; sid += (int64_t)gridDim.x * 4) {
+        const int z0 = (int)(sid % zt) * 64;
+        const double *row = in + (sid / zt) * nz;
+        for (int t = lane; t < span; t += 64) tile[t] = row[min(max(z0 + t - h, 0), nz - 1)];
+        // same-wave LDS write -> read: the wave executes in lockstep, a waitcnt is all that is needed
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const int k = z0 + lane;
+        if (k < nz) {
+            double acc = 0.0;
+            for (int t = 0; t < m; ++t) acc += wl[m - 1 - t] * tile[lane + t];
+            out[(sid / zt) * nz + k] = acc;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename GT, int KIND, bool EXTRAP>
+__global__ void k_interp_points(GridView g, const double *__restrict__ x, const double *__restrict__ y,
+                                const double *__restrict__ z, int64_t n, double *__restrict__ out, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    bool oob = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double px = x[i], py = y[i], pz = z[i];
+        if (!EXTRAP && sample_outside<KIND>(ax, px, py, pz)) {
+            oob = true;
+            out[i] = nan("");
+            continue;
+        }
+        out[i] = sample_at<GT, KIND>(g, ax, px, py, pz);
+    }
+    if (oob) atomicOr(oob_flag, 1);
+}
+
+__global__ void k_trace_straight(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
+                                 int Ns, double *__restrict__ rays) {
+    const int64_t n = R * Ns;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / Ns;
+        const int k = idx % Ns;
+        const StraightRay q = load_straight(origins, dirs, r, tmax, Ns);
+        double x, y, z;
+        straight_point(q, k, Ns, x, y, z);
+        double *o = rays + (size_t)r * 4 * Ns;
+        o[k] = x;
+        o[Ns + k] = y;
+        o[2 * Ns + k] = z;
+        const double frac = (k == Ns - 1) ? 1.0 : (double)k * q.step;
+        o[3 * Ns + k] = q.L * frac / q.pz;     // s = (z - z0)/pz
+    }
+}
+
+// Fermat ray ODE in z (inversion/fermat.py:64-72; notebooks/FermatClass.ipynb c0:76-84):
+//   s' = n/pz, p' = grad(n) n/pz, x' = px/pz, y' = py/pz, z' = 1.   Lanes = rays, RK4.
+struct FState {
+    double px, py, pz, x, y, z, s;
+};
+template <int KIND, bool BEND>
+__device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u) {
+    double n, nx, ny, nz;
+    if (KIND == IONO_INTERP_TRILINEAR) {
+        trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
+    } else {
+        GridView gn = g;
+        gn.M = nM;
+        tricubic_eval<double, true>(gn, g.axes, g.axes + g.nx, g.axes + g.nx + g.ny, u.x, u.y, u.z, n, nx, ny, nz);
+    }
+    if (!BEND) nx = ny = nz = 0.0;
+    const double f = n / u.pz;
+    FState d;
+    d.px = nx * f;
+    d.py = ny * f;
+    d.pz = nz * f;
+    d.x = u.px / u.pz;
+    d.y = u.py / u.pz;
+    d.z = 1.0;
+    d.s = f;
+    return d;
+}
+__device__ __forceinline__ FState axpy(const FState &u, double a, const FState &d) {
+    FState r;
+    r.px = u.px + a * d.px;
+    r.py = u.py + a * d.py;
+    r.pz = u.pz + a * d.pz;
+    r.x = u.x + a * d.x;
+    r.y = u.y + a * d.y;
+    r.z = u.z + a * d.z;
+    r.s = u.s + a * d.s;
+    return r;
+}
+template <int KIND, bool BEND>
+__global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *__restrict__ nM,
+                                                     const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                     int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
+                                                     int *oob_flag) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm;
+    u.py = dy / nrm;
+    u.pz = dz / nrm;
+    u.x = origins[3 * r];
+    u.y = origins[3 * r + 1];
+    u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    double *o = rays + (size_t)r * 4 * Ns;
+    o[0] = u.x;
+    o[Ns] = u.y;
+    o[2 * Ns] = u.z;
+    o[3 * Ns] = u.s;
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    bool oob = false;
+    for (int k = 1; k < Ns; ++k) {
+        for (int sub = 0; sub < substeps; ++sub) {
+            // classic RK4 with the four stages as a loop (one copy of the right-hand side: four inlined
+            // tricubic evaluations need > 512 VGPRs and spill): sum = k1 + 2 k2 + 2 k3 + k4
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs<KIND, BEND>(g, nM, axpy(u, ca, kprev));
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
+        o[k] = u.x;
+        o[Ns + k] = u.y;
+        o[2 * Ns + k] = u.z;
+        o[3 * Ns + k] = u.s;
+    }
+    if (oob) atomicOr(oob_flag, 1);
+}
+
+// ---- cooperative tricubic tracer: 8 lanes per ray -------------------------------------------------------
+// With lanes = rays a 2,604-ray config is 41 waves, each lane serially gathering 216 nodes per RK4
+// stage.  Here a ray is shared by 8 consecutive lanes: lane `sub` (< 6) owns x-tap `a = sub` and
+// contracts its 6 x 6 (y, z) plane (z taps are 6 contiguous doubles per load group); the four partial
+// results (n, nx, ny, nz) are summed over the 8 lanes with three DPP steps (quad_perm xor 1, xor 2,
+// row_half_mirror).  Every lane keeps the full ray state, so no broadcast is needed.
+template <int CTRL>
+__device__ __forceinline__ double dpp_xadd(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double sum8(double v) {
+    v = dpp_xadd<0xB1>(v);      // quad_perm:[1,0,3,2]
+    v = dpp_xadd<0x4E>(v);      // quad_perm:[2,3,0,1]
+    return dpp_xadd<0x141>(v);  // row_half_mirror: lane i <-> 7 - i within each group of 8
+}
+__device__ __forceinline__ void pick_tap(const double w[6], const double dw[6], int a, double &wa, double &da) {
+    wa = a == 0 ? w[0] : a == 1 ? w[1] : a == 2 ? w[2] : a == 3 ? w[3] : a == 4 ? w[4] : a == 5 ? w[5] : 0.0;
+    da = a == 0 ? dw[0] : a == 1 ? dw[1] : a == 2 ? dw[2] : a == 3 ? dw[3] : a == 4 ? dw[4] : a == 5 ? dw[5] : 0.0;
+}
+template <bool BEND>
+__device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const double *__restrict__ nM, const FState &u, int sub) {
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    double wx[6], wy[6], wz[6], dx[6], dy[6], dz[6];
+    const int i = cubic_axis(gx, g.nx, u.x, g.inv_h[0], g.uniform[0], wx, dx, true);
+    const int j = cubic_axis(gy, g.ny, u.y, g.inv_h[1], g.uniform[1], wy, dy, true);
+    const int k = cubic_axis(gz, g.nz, u.z, g.inv_h[2], g.uniform[2], wz, dz, true);
+    double wxa, dxa;
+    pick_tap(wx, dx, sub, wxa, dxa);
+    const int a = min(sub, 5);
+    const double *base = nM + ((size_t)(i - 2 + a) * g.ny + (j - 2)) * g.nz + (k - 2);
+    double fa = 0.0, fya = 0.0, fza = 0.0;
+#pragma unroll
+    for (int b = 0; b < 6; ++b) {
+        const double *p = base + (size_t)b * g.nz;
+        double sv = 0.0, sz = 0.0;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const double v = p[c];
+            sv += v * wz[c];
+            sz += v * dz[c];
+        }
+        fa += sv * wy[b];
+        fya += sv * dy[b];
+        fza += sz * wy[b];
+    }
+    const double n = sum8(fa * wxa);
+    double nx = sum8(fa * dxa), ny = sum8(fya * wxa), nz = sum8(fza * wxa);
+    if (!BEND) nx = ny = nz = 0.0;
+    const double f = n / u.pz;
+    FState d;
+    d.px = nx * f;
+    d.py = ny * f;
+    d.pz = nz * f;
+    d.x = u.px / u.pz;
+    d.y = u.py / u.pz;
+    d.z = 1.0;
+    d.s = f;
+    return d;
+}
+template <bool BEND>
+__global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const double *__restrict__ nM,
+                                                          const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                          int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
+                                                          int *oob_flag) {
+    const int sub = threadIdx.x & 7;
+    int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+    const bool live = r < R;
+    if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm;
+    u.py = dy / nrm;
+    u.pz = dz / nrm;
+    u.x = origins[3 * r];
+    u.y = origins[3 * r + 1];
+    u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    double *o = rays + (size_t)r * 4 * Ns;
+    const bool writer = live && sub == 0;
+    if (writer) {
+        o[0] = u.x;
+        o[Ns] = u.y;
+        o[2 * Ns] = u.z;
+        o[3 * Ns] = u.s;
+    }
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    bool oob = false;
+    for (int k = 1; k < Ns; ++k) {
+        for (int s2 = 0; s2 < substeps; ++s2) {
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs_coop<BEND>(g, nM, axpy(u, ca, kprev), sub);
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
+        if (writer) {
+            o[k] = u.x;
+            o[Ns + k] = u.y;
+            o[2 * Ns + k] = u.z;
+            o[3 * Ns + k] = u.s;
+        }
+    }
+    if (oob && writer) atomicOr(oob_flag, 1);
+}
+
+}  // namespace
+
+#endif

@@ -1,0 +1,435 @@
+// forward (ray-integral) kernels: general, table-uniform, ideal-uniform (v2), explicit-sample, phase
+#ifndef IONO_FORWARD_KERNELS_H
+#define IONO_FORWARD_KERNELS_H
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// forward kernels
+// ------------------------------------------------------------------------------------------------
+template <typename GT, int KIND>
+__global__ __launch_bounds__(256) void k_forward_straight(GridView g, const double *__restrict__ origins,
+                                                          const double *__restrict__ dirs, int64_t R, double tmax, int Ns,
+                                                          const double *__restrict__ unitw, double *__restrict__ tec,
+                                                          int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+        double acc = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            double x, y, z;
+            straight_point(q, k, Ns, x, y, z);
+            if (sample_outside<KIND>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            acc += unitw[k] * sample_at<GT, KIND>(g, ax, x, y, z);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) tec[w.r] = acc * q.h;
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- fast path (trilinear, numerically uniform axes, grid < 4 GB): the instruction diet ---------
+// The general kernel above is issue-bound, not memory-bound (float32 storage buys nothing): three
+// f64 divisions, per-sample bounds tests and looped cell fix-ups dominate.  Here: reciprocal cell
+// widths are tabulated in LDS beside the axes (t = (x - g[i]) * inv[i]), the cell guess
+// floor((x - g0)/h) is verified against the table with one compare pair (the exact searchsorted
+// rule runs only for lanes whose guess is off, i.e. samples within rounding of a node), the
+// bounds test is done once per ray on its two end points (a straight segment in a convex box),
+// and addressing is 32-bit.
+struct FastAxes {
+    const double *g[3];
+    const double *inv[3];
+    double g0[3];
+};
+
+__device__ __forceinline__ FastAxes stage_axes_fast(const GridView &g, double *lds) {
+    const int n = g.nx + g.ny + g.nz;
+    for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = g.axes[t];
+    __syncthreads();
+    for (int t = threadIdx.x; t < n - 1; t += blockDim.x) lds[n + t] = 1.0 / (lds[t + 1] - lds[t]);
+    __syncthreads();
+    FastAxes a;
+    a.g[0] = lds;
+    a.g[1] = lds + g.nx;
+    a.g[2] = lds + g.nx + g.ny;
+    a.inv[0] = lds + n;
+    a.inv[1] = lds + n + g.nx;
+    a.inv[2] = lds + n + g.nx + g.ny;
+    for (int d = 0; d < 3; ++d) a.g0[d] = a.g[d][0];
+    return a;
+}
+
+__device__ __forceinline__ void cell_fast(const double *g, const double *inv, int n, double g0, double ih, double x, int &i,
+                                          double &t) {
+    double f = (x - g0) * ih;
+    f = fmin(fmax(f, 0.0), (double)(n - 2));
+    i = (int)f;
+    double a = g[i];
+    const double b = g[i + 1];
+    if (__builtin_expect(!((a < x) & (x <= b)), 0)) {      // guess off by one, or x on the clipped edge
+        while (i > 0 && !(g[i] < x)) --i;
+        while (i < n - 2 && g[i + 1] < x) ++i;
+        a = g[i];
+    }
+    t = (x - a) * inv[i];
+}
+
+template <typename GT>
+__device__ __forceinline__ double trilinear_fast(const GridView &g, const FastAxes &ax, double x, double y, double z) {
+    int i, j, k;
+    double tx, ty, tz;
+    cell_fast(ax.g[0], ax.inv[0], g.nx, ax.g0[0], g.inv_h[0], x, i, tx);
+    cell_fast(ax.g[1], ax.inv[1], g.ny, ax.g0[1], g.inv_h[1], y, j, ty);
+    cell_fast(ax.g[2], ax.inv[2], g.nz, ax.g0[2], g.inv_h[2], z, k, tz);
+    const unsigned sj = (unsigned)g.nz, si = (unsigned)g.ny * (unsigned)g.nz;
+    const unsigned off = ((unsigned)i * (unsigned)g.ny + (unsigned)j) * sj + (unsigned)k;
+    const GT *p = (const GT *)g.M + off;
+    const double c000 = p[0], c001 = p[1];
+    const double c010 = p[sj], c011 = p[sj + 1];
+    const double c100 = p[si], c101 = p[si + 1];
+    const double c110 = p[si + sj], c111 = p[si + sj + 1];
+    const double c00 = c000 + tz * (c001 - c000);
+    const double c01 = c010 + tz * (c011 - c010);
+    const double c10 = c100 + tz * (c101 - c100);
+    const double c11 = c110 + tz * (c111 - c110);
+    const double c0 = c00 + ty * (c01 - c00);
+    const double c1 = c10 + ty * (c11 - c10);
+    return c0 + tx * (c1 - c0);
+}
+
+__device__ __forceinline__ bool ray_leaves_grid(const FastAxes &ax, const GridView &g, const StraightRay &q) {
+    const double xe = q.ox + q.sx * q.L, ye = q.oy + q.sy * q.L, ze = q.oz + q.L;
+    return outside(ax.g[0], g.nx, q.ox) || outside(ax.g[0], g.nx, xe) || outside(ax.g[1], g.ny, q.oy) ||
+           outside(ax.g[1], g.ny, ye) || outside(ax.g[2], g.nz, q.oz) || outside(ax.g[2], g.nz, ze);
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void k_forward_straight_fast(GridView g, const double *__restrict__ origins,
+                                                               const double *__restrict__ dirs, int64_t R, double tmax, int Ns,
+                                                               const double *__restrict__ unitw, double *__restrict__ tec,
+                                                               int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const FastAxes ax = stage_axes_fast(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+        if (ray_leaves_grid(ax, g, q)) {
+            oob = true;
+            if (lane == 0) tec[w.r] = nan("");
+            continue;
+        }
+        double acc = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            double x, y, z;
+            straight_point(q, k, Ns, x, y, z);
+            acc += unitw[k] * trilinear_fast<GT>(g, ax, x, y, z);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) tec[w.r] = acc * q.h;
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- v2 fast path: "ideal uniform" grid coordinates ------------------------------------------------
+// Taken when every axis equals g0 + i*h to within 2.5e-13 h (what np.linspace produces; checked on
+// the host), so a sample's grid coordinate is ONE fma per axis, f = f0 + k*df, its cell is
+// (int)f and its weight fract(f): no axis tables, no divisions in the loop.  Per-ray work that is
+// wave-uniform in the kernels above (normalisation, slopes, bounds test on the two end points,
+// the <= 8 tail samples when Ns is not a multiple of 64) is done LANE-PARALLEL for a group of up
+// to 16 rays (lane = ray) and broadcast with v_readlane; the Simpson sum is a DPP row_shr /
+// row_bcast reduction (no LDS round trips); the weight table lives in LDS.  `order` (optional)
+// is a permutation of the rays giving the walk order (it matters for the adjoint's LDS
+// pre-reduction; for this kernel it measured neutral).
+#define U_MAXG 16
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return v + __hiloint2double(hi2, lo2);
+}
+// sum over the 64 lanes; the total is returned wave-uniform (read from lane 63)
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v = dpp_add<0x111, 0xf>(v);    // row_shr:1
+    v = dpp_add<0x112, 0xf>(v);    // row_shr:2
+    v = dpp_add<0x114, 0xf>(v);    // row_shr:4
+    v = dpp_add<0x118, 0xf>(v);    // row_shr:8   -> lane 15 of each row holds the row total
+    v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
+    v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3 -> lane 63 holds the total
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bcast_lane(double v, int src) {     // src must be wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+struct URay {            // a straight ray in ideal grid coordinates: f(k) = f0 + k * df per axis
+    double fx0, dfx, fy0, dfy, fz0, dfz, h;
+    bool valid;
+};
+__device__ __forceinline__ URay load_uray(const GridView &g, const double *origins, const double *dirs, int64_t r, double tmax,
+                                          int Ns) {
+    const double ox = origins[3 * r], oy = origins[3 * r + 1], oz = origins[3 * r + 2];
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    const double px = dx / nrm, py = dy / nrm, pz = dz / nrm;
+    const double sx = px / pz, sy = py / pz;
+    const double L = tmax - oz;
+    const double Lstep = L * (1.0 / (double)(Ns - 1));
+    URay u;
+    u.h = Lstep / pz;
+    u.fx0 = (ox - g.g0[0]) * g.inv_h[0];
+    u.fy0 = (oy - g.g0[1]) * g.inv_h[1];
+    u.fz0 = (oz - g.g0[2]) * g.inv_h[2];
+    u.dfx = sx * Lstep * g.inv_h[0];
+    u.dfy = sy * Lstep * g.inv_h[1];
+    u.dfz = Lstep * g.inv_h[2];
+    const double xe = ox + sx * L, ye = oy + sy * L, ze = oz + L;
+    u.valid = (ox >= g.g0[0]) & (ox <= g.glast[0]) & (xe >= g.g0[0]) & (xe <= g.glast[0]) & (oy >= g.g0[1]) &
+              (oy <= g.glast[1]) & (ye >= g.g0[1]) & (ye <= g.glast[1]) & (oz >= g.g0[2]) & (oz <= g.glast[2]) &
+              (ze >= g.g0[2]) & (ze <= g.glast[2]);
+    return u;
+}
+
+// The grid allocation is padded by one plane + one row + 2 zero elements (iono_grid_set), so a
+// sample sitting exactly on the top face of an axis (cell index n-1, weight 0 on the far corner)
+// may read the far corner without a clamp: it is multiplied by 0.
+template <typename GT>
+struct Corners {
+    GT c000, c001, c010, c011, c100, c101, c110, c111;
+    double tx, ty, tz;
+};
+template <typename GT>
+__device__ __forceinline__ Corners<GT> load_corners(const GT *__restrict__ b00, const GT *__restrict__ b01,
+                                                    const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz,
+                                                    double fx, double fy, double fz) {
+    const int i = (int)fx, j = (int)fy, k = (int)fz;
+    Corners<GT> c;
+    c.tx = fx - (double)i;
+    c.ty = fy - (double)j;
+    c.tz = fz - (double)k;
+    const unsigned boff = (((unsigned)i * (unsigned)ny + (unsigned)j) * (unsigned)nz + (unsigned)k) * (unsigned)sizeof(GT);
+    const GT *p00 = (const GT *)((const char *)b00 + boff), *p01 = (const GT *)((const char *)b01 + boff);
+    const GT *p10 = (const GT *)((const char *)b10 + boff), *p11 = (const GT *)((const char *)b11 + boff);
+    c.c000 = p00[0];
+    c.c001 = p00[1];
+    c.c010 = p01[0];
+    c.c011 = p01[1];
+    c.c100 = p10[0];
+    c.c101 = p10[1];
+    c.c110 = p11[0];
+    c.c111 = p11[1];
+    return c;
+}
+template <typename GT>
+__device__ __forceinline__ double lerp_corners(const Corners<GT> &c) {
+    const double c000 = c.c000, c010 = c.c010, c100 = c.c100, c110 = c.c110;
+    const double c00 = c000 + c.tz * ((double)c.c001 - c000);
+    const double c01 = c010 + c.tz * ((double)c.c011 - c010);
+    const double c10 = c100 + c.tz * ((double)c.c101 - c100);
+    const double c11 = c110 + c.tz * ((double)c.c111 - c110);
+    const double c0 = c00 + c.ty * (c01 - c00);
+    const double c1 = c10 + c.ty * (c11 - c10);
+    return c0 + c.tx * (c1 - c0);
+}
+template <typename GT>
+__device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const GT *__restrict__ b01,
+                                              const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz, double fx,
+                                              double fy, double fz) {
+    return lerp_corners<GT>(load_corners<GT>(b00, b01, b10, b11, ny, nz, fx, fy, fz));
+}
+
+// Every wave owns one contiguous, balanced chunk of the walk (floor or ceil of R / #waves rays) and
+// goes through it in groups of up to U_MAXG rays; waves are numbered XCD-major (blocks b, b+8, ...
+// share an XCD), so each XCD's L2 sees one contiguous eighth of the rays.  The grid is sized to
+// what is resident at once, so there is no second, under-occupied round of workgroups.
+struct Chunk {
+    int64_t lo, hi, stride;     // walk positions lo, lo+stride, ... < hi
+};
+// mode 0 (default): one contiguous chunk per wave.  mode bit 0: one contiguous chunk per WORKGROUP, its
+// 4 waves interleaved (wave w takes lo+w, lo+w+4, ...).  mode bit 2: plain block order instead of
+// XCD-major.  Both alternatives measured slower or equal on the bench workload; kept for A/B runs
+// (env IONOTOMO_WALK).
+__device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
+    const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
+    int64_t bidx;
+    if ((gridDim.x & 7) == 0 && !(mode & 4)) {
+        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+        bidx = (int64_t)xcd * nslot + slot;
+    } else {
+        bidx = blockIdx.x;
+    }
+    Chunk c;
+    if (mode & 1) {
+        const int64_t nb = gridDim.x, base = R / nb, rem = R % nb;
+        const int64_t lo = bidx * base + min(bidx, rem);
+        c.hi = lo + base + (bidx < rem ? 1 : 0);
+        c.lo = lo + wid;
+        c.stride = wpb;
+    } else {
+        const int64_t widx = bidx * wpb + wid, nw = (int64_t)gridDim.x * wpb;
+        const int64_t base = R / nw, rem = R % nw;
+        c.lo = widx * base + min(widx, rem);
+        c.hi = c.lo + base + (widx < rem ? 1 : 0);
+        c.stride = 1;
+    }
+    return c;
+}
+
+template <typename GT>
+__global__ __launch_bounds__(256) void k_forward_straight_u(GridView g, const double *__restrict__ origins,
+                                                            const double *__restrict__ dirs, const int *__restrict__ order,
+                                                            int64_t R, double tmax, int Ns, int walk_mode,
+                                                            const double *__restrict__ unitw, double *__restrict__ tec,
+                                                            int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double wlds[];
+    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nfull = Ns >> 6, ntail0 = nfull << 6;        // samples [ntail0, Ns) are the tail
+    const bool tail_by_lane = (Ns - ntail0) <= 8;          // else: one more (masked) wave iteration
+    const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
+    const Chunk ch = wave_chunk(R, walk_mode);
+    const double dlane = (double)lane;
+    const double *wp = wlds + lane;
+    bool oob = false;
+    for (int64_t q0 = ch.lo; q0 < ch.hi; q0 += U_MAXG * ch.stride) {
+        const int cnt = (int)min((int64_t)U_MAXG, (ch.hi - q0 + ch.stride - 1) / ch.stride);
+        // ---- lane-parallel set-up: lane l owns ray q0 + l ------------------------------------------
+        URay u = {};
+        int64_t r = 0;
+        double tail = 0.0;
+        if (lane < cnt) {
+            const int64_t q = q0 + lane * ch.stride;
+            r = order ? (int64_t)order[q] : q;
+            u = load_uray(g, origins, dirs, r, tmax, Ns);
+            if (u.valid && tail_by_lane) {
+                for (int k = ntail0; k < Ns; ++k) {
+                    const double kd = (double)k;
+                    tail += wlds[k] * trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fma(kd, u.dfx, u.fx0),
+                                                       fma(kd, u.dfy, u.fy0), fma(kd, u.dfz, u.fz0));
+                }
+            }
+            if (!u.valid) oob = true;
+        }
+        // ---- one ray at a time, lanes = samples ----------------------------------------------------
+        double res = 0.0;
+        for (int gi = 0; gi < cnt; ++gi) {
+            const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
+            if (!ok) continue;
+            const double dfx = bcast_lane(u.dfx, gi), dfy = bcast_lane(u.dfy, gi), dfz = bcast_lane(u.dfz, gi);
+            double fx = fma(dlane, dfx, bcast_lane(u.fx0, gi));
+            double fy = fma(dlane, dfy, bcast_lane(u.fy0, gi));
+            double fz = fma(dlane, dfz, bcast_lane(u.fz0, gi));
+            const double sx64 = 64.0 * dfx, sy64 = 64.0 * dfy, sz64 = 64.0 * dfz;
+            double acc = 0.0;
+            // (a software-pipelined version of this loop -- next iteration's loads in flight during the
+            //  interpolation -- measured 15 % SLOWER: +26 VGPRs cost more occupancy than the overlap won)
+            for (int it = 0; it < nfull; ++it) {
+                acc = fma(wp[it << 6], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
+                fx += sx64;
+                fy += sy64;
+                fz += sz64;
+            }
+            if (!tail_by_lane && lane + ntail0 < Ns)
+                acc = fma(wp[ntail0], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
+            const double total = wave_sum_dpp(acc);
+            if (lane == gi) res = total;
+        }
+        if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+template <typename GT, int KIND>
+__global__ __launch_bounds__(256) void k_forward_rays(GridView g, const double *__restrict__ rays, int64_t R, int Ns,
+                                                      int rule, double *__restrict__ tec, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
+        double acc = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            const double x = rx[k], y = ry[k], z = rz[k];
+            if (sample_outside<KIND>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            acc += quad_weight(rs, Ns, k, rule) * sample_at<GT, KIND>(g, ax, x, y, z);
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) tec[w.r] = acc;
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// phase observable, per-frequency integrals of 1 - sqrt(1 - ne/n_p) (inversion/iterative_newton.py:108-119)
+template <typename GT, int MAXF>
+__global__ __launch_bounds__(256) void k_forward_phase_rays(GridView g, const double *__restrict__ rays, int64_t R, int Ns,
+                                                            int rule, const double *__restrict__ inv_np, int nf, int ldf,
+                                                            double *__restrict__ phi, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    double inp[MAXF];
+#pragma unroll
+    for (int l = 0; l < MAXF; ++l) inp[l] = l < nf ? inv_np[l] : 0.0;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
+        double acc[MAXF];
+#pragma unroll
+        for (int l = 0; l < MAXF; ++l) acc[l] = 0.0;
+        for (int k = lane; k < Ns; k += 64) {
+            const double x = rx[k], y = ry[k], z = rz[k];
+            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            const double ne = trilinear_at<GT>(g, ax, x, y, z);
+            const double c = quad_weight(rs, Ns, k, rule);
+#pragma unroll
+            for (int l = 0; l < MAXF; ++l) acc[l] += c * (1.0 - sqrt(1.0 - ne * inp[l]));
+        }
+#pragma unroll
+        for (int l = 0; l < MAXF; ++l) {
+            const double v = wave_sum(acc[l]);
+            if (lane == 0 && l < nf) phi[(size_t)w.r * ldf + l] = v;
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// g = const_i + 2 pi nu clock_ij - (phi - phi[i0]) 2 pi nu / c   (inversion/iterative_newton.py:107-123)
+__global__ void k_phase_finish(const double *__restrict__ phi, const double *__restrict__ freqs,
+                               const double *__restrict__ clock, const double *__restrict__ cst, int Na, int Nt, int Nd,
+                               int Nf, int i0, double *__restrict__ gout) {
+    const int64_t n = (int64_t)Na * Nt * Nd * Nf;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int l = idx % Nf;
+        const int64_t r = idx / Nf;
+        const int64_t td = r % ((int64_t)Nt * Nd);
+        const int a = r / ((int64_t)Nt * Nd);
+        const int t = td / Nd;
+        const double a_ = 2.0 * M_PI * freqs[l];
+        const double ph = (phi[r * Nf + l] - phi[((int64_t)i0 * Nt * Nd + td) * Nf + l]) * (a_ / SPEED_OF_LIGHT);
+        gout[idx] = cst[a] + a_ * clock[(int64_t)a * Nt + t] - ph;
+    }
+}
+
+}  // namespace
+
+#endif

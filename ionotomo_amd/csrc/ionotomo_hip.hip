@@ -29,1462 +29,14 @@
 #define PLASMA_A (8.980 * 8.980)             // inversion/fermat.py:42
 #define SPEED_OF_LIGHT 299792458.0           // inversion/iterative_newton.py:15
 
+#include "iono_device_common.h"
+#include "iono_forward_kernels.h"
+#include "iono_adjoint_kernels.h"
+#include "iono_aux_kernels.h"
+
 namespace {
-
 thread_local std::string g_last_error;
-
-// ------------------------------------------------------------------------------------------------
-// device-side grid description
-// ------------------------------------------------------------------------------------------------
-struct GridView {
-    const double *axes;   // xvec | yvec | zvec concatenated (device)
-    const void *M;        // nx*ny*nz values, float64 or float32
-    int nx, ny, nz;
-    double inv_h[3];      // 1/(mean spacing) per axis: first guess of the cell index
-    int uniform[3];       // axis is (numerically) uniform -> guess + fix-up; else binary search
-    double g0[3], glast[3];   // first / last node per axis (host copies)
-};
-
-struct Axes {             // axis tables staged in LDS
-    const double *x, *y, *z;
-    int nx, ny, nz;
-};
-
-__device__ __forceinline__ Axes stage_axes(const GridView &g, double *lds) {
-    const int n = g.nx + g.ny + g.nz;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = g.axes[t];
-    __syncthreads();
-    Axes a;
-    a.x = lds;
-    a.y = lds + g.nx;
-    a.z = lds + g.nx + g.ny;
-    a.nx = g.nx;
-    a.ny = g.ny;
-    a.nz = g.nz;
-    return a;
 }
-
-// scipy RegularGridInterpolator._find_indices: i = clip(searchsorted(g, x) - 1, 0, n-2), i.e.
-// g[i] < x <= g[i+1] inside the grid (tomography/interpolation.py:166-196 spells it out).
-__device__ __forceinline__ int find_cell(const double *g, int n, double x, double inv_h, int uniform) {
-    int i;
-    if (uniform) {
-        double f = (x - g[0]) * inv_h;
-        f = fmin(fmax(f, 0.0), (double)(n - 2));
-        i = (int)f;
-    } else {
-        int lo = 0, hi = n - 1;
-        while (hi - lo > 1) {
-            int mid = (lo + hi) >> 1;
-            if (g[mid] < x) lo = mid; else hi = mid;
-        }
-        i = lo;
-    }
-    while (i > 0 && !(g[i] < x)) --i;
-    while (i < n - 2 && g[i + 1] < x) ++i;
-    return i;
-}
-
-__device__ __forceinline__ bool outside(const double *g, int n, double x) {
-    return !(x >= g[0] && x <= g[n - 1]);     // NaN is outside, like scipy
-}
-
-// ---- trilinear (geometry/tri_cubic.py:69-70 -> scipy RGI 'linear') -----------------------------
-template <typename GT>
-__device__ __forceinline__ double trilinear_at(const GridView &g, const Axes &ax, double x, double y, double z) {
-    const int i = find_cell(ax.x, ax.nx, x, g.inv_h[0], g.uniform[0]);
-    const int j = find_cell(ax.y, ax.ny, y, g.inv_h[1], g.uniform[1]);
-    const int k = find_cell(ax.z, ax.nz, z, g.inv_h[2], g.uniform[2]);
-    const double tx = (x - ax.x[i]) / (ax.x[i + 1] - ax.x[i]);
-    const double ty = (y - ax.y[j]) / (ax.y[j + 1] - ax.y[j]);
-    const double tz = (z - ax.z[k]) / (ax.z[k + 1] - ax.z[k]);
-    const GT *p = (const GT *)g.M + ((size_t)i * g.ny + j) * g.nz + k;
-    const size_t sj = g.nz, si = (size_t)g.ny * g.nz;
-    const double c000 = p[0], c001 = p[1];
-    const double c010 = p[sj], c011 = p[sj + 1];
-    const double c100 = p[si], c101 = p[si + 1];
-    const double c110 = p[si + sj], c111 = p[si + sj + 1];
-    const double c00 = c000 + tz * (c001 - c000);
-    const double c01 = c010 + tz * (c011 - c010);
-    const double c10 = c100 + tz * (c101 - c100);
-    const double c11 = c110 + tz * (c111 - c110);
-    const double c0 = c00 + ty * (c01 - c00);
-    const double c1 = c10 + ty * (c11 - c10);
-    return c0 + tx * (c1 - c0);
-}
-
-// value and analytic gradient of the trilinear cell polynomial (double grid only; tracer)
-__device__ __forceinline__ void trilinear_grad_at(const GridView &g, const double *M, double x, double y, double z,
-                                                  double &f, double &fx, double &fy, double &fz) {
-    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
-    const int i = find_cell(gx, g.nx, x, g.inv_h[0], g.uniform[0]);
-    const int j = find_cell(gy, g.ny, y, g.inv_h[1], g.uniform[1]);
-    const int k = find_cell(gz, g.nz, z, g.inv_h[2], g.uniform[2]);
-    const double hx = gx[i + 1] - gx[i], hy = gy[j + 1] - gy[j], hz = gz[k + 1] - gz[k];
-    const double tx = (x - gx[i]) / hx, ty = (y - gy[j]) / hy, tz = (z - gz[k]) / hz;
-    const double *p = M + ((size_t)i * g.ny + j) * g.nz + k;
-    const size_t sj = g.nz, si = (size_t)g.ny * g.nz;
-    const double wx[2] = {1 - tx, tx}, wy[2] = {1 - ty, ty}, wz[2] = {1 - tz, tz};
-    const double sg[2] = {-1.0, 1.0};
-    f = fx = fy = fz = 0.0;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const double v = p[a * si + b * sj + c];
-                f += v * wx[a] * wy[b] * wz[c];
-                fx += v * sg[a] * wy[b] * wz[c];
-                fy += v * wx[a] * sg[b] * wz[c];
-                fz += v * wx[a] * wy[b] * sg[c];
-            }
-    fx /= hx;
-    fy /= hy;
-    fz /= hz;
-}
-
-// ---- tricubic: Lekien-Marsden with 4th-order central-difference derivative data --------------
-// (notebooks/TricubicInterpolation.ipynb c0:138-1257).  With finite-difference slopes (mixed
-// ones formed by the same 1-D stencil along each axis) the interpolant is the tensor product of
-// 1-D cubic Hermite splines whose slopes are (f[i-2] - 8 f[i-1] + 8 f[i+1] - f[i+2]) /
-// (6 (x[i+1] - x[i-1])): 6 taps per axis, support i-2 .. i+3.  Slopes are scaled to cell units
-// (df/du = h df/dx), which Lekien-Marsden requires; see oracle.tricubic_axis_weights.
-__device__ __forceinline__ int cubic_axis(const double *g, int n, double x, double inv_h, int uniform,
-                                          double w[6], double dw[6], bool want_d) {
-    int i = find_cell(g, n, x, inv_h, uniform);
-    i = min(max(i, 2), n - 4);
-    const double h = g[i + 1] - g[i];
-    const double t = (x - g[i]) / h;
-    const double t2 = t * t, t3 = t2 * t;
-    const double b0 = 2 * t3 - 3 * t2 + 1, b1 = -2 * t3 + 3 * t2, b2 = t3 - 2 * t2 + t, b3 = t3 - t2;
-    const double c0 = h / (6.0 * (g[i + 1] - g[i - 1]));
-    const double c1 = h / (6.0 * (g[i + 2] - g[i]));
-    w[0] = b2 * c0;
-    w[1] = -8.0 * b2 * c0 + b3 * c1;
-    w[2] = b0 - 8.0 * b3 * c1;
-    w[3] = b1 + 8.0 * b2 * c0;
-    w[4] = -b2 * c0 + 8.0 * b3 * c1;
-    w[5] = -b3 * c1;
-    if (want_d) {
-        const double d0 = (6 * t2 - 6 * t) / h, d1 = (-6 * t2 + 6 * t) / h;
-        const double d2 = (3 * t2 - 4 * t + 1) / h, d3 = (3 * t2 - 2 * t) / h;
-        dw[0] = d2 * c0;
-        dw[1] = -8.0 * d2 * c0 + d3 * c1;
-        dw[2] = d0 - 8.0 * d3 * c1;
-        dw[3] = d1 + 8.0 * d2 * c0;
-        dw[4] = -d2 * c0 + 8.0 * d3 * c1;
-        dw[5] = -d3 * c1;
-    }
-    return i;
-}
-
-template <typename GT, bool GRAD>
-__device__ __forceinline__ void tricubic_eval(const GridView &g, const double *gx, const double *gy, const double *gz,
-                                              double x, double y, double z, double &f, double &fx, double &fy, double &fz) {
-    double wx[6], wy[6], wz[6], dx[6], dy[6], dz[6];
-    const int i = cubic_axis(gx, g.nx, x, g.inv_h[0], g.uniform[0], wx, dx, GRAD);
-    const int j = cubic_axis(gy, g.ny, y, g.inv_h[1], g.uniform[1], wy, dy, GRAD);
-    const int k = cubic_axis(gz, g.nz, z, g.inv_h[2], g.uniform[2], wz, dz, GRAD);
-    const GT *base = (const GT *)g.M + ((size_t)(i - 2) * g.ny + (j - 2)) * g.nz + (k - 2);
-    f = fx = fy = fz = 0.0;
-    for (int a = 0; a < 6; ++a) {
-        double fa = 0.0, fya = 0.0, fza = 0.0;
-        for (int b = 0; b < 6; ++b) {
-            const GT *p = base + ((size_t)a * g.ny + b) * g.nz;
-            double s = 0.0, sz = 0.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const double v = p[c];
-                s += v * wz[c];
-                if (GRAD) sz += v * dz[c];
-            }
-            fa += s * wy[b];
-            if (GRAD) {
-                fya += s * dy[b];
-                fza += sz * wy[b];
-            }
-        }
-        f += fa * wx[a];
-        if (GRAD) {
-            fx += fa * dx[a];
-            fy += fya * wx[a];
-            fz += fza * wx[a];
-        }
-    }
-}
-
-template <typename GT, int KIND>
-__device__ __forceinline__ double sample_at(const GridView &g, const Axes &ax, double x, double y, double z) {
-    if (KIND == IONO_INTERP_TRILINEAR) return trilinear_at<GT>(g, ax, x, y, z);
-    double f, fx, fy, fz;
-    tricubic_eval<GT, false>(g, ax.x, ax.y, ax.z, x, y, z, f, fx, fy, fz);
-    return f;
-}
-
-template <int KIND>
-__device__ __forceinline__ bool sample_outside(const Axes &ax, double x, double y, double z) {
-    if (KIND == IONO_INTERP_TRILINEAR)
-        return outside(ax.x, ax.nx, x) || outside(ax.y, ax.ny, y) || outside(ax.z, ax.nz, z);
-    // tricubic needs the 6-node stencil: valid for g[2] <= x <= g[n-3]
-    return !(x >= ax.x[2] && x <= ax.x[ax.nx - 3]) || !(y >= ax.y[2] && y <= ax.y[ax.ny - 3]) ||
-           !(z >= ax.z[2] && z <= ax.z[ax.nz - 3]);
-}
-
-// ------------------------------------------------------------------------------------------------
-// quadrature weights on explicit abscissae s[0..N) (tomography/integrate.py:50-74,130-153;
-// scipy.integrate.simpson for the Cartwright even-N rule)
-// ------------------------------------------------------------------------------------------------
-// composite Simpson weight of sample k within the odd-length sub-range [a, b]
-__device__ __forceinline__ double basic_simpson_weight(const double *s, int a, int b, int k) {
-    if (k < a || k > b || b - a < 2) return 0.0;
-    const int p = k - a;
-    double w = 0.0;
-    if (p & 1) {
-        const double h0 = s[k] - s[k - 1], h1 = s[k + 1] - s[k], hs = h0 + h1;
-        w = hs / 6.0 * (hs * hs / (h0 * h1));
-    } else {
-        if (k > a) {
-            const double h0 = s[k - 1] - s[k - 2], h1 = s[k] - s[k - 1], hs = h0 + h1;
-            w += hs / 6.0 * (2.0 - h0 / h1);
-        }
-        if (k < b) {
-            const double h0 = s[k + 1] - s[k], h1 = s[k + 2] - s[k + 1], hs = h0 + h1;
-            w += hs / 6.0 * (2.0 - h1 / h0);
-        }
-    }
-    return w;
-}
-
-__device__ __forceinline__ double quad_weight(const double *s, int N, int k, int rule) {
-    if (rule == IONO_QUAD_TRAPEZOID || N == 2) {
-        double w = 0.0;
-        if (k > 0) w += 0.5 * (s[k] - s[k - 1]);
-        if (k < N - 1) w += 0.5 * (s[k + 1] - s[k]);
-        return w;
-    }
-    if (N & 1) return basic_simpson_weight(s, 0, N - 1, k);
-    if (rule == IONO_QUAD_SIMPSON_AVG) {
-        double wa = basic_simpson_weight(s, 0, N - 2, k);
-        if (k >= N - 2) wa += 0.5 * (s[N - 1] - s[N - 2]);
-        double wb = basic_simpson_weight(s, 1, N - 1, k);
-        if (k <= 1) wb += 0.5 * (s[1] - s[0]);
-        return 0.5 * (wa + wb);
-    }
-    double w = basic_simpson_weight(s, 0, N - 2, k);
-    const double h0 = s[N - 2] - s[N - 3], h1 = s[N - 1] - s[N - 2];
-    if (k == N - 1) w += (2 * h1 * h1 + 3 * h0 * h1) / (6 * (h0 + h1));
-    if (k == N - 2) w += (h1 * h1 + 3 * h0 * h1) / (6 * h0);
-    if (k == N - 3) w -= h1 * h1 * h1 / (6 * h0 * (h0 + h1));
-    return w;
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-
-// rays are dealt so that each XCD (blocks b, b+8, ... share one) walks a contiguous range of
-// rays: neighbouring rays (same antenna / neighbouring directions) share grid columns, which then
-// stay in that XCD's private L2.  Pure speed heuristic; correctness never depends on placement.
-struct RayWalk {
-    int64_t r, end, stride;
-};
-__device__ __forceinline__ RayWalk ray_walk(int64_t R) {
-    const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
-    RayWalk w;
-    if ((gridDim.x & 7) == 0 && R >= 64 * 8) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-        const int64_t per = (R + 7) / 8;
-        const int64_t lo = per * xcd;
-        w.end = min(R, lo + per);
-        w.r = lo + (int64_t)slot * wpb + wid;
-        w.stride = (int64_t)nslot * wpb;
-    } else {
-        w.r = (int64_t)blockIdx.x * wpb + wid;
-        w.end = R;
-        w.stride = (int64_t)gridDim.x * wpb;
-    }
-    return w;
-}
-
-struct StraightRay {
-    double ox, oy, oz, sx, sy, L, h, step, pz;
-};
-// straight z-parametrised ray: z = linspace(z0, tmax, N), x = x0 + px/pz (z - z0), s = (z - z0)/pz
-// (inversion/fermat.py:64-72,150-174 with n = 1; == tomography/model.py:27-35)
-__device__ __forceinline__ StraightRay load_straight(const double *origins, const double *dirs, int64_t r,
-                                                     double tmax, int Ns) {
-    StraightRay q;
-    q.ox = origins[3 * r];
-    q.oy = origins[3 * r + 1];
-    q.oz = origins[3 * r + 2];
-    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
-    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
-    const double px = dx / nrm, py = dy / nrm, pz = dz / nrm;
-    q.sx = px / pz;
-    q.sy = py / pz;
-    q.L = tmax - q.oz;
-    q.step = 1.0 / (double)(Ns - 1);
-    q.h = q.L * q.step / pz;      // uniform spacing of s
-    q.pz = pz;
-    return q;
-}
-__device__ __forceinline__ void straight_point(const StraightRay &q, int k, int Ns, double &x, double &y, double &z) {
-    const double frac = (k == Ns - 1) ? 1.0 : (double)k * q.step;
-    const double dz = q.L * frac;
-    x = q.ox + q.sx * dz;
-    y = q.oy + q.sy * dz;
-    z = q.oz + dz;
-}
-
-// ------------------------------------------------------------------------------------------------
-// forward kernels
-// ------------------------------------------------------------------------------------------------
-template <typename GT, int KIND>
-__global__ __launch_bounds__(256) void k_forward_straight(GridView g, const double *__restrict__ origins,
-                                                          const double *__restrict__ dirs, int64_t R, double tmax, int Ns,
-                                                          const double *__restrict__ unitw, double *__restrict__ tec,
-                                                          int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Axes ax = stage_axes(g, lds);
-    const int lane = threadIdx.x & 63;
-    bool oob = false;
-    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
-        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
-        double acc = 0.0;
-        for (int k = lane; k < Ns; k += 64) {
-            double x, y, z;
-            straight_point(q, k, Ns, x, y, z);
-            if (sample_outside<KIND>(ax, x, y, z)) {
-                oob = true;
-                continue;
-            }
-            acc += unitw[k] * sample_at<GT, KIND>(g, ax, x, y, z);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) tec[w.r] = acc * q.h;
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-// ---- fast path (trilinear, numerically uniform axes, grid < 4 GB): the instruction diet ---------
-// The general kernel above is issue-bound, not memory-bound (float32 storage buys nothing): three
-// f64 divisions, per-sample bounds tests and looped cell fix-ups dominate.  Here: reciprocal cell
-// widths are tabulated in LDS beside the axes (t = (x - g[i]) * inv[i]), the cell guess
-// floor((x - g0)/h) is verified against the table with one compare pair (the exact searchsorted
-// rule runs only for lanes whose guess is off, i.e. samples within rounding of a node), the
-// bounds test is done once per ray on its two end points (a straight segment in a convex box),
-// and addressing is 32-bit.
-struct FastAxes {
-    const double *g[3];
-    const double *inv[3];
-    double g0[3];
-};
-
-__device__ __forceinline__ FastAxes stage_axes_fast(const GridView &g, double *lds) {
-    const int n = g.nx + g.ny + g.nz;
-    for (int t = threadIdx.x; t < n; t += blockDim.x) lds[t] = g.axes[t];
-    __syncthreads();
-    for (int t = threadIdx.x; t < n - 1; t += blockDim.x) lds[n + t] = 1.0 / (lds[t + 1] - lds[t]);
-    __syncthreads();
-    FastAxes a;
-    a.g[0] = lds;
-    a.g[1] = lds + g.nx;
-    a.g[2] = lds + g.nx + g.ny;
-    a.inv[0] = lds + n;
-    a.inv[1] = lds + n + g.nx;
-    a.inv[2] = lds + n + g.nx + g.ny;
-    for (int d = 0; d < 3; ++d) a.g0[d] = a.g[d][0];
-    return a;
-}
-
-__device__ __forceinline__ void cell_fast(const double *g, const double *inv, int n, double g0, double ih, double x, int &i,
-                                          double &t) {
-    double f = (x - g0) * ih;
-    f = fmin(fmax(f, 0.0), (double)(n - 2));
-    i = (int)f;
-    double a = g[i];
-    const double b = g[i + 1];
-    if (__builtin_expect(!((a < x) & (x <= b)), 0)) {      // guess off by one, or x on the clipped edge
-        while (i > 0 && !(g[i] < x)) --i;
-        while (i < n - 2 && g[i + 1] < x) ++i;
-        a = g[i];
-    }
-    t = (x - a) * inv[i];
-}
-
-template <typename GT>
-__device__ __forceinline__ double trilinear_fast(const GridView &g, const FastAxes &ax, double x, double y, double z) {
-    int i, j, k;
-    double tx, ty, tz;
-    cell_fast(ax.g[0], ax.inv[0], g.nx, ax.g0[0], g.inv_h[0], x, i, tx);
-    cell_fast(ax.g[1], ax.inv[1], g.ny, ax.g0[1], g.inv_h[1], y, j, ty);
-    cell_fast(ax.g[2], ax.inv[2], g.nz, ax.g0[2], g.inv_h[2], z, k, tz);
-    const unsigned sj = (unsigned)g.nz, si = (unsigned)g.ny * (unsigned)g.nz;
-    const unsigned off = ((unsigned)i * (unsigned)g.ny + (unsigned)j) * sj + (unsigned)k;
-    const GT *p = (const GT *)g.M + off;
-    const double c000 = p[0], c001 = p[1];
-    const double c010 = p[sj], c011 = p[sj + 1];
-    const double c100 = p[si], c101 = p[si + 1];
-    const double c110 = p[si + sj], c111 = p[si + sj + 1];
-    const double c00 = c000 + tz * (c001 - c000);
-    const double c01 = c010 + tz * (c011 - c010);
-    const double c10 = c100 + tz * (c101 - c100);
-    const double c11 = c110 + tz * (c111 - c110);
-    const double c0 = c00 + ty * (c01 - c00);
-    const double c1 = c10 + ty * (c11 - c10);
-    return c0 + tx * (c1 - c0);
-}
-
-__device__ __forceinline__ bool ray_leaves_grid(const FastAxes &ax, const GridView &g, const StraightRay &q) {
-    const double xe = q.ox + q.sx * q.L, ye = q.oy + q.sy * q.L, ze = q.oz + q.L;
-    return outside(ax.g[0], g.nx, q.ox) || outside(ax.g[0], g.nx, xe) || outside(ax.g[1], g.ny, q.oy) ||
-           outside(ax.g[1], g.ny, ye) || outside(ax.g[2], g.nz, q.oz) || outside(ax.g[2], g.nz, ze);
-}
-
-template <typename GT>
-__global__ __launch_bounds__(256) void k_forward_straight_fast(GridView g, const double *__restrict__ origins,
-                                                               const double *__restrict__ dirs, int64_t R, double tmax, int Ns,
-                                                               const double *__restrict__ unitw, double *__restrict__ tec,
-                                                               int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const FastAxes ax = stage_axes_fast(g, lds);
-    const int lane = threadIdx.x & 63;
-    bool oob = false;
-    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
-        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
-        if (ray_leaves_grid(ax, g, q)) {
-            oob = true;
-            if (lane == 0) tec[w.r] = nan("");
-            continue;
-        }
-        double acc = 0.0;
-        for (int k = lane; k < Ns; k += 64) {
-            double x, y, z;
-            straight_point(q, k, Ns, x, y, z);
-            acc += unitw[k] * trilinear_fast<GT>(g, ax, x, y, z);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) tec[w.r] = acc * q.h;
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-// ---- v2 fast path: "ideal uniform" grid coordinates ------------------------------------------------
-// Taken when every axis equals g0 + i*h to within 2.5e-13 h (what np.linspace produces; checked on
-// the host), so a sample's grid coordinate is ONE fma per axis, f = f0 + k*df, its cell is
-// (int)f and its weight fract(f): no axis tables, no divisions in the loop.  Per-ray work that is
-// wave-uniform in the kernels above (normalisation, slopes, bounds test on the two end points,
-// the <= 8 tail samples when Ns is not a multiple of 64) is done LANE-PARALLEL for a group of up
-// to 16 rays (lane = ray) and broadcast with v_readlane; the Simpson sum is a DPP row_shr /
-// row_bcast reduction (no LDS round trips); the weight table lives in LDS.  `order` (optional)
-// is a permutation of the rays giving the walk order (it matters for the adjoint's LDS
-// pre-reduction; for this kernel it measured neutral).
-#define U_MAXG 16
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_add(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return v + __hiloint2double(hi2, lo2);
-}
-// sum over the 64 lanes; the total is returned wave-uniform (read from lane 63)
-__device__ __forceinline__ double wave_sum_dpp(double v) {
-    v = dpp_add<0x111, 0xf>(v);    // row_shr:1
-    v = dpp_add<0x112, 0xf>(v);    // row_shr:2
-    v = dpp_add<0x114, 0xf>(v);    // row_shr:4
-    v = dpp_add<0x118, 0xf>(v);    // row_shr:8   -> lane 15 of each row holds the row total
-    v = dpp_add<0x142, 0xa>(v);    // row_bcast:15 into rows 1,3
-    v = dpp_add<0x143, 0xc>(v);    // row_bcast:31 into rows 2,3 -> lane 63 holds the total
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double bcast_lane(double v, int src) {     // src must be wave-uniform
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-
-struct URay {            // a straight ray in ideal grid coordinates: f(k) = f0 + k * df per axis
-    double fx0, dfx, fy0, dfy, fz0, dfz, h;
-    bool valid;
-};
-__device__ __forceinline__ URay load_uray(const GridView &g, const double *origins, const double *dirs, int64_t r, double tmax,
-                                          int Ns) {
-    const double ox = origins[3 * r], oy = origins[3 * r + 1], oz = origins[3 * r + 2];
-    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
-    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
-    const double px = dx / nrm, py = dy / nrm, pz = dz / nrm;
-    const double sx = px / pz, sy = py / pz;
-    const double L = tmax - oz;
-    const double Lstep = L * (1.0 / (double)(Ns - 1));
-    URay u;
-    u.h = Lstep / pz;
-    u.fx0 = (ox - g.g0[0]) * g.inv_h[0];
-    u.fy0 = (oy - g.g0[1]) * g.inv_h[1];
-    u.fz0 = (oz - g.g0[2]) * g.inv_h[2];
-    u.dfx = sx * Lstep * g.inv_h[0];
-    u.dfy = sy * Lstep * g.inv_h[1];
-    u.dfz = Lstep * g.inv_h[2];
-    const double xe = ox + sx * L, ye = oy + sy * L, ze = oz + L;
-    u.valid = (ox >= g.g0[0]) & (ox <= g.glast[0]) & (xe >= g.g0[0]) & (xe <= g.glast[0]) & (oy >= g.g0[1]) &
-              (oy <= g.glast[1]) & (ye >= g.g0[1]) & (ye <= g.glast[1]) & (oz >= g.g0[2]) & (oz <= g.glast[2]) &
-              (ze >= g.g0[2]) & (ze <= g.glast[2]);
-    return u;
-}
-
-// The grid allocation is padded by one plane + one row + 2 zero elements (iono_grid_set), so a
-// sample sitting exactly on the top face of an axis (cell index n-1, weight 0 on the far corner)
-// may read the far corner without a clamp: it is multiplied by 0.
-template <typename GT>
-struct Corners {
-    GT c000, c001, c010, c011, c100, c101, c110, c111;
-    double tx, ty, tz;
-};
-template <typename GT>
-__device__ __forceinline__ Corners<GT> load_corners(const GT *__restrict__ b00, const GT *__restrict__ b01,
-                                                    const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz,
-                                                    double fx, double fy, double fz) {
-    const int i = (int)fx, j = (int)fy, k = (int)fz;
-    Corners<GT> c;
-    c.tx = fx - (double)i;
-    c.ty = fy - (double)j;
-    c.tz = fz - (double)k;
-    const unsigned boff = (((unsigned)i * (unsigned)ny + (unsigned)j) * (unsigned)nz + (unsigned)k) * (unsigned)sizeof(GT);
-    const GT *p00 = (const GT *)((const char *)b00 + boff), *p01 = (const GT *)((const char *)b01 + boff);
-    const GT *p10 = (const GT *)((const char *)b10 + boff), *p11 = (const GT *)((const char *)b11 + boff);
-    c.c000 = p00[0];
-    c.c001 = p00[1];
-    c.c010 = p01[0];
-    c.c011 = p01[1];
-    c.c100 = p10[0];
-    c.c101 = p10[1];
-    c.c110 = p11[0];
-    c.c111 = p11[1];
-    return c;
-}
-template <typename GT>
-__device__ __forceinline__ double lerp_corners(const Corners<GT> &c) {
-    const double c000 = c.c000, c010 = c.c010, c100 = c.c100, c110 = c.c110;
-    const double c00 = c000 + c.tz * ((double)c.c001 - c000);
-    const double c01 = c010 + c.tz * ((double)c.c011 - c010);
-    const double c10 = c100 + c.tz * ((double)c.c101 - c100);
-    const double c11 = c110 + c.tz * ((double)c.c111 - c110);
-    const double c0 = c00 + c.ty * (c01 - c00);
-    const double c1 = c10 + c.ty * (c11 - c10);
-    return c0 + c.tx * (c1 - c0);
-}
-template <typename GT>
-__device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const GT *__restrict__ b01,
-                                              const GT *__restrict__ b10, const GT *__restrict__ b11, int ny, int nz, double fx,
-                                              double fy, double fz) {
-    return lerp_corners<GT>(load_corners<GT>(b00, b01, b10, b11, ny, nz, fx, fy, fz));
-}
-
-// Every wave owns one contiguous, balanced chunk of the walk (floor or ceil of R / #waves rays) and
-// goes through it in groups of up to U_MAXG rays; waves are numbered XCD-major (blocks b, b+8, ...
-// share an XCD), so each XCD's L2 sees one contiguous eighth of the rays.  The grid is sized to
-// what is resident at once, so there is no second, under-occupied round of workgroups.
-struct Chunk {
-    int64_t lo, hi, stride;     // walk positions lo, lo+stride, ... < hi
-};
-// mode 0 (default): one contiguous chunk per wave.  mode bit 0: one contiguous chunk per WORKGROUP, its
-// 4 waves interleaved (wave w takes lo+w, lo+w+4, ...).  mode bit 2: plain block order instead of
-// XCD-major.  Both alternatives measured slower or equal on the bench workload; kept for A/B runs
-// (env IONOTOMO_WALK).
-__device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
-    const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
-    int64_t bidx;
-    if ((gridDim.x & 7) == 0 && !(mode & 4)) {
-        const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-        bidx = (int64_t)xcd * nslot + slot;
-    } else {
-        bidx = blockIdx.x;
-    }
-    Chunk c;
-    if (mode & 1) {
-        const int64_t nb = gridDim.x, base = R / nb, rem = R % nb;
-        const int64_t lo = bidx * base + min(bidx, rem);
-        c.hi = lo + base + (bidx < rem ? 1 : 0);
-        c.lo = lo + wid;
-        c.stride = wpb;
-    } else {
-        const int64_t widx = bidx * wpb + wid, nw = (int64_t)gridDim.x * wpb;
-        const int64_t base = R / nw, rem = R % nw;
-        c.lo = widx * base + min(widx, rem);
-        c.hi = c.lo + base + (widx < rem ? 1 : 0);
-        c.stride = 1;
-    }
-    return c;
-}
-
-template <typename GT>
-__global__ __launch_bounds__(256) void k_forward_straight_u(GridView g, const double *__restrict__ origins,
-                                                            const double *__restrict__ dirs, const int *__restrict__ order,
-                                                            int64_t R, double tmax, int Ns, int walk_mode,
-                                                            const double *__restrict__ unitw, double *__restrict__ tec,
-                                                            int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double wlds[];
-    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int nfull = Ns >> 6, ntail0 = nfull << 6;        // samples [ntail0, Ns) are the tail
-    const bool tail_by_lane = (Ns - ntail0) <= 8;          // else: one more (masked) wave iteration
-    const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
-    const Chunk ch = wave_chunk(R, walk_mode);
-    const double dlane = (double)lane;
-    const double *wp = wlds + lane;
-    bool oob = false;
-    for (int64_t q0 = ch.lo; q0 < ch.hi; q0 += U_MAXG * ch.stride) {
-        const int cnt = (int)min((int64_t)U_MAXG, (ch.hi - q0 + ch.stride - 1) / ch.stride);
-        // ---- lane-parallel set-up: lane l owns ray q0 + l ------------------------------------------
-        URay u = {};
-        int64_t r = 0;
-        double tail = 0.0;
-        if (lane < cnt) {
-            const int64_t q = q0 + lane * ch.stride;
-            r = order ? (int64_t)order[q] : q;
-            u = load_uray(g, origins, dirs, r, tmax, Ns);
-            if (u.valid && tail_by_lane) {
-                for (int k = ntail0; k < Ns; ++k) {
-                    const double kd = (double)k;
-                    tail += wlds[k] * trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fma(kd, u.dfx, u.fx0),
-                                                       fma(kd, u.dfy, u.fy0), fma(kd, u.dfz, u.fz0));
-                }
-            }
-            if (!u.valid) oob = true;
-        }
-        // ---- one ray at a time, lanes = samples ----------------------------------------------------
-        double res = 0.0;
-        for (int gi = 0; gi < cnt; ++gi) {
-            const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
-            if (!ok) continue;
-            const double dfx = bcast_lane(u.dfx, gi), dfy = bcast_lane(u.dfy, gi), dfz = bcast_lane(u.dfz, gi);
-            double fx = fma(dlane, dfx, bcast_lane(u.fx0, gi));
-            double fy = fma(dlane, dfy, bcast_lane(u.fy0, gi));
-            double fz = fma(dlane, dfz, bcast_lane(u.fz0, gi));
-            const double sx64 = 64.0 * dfx, sy64 = 64.0 * dfy, sz64 = 64.0 * dfz;
-            double acc = 0.0;
-            // (a software-pipelined version of this loop -- next iteration's loads in flight during the
-            //  interpolation -- measured 15 % SLOWER: +26 VGPRs cost more occupancy than the overlap won)
-            for (int it = 0; it < nfull; ++it) {
-                acc = fma(wp[it << 6], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
-                fx += sx64;
-                fy += sy64;
-                fz += sz64;
-            }
-            if (!tail_by_lane && lane + ntail0 < Ns)
-                acc = fma(wp[ntail0], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
-            const double total = wave_sum_dpp(acc);
-            if (lane == gi) res = total;
-        }
-        if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-template <typename GT, int KIND>
-__global__ __launch_bounds__(256) void k_forward_rays(GridView g, const double *__restrict__ rays, int64_t R, int Ns,
-                                                      int rule, double *__restrict__ tec, int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Axes ax = stage_axes(g, lds);
-    const int lane = threadIdx.x & 63;
-    bool oob = false;
-    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
-        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
-        double acc = 0.0;
-        for (int k = lane; k < Ns; k += 64) {
-            const double x = rx[k], y = ry[k], z = rz[k];
-            if (sample_outside<KIND>(ax, x, y, z)) {
-                oob = true;
-                continue;
-            }
-            acc += quad_weight(rs, Ns, k, rule) * sample_at<GT, KIND>(g, ax, x, y, z);
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) tec[w.r] = acc;
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-// phase observable, per-frequency integrals of 1 - sqrt(1 - ne/n_p) (inversion/iterative_newton.py:108-119)
-template <typename GT, int MAXF>
-__global__ __launch_bounds__(256) void k_forward_phase_rays(GridView g, const double *__restrict__ rays, int64_t R, int Ns,
-                                                            int rule, const double *__restrict__ inv_np, int nf, int ldf,
-                                                            double *__restrict__ phi, int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Axes ax = stage_axes(g, lds);
-    const int lane = threadIdx.x & 63;
-    bool oob = false;
-    double inp[MAXF];
-#pragma unroll
-    for (int l = 0; l < MAXF; ++l) inp[l] = l < nf ? inv_np[l] : 0.0;
-    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
-        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
-        double acc[MAXF];
-#pragma unroll
-        for (int l = 0; l < MAXF; ++l) acc[l] = 0.0;
-        for (int k = lane; k < Ns; k += 64) {
-            const double x = rx[k], y = ry[k], z = rz[k];
-            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
-                oob = true;
-                continue;
-            }
-            const double ne = trilinear_at<GT>(g, ax, x, y, z);
-            const double c = quad_weight(rs, Ns, k, rule);
-#pragma unroll
-            for (int l = 0; l < MAXF; ++l) acc[l] += c * (1.0 - sqrt(1.0 - ne * inp[l]));
-        }
-#pragma unroll
-        for (int l = 0; l < MAXF; ++l) {
-            const double v = wave_sum(acc[l]);
-            if (lane == 0 && l < nf) phi[(size_t)w.r * ldf + l] = v;
-        }
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-// g = const_i + 2 pi nu clock_ij - (phi - phi[i0]) 2 pi nu / c   (inversion/iterative_newton.py:107-123)
-__global__ void k_phase_finish(const double *__restrict__ phi, const double *__restrict__ freqs,
-                               const double *__restrict__ clock, const double *__restrict__ cst, int Na, int Nt, int Nd,
-                               int Nf, int i0, double *__restrict__ gout) {
-    const int64_t n = (int64_t)Na * Nt * Nd * Nf;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int l = idx % Nf;
-        const int64_t r = idx / Nf;
-        const int64_t td = r % ((int64_t)Nt * Nd);
-        const int a = r / ((int64_t)Nt * Nd);
-        const int t = td / Nd;
-        const double a_ = 2.0 * M_PI * freqs[l];
-        const double ph = (phi[r * Nf + l] - phi[((int64_t)i0 * Nt * Nd + td) * Nf + l]) * (a_ / SPEED_OF_LIGHT);
-        gout[idx] = cst[a] + a_ * clock[(int64_t)a * Nt + t] - ph;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// adjoint kernels: exact transpose of trilinear + quadrature (SURVEY section 8a, A7')
-// ------------------------------------------------------------------------------------------------
-template <typename AT>
-__device__ __forceinline__ void scatter_trilinear(const GridView &g, const Axes &ax, AT *__restrict__ G, double x, double y,
-                                                  double z, double c) {
-    const int i = find_cell(ax.x, ax.nx, x, g.inv_h[0], g.uniform[0]);
-    const int j = find_cell(ax.y, ax.ny, y, g.inv_h[1], g.uniform[1]);
-    const int k = find_cell(ax.z, ax.nz, z, g.inv_h[2], g.uniform[2]);
-    const double tx = (x - ax.x[i]) / (ax.x[i + 1] - ax.x[i]);
-    const double ty = (y - ax.y[j]) / (ax.y[j + 1] - ax.y[j]);
-    const double tz = (z - ax.z[k]) / (ax.z[k + 1] - ax.z[k]);
-    AT *p = G + ((size_t)i * g.ny + j) * g.nz + k;
-    const size_t sj = g.nz, si = (size_t)g.ny * g.nz;
-    const double w0 = c * (1 - tx), w1 = c * tx;
-    const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
-    atomicAdd(p, (AT)(w00 * (1 - tz)));
-    atomicAdd(p + 1, (AT)(w00 * tz));
-    atomicAdd(p + sj, (AT)(w01 * (1 - tz)));
-    atomicAdd(p + sj + 1, (AT)(w01 * tz));
-    atomicAdd(p + si, (AT)(w10 * (1 - tz)));
-    atomicAdd(p + si + 1, (AT)(w10 * tz));
-    atomicAdd(p + si + sj, (AT)(w11 * (1 - tz)));
-    atomicAdd(p + si + sj + 1, (AT)(w11 * tz));
-}
-
-// MODE 0: weights given (w[R]);  MODE 1: fused residual -> differential weights for layout
-// [Na][NtNd]: dd = (tec - tec[i0] - dobs)/(CdCt + 1e-15) (inversion/gradient.py:77-81),
-// w = dd - [a == i0] sum_a' dd[a']  (transpose of "tec - tec[i0]", forward_equation.py:50)
-template <typename AT, int MODE>
-__global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const double *__restrict__ origins,
-                                                          const double *__restrict__ dirs, const double *__restrict__ wray,
-                                                          const double *__restrict__ tec, const double *__restrict__ dobs,
-                                                          const double *__restrict__ cdct, int Na, int64_t NtNd, int i0,
-                                                          int64_t R, double tmax, int Ns, const double *__restrict__ unitw,
-                                                          AT *__restrict__ G, int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Axes ax = stage_axes(g, lds);
-    const int lane = threadIdx.x & 63;
-    bool oob = false;
-    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
-        double wr;
-        if (MODE == 0) {
-            wr = wray[w.r];
-        } else {
-            const int a = (int)(w.r / NtNd);
-            const int64_t p = w.r % NtNd;
-            const double tref = tec[(int64_t)i0 * NtNd + p];
-            wr = (tec[w.r] - tref - dobs[w.r]) / (cdct[w.r] + 1e-15);
-            if (a == i0) {
-                double s = 0.0;
-                for (int a2 = lane; a2 < Na; a2 += 64) {
-                    const int64_t r2 = (int64_t)a2 * NtNd + p;
-                    s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
-                }
-                wr -= wave_sum(s);
-            }
-        }
-        if (wr == 0.0) continue;
-        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
-        const double scale = wr * q.h;
-        for (int k = lane; k < Ns; k += 64) {
-            double x, y, z;
-            straight_point(q, k, Ns, x, y, z);
-            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
-                oob = true;
-                continue;
-            }
-            scatter_trilinear<AT>(g, ax, G, x, y, z, scale * unitw[k]);
-        }
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-// ---- privatised adjoint (ideal-uniform grids) --------------------------------------------------------
-// Plain atomics run at ~0.3 TB/s here: every ray of a station crosses the same low-altitude cells,
-// and rays of neighbouring stations / consecutive timesteps nearly coincide all the way up, so the
-// same addresses are hit thousands of times.  This kernel pre-reduces in LDS.  A workgroup takes a
-// BUNDLE of 64 consecutive rays of the walk (callers order the walk so that consecutive rays are
-// neighbours in space).  Per slab of 64 samples it keeps a SHEARED tile in LDS: for each of T_TK z
-// levels an 8 x 8 window of nodes whose origin follows the bundle's reference ray (its first valid
-// ray) at that level.  Contributions falling inside the tile are LDS float atomics (lanes =
-// consecutive z levels -> consecutive LDS words, conflict-free); anything outside goes straight to
-// global atomics, so the result never depends on how good the ordering is.  After the slab the
-// tile's non-zero nodes are flushed with ONE global atomic each.
-#define T_WIN 8
-#define T_TK 72
-#define T_TKP 73
-
-template <typename AT>
-__device__ __forceinline__ void tile_or_global_add(AT *tile, AT *__restrict__ G, const int *I0, const int *J0, int m, int i, int j,
-                                                   int kk, int ny, int nz, double w00, double w01, double w10, double w11,
-                                                   int dbg = 0) {
-    // the four (i..i+1, j..j+1) nodes of z level kk (tile level m); tile if the 2x2 patch is inside the window
-    bool in = (m >= 0) & (m < T_TK);
-    int a = 0, b = 0;
-    if (in) {
-        a = i - I0[m];
-        b = j - J0[m];
-        in = (a >= 0) & (a + 1 < T_WIN) & (b >= 0) & (b + 1 < T_WIN);
-    }
-    if (in) {
-        AT *t = tile + (a * T_WIN + b) * T_TKP + m;
-        atomicAdd(t, (AT)w00);
-        atomicAdd(t + T_TKP, (AT)w01);
-        atomicAdd(t + T_WIN * T_TKP, (AT)w10);
-        atomicAdd(t + (T_WIN + 1) * T_TKP, (AT)w11);
-    } else if (!(dbg & 4)) {
-        AT *p = G + ((size_t)i * ny + j) * nz + kk;
-        atomicAdd(p, (AT)w00);
-        atomicAdd(p + nz, (AT)w01);
-        atomicAdd(p + (size_t)ny * nz, (AT)w10);
-        atomicAdd(p + (size_t)ny * nz + nz, (AT)w11);
-    }
-}
-
-template <typename AT>
-__device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
-                                                     int kz0, double fx, double fy, double fz, double c, int dbg = 0) {
-    const int i = min((int)fx, g.nx - 2), j = min((int)fy, g.ny - 2), k = min((int)fz, g.nz - 2);
-    const double tx = fx - (double)i, ty = fy - (double)j, tz = fz - (double)k;
-    const double w0 = c * (1 - tx), w1 = c * tx;
-    const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
-    const int m = k - kz0;
-    tile_or_global_add<AT>(tile, G, I0, J0, m, i, j, k, g.ny, g.nz, w00 * (1 - tz), w01 * (1 - tz), w10 * (1 - tz), w11 * (1 - tz), dbg);
-    tile_or_global_add<AT>(tile, G, I0, J0, m + 1, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz, dbg);
-}
-
-// residual -> differential weight of ray r = (a, p) in layout [Na][NtNd] (see k_adjoint_straight MODE 1)
-__device__ __forceinline__ double residual_weight(const double *__restrict__ tec, const double *__restrict__ dobs,
-                                                  const double *__restrict__ cdct, int Na, int64_t NtNd, int i0, int64_t r) {
-    const int a = (int)(r / NtNd);
-    const int64_t p = r % NtNd;
-    const double tref = tec[(int64_t)i0 * NtNd + p];
-    double wr = (tec[r] - tref - dobs[r]) / (cdct[r] + 1e-15);
-    if (a == i0) {
-        double s = 0.0;
-        for (int a2 = 0; a2 < Na; ++a2) {
-            const int64_t r2 = (int64_t)a2 * NtNd + p;
-            s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
-        }
-        wr -= s;
-    }
-    return wr;
-}
-
-// min / max over the 64 lanes (wave-uniform result), same DPP ladder as wave_sum_dpp
-template <int CTRL, int ROW_MASK, bool IS_MAX>
-__device__ __forceinline__ double dpp_minmax(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    const double o = __hiloint2double(hi2, lo2);
-    return IS_MAX ? fmax(v, o) : fmin(v, o);
-}
-template <bool IS_MAX>
-__device__ __forceinline__ double wave_minmax_dpp(double v) {
-    v = dpp_minmax<0x111, 0xf, IS_MAX>(v);
-    v = dpp_minmax<0x112, 0xf, IS_MAX>(v);
-    v = dpp_minmax<0x114, 0xf, IS_MAX>(v);
-    v = dpp_minmax<0x118, 0xf, IS_MAX>(v);
-    v = dpp_minmax<0x142, 0xa, IS_MAX>(v);
-    v = dpp_minmax<0x143, 0xc, IS_MAX>(v);
-    return bcast_lane(v, 63);
-}
-
-struct AdjRay {
-    URay u;
-    double scale;
-};
-// lane-parallel load of `q` rays per wave starting at walk position qw (lanes >= cnt idle)
-template <int MODE>
-__device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *origins, const double *dirs, const int *order,
-                                               const double *wray, const double *tec, const double *dobs, const double *cdct,
-                                               int Na, int64_t NtNd, int i0, int64_t q, bool active, double tmax, int Ns,
-                                               bool &oob) {
-    AdjRay a;
-    a.u = URay{};
-    a.scale = 0.0;
-    if (active) {
-        const int64_t r = order ? (int64_t)order[q] : q;
-        a.u = load_uray(g, origins, dirs, r, tmax, Ns);
-        const double wr = MODE == 0 ? wray[r] : residual_weight(tec, dobs, cdct, Na, NtNd, i0, r);
-        if (a.u.valid) a.scale = wr * a.u.h; else oob = true;
-    }
-    return a;
-}
-
-template <typename AT, int MODE, int NW>
-__global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
-                                                               const double *__restrict__ dirs, const int *__restrict__ order,
-                                                               const double *__restrict__ wray, const double *__restrict__ tec,
-                                                               const double *__restrict__ dobs, const double *__restrict__ cdct,
-                                                               int Na, int64_t NtNd, int i0, int64_t R, double tmax, int Ns,
-                                                               int dbg, const double *__restrict__ unitw, AT *__restrict__ G,
-                                                               int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *wlds = (double *)smem;                                   // [Ns] quadrature weights
-    double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][16] per-wave sums and bounding boxes
-    AT *tile = (AT *)(ref + 16 * NW);                                     // [T_WIN*T_WIN][T_TKP]
-    int *I0 = (int *)(tile + T_WIN * T_WIN * T_TKP);                 // [T_TK] window origins per z level
-    int *J0 = I0 + T_TK;
-    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
-    for (int t = threadIdx.x; t < T_WIN * T_WIN * T_TKP; t += blockDim.x) tile[t] = (AT)0;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int nfull = Ns >> 6, ntail0 = nfull << 6;
-    const bool tail_by_lane = (Ns - ntail0) <= 8;
-    const int nslab = tail_by_lane ? nfull : nfull + 1;
-    const double klast = (double)(Ns - 1);
-    // contiguous balanced range of the walk per workgroup (XCD-major)
-    int64_t bidx = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bidx = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int64_t base = R / gridDim.x, rem = R % gridDim.x;
-    const int64_t lo = bidx * base + min(bidx, rem), hi = lo + base + (bidx < rem ? 1 : 0);
-    const double BIG = 1e300;
-    bool oob = false;
-    __syncthreads();
-    for (int64_t q0 = lo; q0 < hi;) {
-        // ---- candidate bundle: up to 64 rays, wave w lanes 0..15 own walk positions q0 + 16 w + l ----------
-        int q = 16;                                     // rays per wave
-        int64_t qw = q0 + (int64_t)q * wid;
-        int cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
-        AdjRay a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
-                                      Ns, oob);
-        int c = 16 * NW;
-        for (int round = 0; round < 2; ++round) {
-            // per-wave sums (for the mean ray) and bounding boxes at the bottom / top of the rays
-            const bool lv = a.scale != 0.0;
-            const double live = lv ? 1.0 : 0.0;
-            const double xe = fma(klast, a.u.dfx, a.u.fx0), ye = fma(klast, a.u.dfy, a.u.fy0);
-            const double s4 = wave_sum_dpp(live * a.u.fz0), s5 = wave_sum_dpp(live * a.u.dfz), s7 = wave_sum_dpp(live);
-            double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
-            {
-                b0 = wave_minmax_dpp<false>(lv ? a.u.fx0 : BIG);
-                b1 = wave_minmax_dpp<true>(lv ? a.u.fx0 : -BIG);
-                b2 = wave_minmax_dpp<false>(lv ? a.u.fy0 : BIG);
-                b3 = wave_minmax_dpp<true>(lv ? a.u.fy0 : -BIG);
-                b4 = wave_minmax_dpp<false>(lv ? xe : BIG);
-                b5 = wave_minmax_dpp<true>(lv ? xe : -BIG);
-                b6 = wave_minmax_dpp<false>(lv ? ye : BIG);
-                b7 = wave_minmax_dpp<true>(lv ? ye : -BIG);
-            }
-            if (lane == 0) {
-                double *rp = ref + 16 * wid;
-                rp[4] = s4, rp[5] = s5, rp[7] = s7;
-                rp[8] = b0, rp[9] = b1, rp[10] = b2, rp[11] = b3, rp[12] = b4, rp[13] = b5, rp[14] = b6, rp[15] = b7;
-            }
-            __syncthreads();
-            if (round == 1) break;
-            // largest c in {64, 32, 16} whose rays stay within the tile window at both ends (block-uniform)
-            const double lim = (double)(T_WIN - 3);
-            double m0 = BIG, M0 = -BIG, m1 = BIG, M1 = -BIG, m2 = BIG, M2 = -BIG, m3 = BIG, M3 = -BIG;
-            int fit = 0;
-            for (int w2 = 0; w2 < NW; ++w2) {
-                const double *rp = ref + 16 * w2;
-                m0 = fmin(m0, rp[8]), M0 = fmax(M0, rp[9]), m1 = fmin(m1, rp[10]), M1 = fmax(M1, rp[11]);
-                m2 = fmin(m2, rp[12]), M2 = fmax(M2, rp[13]), m3 = fmin(m3, rp[14]), M3 = fmax(M3, rp[15]);
-                const bool ok = (M0 - m0 <= lim) & (M1 - m1 <= lim) & (M2 - m2 <= lim) & (M3 - m3 <= lim);
-                if (ok && ((w2 + 1) & w2) == 0) fit = w2 + 1;           // 1, 2, 4 (, 8) waves' worth of rays
-            }
-            c = 16 * max(fit, 1);
-            if (c == 16 * NW) break;
-            // spread too wide: shrink the bundle and re-deal its rays evenly over the four waves
-            __syncthreads();
-            q = c / NW;
-            qw = q0 + (int64_t)q * wid;
-            cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
-            a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax, Ns,
-                                   oob);
-        }
-        q0 += c;
-        if (a.scale != 0.0 && tail_by_lane) {               // the <= 8 tail samples: straight to global memory
-            for (int k = ntail0; k < Ns; ++k) {
-                const double kd = (double)k;
-                scatter_sample_tiled<AT>(g, tile, G, I0, J0, -(1 << 28), fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
-                                         fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k]);
-            }
-        }
-        double nlive = 0.0, sz0 = 0.0, sdz = 0.0;
-        for (int w2 = 0; w2 < NW; ++w2) nlive += ref[16 * w2 + 7], sz0 += ref[16 * w2 + 4], sdz += ref[16 * w2 + 5];
-        if (nlive == 0.0) {            // nothing to do in this bundle (block-uniform)
-            __syncthreads();
-            continue;
-        }
-        // reference line of the bundle: through the centres of its bounding boxes at the bottom and at the
-        // top (a bundle that passed the spread test then lies entirely inside the windows); z from the mean
-        const double inl = 1.0 / nlive;
-        double bx0 = BIG, bx1 = -BIG, by0 = BIG, by1 = -BIG, tx0 = BIG, tx1 = -BIG, ty0 = BIG, ty1 = -BIG;
-        for (int w2 = 0; w2 < NW; ++w2) {
-            const double *rp = ref + 16 * w2;
-            bx0 = fmin(bx0, rp[8]), bx1 = fmax(bx1, rp[9]), by0 = fmin(by0, rp[10]), by1 = fmax(by1, rp[11]);
-            tx0 = fmin(tx0, rp[12]), tx1 = fmax(tx1, rp[13]), ty0 = fmin(ty0, rp[14]), ty1 = fmax(ty1, rp[15]);
-        }
-        const double rfx0 = 0.5 * (bx0 + bx1), rdfx = (0.5 * (tx0 + tx1) - rfx0) / klast;
-        const double rfy0 = 0.5 * (by0 + by1), rdfy = (0.5 * (ty0 + ty1) - rfy0) / klast;
-        const double rfz0 = sz0 * inl, rdfz = sdz * inl;
-        for (int it = 0; it < nslab; ++it) {
-            const int k0 = it << 6;
-            const int kz0 = max((int)fma((double)k0, rdfz, rfz0) - 1, 0);
-            if (threadIdx.x < T_TK) {     // window origin per z level: follow the reference ray
-                const double kk = ((double)(kz0 + (int)threadIdx.x) - rfz0) / rdfz;      // (real) sample index at that level
-                I0[threadIdx.x] = (int)floor(fma(kk, rdfx, rfx0)) - (T_WIN / 2 - 1);
-                J0[threadIdx.x] = (int)floor(fma(kk, rdfy, rfy0)) - (T_WIN / 2 - 1);
-            }
-            __syncthreads();
-            for (int gi = 0; gi < cnt; ++gi) {
-                const double sc = bcast_lane(a.scale, gi);
-                if (sc == 0.0) continue;
-                const int k = k0 + lane;
-                if (k < Ns && (tail_by_lane ? k < ntail0 : true)) {
-                    const double kd = (double)k;
-                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
-                                             fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
-                                             fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi)), sc * wlds[k], dbg);
-                }
-            }
-            __syncthreads();
-            // ---- flush + re-zero: one global atomic per touched node -------------------------------------
-            for (int e = threadIdx.x; e < T_WIN * T_WIN * T_TKP; e += blockDim.x) {
-                const AT v = tile[e];
-                if (v != (AT)0) {
-                    tile[e] = (AT)0;
-                    const int cell = e / T_TKP, m = e - cell * T_TKP;
-                    const int gi_ = I0[m] + cell / T_WIN, gj_ = J0[m] + cell % T_WIN, gk_ = kz0 + m;
-                    if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz && !(dbg & 8))
-                        atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, v);
-                }
-            }
-            __syncthreads();
-        }
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-template <typename AT>
-__global__ __launch_bounds__(256) void k_adjoint_rays(GridView g, const double *__restrict__ rays,
-                                                      const double *__restrict__ wray, int64_t R, int Ns, int rule,
-                                                      AT *__restrict__ G, int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Axes ax = stage_axes(g, lds);
-    const int lane = threadIdx.x & 63;
-    bool oob = false;
-    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
-        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns, *rs = rz + Ns;
-        const double wr = wray[w.r];
-        if (wr == 0.0) continue;
-        for (int k = lane; k < Ns; k += 64) {
-            const double x = rx[k], y = ry[k], z = rz[k];
-            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
-                oob = true;
-                continue;
-            }
-            scatter_trilinear<AT>(g, ax, G, x, y, z, wr * quad_weight(rs, Ns, k, rule));
-        }
-    }
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
-
-// ------------------------------------------------------------------------------------------------
-// small elementwise / geometry kernels
-// ------------------------------------------------------------------------------------------------
-template <typename GT>
-__global__ void k_set_values(const double *__restrict__ src, GT *__restrict__ dst, int64_t n, int do_exp, double scale,
-                             int *nonfinite) {
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        double v = src[i];
-        if (do_exp) v = exp(v) * scale;
-        if (!isfinite(v)) bad = true;
-        dst[i] = (GT)v;
-    }
-    if (bad) atomicOr(nonfinite, 1);
-}
-
-template <typename GT>
-__global__ void k_get_values(const GT *__restrict__ src, double *__restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = (double)src[i];
-}
-
-// n = sqrt(1 - 8.980^2 ne / nu^2) at the nodes (inversion/fermat.py:36-46)
-template <typename GT>
-__global__ void k_ne_to_n(const GT *__restrict__ ne, double *__restrict__ nM, int64_t n, double freq) {
-    const double A = -PLASMA_A / (freq * freq);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        nM[i] = sqrt(1.0 + (double)ne[i] * A);
-}
-
-template <typename AT, typename GT>
-__global__ void k_scale_by_grid(AT *__restrict__ G, const GT *__restrict__ M, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        G[i] = (AT)((double)G[i] * (double)M[i]);
-}
-
-__global__ void k_subtract_reference(double *__restrict__ tec, int Na, int64_t NtNd, int i0) {
-    // rows other than i0 first (they read row i0), row i0 is zeroed by a second launch
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)Na * NtNd;
-         idx += (int64_t)gridDim.x * blockDim.x) {
-        const int a = idx / NtNd;
-        if (a != i0) tec[idx] -= tec[(int64_t)i0 * NtNd + idx % NtNd];
-    }
-}
-__global__ void k_zero(double *__restrict__ p, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
-}
-
-// C_m smoothing: Covariance.smooth = scipy.ndimage.convolve(phi, c_stencil, mode='nearest')
-// (ionosphere/covariance.py:46-63,383-385).  The reference's stencil is the product of three 1-D
-// exponential kernels, so the (2h+1)^3 convolution is three 1-D passes with edge replication.
-// Lanes run along z (contiguous) in every pass; taps along x / y are whole coalesced rows.
-#define CONV_T 32          // outputs along the filtered axis per workgroup (x / y passes)
-// x / y pass: a workgroup owns 64 consecutive z (lanes) x CONV_T outputs along the axis for one value
-// of the third index; the CONV_T + 2h input rows (edge rows replicated) are staged in LDS once, then
-// every thread produces CONV_T/4 outputs from LDS (2h+1 taps each).  Global loads per output:
-// (CONV_T + 2h) / CONV_T, all coalesced 512-B rows.
-template <int AXIS>
-__global__ __launch_bounds__(256) void k_conv_xy(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int nz,
-                                                 const double *__restrict__ w, int h) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *wl = sm;                      // [2h+1]
-    double *tile = sm + ((2 * h + 2) & ~1);    // [CONV_T + 2h][64]
-    const int m = 2 * h + 1, rows = CONV_T + 2 * h;
-    for (int t = threadIdx.x; t < m; t += blockDim.x) wl[t] = w[t];
-    const int na = AXIS == 0 ? nx : ny;               // filtered axis
-    const int no = AXIS == 0 ? ny : nx;               // the other non-z axis
-    const int64_t sa = AXIS == 0 ? (int64_t)ny * nz : nz, so = AXIS == 0 ? nz : (int64_t)ny * nz;
-    const int zt = (nz + 63) / 64, at = (na + CONV_T - 1) / CONV_T;
-    const int64_t ntile = (int64_t)zt * at * no;
-    const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    for (int64_t tid = blockIdx.x; tid < ntile; tid += gridDim.x) {
-        const int z0 = (int)(tid % zt) * 64;
-        const int a0 = (int)((tid / zt) % at) * CONV_T;
-        const int o = (int)(tid / ((int64_t)zt * at));
-        const int k = z0 + lane;
-        __syncthreads();
-        if (k < nz) {
-            const double *base = in + (int64_t)o * so + k;
-            for (int r = grp; r < rows; r += 4) {
-                const int a = min(max(a0 + r - h, 0), na - 1);
-                tile[r * 64 + lane] = base[(int64_t)a * sa];
-            }
-        }
-        __syncthreads();
-        if (k < nz) {
-            for (int q = grp; q < CONV_T; q += 4) {
-                if (a0 + q >= na) break;
-                double acc = 0.0;
-                const double *tp = tile + q * 64 + lane;
-                for (int t = 0; t < m; ++t) acc += wl[m - 1 - t] * tp[t * 64];
-                out[(int64_t)o * so + (int64_t)(a0 + q) * sa + k] = acc;
-            }
-        }
-    }
-}
-
-// z pass: each wave owns 64 consecutive z of one (i, j) row; the 64 + 2h inputs go through LDS
-__global__ __launch_bounds__(256) void k_conv_z(const double *__restrict__ in, double *__restrict__ out, int nx, int ny, int nz,
-                                                const double *__restrict__ w, int h) {
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    double *wl = sm;
-    const int m = 2 * h + 1, span = 64 + 2 * h;
-    double *tile = sm + ((2 * h + 2) & ~1) + (threadIdx.x >> 6) * span;     // per wave
-    for (int t = threadIdx.x; t < m; t += blockDim.x) wl[t] = w[t];
-    __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int zt = (nz + 63) / 64;
-    const int64_t nseg = (int64_t)nx * ny * zt;
-    for (int64_t sid = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); sid < nseg; sid += (int64_t)gridDim.x * 4) {
-        const int z0 = (int)(sid % zt) * 64;
-        const double *row = in + (sid / zt) * nz;
-        for (int t = lane; t < span; t += 64) tile[t] = row[min(max(z0 + t - h, 0), nz - 1)];
-        // same-wave LDS write -> read: the wave executes in lockstep, a waitcnt is all that is needed
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        const int k = z0 + lane;
-        if (k < nz) {
-            double acc = 0.0;
-            for (int t = 0; t < m; ++t) acc += wl[m - 1 - t] * tile[lane + t];
-            out[(sid / zt) * nz + k] = acc;
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-template <typename GT, int KIND, bool EXTRAP>
-__global__ void k_interp_points(GridView g, const double *__restrict__ x, const double *__restrict__ y,
-                                const double *__restrict__ z, int64_t n, double *__restrict__ out, int *oob_flag) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    const Axes ax = stage_axes(g, lds);
-    bool oob = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double px = x[i], py = y[i], pz = z[i];
-        if (!EXTRAP && sample_outside<KIND>(ax, px, py, pz)) {
-            oob = true;
-            out[i] = nan("");
-            continue;
-        }
-        out[i] = sample_at<GT, KIND>(g, ax, px, py, pz);
-    }
-    if (oob) atomicOr(oob_flag, 1);
-}
-
-__global__ void k_trace_straight(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
-                                 int Ns, double *__restrict__ rays) {
-    const int64_t n = R * Ns;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t r = idx / Ns;
-        const int k = idx % Ns;
-        const StraightRay q = load_straight(origins, dirs, r, tmax, Ns);
-        double x, y, z;
-        straight_point(q, k, Ns, x, y, z);
-        double *o = rays + (size_t)r * 4 * Ns;
-        o[k] = x;
-        o[Ns + k] = y;
-        o[2 * Ns + k] = z;
-        const double frac = (k == Ns - 1) ? 1.0 : (double)k * q.step;
-        o[3 * Ns + k] = q.L * frac / q.pz;     // s = (z - z0)/pz
-    }
-}
-
-// Fermat ray ODE in z (inversion/fermat.py:64-72; notebooks/FermatClass.ipynb c0:76-84):
-//   s' = n/pz, p' = grad(n) n/pz, x' = px/pz, y' = py/pz, z' = 1.   Lanes = rays, RK4.
-struct FState {
-    double px, py, pz, x, y, z, s;
-};
-template <int KIND, bool BEND>
-__device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u) {
-    double n, nx, ny, nz;
-    if (KIND == IONO_INTERP_TRILINEAR) {
-        trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
-    } else {
-        GridView gn = g;
-        gn.M = nM;
-        tricubic_eval<double, true>(gn, g.axes, g.axes + g.nx, g.axes + g.nx + g.ny, u.x, u.y, u.z, n, nx, ny, nz);
-    }
-    if (!BEND) nx = ny = nz = 0.0;
-    const double f = n / u.pz;
-    FState d;
-    d.px = nx * f;
-    d.py = ny * f;
-    d.pz = nz * f;
-    d.x = u.px / u.pz;
-    d.y = u.py / u.pz;
-    d.z = 1.0;
-    d.s = f;
-    return d;
-}
-__device__ __forceinline__ FState axpy(const FState &u, double a, const FState &d) {
-    FState r;
-    r.px = u.px + a * d.px;
-    r.py = u.py + a * d.py;
-    r.pz = u.pz + a * d.pz;
-    r.x = u.x + a * d.x;
-    r.y = u.y + a * d.y;
-    r.z = u.z + a * d.z;
-    r.s = u.s + a * d.s;
-    return r;
-}
-template <int KIND, bool BEND>
-__global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *__restrict__ nM,
-                                                     const double *__restrict__ origins, const double *__restrict__ dirs,
-                                                     int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
-                                                     int *oob_flag) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= R) return;
-    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
-    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
-    FState u;
-    u.px = dx / nrm;
-    u.py = dy / nrm;
-    u.pz = dz / nrm;
-    u.x = origins[3 * r];
-    u.y = origins[3 * r + 1];
-    u.z = origins[3 * r + 2];
-    u.s = 0.0;
-    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
-    double *o = rays + (size_t)r * 4 * Ns;
-    o[0] = u.x;
-    o[Ns] = u.y;
-    o[2 * Ns] = u.z;
-    o[3 * Ns] = u.s;
-    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
-    bool oob = false;
-    for (int k = 1; k < Ns; ++k) {
-        for (int sub = 0; sub < substeps; ++sub) {
-            // classic RK4 with the four stages as a loop (one copy of the right-hand side: four inlined
-            // tricubic evaluations need > 512 VGPRs and spill): sum = k1 + 2 k2 + 2 k3 + k4
-            FState kprev = {}, sum = {};
-#pragma unroll 1
-            for (int st = 0; st < 4; ++st) {
-                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs<KIND, BEND>(g, nM, axpy(u, ca, kprev));
-                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
-            }
-            u = axpy(u, h / 6.0, sum);
-        }
-        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
-        o[k] = u.x;
-        o[Ns + k] = u.y;
-        o[2 * Ns + k] = u.z;
-        o[3 * Ns + k] = u.s;
-    }
-    if (oob) atomicOr(oob_flag, 1);
-}
-
-// ---- cooperative tricubic tracer: 8 lanes per ray -------------------------------------------------------
-// With lanes = rays a 2,604-ray config is 41 waves, each lane serially gathering 216 nodes per RK4
-// stage.  Here a ray is shared by 8 consecutive lanes: lane `sub` (< 6) owns x-tap `a = sub` and
-// contracts its 6 x 6 (y, z) plane (z taps are 6 contiguous doubles per load group); the four partial
-// results (n, nx, ny, nz) are summed over the 8 lanes with three DPP steps (quad_perm xor 1, xor 2,
-// row_half_mirror).  Every lane keeps the full ray state, so no broadcast is needed.
-template <int CTRL>
-__device__ __forceinline__ double dpp_xadd(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
-    return v + __hiloint2double(hi2, lo2);
-}
-__device__ __forceinline__ double sum8(double v) {
-    v = dpp_xadd<0xB1>(v);      // quad_perm:[1,0,3,2]
-    v = dpp_xadd<0x4E>(v);      // quad_perm:[2,3,0,1]
-    return dpp_xadd<0x141>(v);  // row_half_mirror: lane i <-> 7 - i within each group of 8
-}
-__device__ __forceinline__ void pick_tap(const double w[6], const double dw[6], int a, double &wa, double &da) {
-    wa = a == 0 ? w[0] : a == 1 ? w[1] : a == 2 ? w[2] : a == 3 ? w[3] : a == 4 ? w[4] : a == 5 ? w[5] : 0.0;
-    da = a == 0 ? dw[0] : a == 1 ? dw[1] : a == 2 ? dw[2] : a == 3 ? dw[3] : a == 4 ? dw[4] : a == 5 ? dw[5] : 0.0;
-}
-template <bool BEND>
-__device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const double *__restrict__ nM, const FState &u, int sub) {
-    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
-    double wx[6], wy[6], wz[6], dx[6], dy[6], dz[6];
-    const int i = cubic_axis(gx, g.nx, u.x, g.inv_h[0], g.uniform[0], wx, dx, true);
-    const int j = cubic_axis(gy, g.ny, u.y, g.inv_h[1], g.uniform[1], wy, dy, true);
-    const int k = cubic_axis(gz, g.nz, u.z, g.inv_h[2], g.uniform[2], wz, dz, true);
-    double wxa, dxa;
-    pick_tap(wx, dx, sub, wxa, dxa);
-    const int a = min(sub, 5);
-    const double *base = nM + ((size_t)(i - 2 + a) * g.ny + (j - 2)) * g.nz + (k - 2);
-    double fa = 0.0, fya = 0.0, fza = 0.0;
-#pragma unroll
-    for (int b = 0; b < 6; ++b) {
-        const double *p = base + (size_t)b * g.nz;
-        double sv = 0.0, sz = 0.0;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const double v = p[c];
-            sv += v * wz[c];
-            sz += v * dz[c];
-        }
-        fa += sv * wy[b];
-        fya += sv * dy[b];
-        fza += sz * wy[b];
-    }
-    const double n = sum8(fa * wxa);
-    double nx = sum8(fa * dxa), ny = sum8(fya * wxa), nz = sum8(fza * wxa);
-    if (!BEND) nx = ny = nz = 0.0;
-    const double f = n / u.pz;
-    FState d;
-    d.px = nx * f;
-    d.py = ny * f;
-    d.pz = nz * f;
-    d.x = u.px / u.pz;
-    d.y = u.py / u.pz;
-    d.z = 1.0;
-    d.s = f;
-    return d;
-}
-template <bool BEND>
-__global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const double *__restrict__ nM,
-                                                          const double *__restrict__ origins, const double *__restrict__ dirs,
-                                                          int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
-                                                          int *oob_flag) {
-    const int sub = threadIdx.x & 7;
-    int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
-    const bool live = r < R;
-    if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
-    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
-    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
-    FState u;
-    u.px = dx / nrm;
-    u.py = dy / nrm;
-    u.pz = dz / nrm;
-    u.x = origins[3 * r];
-    u.y = origins[3 * r + 1];
-    u.z = origins[3 * r + 2];
-    u.s = 0.0;
-    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
-    double *o = rays + (size_t)r * 4 * Ns;
-    const bool writer = live && sub == 0;
-    if (writer) {
-        o[0] = u.x;
-        o[Ns] = u.y;
-        o[2 * Ns] = u.z;
-        o[3 * Ns] = u.s;
-    }
-    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
-    bool oob = false;
-    for (int k = 1; k < Ns; ++k) {
-        for (int s2 = 0; s2 < substeps; ++s2) {
-            FState kprev = {}, sum = {};
-#pragma unroll 1
-            for (int st = 0; st < 4; ++st) {
-                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs_coop<BEND>(g, nM, axpy(u, ca, kprev), sub);
-                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
-            }
-            u = axpy(u, h / 6.0, sum);
-        }
-        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
-        if (writer) {
-            o[k] = u.x;
-            o[Ns + k] = u.y;
-            o[2 * Ns + k] = u.z;
-            o[3 * Ns + k] = u.s;
-        }
-    }
-    if (oob && writer) atomicOr(oob_flag, 1);
-}
-
-}  // namespace
 
 // ================================================================================================
 // host side
