@@ -11,8 +11,13 @@ from .inversion.forward_equation import forward_equation, forward_equation_dask,
 from .inversion.gradient import compute_gradient, compute_gradient_dask
 from .astro.radio_array import RadioArray, generate_example_radio_array
 from .tomography.linear_operators import RayOp, TECForwardEquation
+from .ionosphere.covariance import Covariance
+from .ionosphere.simulation import IonosphereSimulation
+from .ionosphere.iri import a_priori_model_
+from .utils.timer import clock
 from ._lib import Context, default_context
 
 __all__ = ["TriCubic", "bisection", "calc_rays", "calc_rays_dask", "cast_ray", "Fermat", "forward_equation",
            "forward_equation_dask", "do_forward_equation", "compute_gradient", "compute_gradient_dask", "RadioArray",
-           "generate_example_radio_array", "RayOp", "TECForwardEquation", "Context", "default_context"]
+           "generate_example_radio_array", "RayOp", "TECForwardEquation", "Covariance", "IonosphereSimulation",
+           "a_priori_model_", "clock", "Context", "default_context"]

@@ -165,6 +165,10 @@ def test_matern_field_matches_reference_realisation(golden):
     g = golden("matern_field")
     B = syn.matern52_field(g["xvec"], g["yvec"], g["zvec"], float(g["sigma"]), float(g["corr"]), int(g["seed"]))
     assert np.max(np.abs(B - g["B"])) < 1e-12
+    import ionotomo_amd as it
+    sim = it.IonosphereSimulation(g["xvec"], g["yvec"], g["zvec"], float(g["sigma"]), float(g["corr"]), type='m52')
+    assert np.array_equal(sim.realization(seed=int(g["seed"])), B)
+    assert it.a_priori_model_(np.array([110.0, 300.0]), 45.0).shape == (2,) and it.clock() > 0
 
 
 def test_tricubic_matches_notebook_lekien_marsden_coefficients(golden):
