@@ -83,6 +83,14 @@ def load():
         raise RuntimeError(
             "ionotomo_amd: %s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # PyTorch's ROCm wheels bundle their own libamdhip64 / libhsa-runtime64 with the SAME sonames as
+    # /opt/rocm's, so whichever is loaded first serves every later user in the process.  If ours pulled in
+    # the system runtime first, a later `import torch` would find the GPU "unavailable"; loading torch
+    # first gives one runtime for both (kernels then run on torch-allocated memory without surprises).
+    try:
+        import torch  # noqa: F401
+    except Exception:                                   # torch is plumbing only: the facade works without it
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     lib.iono_ctx_create.argtypes = [_I, ctypes.POINTER(_V)]
     lib.iono_ctx_create.restype = _I

@@ -53,3 +53,61 @@ def test_random_problem(seed):
     g2 = ctx.adjoint_rays(rays, y, rule=rule)
     assert np.max(np.abs(g2 - gref)) < 1e-11 * np.max(np.abs(gref))
     ctx.close()
+
+
+def test_tiled_adjoint_soak():
+    """Many bundle shapes through the LDS-privatised adjoint in one process: dense coincident fans, sparse
+    fans, mixed zero weights, ragged last bundles, with and without a walk order -- each against the C oracle."""
+    import torch
+    from oracle import oracle_c as OC
+    from ionotomo_amd.engine import RayEngine
+    rng = np.random.default_rng(2024)
+    n = 48
+    xv, yv, zv = np.linspace(-60, 60, n), np.linspace(-55, 65, n), np.linspace(-2, 210, n)
+    eng = RayEngine(0)
+    eng.set_grid(xv, yv, zv)
+    eng.set_values(eng.tensor(rng.uniform(1, 2, size=(n, n, n))))
+    for case in range(24):
+        R = int(rng.choice([1, 3, 16, 17, 63, 64, 65, 130, 400, 1000]))
+        Ns = int(rng.choice([9, 64, 65, 70, 129]))
+        nant = int(rng.integers(1, 6))
+        ants = np.stack([rng.uniform(-8, 8, nant), rng.uniform(-8, 8, nant), rng.uniform(0, 1.0, nant)], -1)
+        spread = float(rng.choice([0.002, 0.02, 0.045]))             # coincident ... wide fan (stays inside the grid)
+        a = rng.integers(0, nant, R)
+        o = ants[a] + rng.normal(scale=0.01, size=(R, 3)) * [1, 1, 0]
+        d = np.stack([np.clip(rng.normal(scale=spread, size=R), -0.2, 0.2), np.clip(rng.normal(scale=spread, size=R), -0.2, 0.2),
+                      np.ones(R)], -1)
+        y = rng.normal(size=R)
+        y[rng.random(R) < 0.2] = 0.0
+        ref = OC.adjoint_straight(xv, yv, zv, o, d, y, 200.0, Ns)
+        ot, dt, yt = eng.tensor(o), eng.tensor(d), eng.tensor(y)
+        order = eng.locality_order(ot, dt, 200.0) if case % 2 else None
+        g = eng.adjoint(ot, dt, yt, 200.0, Ns, order=order).cpu().numpy()
+        assert not eng.check_oob(), (case, R, Ns, spread)
+        scale = max(np.max(np.abs(ref)), 1e-300)
+        assert np.max(np.abs(g - ref)) < 1e-11 * scale, (case, R, Ns, spread)
+        if ref.any():
+            t = eng.forward(ot, dt, 200.0, Ns, order=order)
+            lhs = float(torch.dot(t, yt))
+            rhs = float((eng.tensor(g) * eng.tensor(eng.ctx.get_values())).sum())
+            assert abs(lhs - rhs) < 1e-9 * (abs(lhs) + abs(rhs) + 1e-300)
+    assert not eng.check_oob()
+
+
+def test_library_then_torch_in_a_fresh_process():
+    """Load order regression: the C-ABI context first, torch afterwards (torch bundles a HIP runtime with the
+    same soname as the system one; _lib.load() makes sure a single runtime serves both)."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from ionotomo_amd import _lib\n"
+            "c = _lib.Context(0)\n"
+            "import torch\n"
+            "assert torch.cuda.is_available()\n"
+            "from ionotomo_amd.engine import RayEngine\n"
+            "e = RayEngine(0)\n"
+            "print('ok')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
