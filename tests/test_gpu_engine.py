@@ -152,6 +152,13 @@ def test_full_size_properties_256_cubed():
     tec_full = eng.forward(of, df, 1000.0, 257).cpu().numpy()
     tec_ord = eng.forward(of, df, 1000.0, 257, order=order).cpu().numpy()
     assert np.array_equal(tec_full, tec_ord)                      # the walk order never changes a ray's TEC
+    # dot-product test with EVERY ray of the batch, ordered (LDS-tiled) and unordered walks
+    yf = eng.tensor(rng.normal(size=w["origins"].shape[0]))
+    ne_t = eng.tensor(np.exp(w["m"]) * (w["K_ne"] / 1e13)).reshape(-1)
+    for od in (order, None):
+        Gty = eng.adjoint(of, df, yf, 1000.0, 257, order=od)
+        lhs, rhs = float(torch.dot(torch.from_numpy(tec_full).cuda(), yf)), float(torch.dot(ne_t, Gty.reshape(-1)))
+        assert abs(lhs - rhs) < 1e-10 * float(torch.from_numpy(tec_full).norm()) * float(yf.norm())
     pick = rng.choice(w["origins"].shape[0], 600, replace=False)
     ne = np.exp(w["m"]) * (w["K_ne"] / 1e13)
     ref = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], ne, w["origins"][pick], w["directions"][pick], 1000.0, 257)
