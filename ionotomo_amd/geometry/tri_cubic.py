@@ -134,21 +134,29 @@ class TriCubic(object):
         X, Y, Z = np.meshgrid(self.xvec, self.yvec, self.zvec, indexing='ij')
         return X.flatten(order='C'), Y.flatten(order='C'), Z.flatten(order='C')
 
-    # -- HDF5 "TCI/{xvec,yvec,zvec,M}" container (geometry/tri_cubic.py:81-99) ----------------------
+    # -- storage: HDF5 "TCI/{xvec,yvec,zvec,M}" (geometry/tri_cubic.py:81-99) or .npz with the same four names ----
     def load(self, filename, **kwargs):
-        import h5py
-        with h5py.File(filename, 'r') as f:
-            xvec, yvec, zvec, M = f["TCI/xvec"][:], f["TCI/yvec"][:], f["TCI/zvec"][:], f["TCI/M"][:, :, :]
+        if str(filename).endswith(".npz"):
+            with np.load(filename, allow_pickle=False) as z:
+                xvec, yvec, zvec, M = z["xvec"], z["yvec"], z["zvec"], z["M"]
+        else:
+            import h5py                                  # not installed in the build image: branch untested there
+            with h5py.File(filename, 'r') as f:
+                xvec, yvec, zvec, M = f["TCI/xvec"][:], f["TCI/yvec"][:], f["TCI/zvec"][:], f["TCI/M"][:, :, :]
         self.xvec, self.yvec, self.zvec = xvec, yvec, zvec
         self.M = M
 
     def save(self, filename):
+        arrays = {k: np.asarray(v, dtype=np.double) for k, v in
+                  (("xvec", self.xvec), ("yvec", self.yvec), ("zvec", self.zvec), ("M", self.M))}
+        if str(filename).endswith(".npz"):
+            with open(filename, "wb") as f:
+                np.savez(f, **arrays)
+            return
         import h5py
         with h5py.File(filename, 'w') as f:
-            f.create_dataset("TCI/xvec", data=np.asarray(self.xvec, dtype=np.double))
-            f.create_dataset("TCI/yvec", data=np.asarray(self.yvec, dtype=np.double))
-            f.create_dataset("TCI/zvec", data=np.asarray(self.zvec, dtype=np.double))
-            f.create_dataset("TCI/M", data=np.asarray(self.M, dtype=np.double))
+            for k, v in arrays.items():
+                f.create_dataset("TCI/" + k, data=v)
 
 
 def bisection(array, value):

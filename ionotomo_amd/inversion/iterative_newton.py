@@ -29,9 +29,20 @@ def forward_equation(model, tci, rays, freqs, K=1e11, i0=0, quad="avg"):
 
 
 def neg_log_like(g, dobs, CdCt, covariance=None, model=None, model_prior=None, tci=None, full=False):
-    """S = 1/2 sum (dobs - g)^2 / CdCt (inversion/iterative_newton.py:17-38).  The ``full=True`` prior
-    terms need the reference's Covariance object (out of scope, SURVEY.md 8f #3)."""
-    if full:
-        raise NotImplementedError("prior terms need ionosphere.covariance.Covariance (outside the hot path)")
+    """S = 1/2 sum (dobs - g)^2 / CdCt, plus with ``full=True`` the prior terms
+    1/2 sum (clock - clock_prior)^2 / c_clock + 1/2 <dmu, C_mu^{-1} dmu> with the Simpson^3 inner product
+    of ``tci`` (inversion/iterative_newton.py:17-54).  ``covariance = (Covariance, c_clock)``,
+    ``model = (mu, clock, const)``.  C_mu^{-1} is ``Covariance.contract`` (see its deviation note).
+    Like the reference, ``full=True`` leaves ``tci.M = C_mu^{-1} dmu``."""
     dd = dobs - g
-    return float(np.sum(dd * dd / CdCt) / 2.)
+    l2 = float(np.sum(dd * dd / CdCt) / 2.)
+    if full:
+        c_mu, c_clock = covariance
+        mu, clock, const = model
+        mu_prior, clock_prior, const_prior = model_prior
+        dclock = clock - clock_prior
+        l2 += float(np.sum(dclock * dclock / c_clock) / 2.)
+        dmu = np.reshape(mu_prior - mu, (tci.nx, tci.ny, tci.nz))
+        tci.M = c_mu.contract(dmu)
+        l2 += tci.inner(dmu, inplace=False) / 2.
+    return l2

@@ -6,8 +6,17 @@ factors, one per axis (covariance.py:22), sampled on a (2h+1)^3 stencil that gro
 below 5 % of its centre (``create_c_stencil``, :46-63); ``smooth(phi)`` is
 ``scipy.ndimage.convolve(phi, c_stencil, mode='nearest')``.  Because the stencil is separable the GPU
 applies three 1-D passes.  Only this default (separable exponential) kernel is built; the symbolic GP
-kernel machinery (utils/gaussian_process.py) and the ``clean``/``contract`` deconvolution are outside
-the hot path.
+kernel machinery (utils/gaussian_process.py) is outside the hot path.
+
+``contract(phi)`` = C_m^{-1} phi (used by the prior term of ``neg_log_like(full=True)``,
+inversion/iterative_newton.py:49-52).  The reference approximates it with ten sweeps of a gain-0.1 CLEAN
+of the truncated stencil over every voxel in sorted order (covariance.py:284-331): a sequential O(N h^3)
+Python loop whose result depends on the sweep order (and the truncated stencil is not positive definite,
+so it has no stable exact inverse).  Here ``contract`` is the EXACT inverse of the underlying, untruncated
+kernel: an exponential covariance on a uniform axis is a first-order Markov (Ornstein-Uhlenbeck) process
+whose precision matrix is tridiagonal, (1 - a^2)^-1 sigma^-2 tridiag(-a, 1 + a^2, -a) with 1 at the two
+ends and a = exp(-d/l); the separable 3-D inverse is three such 3-point passes (host numpy, O(N)).
+DEVIATION, parity unpinned (the reference's CLEAN needs its symbolic-kernel machinery to run at all).
 """
 import numpy as np
 
@@ -60,3 +69,17 @@ class Covariance(object):
             ctx.set_grid(np.arange(phi.shape[0], dtype=float), np.arange(phi.shape[1], dtype=float),
                          np.arange(phi.shape[2], dtype=float), None)
         return ctx.smooth_separable(phi, self.kx, self.ky, self.kz)
+
+    def contract(self, phi):
+        """C_m^{-1} . phi: exact inverse of the untruncated separable exponential kernel (module docstring)."""
+        out = np.array(phi, dtype=np.float64)
+        for axis, d in enumerate((self.dx, self.dy, self.dz)):
+            a = np.exp(-abs(d) / self.l)
+            x = np.moveaxis(out, axis, 0)
+            y = (1.0 + a * a) * x
+            y[0] = x[0]
+            y[-1] = x[-1]
+            y[1:] -= a * x[:-1]
+            y[:-1] -= a * x[1:]
+            out = np.moveaxis(y / (self.sigma ** 2 * (1.0 - a * a)), 0, axis)
+        return np.ascontiguousarray(out)
