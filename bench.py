@@ -184,50 +184,55 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    # ---- adjoint + one full iteration (forward, fused residual adjoint, all-reduce of the update)
-    rng = np.random.default_rng(2 + rank)
-    dobs_t = eng.tensor(tec_gpu.reshape(NA, -1) - tec_gpu.reshape(NA, -1)[0] + rng.normal(size=(NA, R // NA)) * 1e-3)
-    cdct_t = torch.full((R,), 1e-6, dtype=torch.float64, device=eng.device)
-    grad_t = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
+    # everything below is reported next to the headline number; a failure there (e.g. in the collective of the
+    # iteration leg) must not lose the headline line
+    try:
+        # ---- adjoint + one full iteration (forward, fused residual adjoint, all-reduce of the update)
+        rng = np.random.default_rng(2 + rank)
+        dobs_t = eng.tensor(tec_gpu.reshape(NA, -1) - tec_gpu.reshape(NA, -1)[0] + rng.normal(size=(NA, R // NA)) * 1e-3)
+        cdct_t = torch.full((R,), 1e-6, dtype=torch.float64, device=eng.device)
+        grad_t = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
 
-    def adj():
-        grad_t.zero_()
-        eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t, order=order_t)
-
-    def iteration():
-        fwd()
-        adj()
-        if world > 1:
-            dist.all_reduce(grad_t)
-
-    k2 = max(3, min(25, args.steps // 4))
-    awall, akern = time_steps(adj, k2, 1, torch, dist, world)
-    iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
-    extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
-    extra["adjoint_ms"] = akern * 1e3
-    extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
-    if order_t is not None:
-        def adj_unordered():
+        def adj():
             grad_t.zero_()
-            eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t)
-        wn, kn = time_steps(adj_unordered, k2, 1, torch, dist, world)
-        extra["adjoint_unordered_walk_ms"] = kn * 1e3
-    # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
-    eng32 = RayEngine(local, storage="f32")
-    eng32.set_grid(w["xvec"], w["yvec"], w["zvec"])
-    eng32.set_log_model(m_t, w["K_ne"] / 1e13)
-    tec32 = torch.empty_like(tec_t)
-    w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32), k2, 1, torch, dist, world)
-    extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
-    extra["f32_grid_roofline_frac"] = R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9 / HBM_PEAK_GBS
-    extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
-    # one timestep's worth of rays, contiguous in [Na][Nt*Nd] order is not one timestep; build it explicitly
-    sel = torch.arange(R, device=eng.device).reshape(NA, NT, ND)[:, 0, :].reshape(-1)
-    o1, d1 = o_t[sel].contiguous(), d_t[sel].contiguous()
-    t1 = torch.empty(o1.shape[0], dtype=torch.float64, device=eng.device)
-    _, k1 = time_steps(lambda: eng.forward(o1, d1, TMAX, NS, out=t1), 50, 5, torch, dist, 1)
-    extra["single_timestep_rays"] = int(o1.shape[0])
-    extra["single_timestep_us"] = k1 * 1e6
+            eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t, order=order_t)
+
+        def iteration():
+            fwd()
+            adj()
+            if world > 1:
+                dist.all_reduce(grad_t)
+
+        k2 = max(3, min(25, args.steps // 4))
+        awall, akern = time_steps(adj, k2, 1, torch, dist, world)
+        iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
+        extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
+        extra["adjoint_ms"] = akern * 1e3
+        extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
+        if order_t is not None:
+            def adj_unordered():
+                grad_t.zero_()
+                eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t)
+            wn, kn = time_steps(adj_unordered, k2, 1, torch, dist, world)
+            extra["adjoint_unordered_walk_ms"] = kn * 1e3
+        # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
+        eng32 = RayEngine(local, storage="f32")
+        eng32.set_grid(w["xvec"], w["yvec"], w["zvec"])
+        eng32.set_log_model(m_t, w["K_ne"] / 1e13)
+        tec32 = torch.empty_like(tec_t)
+        w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32), k2, 1, torch, dist, world)
+        extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
+        extra["f32_grid_roofline_frac"] = R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9 / HBM_PEAK_GBS
+        extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
+        # one timestep's worth of rays, contiguous in [Na][Nt*Nd] order is not one timestep; build it explicitly
+        sel = torch.arange(R, device=eng.device).reshape(NA, NT, ND)[:, 0, :].reshape(-1)
+        o1, d1 = o_t[sel].contiguous(), d_t[sel].contiguous()
+        t1 = torch.empty(o1.shape[0], dtype=torch.float64, device=eng.device)
+        _, k1 = time_steps(lambda: eng.forward(o1, d1, TMAX, NS, out=t1), 50, 5, torch, dist, 1)
+        extra["single_timestep_rays"] = int(o1.shape[0])
+        extra["single_timestep_us"] = k1 * 1e6
+    except Exception as exc:                                    # noqa: BLE001
+        extra["error"] = "%s: %s" % (type(exc).__name__, exc)
 
     line = {
         "metric": "ray-integrals/sec through 256^3 ne grid",

@@ -64,6 +64,8 @@ struct iono_ctx {
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     int walk_mode = 0;               // env IONOTOMO_WALK (see wave_chunk)
+    int64_t fermat_coop_max = 49152; // tricubic tracer: 8 lanes per ray up to this many rays, lanes = rays beyond
+                                     // (measured crossover ~40k rays; env IONOTOMO_FERMAT_COOP_MAX)
     int ideal = 0;                   // every axis is g0 + i*h to within 2.5e-13 h (np.linspace)
     double g0[3] = {0, 0, 0}, glast[3] = {0, 0, 0};
 };
@@ -301,6 +303,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
     if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e);
+    if (const char *e = getenv("IONOTOMO_FERMAT_COOP_MAX")) c->fermat_coop_max = atoll(e);
     *out = c;
     return IONO_OK;
 }
@@ -867,9 +870,9 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
     hipLaunchKernelGGL((k_trace_fermat<K, B>), grid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags)
     if (kind == IONO_INTERP_TRILINEAR) {
         if (bend) LAUNCH_F(IONO_INTERP_TRILINEAR, true); else LAUNCH_F(IONO_INTERP_TRILINEAR, false);
-    } else if (c->variant == 3) {           // lanes = rays (kept for A/B)
+    } else if (c->variant == 3 || R > c->fermat_coop_max) {   // lanes = rays: enough rays to fill the chip without splitting them
         if (bend) LAUNCH_F(IONO_INTERP_TRICUBIC, true); else LAUNCH_F(IONO_INTERP_TRICUBIC, false);
-    } else {                                // 8 lanes per ray
+    } else {                                // 8 lanes per ray: the 6x6x6 stencil of one ray spread over 8 lanes
         const dim3 cgrid((unsigned)((R + 7) / 8));
         if (bend)
             hipLaunchKernelGGL((k_trace_fermat_coop<true>), cgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR,

@@ -67,6 +67,17 @@ curved = eng.forward_rays(rays)
 out["cfg3_max_lateral_bending_km"] = float((rays[:, 0, -1] - (o[:, 0] + d[:, 0] / d[:, 2] * (w["tmax"] - o[:, 2]))).abs().max())
 out["cfg3_max_rel_tec_change_from_bending_120MHz"] = float(((curved - straight).abs() / straight.abs()).max())
 assert not eng.check_oob()
+# throughput of the tracer once the batch fills the chip: the same fan x 100 (260 400 rays, jittered origins)
+ob = (o[None] + 0.05 * torch.randn((100, 1, 3), dtype=torch.float64, device="cuda") * torch.tensor([1.0, 1.0, 0.0], device="cuda",
+                                                                                            dtype=torch.float64)).reshape(-1, 3).contiguous()
+db = d[None].expand(100, -1, -1).reshape(-1, 3).contiguous()
+big = torch.empty((ob.shape[0], 4, w["Ns"]), dtype=torch.float64, device="cuda")
+for kind in ("linear", "cubic"):
+    ms = timeit(lambda: eng.trace_fermat(ob, db, w["tmax"], w["Ns"], 120e6, bend=True, kind=kind, substeps=4, out=big), 3, 1)
+    out["fermat_full_batch_%s_ms" % kind] = ms
+    out["fermat_full_batch_%s_rays_per_s" % kind] = ob.shape[0] / ms * 1e3
+assert not eng.check_oob()
+del big
 
 # ---------------------------------------------------------------- PCIe-inclusive facade call (host numpy in/out)
 import ionotomo_amd as it  # noqa: E402

@@ -287,16 +287,24 @@ def test_fermat_shipped_curved_mode_golden(ctx, golden, O):
     assert np.max(np.abs(rays - mine)) < 1e-9
 
 
-def test_fermat_bending_matches_oracle(ctx, O):
+def test_fermat_bending_matches_oracle(ctx, O, monkeypatch):
     from test_oracle_golden import smooth_bending_case
+    from ionotomo_amd import _lib
     xv, yv, zv, nM, o, d, tmax = smooth_bending_case()
     ne = (1.0 - nM ** 2) * (30e6 ** 2 / 8.980 ** 2)
     ctx.set_grid(xv, yv, zv, ne)
+    # the tricubic tracer has two lane mappings, chosen by batch size: 8 lanes per ray (small batches, the default
+    # here) and lanes = rays (large batches; forced through the threshold env var for a second context)
+    monkeypatch.setenv("IONOTOMO_FERMAT_COOP_MAX", "0")
+    big_batch_ctx = _lib.Context()
+    monkeypatch.delenv("IONOTOMO_FERMAT_COOP_MAX")
+    big_batch_ctx.set_grid(xv, yv, zv, ne)
     for kind, field in (("cubic", O.n_field_tricubic(xv, yv, zv, O.ne_to_n(ne, 30e6))),
                         ("linear", O.n_field_trilinear(xv, yv, zv, O.ne_to_n(ne, 30e6)))):
-        rays = ctx.trace_fermat(o, d, tmax, 17, 30e6, bend=True, kind=kind, substeps=4).reshape(o.shape[:-1] + (4, 17))
         ref = O.fermat_trace(o, d, tmax, 17, field, bend=True, substeps=4)
-        assert np.max(np.abs(rays - ref)) < 1e-8
+        for c in (ctx, big_batch_ctx):
+            rays = c.trace_fermat(o, d, tmax, 17, 30e6, bend=True, kind=kind, substeps=4).reshape(o.shape[:-1] + (4, 17))
+            assert np.max(np.abs(rays - ref)) < 1e-8
     straight = O.straight_rays(o, d, tmax, 17)
     assert np.max(np.abs(rays[..., 0, :] - straight[..., 0, :])) > 1.0
 
