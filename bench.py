@@ -209,6 +209,29 @@ def main():
         extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
         extra["adjoint_ms"] = akern * 1e3
         extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
+        if world > 1:
+            # the same iteration with the update exchanged only over the nodes some rank's rays reach
+            # (ionotomo_amd/parallel.py:GradientExchange; the plan is built once per geometry)
+            from ionotomo_amd.parallel import GradientExchange
+            ones = torch.ones(R, dtype=torch.float64, device=eng.device)
+            xch = GradientExchange("compact").plan(eng.adjoint(o_t, d_t, ones, TMAX, NS, order=order_t))
+
+            def iteration_compact():
+                fwd()
+                adj()
+                xch.sum_(grad_t)
+            cwall, _ = time_steps(iteration_compact, k2, 1, torch, dist, world)
+            extra["iteration_ms_compact_exchange"] = cwall / k2 * 1e3
+            extra["exchange_active_node_fraction"] = xch.fraction
+            xch32 = GradientExchange("compact", reduce_dtype=torch.float32)
+            xch32.index, xch32.fraction = xch.index, xch.fraction
+
+            def iteration_compact32():
+                fwd()
+                adj()
+                xch32.sum_(grad_t)
+            c32wall, _ = time_steps(iteration_compact32, k2, 1, torch, dist, world)
+            extra["iteration_ms_compact_exchange_f32"] = c32wall / k2 * 1e3
         if order_t is not None:
             def adj_unordered():
                 grad_t.zero_()

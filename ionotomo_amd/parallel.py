@@ -10,7 +10,13 @@ Here:
   ``tec - tec[i0]`` (forward_equation.py:50) never leaves the GPU;
 * forward: no collective;
 * adjoint: every rank back-projects its rays into a full-size partial gradient, then ONE
-  ``all_reduce(sum)`` (RCCL over xGMI with the nccl backend; gloo in the CPU tests);
+  ``all_reduce(sum)`` (RCCL over xGMI with the nccl backend; gloo in the CPU tests).  xGMI is
+  point-to-point, so the ring all-reduce is bound by one link (~150 GB/s peak): a dense 256^3 f64
+  gradient (128 MiB) costs 2 (N-1)/N x 128 MiB / link rate = milliseconds per iteration, more than
+  the kernels.  The ray fan only touches a fraction of the box (~20 % in the bench geometry), and the
+  geometry is fixed for the whole inversion, so ``exchange="compact"`` finds the union of touched
+  nodes once (one unit-weight back-projection + a MAX all-reduce of the mask) and afterwards
+  all-reduces only those nodes, gathered into a contiguous buffer (optionally in float32);
 * scalars (objective, step lengths): all_reduce of a few doubles.
 
 ``engine`` is any object with ``forward(origins, dirs, tmax, Ns) -> tec`` and
@@ -41,11 +47,59 @@ def all_reduce_sum_(t):
     return t
 
 
+class GradientExchange(object):
+    """Sum of the ranks' partial gradients (module docstring).  ``mode``: "dense" (all-reduce the whole
+    grid), "compact" (only the nodes any rank's rays touch) or "auto" (compact when that set is below
+    ``dense_above`` of the grid).  ``reduce_dtype=torch.float32`` halves the bytes on the links; the sum is
+    then exact to ~1e-7 relative (the solvers' iterates change at that level)."""
+
+    def __init__(self, mode="auto", reduce_dtype=None, dense_above=0.6):
+        assert mode in ("dense", "compact", "auto")
+        self.mode, self.reduce_dtype, self.dense_above = mode, reduce_dtype, float(dense_above)
+        self.index = None          # int64 [n_active] flat node indices, identical on every rank
+        self.fraction = 1.0
+
+    def plan(self, touched):
+        """``touched``: this rank's gradient of unit ray weights (> 0 exactly at the nodes its rays reach)."""
+        world, _ = world_info()
+        if world == 1 or self.mode == "dense":
+            return self
+        mask = (touched.reshape(-1) != 0).to(torch.int32)
+        dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+        index = mask.nonzero().reshape(-1)
+        self.fraction = index.numel() / max(mask.numel(), 1)
+        if self.mode == "compact" or self.fraction < self.dense_above:
+            self.index = index
+        return self
+
+    def sum_(self, g):
+        """In-place sum of ``g`` over ranks; nodes outside the plan are zero on every rank and stay so."""
+        world, _ = world_info()
+        if world == 1:
+            return g
+        if self.index is None:
+            if self.reduce_dtype is not None and self.reduce_dtype != g.dtype:
+                buf = g.to(self.reduce_dtype)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                g.copy_(buf)
+                return g
+            return all_reduce_sum_(g)
+        flat = g.view(-1)
+        buf = flat.index_select(0, self.index)
+        if self.reduce_dtype is not None:
+            buf = buf.to(self.reduce_dtype)
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        flat.index_copy_(0, self.index, buf.to(g.dtype))
+        return g
+
+
 class ShardedRays(object):
     """This rank's slice of a [Na][P] ray bundle (+ optional data), resident on the engine's device."""
 
-    def __init__(self, engine, origins, directions, tmax, Ns, dobs=None, cdct=None, i0=0):
-        """origins/directions: [Na,P,3] (numpy or tensor, FULL problem); dobs/cdct: [Na,P]."""
+    def __init__(self, engine, origins, directions, tmax, Ns, dobs=None, cdct=None, i0=0, exchange="auto",
+                 reduce_dtype=None):
+        """origins/directions: [Na,P,3] (numpy or tensor, FULL problem); dobs/cdct: [Na,P].
+        ``exchange`` / ``reduce_dtype``: see ``GradientExchange``."""
         self.engine = engine
         self.world, self.rank = world_info()
         o = torch.as_tensor(origins, dtype=torch.float64)
@@ -63,6 +117,10 @@ class ShardedRays(object):
         # walk order for the kernels (speed only): spatial neighbours next to each other
         self.order = engine.locality_order(self.origins, self.dirs, self.tmax) if (
             hasattr(engine, "locality_order") and self.R_local > 0) else None
+        self.exchange = GradientExchange(exchange, reduce_dtype)
+        if self.world > 1 and exchange != "dense":
+            ones = torch.ones(self.R_local, dtype=torch.float64, device=dev)
+            self.exchange.plan(engine.adjoint(self.origins, self.dirs, ones, self.tmax, self.Ns, order=self.order))
 
     def slice(self, full):
         """[Na,P] (full problem) -> this rank's [Na*P_local] device vector."""
@@ -83,14 +141,14 @@ class ShardedRays(object):
         w = y.view(self.Na, self.P_local).clone()
         w[self.i0] -= y.view(self.Na, self.P_local).sum(dim=0)
         g = self.engine.adjoint(self.origins, self.dirs, w.reshape(-1), self.tmax, self.Ns, order=self.order)
-        return all_reduce_sum_(g)
+        return self.exchange.sum_(g)
 
     def gradient_from_tec(self, tec):
         """Fused residual -> weights -> back-projection (one launch) + all-reduce:
         G^T diff((tec - tec[i0] - dobs)/(CdCt + 1e-15))."""
         g = self.engine.adjoint_residual(self.origins, self.dirs, tec, self.dobs, self.cdct, self.Na, self.i0,
                                          self.tmax, self.Ns, order=self.order)
-        return all_reduce_sum_(g)
+        return self.exchange.sum_(g)
 
     def dot_rays(self, a, b):
         """<a, b> over ALL rays (local dot + scalar all-reduce)."""

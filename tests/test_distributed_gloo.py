@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _run(world):
+def _run(world, exchange="dense"):
     """Executed by every rank (and with world == 1 in the parent for the reference result)."""
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
@@ -34,7 +34,7 @@ def _run(world):
     d = rng.normal(size=(pb["na"], pb["P"])) * 0.01
     cd = np.full((pb["na"], pb["P"]), 1e-4)
     eng = OracleEngine(w["xvec"], w["yvec"], w["zvec"])
-    prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d, cdct=cd, i0=pb["i0"])
+    prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d, cdct=cd, i0=pb["i0"], exchange=exchange)
     x = torch.from_numpy(pb["x_true"].copy())
     eng.set_values(x)
     fwd = prob.gather_rays(prob.forward()).numpy()
@@ -42,27 +42,33 @@ def _run(world):
     adj = prob.adjoint(prob.slice(y_full)).numpy()
     xc, hc = solvers.cgls(prob, torch.from_numpy(pb["x0"].copy()), n_iter=4)
     xs, hs = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()), n_iter=3)
+    # float32 on the links (compact plan shared with the float64 exchange above)
+    p32 = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], i0=pb["i0"], exchange=exchange,
+                               reduce_dtype=torch.float32)
+    adj32 = p32.adjoint(p32.slice(y_full)).numpy()
     return dict(fwd=fwd, adj=adj, xc=xc.numpy(), hc=np.array(hc), xs=xs.numpy(), hs=np.array(hs),
-                block=(prob.lo, prob.hi))
+                block=(prob.lo, prob.hi), adj32=adj32, active=prob.exchange.fraction,
+                compact=prob.exchange.index is not None)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, exchange):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = _run(world)
+    out = _run(world, exchange)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_path_matches_single_rank(world):
+@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "compact"), (3, "auto")])
+def test_sharded_path_matches_single_rank(world, exchange):
+    """``exchange``: the gradient all-reduce over the whole grid, or only over the nodes some ray touches."""
     ref = _run(1)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=240) for _ in range(world))
@@ -79,3 +85,8 @@ def test_sharded_path_matches_single_rank(world):
         assert np.allclose(res[r]["hs"], ref["hs"], rtol=1e-10)
         assert np.allclose(res[r]["xs"], ref["xs"], rtol=1e-10, atol=1e-14)
         assert np.array_equal(res[r]["xc"], res[0]["xc"])        # replicas stay bit-identical across ranks
+        assert np.allclose(res[r]["adj32"], ref["adj"], rtol=0, atol=3e-7 * np.abs(ref["adj"]).max())
+        assert not np.array_equal(res[r]["adj32"], ref["adj"])
+        assert res[r]["compact"] == (exchange == "compact" or (exchange == "auto" and res[r]["active"] < 0.6))
+        if exchange != "dense":
+            assert 0.0 < res[r]["active"] < 1.0 and res[r]["active"] == res[0]["active"]
