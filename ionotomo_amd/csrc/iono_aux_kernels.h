@@ -273,25 +273,74 @@ __device__ __forceinline__ void pick_tap(const double w[6], const double dw[6], 
     wa = a == 0 ? w[0] : a == 1 ? w[1] : a == 2 ? w[2] : a == 3 ? w[3] : a == 4 ? w[4] : a == 5 ? w[5] : 0.0;
     da = a == 0 ? dw[0] : a == 1 ? dw[1] : a == 2 ? dw[2] : a == 3 ? dw[3] : a == 4 ? dw[4] : a == 5 ? dw[5] : 0.0;
 }
+// Per-axis constants of the current cell, kept while the ray stays inside it: the seven divisions per axis of
+// cubic_axis (t, the two slope scales, the four derivative scalings) become multiplications by cached
+// reciprocals (ulp-level differences), and the cell search is skipped.
+struct CubicAxisCache {
+    int ic, i;                  // found cell (ic = -1: nothing cached) and stencil centre i = clamp(ic, 2, n - 4)
+    double lo, hi;              // g[ic] < x <= g[ic + 1]
+    double gi, rh, c0, c1;      // g[i], 1 / (g[i+1] - g[i]), h / (6 (g[i+1] - g[i-1])), h / (6 (g[i+2] - g[i]))
+};
+__device__ __forceinline__ int cubic_axis_cached(const double *g, int n, double x, double inv_h, int uniform,
+                                                 CubicAxisCache &cc, double w[6], double dw[6]) {
+    if (cc.ic < 0 || !((x > cc.lo || cc.ic == 0) && x <= cc.hi)) {
+        const int ic = find_cell(g, n, x, inv_h, uniform);
+        const int i = min(max(ic, 2), n - 4);
+        const double h = g[i + 1] - g[i];
+        cc.ic = ic, cc.i = i, cc.lo = g[ic], cc.hi = g[ic + 1];
+        cc.gi = g[i], cc.rh = 1.0 / h;
+        cc.c0 = h / (6.0 * (g[i + 1] - g[i - 1]));
+        cc.c1 = h / (6.0 * (g[i + 2] - g[i]));
+    }
+    const double t = (x - cc.gi) * cc.rh, c0 = cc.c0, c1 = cc.c1;
+    const double t2 = t * t, t3 = t2 * t;
+    const double b0 = 2 * t3 - 3 * t2 + 1, b1 = -2 * t3 + 3 * t2, b2 = t3 - 2 * t2 + t, b3 = t3 - t2;
+    w[0] = b2 * c0;
+    w[1] = -8.0 * b2 * c0 + b3 * c1;
+    w[2] = b0 - 8.0 * b3 * c1;
+    w[3] = b1 + 8.0 * b2 * c0;
+    w[4] = -b2 * c0 + 8.0 * b3 * c1;
+    w[5] = -b3 * c1;
+    const double d0 = (6 * t2 - 6 * t) * cc.rh, d1 = -d0;
+    const double d2 = (3 * t2 - 4 * t + 1) * cc.rh, d3 = (3 * t2 - 2 * t) * cc.rh;
+    dw[0] = d2 * c0;
+    dw[1] = -8.0 * d2 * c0 + d3 * c1;
+    dw[2] = d0 - 8.0 * d3 * c1;
+    dw[3] = d1 + 8.0 * d2 * c0;
+    dw[4] = -d2 * c0 + 8.0 * d3 * c1;
+    dw[5] = -d3 * c1;
+    return cc.i;
+}
+struct StencilPlane {
+    int i, j, k;                // stencil centre the values belong to (i = -1: nothing cached)
+    double v[6][6];             // nM at (i - 2 + a, j - 2 + b, k - 2 + c) for this lane's x tap a
+};
 template <bool BEND>
-__device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const double *__restrict__ nM, const FState &u, int sub) {
-    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+__device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const double *gx, const double *gy, const double *gz,
+                                                  const double *__restrict__ nM, const FState &u, int sub,
+                                                  CubicAxisCache (&cc)[3], StencilPlane &nc) {
     double wx[6], wy[6], wz[6], dx[6], dy[6], dz[6];
-    const int i = cubic_axis(gx, g.nx, u.x, g.inv_h[0], g.uniform[0], wx, dx, true);
-    const int j = cubic_axis(gy, g.ny, u.y, g.inv_h[1], g.uniform[1], wy, dy, true);
-    const int k = cubic_axis(gz, g.nz, u.z, g.inv_h[2], g.uniform[2], wz, dz, true);
+    const int i = cubic_axis_cached(gx, g.nx, u.x, g.inv_h[0], g.uniform[0], cc[0], wx, dx);
+    const int j = cubic_axis_cached(gy, g.ny, u.y, g.inv_h[1], g.uniform[1], cc[1], wy, dy);
+    const int k = cubic_axis_cached(gz, g.nz, u.z, g.inv_h[2], g.uniform[2], cc[2], wz, dz);
     double wxa, dxa;
     pick_tap(wx, dx, sub, wxa, dxa);
     const int a = min(sub, 5);
-    const double *base = nM + ((size_t)(i - 2 + a) * g.ny + (j - 2)) * g.nz + (k - 2);
+    if (i != nc.i || j != nc.j || k != nc.k) {      // this lane's 6 x 6 (y, z) plane of the stencil: reload on a cell change
+        const double *base = nM + ((size_t)(i - 2 + a) * g.ny + (j - 2)) * g.nz + (k - 2);
+#pragma unroll
+        for (int b = 0; b < 6; ++b)
+#pragma unroll
+            for (int c = 0; c < 6; ++c) nc.v[b][c] = base[(size_t)b * g.nz + c];
+        nc.i = i, nc.j = j, nc.k = k;
+    }
     double fa = 0.0, fya = 0.0, fza = 0.0;
 #pragma unroll
     for (int b = 0; b < 6; ++b) {
-        const double *p = base + (size_t)b * g.nz;
         double sv = 0.0, sz = 0.0;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const double v = p[c];
+            const double v = nc.v[b][c];
             sv += v * wz[c];
             sz += v * dz[c];
         }
@@ -302,13 +351,14 @@ __device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const doubl
     const double n = sum8(fa * wxa);
     double nx = sum8(fa * dxa), ny = sum8(fya * wxa), nz = sum8(fza * wxa);
     if (!BEND) nx = ny = nz = 0.0;
-    const double f = n / u.pz;
+    const double ipz = 1.0 / u.pz;
+    const double f = n * ipz;
     FState d;
     d.px = nx * f;
     d.py = ny * f;
     d.pz = nz * f;
-    d.x = u.px / u.pz;
-    d.y = u.py / u.pz;
+    d.x = u.px * ipz;
+    d.y = u.py * ipz;
     d.z = 1.0;
     d.s = f;
     return d;
@@ -317,9 +367,18 @@ template <bool BEND>
 __global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const double *__restrict__ nM,
                                                           const double *__restrict__ origins, const double *__restrict__ dirs,
                                                           int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
-                                                          int *oob_flag) {
+                                                          int *oob_flag, int axes_in_lds, int rays_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    if (axes_in_lds) {              // the cell search and the slope weights read 7 axis values per axis per stage
+        const Axes ax = stage_axes(g, (double *)smem);
+        gx = ax.x, gy = ax.y, gz = ax.z;
+    }
+    // fewer than 8 rays per wave leaves lanes idle on purpose (small batches): a wave reloads whenever ANY of its
+    // rays changes cell
+    if ((int)(threadIdx.x >> 3) >= rays_per_wave) return;
     const int sub = threadIdx.x & 7;
-    int64_t r = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 3);
+    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x >> 3);
     const bool live = r < R;
     if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
     const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
@@ -341,7 +400,139 @@ __global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const doub
         o[2 * Ns] = u.z;
         o[3 * Ns] = u.s;
     }
-    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    bool oob = false;
+    CubicAxisCache cc[3] = {};
+    cc[0].ic = cc[1].ic = cc[2].ic = -1;
+    StencilPlane nc = {};
+    nc.i = nc.j = nc.k = -1;
+    for (int k = 1; k < Ns; ++k) {
+        for (int s2 = 0; s2 < substeps; ++s2) {
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs_coop<BEND>(g, gx, gy, gz, nM, axpy(u, ca, kprev), sub, cc, nc);
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
+        if (writer) {
+            o[k] = u.x;
+            o[Ns + k] = u.y;
+            o[2 * Ns + k] = u.z;
+            o[3 * Ns + k] = u.s;
+        }
+    }
+    if (oob && writer) atomicOr(oob_flag, 1);
+}
+
+// ---- trilinear tracer for small batches: 4 lanes per ray, axes in LDS, cell-cached corners ---------------
+// With lanes = rays every RK4 stage is a chain of dependent global loads (axis look-ups for the cell, then 8
+// corners spread over 4 cache lines per lane: 64 lanes x 4 lines = the whole 32 KB L1), ~1.4 us per stage and
+// 2 064 stages per ray.  Here a ray is shared by 4 consecutive lanes: lane (a, b) = (sub >> 1, sub & 1) owns the
+// corner column (i + a, j + b) and KEEPS a run of 8 of its z nodes in registers, so global memory is touched
+// only when the ray changes column or runs off the run (every ~7 cells = ~100 stages at 4 sub-steps per
+// sample); the cell bounds are cached too, so a stage inside the same cell needs no axis look-up; the axis
+// tables sit in LDS and the four partial results are summed with two DPP steps.  Same cell rule as find_cell,
+// same cell polynomial as trilinear_grad_at (reciprocal widths instead of divisions: ulp-level differences).
+__device__ __forceinline__ double sum4(double v) {
+    v = dpp_xadd<0xB1>(v);      // quad_perm:[1,0,3,2]
+    return dpp_xadd<0x4E>(v);   // quad_perm:[2,3,0,1]
+}
+constexpr int L4_RUN = 8;       // z-run of nodes cached per lane: cells kb .. kb + L4_RUN - 2 need no reload
+struct CornerPair {
+    int i, j, k, kb;            // cached cell (i, j, k) and first node of the cached z-run (-1: nothing cached)
+    double run[L4_RUN];         // nM at (i + a, j + b, kb .. kb + L4_RUN - 1)
+    double v0, v1;              // the pair of the current cell: run[k - kb], run[k - kb + 1]
+    double x0, x1, y0, y1, z0, z1, rhx, rhy, rhz;   // cell bounds (g[i] < x <= g[i+1]) and reciprocal widths
+};
+__device__ __forceinline__ double pick_run(const double (&v)[L4_RUN], int t) {
+    const double a0 = (t & 1) ? v[1] : v[0], a1 = (t & 1) ? v[3] : v[2], a2 = (t & 1) ? v[5] : v[4], a3 = (t & 1) ? v[7] : v[6];
+    const double b0 = (t & 2) ? a1 : a0, b1 = (t & 2) ? a3 : a2;
+    return (t & 4) ? b1 : b0;
+}
+template <bool BEND>
+__device__ __forceinline__ FState fermat_rhs_lin4(const GridView &g, const Axes &ax, const double *__restrict__ nM,
+                                                  const FState &u, int a, int b, CornerPair &cc) {
+    // fast path: still inside the cached cell (same rule as find_cell: g[i] < x <= g[i+1]; the first cell also
+    // owns its lower face).  The 4 lanes of a ray hold the same state, so they take the same branch.
+    const bool in_x = (u.x > cc.x0 || cc.i == 0) && u.x <= cc.x1, in_y = (u.y > cc.y0 || cc.j == 0) && u.y <= cc.y1;
+    const bool in_z = (u.z > cc.z0 || cc.k == 0) && u.z <= cc.z1;
+    if (!(in_x && in_y && in_z) || cc.kb < 0) {
+        const int i = find_cell(ax.x, ax.nx, u.x, g.inv_h[0], g.uniform[0]);
+        const int j = find_cell(ax.y, ax.ny, u.y, g.inv_h[1], g.uniform[1]);
+        const int k = find_cell(ax.z, ax.nz, u.z, g.inv_h[2], g.uniform[2]);
+        if (i != cc.i || j != cc.j || cc.kb < 0 || k < cc.kb || k > cc.kb + L4_RUN - 2) {
+            // (re)load the z-run of this lane's corner column; the run is clamped to the axis, so a run that
+            // would stick out at the top starts lower instead
+            const int kb = max(0, min(k, g.nz - L4_RUN));
+            const double *p = nM + ((size_t)(i + a) * g.ny + (j + b)) * g.nz + kb;
+#pragma unroll
+            for (int t = 0; t < L4_RUN; ++t) cc.run[t] = (kb + t < g.nz) ? p[t] : 0.0;
+            cc.kb = kb;
+        }
+        cc.i = i, cc.j = j, cc.k = k;
+        cc.v0 = pick_run(cc.run, k - cc.kb);
+        cc.v1 = pick_run(cc.run, k - cc.kb + 1);
+        cc.x0 = ax.x[i], cc.x1 = ax.x[i + 1], cc.y0 = ax.y[j], cc.y1 = ax.y[j + 1], cc.z0 = ax.z[k], cc.z1 = ax.z[k + 1];
+        cc.rhx = 1.0 / (cc.x1 - cc.x0), cc.rhy = 1.0 / (cc.y1 - cc.y0), cc.rhz = 1.0 / (cc.z1 - cc.z0);
+    }
+    const double tx = (u.x - cc.x0) * cc.rhx, ty = (u.y - cc.y0) * cc.rhy, tz = (u.z - cc.z0) * cc.rhz;
+    const double wxa = a ? tx : 1.0 - tx, wyb = b ? ty : 1.0 - ty;
+    const double sa = a ? 1.0 : -1.0, sb = b ? 1.0 : -1.0;
+    const double dvz = cc.v1 - cc.v0, vz = cc.v0 + tz * dvz;
+    const double n = sum4(vz * wxa * wyb);
+    double nx = sum4(vz * sa * wyb) * cc.rhx, ny = sum4(vz * wxa * sb) * cc.rhy, nz = sum4(dvz * wxa * wyb) * cc.rhz;
+    if (!BEND) nx = ny = nz = 0.0;
+    const double ipz = 1.0 / u.pz;              // one reciprocal instead of three divisions per stage
+    const double f = n * ipz;
+    FState d;
+    d.px = nx * f;
+    d.py = ny * f;
+    d.pz = nz * f;
+    d.x = u.px * ipz;
+    d.y = u.py * ipz;
+    d.z = 1.0;
+    d.s = f;
+    return d;
+}
+template <bool BEND>
+__global__ __launch_bounds__(64) void k_trace_fermat_lin4(GridView g, const double *__restrict__ nM,
+                                                          const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                          int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
+                                                          int *oob_flag, int rays_per_wave) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const Axes ax = stage_axes(g, (double *)smem);
+    __syncthreads();
+    // rays_per_wave < 16 leaves lanes idle on purpose: the wave takes the slow path whenever ANY of its rays changes
+    // cell, so while the batch does not fill the chip anyway, fewer rays per wave means fewer slow stages per ray
+    if ((int)(threadIdx.x >> 2) >= rays_per_wave) return;
+    const int sub = threadIdx.x & 3, a = sub >> 1, b = sub & 1;
+    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x >> 2);
+    const bool live = r < R;
+    if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm;
+    u.py = dy / nrm;
+    u.pz = dz / nrm;
+    u.x = origins[3 * r];
+    u.y = origins[3 * r + 1];
+    u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    double *o = rays + (size_t)r * 4 * Ns;
+    const bool writer = live && sub == 0;
+    if (writer) {
+        o[0] = u.x;
+        o[Ns] = u.y;
+        o[2 * Ns] = u.z;
+        o[3 * Ns] = u.s;
+    }
+    CornerPair cc = {};
+    cc.i = cc.j = cc.k = cc.kb = -1;
     bool oob = false;
     for (int k = 1; k < Ns; ++k) {
         for (int s2 = 0; s2 < substeps; ++s2) {
@@ -349,12 +540,13 @@ __global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const doub
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs_coop<BEND>(g, nM, axpy(u, ca, kprev), sub);
+                kprev = fermat_rhs_lin4<BEND>(g, ax, nM, axpy(u, ca, kprev), a, b, cc);
                 sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
             }
             u = axpy(u, h / 6.0, sum);
         }
-        oob |= outside(gx, g.nx, u.x) || outside(gy, g.ny, u.y) || !(u.z >= gz[0] && u.z <= gz[g.nz - 1] + 1e-9 * fabs(tmax));
+        oob |= outside(ax.x, ax.nx, u.x) || outside(ax.y, ax.ny, u.y) ||
+               !(u.z >= ax.z[0] && u.z <= ax.z[ax.nz - 1] + 1e-9 * fabs(tmax));
         if (writer) {
             o[k] = u.x;
             o[Ns + k] = u.y;

@@ -64,8 +64,12 @@ struct iono_ctx {
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     int walk_mode = 0;               // env IONOTOMO_WALK (see wave_chunk)
-    int64_t fermat_coop_max = 49152; // tricubic tracer: 8 lanes per ray up to this many rays, lanes = rays beyond
-                                     // (measured crossover ~40k rays; env IONOTOMO_FERMAT_COOP_MAX)
+    int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
+                                           // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
+    int fermat_coop_rpw = 0;               // rays per wave of that kernel, 1..8: 0 = default (env IONOTOMO_FERMAT_COOP_RPW)
+    int64_t fermat_lin4_max = 131072;   // trilinear tracer: 4 lanes per ray up to this many rays, lanes = rays beyond
+                                        // (measured crossover ~150k rays; env IONOTOMO_FERMAT_LIN4_MAX)
+    int fermat_lin4_rpw = 0;            // rays per wave of that kernel: 0 = by batch size (env IONOTOMO_FERMAT_LIN4_RPW)
     int ideal = 0;                   // every axis is g0 + i*h to within 2.5e-13 h (np.linspace)
     double g0[3] = {0, 0, 0}, glast[3] = {0, 0, 0};
 };
@@ -304,6 +308,9 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
     if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_COOP_MAX")) c->fermat_coop_max = atoll(e);
+    if (const char *e = getenv("IONOTOMO_FERMAT_COOP_RPW")) c->fermat_coop_rpw = std::min(8, std::max(1, atoi(e)));
+    if (const char *e = getenv("IONOTOMO_FERMAT_LIN4_MAX")) c->fermat_lin4_max = atoll(e);
+    if (const char *e = getenv("IONOTOMO_FERMAT_LIN4_RPW")) c->fermat_lin4_rpw = std::min(16, std::max(1, atoi(e)));
     *out = c;
     return IONO_OK;
 }
@@ -868,18 +875,31 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
     double *dN = c->d_nM;
 #define LAUNCH_F(K, B) \
     hipLaunchKernelGGL((k_trace_fermat<K, B>), grid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags)
-    if (kind == IONO_INTERP_TRILINEAR) {
+    const size_t axes_bytes = (size_t)(c->nx + c->ny + c->nz) * 8;
+    if (kind == IONO_INTERP_TRILINEAR && c->variant != 3 && R <= c->fermat_lin4_max && axes_bytes <= 48 * 1024) {
+        // small batch: 4 lanes per ray, axes in LDS, corners cached per cell (latency-bound regime)
+        const int rpw = c->fermat_lin4_rpw > 0 ? c->fermat_lin4_rpw : (R <= 4096 ? 4 : 16);   // measured
+        const dim3 qgrid((unsigned)((R + rpw - 1) / rpw));
+        if (bend)
+            hipLaunchKernelGGL((k_trace_fermat_lin4<true>), qgrid, block, axes_bytes, c->stream, g, dN, dO, dD, R, tmax, Ns,
+                               substeps, dR, c->d_flags, rpw);
+        else
+            hipLaunchKernelGGL((k_trace_fermat_lin4<false>), qgrid, block, axes_bytes, c->stream, g, dN, dO, dD, R, tmax, Ns,
+                               substeps, dR, c->d_flags, rpw);
+    } else if (kind == IONO_INTERP_TRILINEAR) {
         if (bend) LAUNCH_F(IONO_INTERP_TRILINEAR, true); else LAUNCH_F(IONO_INTERP_TRILINEAR, false);
     } else if (c->variant == 3 || R > c->fermat_coop_max) {   // lanes = rays: enough rays to fill the chip without splitting them
         if (bend) LAUNCH_F(IONO_INTERP_TRICUBIC, true); else LAUNCH_F(IONO_INTERP_TRICUBIC, false);
     } else {                                // 8 lanes per ray: the 6x6x6 stencil of one ray spread over 8 lanes
-        const dim3 cgrid((unsigned)((R + 7) / 8));
+        const int rpw = c->fermat_coop_rpw > 0 ? c->fermat_coop_rpw : 8;
+        const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
+        const int in_lds = axes_bytes <= 48 * 1024;         // axis tables staged in LDS when they fit
         if (bend)
-            hipLaunchKernelGGL((k_trace_fermat_coop<true>), cgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR,
-                               c->d_flags);
+            hipLaunchKernelGGL((k_trace_fermat_coop<true>), cgrid, block, in_lds ? axes_bytes : 0, c->stream, g, dN, dO, dD, R,
+                               tmax, Ns, substeps, dR, c->d_flags, in_lds, rpw);
         else
-            hipLaunchKernelGGL((k_trace_fermat_coop<false>), cgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR,
-                               c->d_flags);
+            hipLaunchKernelGGL((k_trace_fermat_coop<false>), cgrid, block, in_lds ? axes_bytes : 0, c->stream, g, dN, dO, dD, R,
+                               tmax, Ns, substeps, dR, c->d_flags, in_lds, rpw);
     }
 #undef LAUNCH_F
     HIP_TRY(c, hipGetLastError());

@@ -10,7 +10,7 @@ eng = RayEngine(0, interp="linear")
 eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
 eng.set_values(eng.tensor(w["ne"]))
 o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
-out = {"variant": os.environ.get("IONOTOMO_VARIANT", "default")}
+out = {"variant": os.environ.get("IONOTOMO_VARIANT", "default"), "lin4_max": os.environ.get("IONOTOMO_FERMAT_LIN4_MAX", "default")}
 for rep in (1, 4, 10, 30, 100):
     jit = 0.05 * torch.randn((rep, 1, 3), dtype=torch.float64, device="cuda") * torch.tensor([1.0, 1.0, 0.0], device="cuda", dtype=torch.float64)
     ob = (o[None] + jit).reshape(-1, 3).contiguous()
