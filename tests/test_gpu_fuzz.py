@@ -55,6 +55,55 @@ def test_random_problem(seed):
     ctx.close()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_tracer_lane_mappings_agree_on_hard_geometry(seed, monkeypatch):
+    """The cell-cached tracers (4 / 8 lanes per ray) against the plain lanes = rays kernels and the oracle: strongly
+    tilted rays that change (i, j) column every few cells, origins exactly on grid nodes, the top reached exactly
+    (z-run clamp at the axis end), non-uniform axes, smooth refractive-index field with real bending."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(500 + seed)
+    kinds = [("ideal", "ideal", "ideal"), ("table", "ideal", "nonuniform"), ("nonuniform", "nonuniform", "nonuniform"),
+             ("ideal", "nonuniform", "ideal")][seed]
+    nx, ny, nz = 30 + seed, 27, 33 + 2 * seed
+    xv = random_axis(rng, nx, kinds[0], -60.0, 60.0)
+    yv = random_axis(rng, ny, kinds[1], -55.0, 65.0)
+    zv = random_axis(rng, nz, kinds[2], 0.0, 160.0)
+    X, Y, Z = np.meshgrid(xv, yv, zv, indexing="ij")
+    freq = 40e6
+    ne = 4e11 * np.exp(-((Z - 80.0) / 40.0) ** 2) * (1.0 + 0.3 * np.sin(X / 17.0) * np.cos(Y / 23.0))
+    assert np.all(8.980 ** 2 * ne / freq ** 2 < 0.5)
+    R = 37
+    o = np.stack([rng.uniform(-12, 12, R), rng.uniform(-12, 12, R), rng.uniform(zv[2], zv[3], R)], -1)
+    o[:5] = np.stack([xv[nx // 2 + np.arange(5)], yv[ny // 2 - np.arange(5)], np.full(5, zv[2])], -1)   # on nodes
+    d = np.stack([rng.uniform(-0.25, 0.25, R), rng.uniform(-0.25, 0.25, R), np.ones(R)], -1)
+    tmax = zv[-3]
+    o[5:8, 2] = zv[0]
+    Ns, sub = 41, 3
+    ctxs = []
+    for env in ({}, {"IONOTOMO_FERMAT_COOP_MAX": "0", "IONOTOMO_FERMAT_LIN4_MAX": "0"}, {"IONOTOMO_FERMAT_LIN4_RPW": "16"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        c = _lib.Context(0)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        c.set_grid(xv, yv, zv, ne)
+        ctxs.append(c)
+    nM = O.ne_to_n(ne, freq)
+    for kind, field in (("linear", O.n_field_trilinear(xv, yv, zv, nM)), ("cubic", O.n_field_tricubic(xv, yv, zv, nM))):
+        out = [c.trace_fermat(o, d, tmax, Ns, freq, bend=True, kind=kind, substeps=sub) for c in ctxs]
+        assert not any(c.check_oob() for c in ctxs)
+        ref = O.fermat_trace(o, d, tmax, Ns, field, bend=True, substeps=sub)
+        for r in out:
+            assert np.max(np.abs(r.reshape(ref.shape) - ref)) < 1e-8
+        straight = O.straight_rays(o, d, tmax, Ns)
+        assert np.max(np.abs(out[0].reshape(ref.shape)[..., 0, -1] - straight[..., 0, -1])) > 1e-3   # it does bend
+    # tracing to the very top of the grid: every mapping must stay in bounds (the run of cached nodes is clamped)
+    top = [c.trace_fermat(o, d * np.array([0.02, 0.02, 1.0]), zv[-1], Ns, freq, bend=True, kind="linear", substeps=sub) for c in ctxs]
+    assert np.max(np.abs(top[0] - top[1])) < 1e-8 and np.max(np.abs(top[0] - top[2])) < 1e-8
+    for c in ctxs:
+        c.close()
+
+
 def test_tiled_adjoint_soak():
     """Many bundle shapes through the LDS-privatised adjoint in one process: dense coincident fans, sparse
     fans, mixed zero weights, ragged last bundles, with and without a walk order -- each against the C oracle."""

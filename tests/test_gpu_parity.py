@@ -293,16 +293,22 @@ def test_fermat_bending_matches_oracle(ctx, O, monkeypatch):
     xv, yv, zv, nM, o, d, tmax = smooth_bending_case()
     ne = (1.0 - nM ** 2) * (30e6 ** 2 / 8.980 ** 2)
     ctx.set_grid(xv, yv, zv, ne)
-    # the tricubic tracer has two lane mappings, chosen by batch size: 8 lanes per ray (small batches, the default
-    # here) and lanes = rays (large batches; forced through the threshold env var for a second context)
-    monkeypatch.setenv("IONOTOMO_FERMAT_COOP_MAX", "0")
-    big_batch_ctx = _lib.Context()
-    monkeypatch.delenv("IONOTOMO_FERMAT_COOP_MAX")
-    big_batch_ctx.set_grid(xv, yv, zv, ne)
+    # the tracer picks its lane mapping by batch size: 4 (trilinear) / 8 (tricubic) lanes per ray with cell-cached
+    # stencils, fewer rays per wave for small batches, lanes = rays for very large ones.  Force each through the
+    # threshold env vars (read when a context is created) so all of them are checked on the same rays.
+    contexts = [ctx]
+    for env in ({"IONOTOMO_FERMAT_COOP_MAX": "0", "IONOTOMO_FERMAT_LIN4_MAX": "0"},
+                {"IONOTOMO_FERMAT_LIN4_RPW": "16", "IONOTOMO_FERMAT_COOP_RPW": "3"}):
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        contexts.append(_lib.Context())
+        for k_ in env:
+            monkeypatch.delenv(k_)
+        contexts[-1].set_grid(xv, yv, zv, ne)
     for kind, field in (("cubic", O.n_field_tricubic(xv, yv, zv, O.ne_to_n(ne, 30e6))),
                         ("linear", O.n_field_trilinear(xv, yv, zv, O.ne_to_n(ne, 30e6)))):
         ref = O.fermat_trace(o, d, tmax, 17, field, bend=True, substeps=4)
-        for c in (ctx, big_batch_ctx):
+        for c in contexts:
             rays = c.trace_fermat(o, d, tmax, 17, 30e6, bend=True, kind=kind, substeps=4).reshape(o.shape[:-1] + (4, 17))
             assert np.max(np.abs(rays - ref)) < 1e-8
     straight = O.straight_rays(o, d, tmax, 17)
