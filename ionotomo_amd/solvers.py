@@ -100,7 +100,7 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
         r.addcmul_(q, -alpha)
         s = normal_residual(r)
         gnew = torch.dot(s.reshape(-1), s.reshape(-1))
-        p.mul_(gnew / gamma).add_(s)             # p = s + beta p, in place
+        torch.addcmul(s, p, gnew / gamma, out=p)  # p = s + beta p: one pass, beta stays on the device
         gamma = gnew
     return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
 
