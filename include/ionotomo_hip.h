@@ -143,6 +143,12 @@ int iono_adjoint_residual_straight_dev(iono_ctx *ctx, const double *origins_dev,
                                        int Na, int64_t NtNd, int i0, double tmax, int Ns, int quad_rule,
                                        void *grad_dev, int accum_dtype);
 int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);
+/* Solver vector update  y = a x + b y  on device vectors (16-byte aligned), one pass.  The coefficients are ratios
+ * of DEVICE scalars, a = a_sign * a_num[0] / a_den[0], b = b_num[0] / b_den[0] (a null pointer stands for 1), so the
+ * step lengths of the iteration -- eps = sum(Gdm dd/Cd) / sum(Gdm^2/Cd), inversion/iterative_newton.py:542-554; the
+ * model update m <- m - eps (...), geometry/oct_trees/Inversion.py:533 -- never visit the host. */
+int iono_vec_axpby_dev(iono_ctx *ctx, double *y_dev, const double *x_dev, int64_t n, const double *a_num_dev,
+                       const double *a_den_dev, double a_sign, const double *b_num_dev, const double *b_den_dev);
 /* Fermat tracer with device buffers (rays_dev[R][4][Ns]); the refractive-index nodes are cached in the
  * ctx and rebuilt when the grid values or the frequency change.  Feed rays_dev to
  * iono_forward_tec_rays_dev for the curved-ray TEC (BASELINE config 3) without leaving the GPU. */

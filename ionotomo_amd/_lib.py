@@ -64,6 +64,7 @@ _SIGNATURES = {
     "iono_adjoint_rays_dev": [_V, _V, _L, _I, _I, _V, _I],
     "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _V, _I],
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
+    "iono_vec_axpby_dev": [_V, _V, _L, _V, _V, _D, _V, _V],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],

@@ -560,6 +560,19 @@ int iono_subtract_reference_dev(iono_ctx *c, double *tec, int Na, int64_t NtNd, 
     return IONO_OK;
 }
 
+int iono_vec_axpby_dev(iono_ctx *c, double *y, const double *x, int64_t n, const double *a_num, const double *a_den,
+                       double a_sign, const double *b_num, const double *b_den) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (n < 0 || (n > 0 && (!y || !x))) return fail(c, IONO_ERR_ARG, "iono_vec_axpby_dev: null vector");
+    if (n == 0) return IONO_OK;
+    if ((((uintptr_t)y) | ((uintptr_t)x)) & 15) return fail(c, IONO_ERR_ARG, "iono_vec_axpby_dev: vectors must be 16-byte aligned");
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(c, (n + 1) / 2)), dim3(256), 0, c->stream, y, x, n, a_num, a_den, a_sign, b_num,
+                       b_den);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
 // ---- adjoint (device pointers) ----------------------------------------------------------------
 static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const double *d, const int *order, const double *w,
                                    const double *tec, const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0,

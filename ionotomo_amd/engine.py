@@ -153,5 +153,15 @@ class RayEngine(object):
         self.ctx.call("iono_subtract_reference_dev", _ptr(tec_t), int(Na), tec_t.numel() // Na, int(i0))
         return tec_t
 
+    def axpby_(self, y, x, a_num=None, a_den=None, a_sign=1.0, b_num=None, b_den=None):
+        """y = (a_sign a_num / a_den) x + (b_num / b_den) y in one pass; the coefficients are 0-dim DEVICE tensors
+        (None = 1), so step lengths built from all-reduced dot products never synchronise with the host."""
+        self._sync_stream()
+        assert y.is_contiguous() and x.is_contiguous() and y.numel() == x.numel() and y.dtype == x.dtype == torch.float64
+        sc = [None if t is None else t.reshape(1) for t in (a_num, a_den, b_num, b_den)]     # keep alive over the call
+        self.ctx.call("iono_vec_axpby_dev", _ptr(y), _ptr(x), y.numel(), *[0 if t is None else _ptr(t) for t in sc[:2]],
+                      float(a_sign), *[0 if t is None else _ptr(t) for t in sc[2:]])
+        return y
+
     def check_oob(self):
         return self.ctx.check_oob()

@@ -129,7 +129,8 @@ class ShardedRays(object):
 
     # -- operators ---------------------------------------------------------------------------------
     def forward_tec(self):
-        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns, order=self.order)
+        # no walk order here: the forward reads only, and its plain XCD-major walk measured faster
+        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns)
 
     def forward(self):
         """differential TEC of the current grid values, local rays: A x = G x - (G x)[i0]."""

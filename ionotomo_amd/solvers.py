@@ -58,7 +58,7 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None):
         hist.append(0.5 * problem.dot_rays_t(r, r * Wt))        # stays on the device (see cgls)
         if callback:
             callback(k, x, float(hist[-1]))
-        x += relax * C * problem.adjoint(L * r)
+        x.addcmul_(C, problem.adjoint(L * r), value=relax)         # one pass
         if nonneg:
             x.clamp_(min=0)
     return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
@@ -75,6 +75,7 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
     """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2 + damp/2 ||x||^2,  W = 1/(CdCt + 1e-15).
     All scalars (alpha, beta, objective) stay on the device; the history is read back once at the
     end, so an iteration never waits for the host (``callback`` forces a read-back per iteration)."""
+    eng = problem.engine
     x = x0.clone()
     Wh = torch.rsqrt(problem.cdct + 1e-15)
 
@@ -95,12 +96,13 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
         _set_x(problem, p)
         q = Wh * problem.forward()
         qq = problem.dot_rays_t(q, q)
-        alpha = gamma / (qq + damp * torch.dot(p.reshape(-1), p.reshape(-1)) if damp != 0.0 else qq)
-        x.addcmul_(p, alpha)                     # x += alpha p   (alpha is a 0-dim device tensor)
-        r.addcmul_(q, -alpha)
+        den = qq + damp * torch.dot(p.reshape(-1), p.reshape(-1)) if damp != 0.0 else qq
+        # alpha = gamma / den and beta = gnew / gamma are 0-dim device tensors: one fused pass per update
+        eng.axpby_(x, p, a_num=gamma, a_den=den)                      # x += alpha p
+        eng.axpby_(r, q, a_num=gamma, a_den=den, a_sign=-1.0)         # r -= alpha q
         s = normal_residual(r)
         gnew = torch.dot(s.reshape(-1), s.reshape(-1))
-        torch.addcmul(s, p, gnew / gamma, out=p)  # p = s + beta p: one pass, beta stays on the device
+        eng.axpby_(p, s, b_num=gnew, b_den=gamma)                     # p = s + beta p
         gamma = gnew
     return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
 

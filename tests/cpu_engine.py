@@ -44,3 +44,10 @@ class OracleEngine(object):
         for ax, k in enumerate((kx, ky, kz)):
             a = convolve1d(a, np.asarray(k), axis=ax, mode='nearest')
         return torch.from_numpy(a.copy())
+
+    def axpby_(self, y, x, a_num=None, a_den=None, a_sign=1.0, b_num=None, b_den=None):
+        one = torch.ones((), dtype=torch.float64)
+        a = a_sign * (one if a_num is None else a_num) / (one if a_den is None else a_den)
+        b = (one if b_num is None else b_num) / (one if b_den is None else b_den)
+        y.mul_(b).add_(a * x)
+        return y

@@ -257,3 +257,22 @@ def test_very_long_rays_fall_back_to_the_table_kernels():
         g = eng.adjoint(eng.tensor(oo), eng.tensor(dd), eng.tensor(y), w["tmax"], Ns).cpu().numpy()
         gref = OC.adjoint_straight(w["xvec"], w["yvec"], w["zvec"], oo, dd, y, w["tmax"], Ns)
         assert np.max(np.abs(g - gref)) < 1e-11 * np.max(np.abs(gref))
+
+
+def test_fused_vector_update_with_device_scalars():
+    """iono_vec_axpby_dev: y = (sa a_num / a_den) x + (b_num / b_den) y, odd and even lengths, missing scalars = 1."""
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0)
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 4096, 100003):
+        x, y = rng.normal(size=n), rng.normal(size=n)
+        an, ad, bn, bd = rng.uniform(0.5, 2.0, 4)
+        t = lambda v: eng.tensor(np.asarray(v, dtype=np.float64))            # noqa: E731
+        for kw, a, b in ((dict(a_num=t(an), a_den=t(ad)), an / ad, 1.0),
+                         (dict(a_num=t(an), a_den=t(ad), a_sign=-1.0), -an / ad, 1.0),
+                         (dict(b_num=t(bn), b_den=t(bd)), 1.0, bn / bd),
+                         (dict(a_num=t(an), b_den=t(bd), a_sign=2.0), 2.0 * an, 1.0 / bd)):
+            yt = eng.tensor(y)
+            out = eng.axpby_(yt, eng.tensor(x), **kw)
+            assert out is yt
+            assert np.max(np.abs(yt.cpu().numpy() - (a * x + b * y))) < 1e-14 * (1 + abs(a) + abs(b)) * 5
