@@ -204,6 +204,9 @@ def main():
                 dist.all_reduce(grad_t)
 
         k2 = max(3, min(25, args.steps // 4))
+        # work partition of the back-projection balanced by measured cost: like the walk order it depends on the ray
+        # geometry only, is computed once per inversion and never changes results (engine.tune_adjoint_partition)
+        extra["adjoint_partition"] = eng.tune_adjoint_partition(adj, R) if args.order else None
         awall, akern = time_steps(adj, k2, 1, torch, dist, world)
         iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
         extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
@@ -233,6 +236,8 @@ def main():
             c32wall, _ = time_steps(iteration_compact32, k2, 1, torch, dist, world)
             extra["iteration_ms_compact_exchange_f32"] = c32wall / k2 * 1e3
         if order_t is not None:
+            eng.ctx.adjoint_partition_set(None, R)       # the tuned partition belongs to the ordered walk
+
             def adj_unordered():
                 grad_t.zero_()
                 eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t)

@@ -65,6 +65,8 @@ _SIGNATURES = {
     "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _V, _I],
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
     "iono_vec_axpby_dev": [_V, _V, _L, _V, _V, _D, _V, _V],
+    "iono_adjoint_block_cycles": [_V, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+    "iono_adjoint_partition_set": [_V, _I, _L],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],
@@ -215,6 +217,23 @@ class Context(object):
         v = ctypes.c_int(0)
         self.call("iono_check_oob", ctypes.byref(v))
         return bool(v.value)
+
+    # -- measured load balance of the LDS-tiled adjoint (include/ionotomo_hip.h) -------------------------
+    def adjoint_block_cycles(self):
+        """(cycles per chunk in walk order, resident workgroups) of the last tiled-adjoint launch; empty if none."""
+        n, wg = ctypes.c_int(0), ctypes.c_int(0)
+        self.call("iono_adjoint_block_cycles", None, 0, ctypes.byref(n), ctypes.byref(wg))
+        out = np.zeros(n.value, dtype=np.uint64)
+        if n.value:
+            self.call("iono_adjoint_block_cycles", out.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n), ctypes.byref(wg))
+        return out, wg.value
+
+    def adjoint_partition_set(self, starts, R):
+        if starts is None:
+            self.call("iono_adjoint_partition_set", None, 0, int(R))
+            return
+        st = np.ascontiguousarray(starts, dtype=np.int64)
+        self.call("iono_adjoint_partition_set", st.ctypes.data_as(ctypes.c_void_p), st.size - 1, int(R))
 
     # -- host-pointer numerics -----------------------------------------------------------------------
     def interp(self, x, y, z, kind="linear", extrapolate=False):

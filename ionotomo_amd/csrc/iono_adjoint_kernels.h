@@ -170,6 +170,23 @@ __device__ __forceinline__ double wave_minmax_dpp(double v) {
     return bcast_lane(v, 63);
 }
 
+// min / max over the wave's first 8, 16, 32 and 64 lanes from ONE ladder: after row_shr 1, 2, 4 lane 7 holds lanes
+// 0..7, after row_shr 8 lane 15 of each row holds its row (lanes without a source keep their own value)
+template <bool IS_MAX>
+__device__ __forceinline__ void wave_prefix_minmax(double v, double &p8, double &p16, double &p32, double &p64) {
+    v = dpp_minmax<0x111, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x112, 0xf, IS_MAX>(v);
+    v = dpp_minmax<0x114, 0xf, IS_MAX>(v);
+    p8 = bcast_lane(v, 7);
+    v = dpp_minmax<0x118, 0xf, IS_MAX>(v);
+    p16 = bcast_lane(v, 15);
+    const double r1 = bcast_lane(v, 31), r2 = bcast_lane(v, 47), r3 = bcast_lane(v, 63);
+    p32 = IS_MAX ? fmax(p16, r1) : fmin(p16, r1);
+    p64 = IS_MAX ? fmax(fmax(p32, r2), r3) : fmin(fmin(p32, r2), r3);
+}
+constexpr int ADJ_REF = 16;     // doubles per wave in the bundle scratch: [4,5,7] sums, [8..15] box of its 64 lanes
+constexpr int ADJ_SUB = 24;     // + wave 0's boxes of its first 32 / 16 / 8 lanes (kept small: 4 workgroups per CU)
+
 struct AdjRay {
     URay u;
     double scale;
@@ -199,11 +216,14 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                                                                const double *__restrict__ dobs, const double *__restrict__ cdct,
                                                                int Na, int64_t NtNd, int i0, int64_t R, double tmax, int Ns,
                                                                int dbg, const double *__restrict__ unitw, AT *__restrict__ G,
-                                                               int *oob_flag) {
+                                                               int *oob_flag, const int64_t *__restrict__ part, int n_chunks,
+                                                               unsigned int *__restrict__ chunk_counter,
+                                                               unsigned long long *__restrict__ blk_cycles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
-    double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][16] per-wave sums and bounding boxes
-    AT *tile = (AT *)(ref + 16 * NW);                                     // [T_WIN*T_WIN][T_TKP]
+    double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][ADJ_REF] per-wave sums and bounding boxes
+    double *sub = ref + ADJ_REF * NW;                                // [3 levels][8] wave 0's nested boxes
+    AT *tile = (AT *)(sub + ADJ_SUB);                                     // [T_WIN*T_WIN][T_TKP]
     int *I0 = (int *)(tile + T_WIN * T_WIN * T_TKP);                 // [T_TK] window origins per z level
     int *J0 = I0 + T_TK;
     for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
@@ -213,60 +233,88 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     const bool tail_by_lane = (Ns - ntail0) <= 8;
     const int nslab = tail_by_lane ? nfull : nfull + 1;
     const double klast = (double)(Ns - 1);
-    // contiguous balanced range of the walk per workgroup (XCD-major)
+    // Contiguous chunks of the walk per workgroup.  Without `part`: one chunk of equal ray count each (XCD-major).
+    // With `part` (n_chunks + 1 boundaries from iono_adjoint_partition_set, cost-balanced from measured cycles):
+    // chunk b goes to workgroup b, and the remaining -- progressively smaller -- chunks are handed out through an
+    // atomic counter as workgroups finish (guided self-scheduling: the tail is made of small chunks).
     int64_t bidx = blockIdx.x;
     if ((gridDim.x & 7) == 0) bidx = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const int64_t base = R / gridDim.x, rem = R % gridDim.x;
-    const int64_t lo = bidx * base + min(bidx, rem), hi = lo + base + (bidx < rem ? 1 : 0);
+    long long *next_chunk = (long long *)(J0 + T_TK);
     const double BIG = 1e300;
     bool oob = false;
     __syncthreads();
+  for (int64_t chunk = bidx;;) {
+    const int64_t lo = part ? part[chunk] : chunk * base + min(chunk, rem);
+    const int64_t hi = part ? part[chunk + 1] : lo + base + (chunk < rem ? 1 : 0);
+    const unsigned long long t_start = __builtin_readcyclecounter();
+    int cw = (dbg & 64) ? 64 : ((dbg & 128) ? 128 : 64 * NW);                                   // candidate width of the next bundle
     for (int64_t q0 = lo; q0 < hi;) {
-        // ---- candidate bundle: up to 64 rays, wave w lanes 0..15 own walk positions q0 + 16 w + l ----------
-        int q = 16;                                     // rays per wave
+        // ---- candidate bundle: up to 64 NW rays, wave w lanes 0..63 own walk positions q0 + 64 w + l ----------
+        // (only the first `cw` walk positions are examined: cw follows the size of the previous bundle, so a sparse
+        // stretch of the walk does not load 256 candidates for every 8 rays it consumes)
+        int q = 64;                                     // rays per wave
         int64_t qw = q0 + (int64_t)q * wid;
-        int cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
+        int cnt = (int)max((int64_t)0, min((int64_t)q, min(hi, q0 + (int64_t)cw) - qw));
         AdjRay a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
                                       Ns, oob);
-        int c = 16 * NW;
+        int c = 64 * NW;
         for (int round = 0; round < 2; ++round) {
-            // per-wave sums (for the mean ray) and bounding boxes at the bottom / top of the rays
+            // per-wave sums (for the mean ray) and bounding boxes at the bottom / top of the rays, for the wave's
+            // first 64 / 32 / 16 / 8 rays (levels 0..3: the nested candidates for the bundle size)
             const bool lv = a.scale != 0.0;
             const double live = lv ? 1.0 : 0.0;
             const double xe = fma(klast, a.u.dfx, a.u.fx0), ye = fma(klast, a.u.dfy, a.u.fy0);
             const double s4 = wave_sum_dpp(live * a.u.fz0), s5 = wave_sum_dpp(live * a.u.dfz), s7 = wave_sum_dpp(live);
-            double b0 = 0, b1 = 0, b2 = 0, b3 = 0, b4 = 0, b5 = 0, b6 = 0, b7 = 0;
-            {
-                b0 = wave_minmax_dpp<false>(lv ? a.u.fx0 : BIG);
-                b1 = wave_minmax_dpp<true>(lv ? a.u.fx0 : -BIG);
-                b2 = wave_minmax_dpp<false>(lv ? a.u.fy0 : BIG);
-                b3 = wave_minmax_dpp<true>(lv ? a.u.fy0 : -BIG);
-                b4 = wave_minmax_dpp<false>(lv ? xe : BIG);
-                b5 = wave_minmax_dpp<true>(lv ? xe : -BIG);
-                b6 = wave_minmax_dpp<false>(lv ? ye : BIG);
-                b7 = wave_minmax_dpp<true>(lv ? ye : -BIG);
-            }
+            double bb[8][4];        // [quantity][level 3..0 = first 8, 16, 32, 64 lanes]
+            wave_prefix_minmax<false>(lv ? a.u.fx0 : BIG, bb[0][3], bb[0][2], bb[0][1], bb[0][0]);
+            wave_prefix_minmax<true>(lv ? a.u.fx0 : -BIG, bb[1][3], bb[1][2], bb[1][1], bb[1][0]);
+            wave_prefix_minmax<false>(lv ? a.u.fy0 : BIG, bb[2][3], bb[2][2], bb[2][1], bb[2][0]);
+            wave_prefix_minmax<true>(lv ? a.u.fy0 : -BIG, bb[3][3], bb[3][2], bb[3][1], bb[3][0]);
+            wave_prefix_minmax<false>(lv ? xe : BIG, bb[4][3], bb[4][2], bb[4][1], bb[4][0]);
+            wave_prefix_minmax<true>(lv ? xe : -BIG, bb[5][3], bb[5][2], bb[5][1], bb[5][0]);
+            wave_prefix_minmax<false>(lv ? ye : BIG, bb[6][3], bb[6][2], bb[6][1], bb[6][0]);
+            wave_prefix_minmax<true>(lv ? ye : -BIG, bb[7][3], bb[7][2], bb[7][1], bb[7][0]);
             if (lane == 0) {
-                double *rp = ref + 16 * wid;
+                double *rp = ref + ADJ_REF * wid;
                 rp[4] = s4, rp[5] = s5, rp[7] = s7;
-                rp[8] = b0, rp[9] = b1, rp[10] = b2, rp[11] = b3, rp[12] = b4, rp[13] = b5, rp[14] = b6, rp[15] = b7;
+#pragma unroll
+                for (int qi = 0; qi < 8; ++qi) rp[8 + qi] = bb[qi][0];
+                if (wid == 0) {
+#pragma unroll
+                    for (int lev = 1; lev < 4; ++lev)
+#pragma unroll
+                        for (int qi = 0; qi < 8; ++qi) sub[8 * (lev - 1) + qi] = bb[qi][lev];
+                }
             }
             __syncthreads();
             if (round == 1) break;
-            // largest c in {64, 32, 16} whose rays stay within the tile window at both ends (block-uniform)
+            // largest nested candidate whose rays stay within the tile window at both ends (block-uniform): all NW
+            // waves' rays, the first NW/2 waves', ..., wave 0's 64, then wave 0's first 32 / 16 / 8
             const double lim = (double)(T_WIN - 3);
             double m0 = BIG, M0 = -BIG, m1 = BIG, M1 = -BIG, m2 = BIG, M2 = -BIG, m3 = BIG, M3 = -BIG;
             int fit = 0;
             for (int w2 = 0; w2 < NW; ++w2) {
-                const double *rp = ref + 16 * w2;
-                m0 = fmin(m0, rp[8]), M0 = fmax(M0, rp[9]), m1 = fmin(m1, rp[10]), M1 = fmax(M1, rp[11]);
-                m2 = fmin(m2, rp[12]), M2 = fmax(M2, rp[13]), m3 = fmin(m3, rp[14]), M3 = fmax(M3, rp[15]);
+                const double *rp = ref + ADJ_REF * w2 + 8;
+                m0 = fmin(m0, rp[0]), M0 = fmax(M0, rp[1]), m1 = fmin(m1, rp[2]), M1 = fmax(M1, rp[3]);
+                m2 = fmin(m2, rp[4]), M2 = fmax(M2, rp[5]), m3 = fmin(m3, rp[6]), M3 = fmax(M3, rp[7]);
                 const bool ok = (M0 - m0 <= lim) & (M1 - m1 <= lim) & (M2 - m2 <= lim) & (M3 - m3 <= lim);
-                if (ok && ((w2 + 1) & w2) == 0) fit = w2 + 1;           // 1, 2, 4 (, 8) waves' worth of rays
+                if (ok && ((w2 + 1) & w2) == 0) fit = 64 * (w2 + 1);      // 1, 2, 4 (, 8) waves' worth of rays
             }
-            c = 16 * max(fit, 1);
-            if (c == 16 * NW) break;
-            // spread too wide: shrink the bundle and re-deal its rays evenly over the four waves
+            if (fit == 0) {
+                for (int lev = 1; lev < 4 && fit == 0; ++lev) {
+                    const double *rp = sub + 8 * (lev - 1);                // wave 0's first 64 >> lev rays
+                    const bool ok = (rp[1] - rp[0] <= lim) & (rp[3] - rp[2] <= lim) & (rp[5] - rp[4] <= lim) &
+                                    (rp[7] - rp[6] <= lim);
+                    if (ok) fit = 64 >> lev;
+                }
+            }
+            const int cmin = (dbg & 32) ? 16 : 8, cmax = (dbg & 64) ? 64 : ((dbg & 128) ? 128 : 64 * NW);
+            if (fit < cmin) fit = 0;
+            c = min(min(fit ? fit : cmin, cw), cmax);    // nothing fits: cmin rays, their out-of-window parts go straight to global memory
+            cw = min(cmax, max(16, 2 * c));
+            if (c == 64 * NW) break;
+            // re-deal the chosen rays evenly over the waves
             __syncthreads();
             q = c / NW;
             qw = q0 + (int64_t)q * wid;
@@ -283,7 +331,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
             }
         }
         double nlive = 0.0, sz0 = 0.0, sdz = 0.0;
-        for (int w2 = 0; w2 < NW; ++w2) nlive += ref[16 * w2 + 7], sz0 += ref[16 * w2 + 4], sdz += ref[16 * w2 + 5];
+        for (int w2 = 0; w2 < NW; ++w2) nlive += ref[ADJ_REF * w2 + 7], sz0 += ref[ADJ_REF * w2 + 4], sdz += ref[ADJ_REF * w2 + 5];
         if (nlive == 0.0) {            // nothing to do in this bundle (block-uniform)
             __syncthreads();
             continue;
@@ -293,7 +341,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
         const double inl = 1.0 / nlive;
         double bx0 = BIG, bx1 = -BIG, by0 = BIG, by1 = -BIG, tx0 = BIG, tx1 = -BIG, ty0 = BIG, ty1 = -BIG;
         for (int w2 = 0; w2 < NW; ++w2) {
-            const double *rp = ref + 16 * w2;
+            const double *rp = ref + ADJ_REF * w2;
             bx0 = fmin(bx0, rp[8]), bx1 = fmax(bx1, rp[9]), by0 = fmin(by0, rp[10]), by1 = fmax(by1, rp[11]);
             tx0 = fmin(tx0, rp[12]), tx1 = fmax(tx1, rp[13]), ty0 = fmin(ty0, rp[14]), ty1 = fmax(ty1, rp[15]);
         }
@@ -335,6 +383,14 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
             __syncthreads();
         }
     }
+    if (blk_cycles && threadIdx.x == 0) blk_cycles[chunk] = __builtin_readcyclecounter() - t_start;   // per chunk, walk order
+    if (!part || n_chunks <= (int)gridDim.x) break;
+    __syncthreads();
+    if (threadIdx.x == 0) *next_chunk = (long long)gridDim.x + (long long)atomicAdd(chunk_counter, 1u);
+    __syncthreads();
+    chunk = *next_chunk;
+    if (chunk >= n_chunks) break;
+  }
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 

@@ -56,6 +56,15 @@ struct iono_ctx {
     int num_cus = 256;
     int force_general = 0;           // testing/ablation: 1 = general kernels only, 2 = no "ideal uniform" kernels
     void *d_work = nullptr;          // workspace of the host-pointer entry points (grow-only)
+    // cost-balanced partition of the ray walk for the LDS-tiled adjoint (iono_adjoint_partition_set) and the
+    // per-chunk cycle counts of its last launch (iono_adjoint_block_cycles)
+    int64_t *d_part = nullptr;
+    unsigned int *d_chunk_counter = nullptr;
+    int part_nb = 0;                 // chunks in d_part (0 = none)
+    int last_adj_wg = 0;             // workgroups of the last tiled-adjoint launch
+    int64_t part_R = -1;             // ray count it was built for
+    unsigned long long *d_blkcyc = nullptr;
+    int blkcyc_cap = 0, last_adj_nb = 0;
     size_t work_cap = 0;
     double *d_kern = nullptr;        // 3 x (2h+1) smoothing kernels
     int kern_cap = 0;
@@ -326,6 +335,9 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
+    if (c->d_part) (void)hipFree(c->d_part);
+    if (c->d_chunk_counter) (void)hipFree(c->d_chunk_counter);
+    if (c->d_blkcyc) (void)hipFree(c->d_blkcyc);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return IONO_OK;
@@ -573,6 +585,37 @@ int iono_vec_axpby_dev(iono_ctx *c, double *y, const double *x, int64_t n, const
     return IONO_OK;
 }
 
+// ---- measured load balance of the LDS-tiled adjoint ---------------------------------------------
+int iono_adjoint_block_cycles(iono_ctx *c, uint64_t *out, int cap, int *n_blocks, int *n_workgroups) {
+    if (!c || !n_blocks) return fail(c, IONO_ERR_ARG, "null argument");
+    *n_blocks = c->last_adj_nb;
+    if (n_workgroups) *n_workgroups = c->last_adj_wg;
+    if (c->last_adj_nb == 0 || !out || cap <= 0) return IONO_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->d_blkcyc, (size_t)std::min(cap, c->last_adj_nb) * 8, hipMemcpyDeviceToHost));
+    return IONO_OK;
+}
+
+int iono_adjoint_partition_set(iono_ctx *c, const int64_t *starts, int n_blocks, int64_t R) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (!starts || n_blocks <= 0) {          // clear: back to equal ray counts
+        c->part_nb = 0, c->part_R = -1;
+        return IONO_OK;
+    }
+    if (starts[0] != 0 || starts[n_blocks] != R) return fail(c, IONO_ERR_ARG, "partition must start at 0 and end at R");
+    for (int b = 0; b < n_blocks; ++b)
+        if (starts[b + 1] < starts[b]) return fail(c, IONO_ERR_ARG, "partition boundaries must not decrease");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));           // a launch still reading the old boundaries
+    if (c->d_part) (void)hipFree(c->d_part);
+    c->d_part = nullptr, c->part_nb = 0, c->part_R = -1;
+    HIP_TRY(c, hipMalloc((void **)&c->d_part, (size_t)(n_blocks + 1) * 8));
+    HIP_TRY(c, hipMemcpy(c->d_part, starts, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice));
+    c->part_nb = n_blocks, c->part_R = R;
+    return IONO_OK;
+}
+
 // ---- adjoint (device pointers) ----------------------------------------------------------------
 static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const double *d, const int *order, const double *w,
                                    const double *tec, const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0,
@@ -588,7 +631,7 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
     if (ideal_path_ok(c, Ns) && c->variant != 2) {
         const size_t esz = accum == IONO_F64 ? 8 : 4;
         constexpr int NWv = 4;    // waves per workgroup (8 waves sharing one tile, bundles of 128: measured 8 % slower)
-        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + 16 * NWv * sizeof(double) +
+        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + (ADJ_REF * NWv + ADJ_SUB) * sizeof(double) +
                           esz * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
 #define LAUNCH_ADJT(AT, MODE, NW)                                                                                          \
     do {                                                                                                                   \
@@ -597,12 +640,23 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
                 hipSuccess || per_cu < 1)                                                                                  \
             per_cu = 1;                                                                                                    \
         int nb = per_cu * c->num_cus;                                                                                      \
-        const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);                                                               \
+        const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);   /* at least ~64 rays per workgroup */                       \
         if (nb > nbund) nb = (int)nbund;                                                                                   \
         if (nb >= 8) nb = nb / 8 * 8;                                                                                      \
+        const bool use_part = c->part_nb >= nb && c->part_R == R;                                                          \
+        const int nchunks = use_part ? c->part_nb : nb;                                                                    \
+        if (nchunks > c->blkcyc_cap) {                                                                                     \
+            if (c->d_blkcyc) (void)hipFree(c->d_blkcyc);                                                                   \
+            c->d_blkcyc = nullptr, c->blkcyc_cap = 0;                                                                      \
+            HIP_TRY(c, hipMalloc((void **)&c->d_blkcyc, (size_t)nchunks * 8));                                             \
+            c->blkcyc_cap = nchunks;                                                                                       \
+        }                                                                                                                  \
+        if (!c->d_chunk_counter) HIP_TRY(c, hipMalloc((void **)&c->d_chunk_counter, 4));                                   \
+        if (use_part) HIP_TRY(c, hipMemsetAsync(c->d_chunk_counter, 0, 4, c->stream));                                     \
+        c->last_adj_nb = nchunks, c->last_adj_wg = nb;                                                                     \
         hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE, NW>), dim3(nb), dim3(64 * NW), tl, c->stream, g, o, d,      \
                            order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->walk_mode, c->d_unitw, (AT *)grad,     \
-                           c->d_flags);                                                                                    \
+                           c->d_flags, use_part ? c->d_part : nullptr, nchunks, c->d_chunk_counter, c->d_blkcyc);                                                                 \
     } while (0)
 #define LAUNCH_ADJT_NW(AT, MODE) LAUNCH_ADJT(AT, MODE, NWv)
         if (accum == IONO_F64) {

@@ -97,9 +97,10 @@ class ShardedRays(object):
     """This rank's slice of a [Na][P] ray bundle (+ optional data), resident on the engine's device."""
 
     def __init__(self, engine, origins, directions, tmax, Ns, dobs=None, cdct=None, i0=0, exchange="auto",
-                 reduce_dtype=None):
+                 reduce_dtype=None, tune=True):
         """origins/directions: [Na,P,3] (numpy or tensor, FULL problem); dobs/cdct: [Na,P].
-        ``exchange`` / ``reduce_dtype``: see ``GradientExchange``."""
+        ``exchange`` / ``reduce_dtype``: see ``GradientExchange``; ``tune``: balance the back-projection's work
+        partition by measurement (a few extra launches, once)."""
         self.engine = engine
         self.world, self.rank = world_info()
         o = torch.as_tensor(origins, dtype=torch.float64)
@@ -117,6 +118,17 @@ class ShardedRays(object):
         # walk order for the kernels (speed only): spatial neighbours next to each other
         self.order = engine.locality_order(self.origins, self.dirs, self.tmax) if (
             hasattr(engine, "locality_order") and self.R_local > 0) else None
+        # measured load balance of the back-projection (speed only, once per geometry; engine.tune_adjoint_partition)
+        self.partition = None
+        if tune and hasattr(engine, "tune_adjoint_partition") and self.R_local > 0:
+            ones = torch.ones(self.R_local, dtype=torch.float64, device=dev)
+            scratch = torch.zeros(engine.shape, dtype=torch.float64, device=dev)
+
+            def launch():
+                scratch.zero_()
+                engine.adjoint(self.origins, self.dirs, ones, self.tmax, self.Ns, out=scratch, order=self.order)
+            self.partition = engine.tune_adjoint_partition(launch, self.R_local)
+            del scratch
         self.exchange = GradientExchange(exchange, reduce_dtype)
         if self.world > 1 and exchange != "dense":
             ones = torch.ones(self.R_local, dtype=torch.float64, device=dev)

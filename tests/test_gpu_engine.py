@@ -276,3 +276,43 @@ def test_fused_vector_update_with_device_scalars():
             out = eng.axpby_(yt, eng.tensor(x), **kw)
             assert out is yt
             assert np.max(np.abs(yt.cpu().numpy() - (a * x + b * y))) < 1e-14 * (1 + abs(a) + abs(b)) * 5
+
+
+def test_adjoint_partition_never_changes_results(O):
+    """iono_adjoint_partition_set / iono_adjoint_block_cycles: any valid chunking of the walk -- equal counts, empty
+    chunks, many more chunks than workgroups (handed out dynamically), the tuner's own -- gives the same gradient."""
+    w = syn.make_workload("cfg2")
+    eng = make_engine(w)
+    o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+    R = o.shape[0]
+    order = eng.locality_order(o, d, w["tmax"])
+    y = eng.tensor(np.random.default_rng(1).normal(size=R))
+    eng.ctx.adjoint_partition_set(None, R)
+    ref = eng.adjoint(o, d, y, w["tmax"], w["Ns"], order=order).clone()
+    cyc, wg = eng.ctx.adjoint_block_cycles()
+    assert wg >= 2 and cyc.size == wg and np.all(cyc > 0)
+    rng = np.random.default_rng(2)
+    scale = float(ref.abs().max())
+    for n_chunks in (wg, wg + 1, 3 * wg, 7 * wg + 5):
+        cuts = np.sort(rng.integers(0, R + 1, n_chunks - 1))
+        cuts[: n_chunks // 3] = cuts[n_chunks // 3]                     # a run of empty chunks
+        starts = np.concatenate([[0], np.sort(cuts), [R]]).astype(np.int64)
+        eng.ctx.adjoint_partition_set(starts, R)
+        g = eng.adjoint(o, d, y, w["tmax"], w["Ns"], order=order)
+        c2, wg2 = eng.ctx.adjoint_block_cycles()
+        assert wg2 == wg and c2.size == n_chunks
+        assert float((g - ref).abs().max()) < 1e-12 * scale
+        # fused-residual launch shares the partition
+    stats = eng.tune_adjoint_partition(lambda: eng.adjoint(o, d, y, w["tmax"], w["Ns"], order=order), R)
+    assert stats is not None and stats["tuned_ms"] <= stats["equal_count_ms"] * 1.0001
+    g = eng.adjoint(o, d, y, w["tmax"], w["Ns"], order=order)
+    assert float((g - ref).abs().max()) < 1e-12 * scale
+    # a partition for another ray count is ignored, malformed ones are refused
+    g = eng.adjoint(o[:-7].contiguous(), d[:-7].contiguous(), y[:-7].contiguous(), w["tmax"], w["Ns"])
+    gref = O.adjoint_tec(O.straight_rays(w["origins"].reshape(-1, 3)[:-7], w["directions"].reshape(-1, 3)[:-7], w["tmax"], w["Ns"]),
+                         w["xvec"], w["yvec"], w["zvec"], y[:-7].cpu().numpy())
+    assert np.max(np.abs(g.cpu().numpy() - gref)) < 1e-11 * np.max(np.abs(gref))
+    for bad in (np.array([1, R]), np.array([0, R - 1]), np.array([0, 50, 20, R])):
+        with pytest.raises(ValueError):
+            eng.ctx.adjoint_partition_set(bad.astype(np.int64), R)
+    eng.ctx.adjoint_partition_set(None, R)
