@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                                    oob);
         }
         q0 += c;
-        if (a.scale != 0.0 && tail_by_lane) {               // the <= 8 tail samples: straight to global memory
+        if (a.scale != 0.0 && tail_by_lane && nslab == 0) {  // fewer than 9 samples in all: straight to global memory
             for (int k = ntail0; k < Ns; ++k) {
                 const double kd = (double)k;
                 scatter_sample_tiled<AT>(g, tile, G, I0, J0, -(1 << 28), fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
@@ -366,6 +366,15 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                     scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
                                              fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
                                              fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi)), sc * wlds[k], dbg);
+                }
+            }
+            if (tail_by_lane && it == nslab - 1 && a.scale != 0.0) {
+                // the <= 8 samples after the last full slab, lanes = rays: the tile spans 72 levels for exactly this
+                // (anything that still falls outside goes to global memory as everywhere else)
+                for (int k = ntail0; k < Ns; ++k) {
+                    const double kd = (double)k;
+                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
+                                             fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k], dbg);
                 }
             }
             __syncthreads();
