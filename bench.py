@@ -236,7 +236,7 @@ def main():
             c32wall, _ = time_steps(iteration_compact32, k2, 1, torch, dist, world)
             extra["iteration_ms_compact_exchange_f32"] = c32wall / k2 * 1e3
         if order_t is not None:
-            eng.ctx.adjoint_partition_set(None, R)       # the tuned partition belongs to the ordered walk
+            eng.ctx.walk_partition_set(1, None, R)       # the tuned partition belongs to the ordered walk
 
             def adj_unordered():
                 grad_t.zero_()

@@ -143,22 +143,26 @@ int iono_adjoint_residual_straight_dev(iono_ctx *ctx, const double *origins_dev,
                                        int Na, int64_t NtNd, int i0, double tmax, int Ns, int quad_rule,
                                        void *grad_dev, int accum_dtype);
 int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);
-/* Measured load balance of the LDS-tiled adjoint.  Its workgroups take contiguous chunks of the ray walk; the cost
- * per ray varies several-fold with the local ray density (dense bundles share one tile flush, sparse fans do not), so
- * equal ray counts leave most workgroups idle while the slowest finish.  The ray geometry is fixed for a whole
- * inversion (it is what the reference's per-direction dask tasks re-derive on every call,
- * inversion/gradient.py:22-54), so the balance is tuned once:
- *   iono_adjoint_block_cycles   -> cycles each chunk of the LAST tiled-adjoint launch took, in walk order; n_chunks
- *                                  entries; n_workgroups = resident workgroups that launch used (cycles_out may be
- *                                  NULL to query the two counts);
- *   iono_adjoint_partition_set  -> n_chunks + 1 non-decreasing chunk boundaries (host), starts[0] = 0,
- *                                  starts[n_chunks] = R, n_chunks >= n_workgroups.  Chunk b < n_workgroups is taken
- *                                  by workgroup b; the rest are handed out through an atomic counter as workgroups
- *                                  finish, so make them progressively smaller (guided self-scheduling).  Used by later
- *                                  launches with the same R; any other launch falls back to equal counts.  NULL
- *                                  clears it.  Never affects results, only which workgroup back-projects which rays. */
-int iono_adjoint_block_cycles(iono_ctx *ctx, uint64_t *cycles_out, int capacity, int *n_chunks, int *n_workgroups);
-int iono_adjoint_partition_set(iono_ctx *ctx, const int64_t *starts, int n_chunks, int64_t R);
+/* Measured load balance of the two chunked kernels.  The straight-ray forward gives every resident wave one
+ * contiguous chunk of the ray walk, the LDS-tiled adjoint every resident workgroup; the cost per ray varies with where
+ * the ray runs (cache locality for the forward; for the adjoint several-fold with the local ray density: dense bundles
+ * share one tile flush, sparse fans do not), so chunks of equal ray COUNT leave much of the chip idle while the slowest
+ * chunk finishes.  The ray geometry is fixed for a whole inversion (it is what the reference's per-direction dask tasks
+ * re-derive on every call, inversion/forward_equation.py:60-67, inversion/gradient.py:22-54), so the balance is tuned
+ * once.  `which`: IONO_WALK_FORWARD or IONO_WALK_ADJOINT.
+ *   iono_walk_cycles         -> cycles each chunk of the LAST such launch took, in walk order; n_chunks entries;
+ *                               n_units = resident waves (forward) / workgroups (adjoint) of that launch
+ *                               (cycles_out may be NULL to query the two counts);
+ *   iono_walk_partition_set  -> n_chunks + 1 non-decreasing chunk boundaries (host), starts[0] = 0,
+ *                               starts[n_chunks] = R.  Forward: n_chunks must equal n_units (used only for launches
+ *                               without an `order`).  Adjoint: n_chunks >= n_units; chunk b < n_units is taken by
+ *                               workgroup b, the rest are handed out through an atomic counter as workgroups finish, so
+ *                               make them progressively smaller (guided self-scheduling).  Used by later launches with
+ *                               the same R; any other launch falls back to equal counts.  NULL clears it.  Never
+ *                               affects results, only which wave / workgroup handles which rays. */
+enum { IONO_WALK_FORWARD = 0, IONO_WALK_ADJOINT = 1 };
+int iono_walk_cycles(iono_ctx *ctx, int which, uint64_t *cycles_out, int capacity, int *n_chunks, int *n_units);
+int iono_walk_partition_set(iono_ctx *ctx, int which, const int64_t *starts, int n_chunks, int64_t R);
 /* Solver vector update  y = a x + b y  on device vectors (16-byte aligned), one pass.  The coefficients are ratios
  * of DEVICE scalars, a = a_sign * a_num[0] / a_den[0], b = b_num[0] / b_den[0] (a null pointer stands for 1), so the
  * step lengths of the iteration -- eps = sum(Gdm dd/Cd) / sum(Gdm^2/Cd), inversion/iterative_newton.py:542-554; the

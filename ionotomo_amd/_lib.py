@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libionotomo_hip.so")
 
 OK, ERR_OOB, ERR_NONFINITE, ERR_SHAPE, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
+WALK_FORWARD, WALK_ADJOINT = 0, 1          # iono_walk_cycles / iono_walk_partition_set
 F64, F32 = 0, 1
 INTERP_TRILINEAR, INTERP_TRICUBIC = 0, 1
 QUAD_SIMPSON_AVG, QUAD_SIMPSON_SCIPY, QUAD_TRAPEZOID = 0, 1, 2
@@ -65,8 +66,8 @@ _SIGNATURES = {
     "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _V, _I],
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
     "iono_vec_axpby_dev": [_V, _V, _L, _V, _V, _D, _V, _V],
-    "iono_adjoint_block_cycles": [_V, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
-    "iono_adjoint_partition_set": [_V, _I, _L],
+    "iono_walk_cycles": [_I, _V, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+    "iono_walk_partition_set": [_I, _V, _I, _L],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],
@@ -218,22 +219,24 @@ class Context(object):
         self.call("iono_check_oob", ctypes.byref(v))
         return bool(v.value)
 
-    # -- measured load balance of the LDS-tiled adjoint (include/ionotomo_hip.h) -------------------------
-    def adjoint_block_cycles(self):
-        """(cycles per chunk in walk order, resident workgroups) of the last tiled-adjoint launch; empty if none."""
-        n, wg = ctypes.c_int(0), ctypes.c_int(0)
-        self.call("iono_adjoint_block_cycles", None, 0, ctypes.byref(n), ctypes.byref(wg))
+    # -- measured load balance of the chunked kernels (include/ionotomo_hip.h) -----------------------------
+    def walk_cycles(self, which):
+        """(cycles per chunk in walk order, resident waves / workgroups) of the last forward (WALK_FORWARD) or
+        tiled-adjoint (WALK_ADJOINT) launch; empty if there was none."""
+        n, units = ctypes.c_int(0), ctypes.c_int(0)
+        self.call("iono_walk_cycles", int(which), None, 0, ctypes.byref(n), ctypes.byref(units))
         out = np.zeros(n.value, dtype=np.uint64)
         if n.value:
-            self.call("iono_adjoint_block_cycles", out.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n), ctypes.byref(wg))
-        return out, wg.value
+            self.call("iono_walk_cycles", int(which), out.ctypes.data_as(ctypes.c_void_p), n.value, ctypes.byref(n),
+                      ctypes.byref(units))
+        return out, units.value
 
-    def adjoint_partition_set(self, starts, R):
+    def walk_partition_set(self, which, starts, R):
         if starts is None:
-            self.call("iono_adjoint_partition_set", None, 0, int(R))
+            self.call("iono_walk_partition_set", int(which), None, 0, int(R))
             return
         st = np.ascontiguousarray(starts, dtype=np.int64)
-        self.call("iono_adjoint_partition_set", st.ctypes.data_as(ctypes.c_void_p), st.size - 1, int(R))
+        self.call("iono_walk_partition_set", int(which), st.ctypes.data_as(ctypes.c_void_p), st.size - 1, int(R))
 
     # -- host-pointer numerics -----------------------------------------------------------------------
     def interp(self, x, y, z, kind="linear", extrapolate=False):

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     const int nslab = tail_by_lane ? nfull : nfull + 1;
     const double klast = (double)(Ns - 1);
     // Contiguous chunks of the walk per workgroup.  Without `part`: one chunk of equal ray count each (XCD-major).
-    // With `part` (n_chunks + 1 boundaries from iono_adjoint_partition_set, cost-balanced from measured cycles):
+    // With `part` (n_chunks + 1 boundaries from iono_walk_partition_set, cost-balanced from measured cycles):
     // chunk b goes to workgroup b, and the remaining -- progressively smaller -- chunks are handed out through an
     // atomic counter as workgroups finish (guided self-scheduling: the tail is made of small chunks).
     int64_t bidx = blockIdx.x;

@@ -259,12 +259,14 @@ __device__ __forceinline__ double trilinear_u(const GT *__restrict__ b00, const 
 // what is resident at once, so there is no second, under-occupied round of workgroups.
 struct Chunk {
     int64_t lo, hi, stride;     // walk positions lo, lo+stride, ... < hi
+    int64_t widx;               // index of this wave's chunk in walk order
 };
 // mode 0 (default): one contiguous chunk per wave.  mode bit 0: one contiguous chunk per WORKGROUP, its
 // 4 waves interleaved (wave w takes lo+w, lo+w+4, ...).  mode bit 2: plain block order instead of
 // XCD-major.  Both alternatives measured slower or equal on the bench workload; kept for A/B runs
 // (env IONOTOMO_WALK).
-__device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
+// `part` (optional): one boundary per wave + 1, balanced by measured cost (iono_walk_partition_set).
+__device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode, const int64_t *__restrict__ part = nullptr) {
     const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
     int64_t bidx;
     if ((gridDim.x & 7) == 0 && !(mode & 4)) {
@@ -274,7 +276,12 @@ __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode) {
         bidx = blockIdx.x;
     }
     Chunk c;
-    if (mode & 1) {
+    c.widx = bidx * wpb + wid;
+    if (part) {
+        c.lo = part[c.widx];
+        c.hi = part[c.widx + 1];
+        c.stride = 1;
+    } else if (mode & 1) {
         const int64_t nb = gridDim.x, base = R / nb, rem = R % nb;
         const int64_t lo = bidx * base + min(bidx, rem);
         c.hi = lo + base + (bidx < rem ? 1 : 0);
@@ -295,7 +302,8 @@ __global__ __launch_bounds__(256, 6) void k_forward_straight_u(GridView g, const
                                                             const double *__restrict__ dirs, const int *__restrict__ order,
                                                             int64_t R, double tmax, int Ns, int walk_mode,
                                                             const double *__restrict__ unitw, double *__restrict__ tec,
-                                                            int *oob_flag) {
+                                                            int *oob_flag, const int64_t *__restrict__ part,
+                                                            unsigned long long *__restrict__ wave_cycles) {
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
     __syncthreads();
@@ -303,7 +311,8 @@ __global__ __launch_bounds__(256, 6) void k_forward_straight_u(GridView g, const
     const int nfull = Ns >> 6, ntail0 = nfull << 6;        // samples [ntail0, Ns) are the tail
     const bool tail_by_lane = (Ns - ntail0) <= 8;          // else: one more (masked) wave iteration
     const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
-    const Chunk ch = wave_chunk(R, walk_mode);
+    const Chunk ch = wave_chunk(R, walk_mode, part);
+    const unsigned long long t_dbg0 = __builtin_readcyclecounter();
     const double dlane = (double)lane;
     const double *wp = wlds + lane;
     bool oob = false;
@@ -352,6 +361,7 @@ __global__ __launch_bounds__(256, 6) void k_forward_straight_u(GridView g, const
         }
         if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
     }
+    if (wave_cycles && lane == 0) wave_cycles[ch.widx] = __builtin_readcyclecounter() - t_dbg0;    // per chunk, walk order
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 

@@ -56,15 +56,16 @@ struct iono_ctx {
     int num_cus = 256;
     int force_general = 0;           // testing/ablation: 1 = general kernels only, 2 = no "ideal uniform" kernels
     void *d_work = nullptr;          // workspace of the host-pointer entry points (grow-only)
-    // cost-balanced partition of the ray walk for the LDS-tiled adjoint (iono_adjoint_partition_set) and the
-    // per-chunk cycle counts of its last launch (iono_adjoint_block_cycles)
-    int64_t *d_part = nullptr;
+    // measured load balance (iono_walk_cycles / iono_walk_partition_set): [0] forward (one chunk per wave),
+    // [1] LDS-tiled adjoint (one chunk per workgroup + dynamically handed-out extras)
+    struct WalkPart {
+        int64_t *d_starts = nullptr;
+        int n = 0;                       // chunks in d_starts (0 = none)
+        int64_t R = -1;                  // ray count it was built for
+        unsigned long long *d_cyc = nullptr;
+        int cyc_cap = 0, last_n = 0, last_units = 0;     // cycles of the last launch: entries, resident waves / workgroups
+    } walk[2];
     unsigned int *d_chunk_counter = nullptr;
-    int part_nb = 0;                 // chunks in d_part (0 = none)
-    int last_adj_wg = 0;             // workgroups of the last tiled-adjoint launch
-    int64_t part_R = -1;             // ray count it was built for
-    unsigned long long *d_blkcyc = nullptr;
-    int blkcyc_cap = 0, last_adj_nb = 0;
     size_t work_cap = 0;
     double *d_kern = nullptr;        // 3 x (2h+1) smoothing kernels
     int kern_cap = 0;
@@ -335,9 +336,11 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
-    if (c->d_part) (void)hipFree(c->d_part);
+    for (auto &wp : c->walk) {
+        if (wp.d_starts) (void)hipFree(wp.d_starts);
+        if (wp.d_cyc) (void)hipFree(wp.d_cyc);
+    }
     if (c->d_chunk_counter) (void)hipFree(c->d_chunk_counter);
-    if (c->d_blkcyc) (void)hipFree(c->d_blkcyc);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return IONO_OK;
@@ -509,6 +512,19 @@ int iono_interp(iono_ctx *c, const double *x, const double *y, const double *z, 
     return finish_host_call(c, "iono_interp");
 }
 
+// room for the per-chunk cycle counts of the launch about to be made
+static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks, int units) {
+    if (n_chunks > wp.cyc_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (wp.d_cyc) (void)hipFree(wp.d_cyc);
+        wp.d_cyc = nullptr, wp.cyc_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&wp.d_cyc, (size_t)n_chunks * 8));
+        wp.cyc_cap = n_chunks;
+    }
+    wp.last_n = n_chunks, wp.last_units = units;
+    return IONO_OK;
+}
+
 // ---- forward (device pointers) ---------------------------------------------------------------
 int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, int64_t R, double tmax,
                                   int Ns, int kind, int rule, double *tec) {
@@ -520,13 +536,18 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
     const GridView g = view(c);
     const dim3 grid(ray_grid_blocks(c, R)), block(256);
     const size_t lds = lds_bytes(c);
-    dispatch_storage(c, [&](auto *tag) {
+    rc = dispatch_storage(c, [&](auto *tag) -> int {
         using GT = std::remove_pointer_t<decltype(tag)>;
         if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
+            iono_ctx::WalkPart &wp = c->walk[0];
+            const int nw = nb * 4;                              // one chunk per wave
+            const bool use_part = wp.n == nw && wp.R == R && !(c->walk_mode & 1) && order == nullptr;
+            const int rc2 = walk_cycles_reserve(c, wp, nw, nw);
+            if (rc2) return rc2;
             hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
-                               c->walk_mode, c->d_unitw, tec, c->d_flags);
+                               c->walk_mode, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
         } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))      // (`order` is a speed hint: ignored here)
             hipLaunchKernelGGL((k_forward_straight_fast<GT>), grid, block, 2 * lds, c->stream, g, o, d, R, tmax, Ns,
                                c->d_unitw, tec, c->d_flags);
@@ -585,34 +606,36 @@ int iono_vec_axpby_dev(iono_ctx *c, double *y, const double *x, int64_t n, const
     return IONO_OK;
 }
 
-// ---- measured load balance of the LDS-tiled adjoint ---------------------------------------------
-int iono_adjoint_block_cycles(iono_ctx *c, uint64_t *out, int cap, int *n_blocks, int *n_workgroups) {
-    if (!c || !n_blocks) return fail(c, IONO_ERR_ARG, "null argument");
-    *n_blocks = c->last_adj_nb;
-    if (n_workgroups) *n_workgroups = c->last_adj_wg;
-    if (c->last_adj_nb == 0 || !out || cap <= 0) return IONO_OK;
+// ---- measured load balance of the chunked kernels -----------------------------------------------
+int iono_walk_cycles(iono_ctx *c, int which, uint64_t *out, int cap, int *n_chunks, int *n_units) {
+    if (!c || !n_chunks || which < 0 || which > 1) return fail(c, IONO_ERR_ARG, "iono_walk_cycles: bad argument");
+    const iono_ctx::WalkPart &wp = c->walk[which];
+    *n_chunks = wp.last_n;
+    if (n_units) *n_units = wp.last_units;
+    if (wp.last_n == 0 || !out || cap <= 0) return IONO_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, c->d_blkcyc, (size_t)std::min(cap, c->last_adj_nb) * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, wp.d_cyc, (size_t)std::min(cap, wp.last_n) * 8, hipMemcpyDeviceToHost));
     return IONO_OK;
 }
 
-int iono_adjoint_partition_set(iono_ctx *c, const int64_t *starts, int n_blocks, int64_t R) {
-    if (!c) return fail(c, IONO_ERR_ARG, "null context");
-    if (!starts || n_blocks <= 0) {          // clear: back to equal ray counts
-        c->part_nb = 0, c->part_R = -1;
+int iono_walk_partition_set(iono_ctx *c, int which, const int64_t *starts, int n_chunks, int64_t R) {
+    if (!c || which < 0 || which > 1) return fail(c, IONO_ERR_ARG, "iono_walk_partition_set: bad argument");
+    iono_ctx::WalkPart &wp = c->walk[which];
+    if (!starts || n_chunks <= 0) {          // clear: back to equal ray counts
+        wp.n = 0, wp.R = -1;
         return IONO_OK;
     }
-    if (starts[0] != 0 || starts[n_blocks] != R) return fail(c, IONO_ERR_ARG, "partition must start at 0 and end at R");
-    for (int b = 0; b < n_blocks; ++b)
+    if (starts[0] != 0 || starts[n_chunks] != R) return fail(c, IONO_ERR_ARG, "partition must start at 0 and end at R");
+    for (int b = 0; b < n_chunks; ++b)
         if (starts[b + 1] < starts[b]) return fail(c, IONO_ERR_ARG, "partition boundaries must not decrease");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));           // a launch still reading the old boundaries
-    if (c->d_part) (void)hipFree(c->d_part);
-    c->d_part = nullptr, c->part_nb = 0, c->part_R = -1;
-    HIP_TRY(c, hipMalloc((void **)&c->d_part, (size_t)(n_blocks + 1) * 8));
-    HIP_TRY(c, hipMemcpy(c->d_part, starts, (size_t)(n_blocks + 1) * 8, hipMemcpyHostToDevice));
-    c->part_nb = n_blocks, c->part_R = R;
+    if (wp.d_starts) (void)hipFree(wp.d_starts);
+    wp.d_starts = nullptr, wp.n = 0, wp.R = -1;
+    HIP_TRY(c, hipMalloc((void **)&wp.d_starts, (size_t)(n_chunks + 1) * 8));
+    HIP_TRY(c, hipMemcpy(wp.d_starts, starts, (size_t)(n_chunks + 1) * 8, hipMemcpyHostToDevice));
+    wp.n = n_chunks, wp.R = R;
     return IONO_OK;
 }
 
@@ -643,20 +666,15 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
         const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);   /* at least ~64 rays per workgroup */                       \
         if (nb > nbund) nb = (int)nbund;                                                                                   \
         if (nb >= 8) nb = nb / 8 * 8;                                                                                      \
-        const bool use_part = c->part_nb >= nb && c->part_R == R;                                                          \
-        const int nchunks = use_part ? c->part_nb : nb;                                                                    \
-        if (nchunks > c->blkcyc_cap) {                                                                                     \
-            if (c->d_blkcyc) (void)hipFree(c->d_blkcyc);                                                                   \
-            c->d_blkcyc = nullptr, c->blkcyc_cap = 0;                                                                      \
-            HIP_TRY(c, hipMalloc((void **)&c->d_blkcyc, (size_t)nchunks * 8));                                             \
-            c->blkcyc_cap = nchunks;                                                                                       \
-        }                                                                                                                  \
+        iono_ctx::WalkPart &wp = c->walk[1];                                                                               \
+        const bool use_part = wp.n >= nb && wp.R == R;                                                                     \
+        const int nchunks = use_part ? wp.n : nb;                                                                          \
+        { const int rc2 = walk_cycles_reserve(c, wp, nchunks, nb); if (rc2) return rc2; }                                  \
         if (!c->d_chunk_counter) HIP_TRY(c, hipMalloc((void **)&c->d_chunk_counter, 4));                                   \
         if (use_part) HIP_TRY(c, hipMemsetAsync(c->d_chunk_counter, 0, 4, c->stream));                                     \
-        c->last_adj_nb = nchunks, c->last_adj_wg = nb;                                                                     \
         hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE, NW>), dim3(nb), dim3(64 * NW), tl, c->stream, g, o, d,      \
                            order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->walk_mode, c->d_unitw, (AT *)grad,     \
-                           c->d_flags, use_part ? c->d_part : nullptr, nchunks, c->d_chunk_counter, c->d_blkcyc);                                                                 \
+                           c->d_flags, use_part ? wp.d_starts : nullptr, nchunks, c->d_chunk_counter, wp.d_cyc);                                                                 \
     } while (0)
 #define LAUNCH_ADJT_NW(AT, MODE) LAUNCH_ADJT(AT, MODE, NWv)
         if (accum == IONO_F64) {

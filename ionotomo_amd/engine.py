@@ -153,18 +153,24 @@ class RayEngine(object):
         self.ctx.call("iono_subtract_reference_dev", _ptr(tec_t), int(Na), tec_t.numel() // Na, int(i0))
         return tec_t
 
-    def tune_adjoint_partition(self, launch, R, fractions=(0.75, 0.25), refine=2):
-        """Balance the tiled adjoint's work over the chip by MEASURED cost.  ``launch()`` runs the adjoint to be tuned
-        (same rays, same walk order; any weights).  The kernel reports the cycles each contiguous chunk of the walk
-        took; from them a cost-per-ray profile is built and the walk is cut into ``len(fractions)`` levels of
-        equal-cost chunks, one chunk per resident workgroup and level, level l holding ``fractions[l]`` of the total
-        cost: the first level is assigned statically, the later -- smaller and smaller -- chunks are handed out as
-        workgroups finish (guided self-scheduling).  ``refine`` further rounds re-measure with the finer chunks.  The
-        fastest partition (timed with events) is kept in the context and used by every later launch with the same
-        ray count.  Geometry only, like ``locality_order``: results never depend on it.  Returns a dict of timings,
-        or None when the launch did not go through the tiled kernel."""
+    def tune_partition(self, which, launch, R, fractions=None, refine=2):
+        """Balance a chunked kernel's work over the chip by MEASURED cost.  ``which``: ``_lib.WALK_FORWARD`` (one
+        chunk of the ray walk per resident wave) or ``_lib.WALK_ADJOINT`` (LDS-tiled back-projection, one chunk per
+        resident workgroup).  ``launch()`` runs the kernel to be tuned (same rays, same walk order).  The kernel
+        reports the cycles each contiguous chunk of the walk took; from them a cost-per-ray profile is built and the
+        walk is re-cut into equal-COST chunks.  For the adjoint the walk is cut into ``len(fractions)`` levels, one
+        chunk per workgroup and level, level l holding ``fractions[l]`` of the total cost: the first level is
+        assigned statically, the later -- smaller -- chunks are handed out as workgroups finish (guided
+        self-scheduling).  ``refine`` further rounds re-measure with the new chunks.  The fastest partition (timed
+        with events) is kept in the context and used by every later launch with the same ray count.  Geometry only,
+        like ``locality_order``: results never depend on it.  Returns a dict of timings, or None when the launch did
+        not go through a chunked kernel."""
         ctx = self.ctx
         R = int(R)
+        if fractions is None:
+            fractions = (0.75, 0.25) if which == _lib.WALK_ADJOINT else (1.0,)
+        if which == _lib.WALK_FORWARD:
+            fractions = (1.0,)
 
         def timed(n=3):
             best = float("inf")
@@ -181,41 +187,47 @@ class RayEngine(object):
             lens = np.diff(starts)
             return np.repeat(cyc / np.maximum(lens, 1), lens)
 
-        def guided(dens, wg):
+        def guided(dens, units):
             cum = np.concatenate([[0.0], np.cumsum(dens)])
             edges = np.concatenate([[0.0], np.cumsum(fractions) / np.sum(fractions)]) * cum[-1]
-            targets = np.concatenate([np.linspace(edges[l], edges[l + 1], wg, endpoint=False) for l in range(len(fractions))]
-                                     + [[cum[-1]]])
+            targets = np.concatenate([np.linspace(edges[l], edges[l + 1], units, endpoint=False)
+                                      for l in range(len(fractions))] + [[cum[-1]]])
             starts = np.maximum.accumulate(np.searchsorted(cum, targets, side="left").astype(np.int64))
             starts[0], starts[-1] = 0, R
             return np.minimum(starts, R)
 
-        ctx.adjoint_partition_set(None, R)
+        ctx.walk_partition_set(which, None, R)
         launch()                                             # warm-up, and tells us the kernel's geometry
-        cyc, wg = ctx.adjoint_block_cycles()
-        if wg < 2 or cyc.size != wg or not np.all(cyc > 0):
+        cyc, units = ctx.walk_cycles(which)
+        if units < 2 or cyc.size != units or not np.all(cyc > 0):
             return None
         t_equal = timed()
         launch()
-        cyc, _ = ctx.adjoint_block_cycles()
-        base, rem = divmod(R, wg)
-        starts = np.array([b * base + min(b, rem) for b in range(wg + 1)], dtype=np.int64)
+        cyc, _ = ctx.walk_cycles(which)
+        base, rem = divmod(R, units)
+        starts = np.array([b * base + min(b, rem) for b in range(units + 1)], dtype=np.int64)
         dens = density(cyc.astype(np.float64), starts)
         best_t, best_starts, tried = t_equal, None, []
         for it in range(refine + 1):
-            starts = guided(dens, wg)
-            ctx.adjoint_partition_set(starts, R)
+            starts = guided(dens, units)
+            ctx.walk_partition_set(which, starts, R)
             t = timed()
             tried.append(t)
             if t < best_t:
                 best_t, best_starts = t, starts
             if it < refine:
                 launch()
-                cyc, _ = ctx.adjoint_block_cycles()
+                cyc, _ = ctx.walk_cycles(which)
                 dens = 0.5 * dens + 0.5 * density(cyc.astype(np.float64), starts)
-        ctx.adjoint_partition_set(best_starts, R)
-        return {"equal_count_ms": t_equal, "tuned_ms": best_t, "tried_ms": tried, "workgroups": int(wg),
+        ctx.walk_partition_set(which, best_starts, R)
+        return {"equal_count_ms": t_equal, "tuned_ms": best_t, "tried_ms": tried, "units": int(units),
                 "chunks": int(0 if best_starts is None else best_starts.size - 1)}
+
+    def tune_adjoint_partition(self, launch, R, fractions=(0.75, 0.25), refine=2):
+        return self.tune_partition(_lib.WALK_ADJOINT, launch, R, fractions, refine)
+
+    def tune_forward_partition(self, launch, R, refine=3):
+        return self.tune_partition(_lib.WALK_FORWARD, launch, R, None, refine)
 
     def axpby_(self, y, x, a_num=None, a_den=None, a_sign=1.0, b_num=None, b_den=None):
         """y = (a_sign a_num / a_den) x + (b_num / b_den) y in one pass; the coefficients are 0-dim DEVICE tensors

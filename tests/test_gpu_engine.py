@@ -279,7 +279,7 @@ def test_fused_vector_update_with_device_scalars():
 
 
 def test_adjoint_partition_never_changes_results(O):
-    """iono_adjoint_partition_set / iono_adjoint_block_cycles: any valid chunking of the walk -- equal counts, empty
+    """iono_walk_partition_set / iono_walk_cycles: any valid chunking of the walk -- equal counts, empty
     chunks, many more chunks than workgroups (handed out dynamically), the tuner's own -- gives the same gradient."""
     w = syn.make_workload("cfg2")
     eng = make_engine(w)
@@ -287,9 +287,9 @@ def test_adjoint_partition_never_changes_results(O):
     R = o.shape[0]
     order = eng.locality_order(o, d, w["tmax"])
     y = eng.tensor(np.random.default_rng(1).normal(size=R))
-    eng.ctx.adjoint_partition_set(None, R)
+    eng.ctx.walk_partition_set(1, None, R)
     ref = eng.adjoint(o, d, y, w["tmax"], w["Ns"], order=order).clone()
-    cyc, wg = eng.ctx.adjoint_block_cycles()
+    cyc, wg = eng.ctx.walk_cycles(1)
     assert wg >= 2 and cyc.size == wg and np.all(cyc > 0)
     rng = np.random.default_rng(2)
     scale = float(ref.abs().max())
@@ -297,9 +297,9 @@ def test_adjoint_partition_never_changes_results(O):
         cuts = np.sort(rng.integers(0, R + 1, n_chunks - 1))
         cuts[: n_chunks // 3] = cuts[n_chunks // 3]                     # a run of empty chunks
         starts = np.concatenate([[0], np.sort(cuts), [R]]).astype(np.int64)
-        eng.ctx.adjoint_partition_set(starts, R)
+        eng.ctx.walk_partition_set(1, starts, R)
         g = eng.adjoint(o, d, y, w["tmax"], w["Ns"], order=order)
-        c2, wg2 = eng.ctx.adjoint_block_cycles()
+        c2, wg2 = eng.ctx.walk_cycles(1)
         assert wg2 == wg and c2.size == n_chunks
         assert float((g - ref).abs().max()) < 1e-12 * scale
         # fused-residual launch shares the partition
@@ -314,5 +314,27 @@ def test_adjoint_partition_never_changes_results(O):
     assert np.max(np.abs(g.cpu().numpy() - gref)) < 1e-11 * np.max(np.abs(gref))
     for bad in (np.array([1, R]), np.array([0, R - 1]), np.array([0, 50, 20, R])):
         with pytest.raises(ValueError):
-            eng.ctx.adjoint_partition_set(bad.astype(np.int64), R)
-    eng.ctx.adjoint_partition_set(None, R)
+            eng.ctx.walk_partition_set(1, bad.astype(np.int64), R)
+    eng.ctx.walk_partition_set(1, None, R)
+
+
+def test_forward_partition_never_changes_results():
+    """The same mechanism for the forward kernel (one chunk per resident wave): arbitrary boundaries, same TEC."""
+    from ionotomo_amd import _lib
+    w = syn.make_workload("cfg2")
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+    R = o.shape[0]
+    ref = eng.forward(o, d, w["tmax"], w["Ns"]).clone()
+    cyc, units = eng.ctx.walk_cycles(_lib.WALK_FORWARD)
+    assert units >= 2 and cyc.size == units and np.all(cyc > 0)
+    rng = np.random.default_rng(3)
+    cuts = np.sort(rng.integers(0, R + 1, units - 1))
+    cuts[: units // 4] = cuts[units // 4]
+    eng.ctx.walk_partition_set(_lib.WALK_FORWARD, np.concatenate([[0], np.sort(cuts), [R]]), R)
+    assert torch.equal(eng.forward(o, d, w["tmax"], w["Ns"]), ref)
+    stats = eng.tune_forward_partition(lambda: eng.forward(o, d, w["tmax"], w["Ns"]), R, refine=1)
+    assert stats is not None and stats["tuned_ms"] <= stats["equal_count_ms"]
+    assert torch.equal(eng.forward(o, d, w["tmax"], w["Ns"]), ref)
+    eng.ctx.walk_partition_set(_lib.WALK_FORWARD, None, R)
