@@ -209,6 +209,9 @@ __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *
     return a;
 }
 
+// `dbg` = env IONOTOMO_WALK, A/B and ablation switches only (results unchanged except for the two ablations):
+// 4 drop out-of-window contributions, 8 drop tile flushes (timing ablations: WRONG results); 32 smallest bundle 16
+// instead of 8; 64 / 128 largest bundle 64 / 128 instead of 64 NW.
 template <typename AT, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
                                                                const double *__restrict__ dirs, const int *__restrict__ order,
