@@ -93,43 +93,58 @@ __global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const doub
 #define T_TK 72
 #define T_TKP 73
 
+static_assert(T_WIN == 8 && T_TKP == 73, "tile_offset spells out these strides as shifts");
+// (a * T_WIN + b) * T_TKP + m without an integer multiply (v_mul_lo_u32 is quarter rate)
+__device__ __forceinline__ int tile_offset(int a, int b, int m) {
+    const int cell = (a << 3) + b;
+    return (cell << 6) + (cell << 3) + cell + m;
+}
 template <typename AT>
-__device__ __forceinline__ void tile_or_global_add(AT *tile, AT *__restrict__ G, const int *I0, const int *J0, int m, int i, int j,
-                                                   int kk, int ny, int nz, double w00, double w01, double w10, double w11,
-                                                   int dbg = 0) {
-    // the four (i..i+1, j..j+1) nodes of z level kk (tile level m); tile if the 2x2 patch is inside the window
-    bool in = (m >= 0) & (m < T_TK);
-    int a = 0, b = 0;
-    if (in) {
-        a = i - I0[m];
-        b = j - J0[m];
-        in = (a >= 0) & (a + 1 < T_WIN) & (b >= 0) & (b + 1 < T_WIN);
-    }
-    if (in) {
-        AT *t = tile + (a * T_WIN + b) * T_TKP + m;
-        atomicAdd(t, (AT)w00);
-        atomicAdd(t + T_TKP, (AT)w01);
-        atomicAdd(t + T_WIN * T_TKP, (AT)w10);
-        atomicAdd(t + (T_WIN + 1) * T_TKP, (AT)w11);
-    } else if (!(dbg & 4)) {
-        AT *p = G + ((size_t)i * ny + j) * nz + kk;
-        atomicAdd(p, (AT)w00);
-        atomicAdd(p + nz, (AT)w01);
-        atomicAdd(p + (size_t)ny * nz, (AT)w10);
-        atomicAdd(p + (size_t)ny * nz + nz, (AT)w11);
-    }
+__device__ __forceinline__ void tile_add4(AT *t, double w00, double w01, double w10, double w11) {
+    atomicAdd(t, (AT)w00);
+    atomicAdd(t + T_TKP, (AT)w01);
+    atomicAdd(t + T_WIN * T_TKP, (AT)w10);
+    atomicAdd(t + (T_WIN + 1) * T_TKP, (AT)w11);
+}
+template <typename AT>
+__device__ __forceinline__ void global_add4(AT *__restrict__ G, int i, int j, int kk, int ny, int nz, double w00, double w01,
+                                            double w10, double w11) {
+    AT *p = G + ((size_t)i * ny + j) * nz + kk;
+    atomicAdd(p, (AT)w00);
+    atomicAdd(p + nz, (AT)w01);
+    atomicAdd(p + (size_t)ny * nz, (AT)w10);
+    atomicAdd(p + (size_t)ny * nz + nz, (AT)w11);
 }
 
+// One sample's 8 trilinear contributions: the four (i..i+1, j..j+1) nodes of z levels k and k+1 (tile levels m, m+1).
+// A 2x2 patch goes to the tile when it lies inside that level's window, to global memory otherwise.  The common case
+// -- every lane of the wave inside on both levels, which the bundle selection guarantees for bundles that fit -- is
+// a branch-free straight line.
 template <typename AT>
 __device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
                                                      int kz0, double fx, double fy, double fz, double c, int dbg = 0) {
-    const int i = min((int)fx, g.nx - 2), j = min((int)fy, g.ny - 2), k = min((int)fz, g.nz - 2);
-    const double tx = fx - (double)i, ty = fy - (double)j, tz = fz - (double)k;
+    const double fi = fmin(__builtin_floor(fx), (double)(g.nx - 2)), fj = fmin(__builtin_floor(fy), (double)(g.ny - 2));
+    const double fk = fmin(__builtin_floor(fz), (double)(g.nz - 2));
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    const double tx = fx - fi, ty = fy - fj, tz = fz - fk;
     const double w0 = c * (1 - tx), w1 = c * tx;
     const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
+    const double uz = 1 - tz;
     const int m = k - kz0;
-    tile_or_global_add<AT>(tile, G, I0, J0, m, i, j, k, g.ny, g.nz, w00 * (1 - tz), w01 * (1 - tz), w10 * (1 - tz), w11 * (1 - tz), dbg);
-    tile_or_global_add<AT>(tile, G, I0, J0, m + 1, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz, dbg);
+    const int m0 = min(max(m, 0), T_TK - 1), m1 = min(max(m + 1, 0), T_TK - 1);      // clamped for the window look-up only
+    const unsigned a0 = (unsigned)(i - I0[m0]), b0 = (unsigned)(j - J0[m0]);
+    const unsigned a1 = (unsigned)(i - I0[m1]), b1 = (unsigned)(j - J0[m1]);
+    const bool in0 = ((unsigned)m < (unsigned)T_TK) & (a0 < (unsigned)(T_WIN - 1)) & (b0 < (unsigned)(T_WIN - 1));
+    const bool in1 = ((unsigned)(m + 1) < (unsigned)T_TK) & (a1 < (unsigned)(T_WIN - 1)) & (b1 < (unsigned)(T_WIN - 1));
+    if (__all(in0 & in1)) {
+        tile_add4<AT>(tile + tile_offset((int)a0, (int)b0, m), w00 * uz, w01 * uz, w10 * uz, w11 * uz);
+        tile_add4<AT>(tile + tile_offset((int)a1, (int)b1, m + 1), w00 * tz, w01 * tz, w10 * tz, w11 * tz);
+        return;
+    }
+    if (in0) tile_add4<AT>(tile + tile_offset((int)a0, (int)b0, m), w00 * uz, w01 * uz, w10 * uz, w11 * uz);
+    else if (!(dbg & 4)) global_add4<AT>(G, i, j, k, g.ny, g.nz, w00 * uz, w01 * uz, w10 * uz, w11 * uz);
+    if (in1) tile_add4<AT>(tile + tile_offset((int)a1, (int)b1, m + 1), w00 * tz, w01 * tz, w10 * tz, w11 * tz);
+    else if (!(dbg & 4)) global_add4<AT>(G, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz);
 }
 
 // residual -> differential weight of ray r = (a, p) in layout [Na][NtNd] (see k_adjoint_straight MODE 1)
@@ -212,6 +227,14 @@ __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *
 // `dbg` = env IONOTOMO_WALK, A/B and ablation switches only (results unchanged except for the two ablations):
 // 4 drop out-of-window contributions, 8 drop tile flushes (timing ablations: WRONG results); 32 smallest bundle 16
 // instead of 8; 64 / 128 largest bundle 64 / 128 instead of 64 NW.
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits until every global
+// atomic the wave has in flight is acknowledged (2-3 k cycles under load) -- but everything the tile kernel's barriers
+// protect lives in LDS (windows, tile, bundle scratch), and its global atomics are fire-and-forget: they may complete
+// in the background while the next slab is scattered.  The hardware drains them at s_endpgm.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <typename AT, int MODE, int NW>
 __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
                                                                const double *__restrict__ dirs, const int *__restrict__ order,
@@ -246,7 +269,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     long long *next_chunk = (long long *)(J0 + T_TK);
     const double BIG = 1e300;
     bool oob = false;
-    __syncthreads();
+    lds_barrier();
   for (int64_t chunk = bidx;;) {
     const int64_t lo = part ? part[chunk] : chunk * base + min(chunk, rem);
     const int64_t hi = part ? part[chunk + 1] : lo + base + (chunk < rem ? 1 : 0);
@@ -290,7 +313,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                         for (int qi = 0; qi < 8; ++qi) sub[8 * (lev - 1) + qi] = bb[qi][lev];
                 }
             }
-            __syncthreads();
+            lds_barrier();
             if (round == 1) break;
             // largest nested candidate whose rays stay within the tile window at both ends (block-uniform): all NW
             // waves' rays, the first NW/2 waves', ..., wave 0's 64, then wave 0's first 32 / 16 / 8
@@ -318,7 +341,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
             cw = min(cmax, max(16, 2 * c));
             if (c == 64 * NW) break;
             // re-deal the chosen rays evenly over the waves
-            __syncthreads();
+            lds_barrier();
             q = c / NW;
             qw = q0 + (int64_t)q * wid;
             cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
@@ -336,7 +359,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
         double nlive = 0.0, sz0 = 0.0, sdz = 0.0;
         for (int w2 = 0; w2 < NW; ++w2) nlive += ref[ADJ_REF * w2 + 7], sz0 += ref[ADJ_REF * w2 + 4], sdz += ref[ADJ_REF * w2 + 5];
         if (nlive == 0.0) {            // nothing to do in this bundle (block-uniform)
-            __syncthreads();
+            lds_barrier();
             continue;
         }
         // reference line of the bundle: through the centres of its bounding boxes at the bottom and at the
@@ -359,7 +382,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                 I0[threadIdx.x] = (int)floor(fma(kk, rdfx, rfx0)) - (T_WIN / 2 - 1);
                 J0[threadIdx.x] = (int)floor(fma(kk, rdfy, rfy0)) - (T_WIN / 2 - 1);
             }
-            __syncthreads();
+            lds_barrier();
             for (int gi = 0; gi < cnt; ++gi) {
                 const double sc = bcast_lane(a.scale, gi);
                 if (sc == 0.0) continue;
@@ -380,7 +403,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                                              fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k], dbg);
                 }
             }
-            __syncthreads();
+            lds_barrier();
             // ---- flush + re-zero: one global atomic per touched node -------------------------------------
             for (int e = threadIdx.x; e < T_WIN * T_WIN * T_TKP; e += blockDim.x) {
                 const AT v = tile[e];
@@ -392,14 +415,14 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                         atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, v);
                 }
             }
-            __syncthreads();
+            lds_barrier();
         }
     }
     if (blk_cycles && threadIdx.x == 0) blk_cycles[chunk] = __builtin_readcyclecounter() - t_start;   // per chunk, walk order
     if (!part || n_chunks <= (int)gridDim.x) break;
-    __syncthreads();
+    lds_barrier();
     if (threadIdx.x == 0) *next_chunk = (long long)gridDim.x + (long long)atomicAdd(chunk_counter, 1u);
-    __syncthreads();
+    lds_barrier();
     chunk = *next_chunk;
     if (chunk >= n_chunks) break;
   }
