@@ -24,6 +24,21 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.iono_version() >= 100
 
 
+def test_header_constants_match_the_binding():
+    """Enumerators of include/ionotomo_hip.h against the Python constants that mirror them."""
+    hdr = open(os.path.join(ROOT, "include", "ionotomo_hip.h")).read()
+    enums = {}
+    for body in re.findall(r"enum\s*\{([^}]*)\}", hdr):
+        for name, val in re.findall(r"(IONO_[A-Z0-9_]+)\s*=\s*(-?\d+)", body):
+            enums[name] = int(val)
+    for name, py in (("IONO_OK", _lib.OK), ("IONO_ERR_OOB", _lib.ERR_OOB), ("IONO_ERR_NONFINITE", _lib.ERR_NONFINITE),
+                     ("IONO_ERR_SHAPE", _lib.ERR_SHAPE), ("IONO_ERR_HIP", _lib.ERR_HIP), ("IONO_ERR_ARG", _lib.ERR_ARG),
+                     ("IONO_F64", _lib.F64), ("IONO_F32", _lib.F32), ("IONO_WALK_FORWARD", _lib.WALK_FORWARD),
+                     ("IONO_WALK_ADJOINT", _lib.WALK_ADJOINT), ("IONO_INTERP_TRILINEAR", _lib.interp_kind("linear")),
+                     ("IONO_INTERP_TRICUBIC", _lib.interp_kind("cubic"))):
+        assert enums.get(name) == py, (name, enums.get(name), py)
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     import torch
     if torch.cuda.is_available():
