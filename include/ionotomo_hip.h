@@ -81,14 +81,17 @@ int iono_interp(iono_ctx *ctx, const double *x, const double *y, const double *z
 
 /* ---- ray geometry: cast_ray / Fermat.integrate_ray (geometry/calc_rays.py:61-96,
  *      inversion/fermat.py:150-174).  rays_out[R][4][Ns] = x,y,z,s ----------------------------- */
+/* independent: IONO_RAY_Z = Fermat(type='z') -- z = linspace(z0, tmax, Ns), the mode every reference call site uses;
+ * IONO_RAY_S = Fermat(type='s') -- arc length s = linspace(0, tmax, Ns) (inversion/fermat.py:74-82,165-166). */
+enum { IONO_RAY_Z = 0, IONO_RAY_S = 1 };
 int iono_trace_straight(iono_ctx *ctx, const double *origins, const double *directions, int64_t R,
-                        double tmax, int Ns, double *rays_out);
+                        double tmax, int Ns, int independent, double *rays_out);
 /* grid must hold ne [m^-3].  bend = 0 reproduces the shipped "curved" mode (grad n forced to 0,
  * fermat.py:54-55: straight x,y,z and s = int n/pz dz); bend = 1 integrates the true equations
  * (notebooks/FermatClass.ipynb c0:60-96) with fixed-step RK4, `substeps` steps per output sample. */
 int iono_trace_fermat(iono_ctx *ctx, const double *origins, const double *directions, int64_t R,
                       double tmax, int Ns, double frequency, int bend, int interp_kind, int substeps,
-                      double *rays_out);
+                      int independent, double *rays_out);
 
 /* ---- forward: tec[r] = simps(interp(M; x,y,z), s) (inversion/forward_equation.py:13-33) ------ */
 /* samples generated in-kernel on straight z-parametrised rays (never materialises rays[R,4,Ns]) */
@@ -161,6 +164,11 @@ int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t 
  *                               the same R; any other launch falls back to equal counts.  NULL clears it.  Never
  *                               affects results, only which wave / workgroup handles which rays. */
 enum { IONO_WALK_FORWARD = 0, IONO_WALK_ADJOINT = 1 };
+/* Walk order for `order_dev` above (host arrays in, int32[R] host permutation out): 4-D Morton order of the rays'
+ * foot points and far ends in grid cells, so that consecutive rays of the walk nearly coincide.  Geometry only --
+ * compute once per ray set (the reference re-derives its per-direction task split on every call,
+ * inversion/gradient.py:22-54); the host-pointer iono_adjoint_straight applies it internally. */
+int iono_walk_order(iono_ctx *ctx, const double *origins, const double *directions, int64_t R, double tmax, int *order_out);
 int iono_walk_cycles(iono_ctx *ctx, int which, uint64_t *cycles_out, int capacity, int *n_chunks, int *n_units);
 int iono_walk_partition_set(iono_ctx *ctx, int which, const int64_t *starts, int n_chunks, int64_t R);
 /* Solver vector update  y = a x + b y  on device vectors (16-byte aligned), one pass.  The coefficients are ratios
@@ -174,7 +182,7 @@ int iono_vec_axpby_dev(iono_ctx *ctx, double *y_dev, const double *x_dev, int64_
  * iono_forward_tec_rays_dev for the curved-ray TEC (BASELINE config 3) without leaving the GPU. */
 int iono_trace_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R,
                           double tmax, int Ns, double frequency, int bend, int interp_kind, int substeps,
-                          double *rays_dev);
+                          int independent, double *rays_dev);
 int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
 
 /* ---- model-covariance smoothing C_m: Covariance.smooth =

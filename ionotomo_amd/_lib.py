@@ -16,6 +16,7 @@ OK, ERR_OOB, ERR_NONFINITE, ERR_SHAPE, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 WALK_FORWARD, WALK_ADJOINT = 0, 1          # iono_walk_cycles / iono_walk_partition_set
 F64, F32 = 0, 1
 INTERP_TRILINEAR, INTERP_TRICUBIC = 0, 1
+RAY_Z, RAY_S = 0, 1                        # independent variable of a ray: Fermat(type='z' | 's')
 QUAD_SIMPSON_AVG, QUAD_SIMPSON_SCIPY, QUAD_TRAPEZOID = 0, 1, 2
 
 _INTERP = {"linear": 0, "trilinear": 0, 0: 0, "cubic": 1, "tricubic": 1, 1: 1}
@@ -25,6 +26,10 @@ _STORAGE = {"f64": 0, "float64": 0, np.float64: 0, 0: 0, "f32": 1, "float32": 1,
 
 def interp_kind(k):
     return _INTERP[k]
+
+
+def ray_type(t):
+    return {"z": RAY_Z, "s": RAY_S, RAY_Z: RAY_Z, RAY_S: RAY_S}[t]
 
 
 def quad_rule(q):
@@ -51,8 +56,8 @@ _SIGNATURES = {
     "iono_grid_set_exp": [_P, _D],
     "iono_grid_set_exp_dev": [_V, _D],
     "iono_interp": [_P, _P, _P, _L, _I, _I, _P],
-    "iono_trace_straight": [_P, _P, _L, _D, _I, _P],
-    "iono_trace_fermat": [_P, _P, _L, _D, _I, _D, _I, _I, _I, _P],
+    "iono_trace_straight": [_P, _P, _L, _D, _I, _I, _P],
+    "iono_trace_fermat": [_P, _P, _L, _D, _I, _D, _I, _I, _I, _I, _P],
     "iono_forward_tec_straight": [_P, _P, _L, _D, _I, _I, _I, _P],
     "iono_forward_tec_rays": [_P, _L, _I, _I, _I, _P],
     "iono_subtract_reference": [_P, _I, _L, _I],
@@ -68,7 +73,8 @@ _SIGNATURES = {
     "iono_vec_axpby_dev": [_V, _V, _L, _V, _V, _D, _V, _V],
     "iono_walk_cycles": [_I, _V, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "iono_walk_partition_set": [_I, _V, _I, _L],
-    "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _V],
+    "iono_walk_order": [_P, _P, _L, _D, ctypes.POINTER(ctypes.c_int)],
+    "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],
     "iono_smooth_separable_dev": [_V, _V, _V, _P, _P, _P, _I],
@@ -231,6 +237,13 @@ class Context(object):
                       ctypes.byref(units))
         return out, units.value
 
+    def walk_order(self, origins, directions, tmax):
+        """int32 permutation: Morton walk order of the rays (speed only; include/ionotomo_hip.h:iono_walk_order)."""
+        o, d, R = _rays_in(origins, directions)
+        out = np.empty(R, dtype=np.int32)
+        self.call("iono_walk_order", _dp(o), _dp(d), R, float(tmax), out.ctypes.data_as(ctypes.POINTER(ctypes.c_int)))
+        return out
+
     def walk_partition_set(self, which, starts, R):
         if starts is None:
             self.call("iono_walk_partition_set", int(which), None, 0, int(R))
@@ -248,17 +261,17 @@ class Context(object):
         self.call("iono_interp", _dp(x), _dp(y), _dp(z), x.size, interp_kind(kind), int(bool(extrapolate)), _dp(out))
         return out.reshape(shp)
 
-    def trace_straight(self, origins, directions, tmax, Ns):
+    def trace_straight(self, origins, directions, tmax, Ns, type="z"):
         o, d, R = _rays_in(origins, directions)
         out = np.empty((R, 4, int(Ns)), dtype=np.float64)
-        self.call("iono_trace_straight", _dp(o), _dp(d), R, float(tmax), int(Ns), _dp(out))
+        self.call("iono_trace_straight", _dp(o), _dp(d), R, float(tmax), int(Ns), ray_type(type), _dp(out))
         return out
 
-    def trace_fermat(self, origins, directions, tmax, Ns, frequency, bend=True, kind="cubic", substeps=4):
+    def trace_fermat(self, origins, directions, tmax, Ns, frequency, bend=False, kind="linear", substeps=4, type="z"):
         o, d, R = _rays_in(origins, directions)
         out = np.empty((R, 4, int(Ns)), dtype=np.float64)
         self.call("iono_trace_fermat", _dp(o), _dp(d), R, float(tmax), int(Ns), float(frequency), int(bool(bend)),
-                  interp_kind(kind), int(substeps), _dp(out))
+                  interp_kind(kind), int(substeps), ray_type(type), _dp(out))
         return out
 
     def forward_tec_straight(self, origins, directions, tmax, Ns, kind="linear", rule="avg"):

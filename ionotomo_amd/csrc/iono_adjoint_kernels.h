@@ -92,6 +92,13 @@ __global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const doub
 #define T_WIN 8
 #define T_TK 72
 #define T_TKP 73
+// Timing ablations (drop out-of-window contributions / tile flushes: WRONG results) exist only in the
+// -DIONO_ABLATION build that profiles/tools uses; the shipped library has no switch that changes results.
+#ifdef IONO_ABLATION
+#define ADJ_ABLATE(dbg, bit) ((dbg) & (bit))
+#else
+#define ADJ_ABLATE(dbg, bit) false
+#endif
 
 static_assert(T_WIN == 8 && T_TKP == 73, "tile_offset spells out these strides as shifts");
 // (a * T_WIN + b) * T_TKP + m without an integer multiply (v_mul_lo_u32 is quarter rate)
@@ -123,8 +130,10 @@ __device__ __forceinline__ void global_add4(AT *__restrict__ G, int i, int j, in
 template <typename AT>
 __device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
                                                      int kz0, double fx, double fy, double fz, double c, int dbg = 0) {
-    const double fi = fmin(__builtin_floor(fx), (double)(g.nx - 2)), fj = fmin(__builtin_floor(fy), (double)(g.ny - 2));
-    const double fk = fmin(__builtin_floor(fz), (double)(g.nz - 2));
+    // floor(|f|): see load_corners (a validated ray may graze a low face at f = -1e-14; never cell -1)
+    const double fi = fmin(__builtin_floor(__builtin_fabs(fx)), (double)(g.nx - 2)),
+                 fj = fmin(__builtin_floor(__builtin_fabs(fy)), (double)(g.ny - 2));
+    const double fk = fmin(__builtin_floor(__builtin_fabs(fz)), (double)(g.nz - 2));
     const int i = (int)fi, j = (int)fj, k = (int)fk;
     const double tx = fx - fi, ty = fy - fj, tz = fz - fk;
     const double w0 = c * (1 - tx), w1 = c * tx;
@@ -142,9 +151,9 @@ __device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile
         return;
     }
     if (in0) tile_add4<AT>(tile + tile_offset((int)a0, (int)b0, m), w00 * uz, w01 * uz, w10 * uz, w11 * uz);
-    else if (!(dbg & 4)) global_add4<AT>(G, i, j, k, g.ny, g.nz, w00 * uz, w01 * uz, w10 * uz, w11 * uz);
+    else if (!ADJ_ABLATE(dbg, 4)) global_add4<AT>(G, i, j, k, g.ny, g.nz, w00 * uz, w01 * uz, w10 * uz, w11 * uz);
     if (in1) tile_add4<AT>(tile + tile_offset((int)a1, (int)b1, m + 1), w00 * tz, w01 * tz, w10 * tz, w11 * tz);
-    else if (!(dbg & 4)) global_add4<AT>(G, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz);
+    else if (!ADJ_ABLATE(dbg, 4)) global_add4<AT>(G, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz);
 }
 
 // residual -> differential weight of ray r = (a, p) in layout [Na][NtNd] (see k_adjoint_straight MODE 1)
@@ -224,9 +233,9 @@ __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *
     return a;
 }
 
-// `dbg` = env IONOTOMO_WALK, A/B and ablation switches only (results unchanged except for the two ablations):
-// 4 drop out-of-window contributions, 8 drop tile flushes (timing ablations: WRONG results); 32 smallest bundle 16
-// instead of 8; 64 / 128 largest bundle 64 / 128 instead of 64 NW.
+// `dbg` = env IONOTOMO_ADJ_BUNDLE, A/B switches that never change results: 32 smallest bundle 16 instead of 8;
+// 64 / 128 largest bundle 64 / 128 instead of 64 NW.  (Bits 4 / 8 -- drop out-of-window contributions / tile
+// flushes -- are timing ablations compiled in only with -DIONO_ABLATION.)
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits until every global
 // atomic the wave has in flight is acknowledged (2-3 k cycles under load) -- but everything the tile kernel's barriers
 // protect lives in LDS (windows, tile, bundle scratch), and its global atomics are fire-and-forget: they may complete
@@ -411,7 +420,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                     tile[e] = (AT)0;
                     const int cell = e / T_TKP, m = e - cell * T_TKP;
                     const int gi_ = I0[m] + cell / T_WIN, gj_ = J0[m] + cell % T_WIN, gk_ = kz0 + m;
-                    if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz && !(dbg & 8))
+                    if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz && !ADJ_ABLATE(dbg, 8))
                         atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, v);
                 }
             }

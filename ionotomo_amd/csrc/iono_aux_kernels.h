@@ -167,12 +167,25 @@ __global__ void k_interp_points(GridView g, const double *__restrict__ x, const 
     if (oob) atomicOr(oob_flag, 1);
 }
 
+// stype = 1: arc length is the independent variable (Fermat type='s', inversion/fermat.py:74-82,165-166):
+// s = linspace(0, tmax, Ns), position = origin + p s
 __global__ void k_trace_straight(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
-                                 int Ns, double *__restrict__ rays) {
+                                 int Ns, int stype, double *__restrict__ rays) {
     const int64_t n = R * Ns;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t r = idx / Ns;
         const int k = idx % Ns;
+        if (stype) {
+            const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+            const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+            const double sv = (k == Ns - 1) ? tmax : tmax * ((double)k * (1.0 / (double)(Ns - 1)));
+            double *o = rays + (size_t)r * 4 * Ns;
+            o[k] = origins[3 * r] + dx / nrm * sv;
+            o[Ns + k] = origins[3 * r + 1] + dy / nrm * sv;
+            o[2 * Ns + k] = origins[3 * r + 2] + dz / nrm * sv;
+            o[3 * Ns + k] = sv;
+            continue;
+        }
         const StraightRay q = load_straight(origins, dirs, r, tmax, Ns);
         double x, y, z;
         straight_point(q, k, Ns, x, y, z);
@@ -190,8 +203,28 @@ __global__ void k_trace_straight(const double *__restrict__ origins, const doubl
 struct FState {
     double px, py, pz, x, y, z, s;
 };
+// stype (wave-uniform): 0 = d/dz (type='z'), 1 = d/ds (type='s': s' = 1, p' = grad n, x' = p / n; fermat.py:74-82)
+__device__ __forceinline__ FState fermat_rates(double n, double nx, double ny, double nz, const FState &u, int stype) {
+    FState d;
+    if (stype) {
+        const double rn = 1.0 / n;
+        d.px = nx, d.py = ny, d.pz = nz;
+        d.x = u.px * rn, d.y = u.py * rn, d.z = u.pz * rn;
+        d.s = 1.0;
+        return d;
+    }
+    const double ipz = 1.0 / u.pz;              // one reciprocal instead of three divisions per stage
+    const double f = n * ipz;
+    d.px = nx * f, d.py = ny * f, d.pz = nz * f;
+    d.x = u.px * ipz, d.y = u.py * ipz, d.z = 1.0;
+    d.s = f;
+    return d;
+}
+__device__ __forceinline__ double fermat_step(double tmax, double z0, int Ns, int substeps, int stype) {
+    return (stype ? tmax : tmax - z0) / (double)((Ns - 1) * substeps);
+}
 template <int KIND, bool BEND>
-__device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u) {
+__device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u, int stype) {
     double n, nx, ny, nz;
     if (KIND == IONO_INTERP_TRILINEAR) {
         trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
@@ -201,6 +234,7 @@ __device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM
         tricubic_eval<double, true>(gn, g.axes, g.axes + g.nx, g.axes + g.nx + g.ny, u.x, u.y, u.z, n, nx, ny, nz);
     }
     if (!BEND) nx = ny = nz = 0.0;
+    if (stype) return fermat_rates(n, nx, ny, nz, u, 1);
     const double f = n / u.pz;
     FState d;
     d.px = nx * f;
@@ -227,7 +261,7 @@ template <int KIND, bool BEND>
 __global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *__restrict__ nM,
                                                      const double *__restrict__ origins, const double *__restrict__ dirs,
                                                      int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
-                                                     int *oob_flag) {
+                                                     int *oob_flag, int stype) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
     const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
@@ -240,7 +274,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *_
     u.y = origins[3 * r + 1];
     u.z = origins[3 * r + 2];
     u.s = 0.0;
-    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
     double *o = rays + (size_t)r * 4 * Ns;
     o[0] = u.x;
     o[Ns] = u.y;
@@ -256,7 +290,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *_
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs<KIND, BEND>(g, nM, axpy(u, ca, kprev));
+                kprev = fermat_rhs<KIND, BEND>(g, nM, axpy(u, ca, kprev), stype);
                 sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
             }
             u = axpy(u, h / 6.0, sum);
@@ -337,7 +371,7 @@ struct StencilPlane {
 template <bool BEND>
 __device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const double *gx, const double *gy, const double *gz,
                                                   const double *__restrict__ nM, const FState &u, int sub,
-                                                  CubicAxisCache (&cc)[3], StencilPlane &nc) {
+                                                  CubicAxisCache (&cc)[3], StencilPlane &nc, int stype) {
     double wx[6], wy[6], wz[6], dx[6], dy[6], dz[6];
     const int i = cubic_axis_cached(gx, g.nx, u.x, g.inv_h[0], g.uniform[0], cc[0], wx, dx);
     const int j = cubic_axis_cached(gy, g.ny, u.y, g.inv_h[1], g.uniform[1], cc[1], wy, dy);
@@ -370,23 +404,13 @@ __device__ __forceinline__ FState fermat_rhs_coop(const GridView &g, const doubl
     const double n = sum8(fa * wxa);
     double nx = sum8(fa * dxa), ny = sum8(fya * wxa), nz = sum8(fza * wxa);
     if (!BEND) nx = ny = nz = 0.0;
-    const double ipz = 1.0 / u.pz;
-    const double f = n * ipz;
-    FState d;
-    d.px = nx * f;
-    d.py = ny * f;
-    d.pz = nz * f;
-    d.x = u.px * ipz;
-    d.y = u.py * ipz;
-    d.z = 1.0;
-    d.s = f;
-    return d;
+    return fermat_rates(n, nx, ny, nz, u, stype);
 }
 template <bool BEND>
 __global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const double *__restrict__ nM,
                                                           const double *__restrict__ origins, const double *__restrict__ dirs,
                                                           int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
-                                                          int *oob_flag, int axes_in_lds, int rays_per_wave) {
+                                                          int *oob_flag, int axes_in_lds, int rays_per_wave, int stype) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
     if (axes_in_lds) {              // the cell search and the slope weights read 7 axis values per axis per stage
@@ -410,7 +434,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const doub
     u.y = origins[3 * r + 1];
     u.z = origins[3 * r + 2];
     u.s = 0.0;
-    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
     double *o = rays + (size_t)r * 4 * Ns;
     const bool writer = live && sub == 0;
     if (writer) {
@@ -430,7 +454,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const doub
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs_coop<BEND>(g, gx, gy, gz, nM, axpy(u, ca, kprev), sub, cc, nc);
+                kprev = fermat_rhs_coop<BEND>(g, gx, gy, gz, nM, axpy(u, ca, kprev), sub, cc, nc, stype);
                 sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
             }
             u = axpy(u, h / 6.0, sum);
@@ -473,7 +497,7 @@ __device__ __forceinline__ double pick_run(const double (&v)[L4_RUN], int t) {
 }
 template <bool BEND>
 __device__ __forceinline__ FState fermat_rhs_lin4(const GridView &g, const Axes &ax, const double *__restrict__ nM,
-                                                  const FState &u, int a, int b, CornerPair &cc) {
+                                                  const FState &u, int a, int b, CornerPair &cc, int stype) {
     // fast path: still inside the cached cell (same rule as find_cell: g[i] < x <= g[i+1]; the first cell also
     // owns its lower face).  The 4 lanes of a ray hold the same state, so they take the same branch.
     const bool in_x = (u.x > cc.x0 || cc.i == 0) && u.x <= cc.x1, in_y = (u.y > cc.y0 || cc.j == 0) && u.y <= cc.y1;
@@ -504,23 +528,13 @@ __device__ __forceinline__ FState fermat_rhs_lin4(const GridView &g, const Axes 
     const double n = sum4(vz * wxa * wyb);
     double nx = sum4(vz * sa * wyb) * cc.rhx, ny = sum4(vz * wxa * sb) * cc.rhy, nz = sum4(dvz * wxa * wyb) * cc.rhz;
     if (!BEND) nx = ny = nz = 0.0;
-    const double ipz = 1.0 / u.pz;              // one reciprocal instead of three divisions per stage
-    const double f = n * ipz;
-    FState d;
-    d.px = nx * f;
-    d.py = ny * f;
-    d.pz = nz * f;
-    d.x = u.px * ipz;
-    d.y = u.py * ipz;
-    d.z = 1.0;
-    d.s = f;
-    return d;
+    return fermat_rates(n, nx, ny, nz, u, stype);
 }
 template <bool BEND>
 __global__ __launch_bounds__(64) void k_trace_fermat_lin4(GridView g, const double *__restrict__ nM,
                                                           const double *__restrict__ origins, const double *__restrict__ dirs,
                                                           int64_t R, double tmax, int Ns, int substeps, double *__restrict__ rays,
-                                                          int *oob_flag, int rays_per_wave) {
+                                                          int *oob_flag, int rays_per_wave, int stype) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const Axes ax = stage_axes(g, (double *)smem);
     __syncthreads();
@@ -541,7 +555,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat_lin4(GridView g, const doub
     u.y = origins[3 * r + 1];
     u.z = origins[3 * r + 2];
     u.s = 0.0;
-    const double h = (tmax - u.z) / (double)((Ns - 1) * substeps);
+    const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
     double *o = rays + (size_t)r * 4 * Ns;
     const bool writer = live && sub == 0;
     if (writer) {
@@ -559,7 +573,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat_lin4(GridView g, const doub
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs_lin4<BEND>(g, ax, nM, axpy(u, ca, kprev), a, b, cc);
+                kprev = fermat_rhs_lin4<BEND>(g, ax, nM, axpy(u, ca, kprev), a, b, cc, stype);
                 sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
             }
             u = axpy(u, h / 6.0, sum);

@@ -216,7 +216,11 @@ __device__ __forceinline__ Corners<GT> load_corners(const GT *__restrict__ b00, 
                                                     double fx, double fy, double fz) {
     // cell index and node offset in f64 (floor / fma are full-rate; the integer route costs two quarter-rate
     // multiplies and six conversions per sample).  All values are small non-negative integers: exact.
-    const double fi = __builtin_floor(fx), fj = __builtin_floor(fy), fk = __builtin_floor(fz);
+    // floor(|f|): a ray validated on its real end points can still come out at f = -1e-14 on a low face (the grid
+    // coordinate is recomputed with fma / accumulation); |.| is a free source modifier of v_floor_f64 and sends that
+    // sample to cell 0 with weight t = -1e-14 instead of to cell -1 (an out-of-bounds read).
+    const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)),
+                 fk = __builtin_floor(__builtin_fabs(fz));
     Corners<GT> c;
     c.tx = fx - fi;
     c.ty = fy - fj;

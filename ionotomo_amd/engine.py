@@ -119,14 +119,14 @@ class RayEngine(object):
                       _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 
-    def trace_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=True, kind="cubic", substeps=4, out=None):
+    def trace_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=False, kind="linear", substeps=4, out=None, type="z"):
         """rays[R,4,Ns] (x,y,z,s) of the Fermat ray ODE, on the device; the grid must hold ne [m^-3]."""
         self._sync_stream()
         R = origins_t.shape[0]
         if out is None:
             out = torch.empty((R, 4, int(Ns)), dtype=torch.float64, device=self.device)
         self.ctx.call("iono_trace_fermat_dev", _ptr(origins_t), _ptr(dirs_t), R, float(tmax), int(Ns), float(frequency),
-                      int(bool(bend)), _lib.interp_kind(kind), int(substeps), _ptr(out))
+                      int(bool(bend)), _lib.interp_kind(kind), int(substeps), _lib.ray_type(type), _ptr(out))
         return out
 
     def forward_rays(self, rays_t, out=None, kind=None):

@@ -1,14 +1,19 @@
 """``Fermat`` -- drop-in for ``ionotomo.inversion.fermat.Fermat`` (inversion/fermat.py:5-174).
 
-``integrate_ray`` returns (x, y, z, s) sampled at ``N`` points, independent variable z
-(``type='z'``, the only mode any reference call site uses).
+``integrate_ray`` returns (x, y, z, s) sampled at ``N`` points of the independent variable:
+z from z0 to ``tmax`` (``type='z'``, what every reference call site uses) or arc length from 0 to
+``tmax`` (``type='s'``, inversion/fermat.py:74-82,165-166).
 
 * ``straight_line_approx=True``  : closed-form straight ray (n = 1), what every reference call
   site passes (inversion/inversion_pipeline.py:197, astro/simulate_observables.py:62).
 * ``straight_line_approx=False`` : as SHIPPED the reference zeroes grad n (fermat.py:54-55), so
-  x,y,z stay straight and only s = int n/pz dz changes; ``bend=False`` reproduces exactly that.
-  ``bend=True`` (default) integrates the true Fermat equations the reference's notebooks specify
-  (notebooks/FermatClass.ipynb c0:60-96) with grad n from the ``kind`` interpolant.
+  the path stays straight and only the s (type 'z': s = int n/pz dz) or position (type 's':
+  x' = p/n) parametrisation changes.  That is the DEFAULT here (``bend=False``, trilinear n like
+  ``n_tci.interp``): a drop-in caller gets the shipped reference's rays, pinned to its output in
+  tests/golden/fermat_shipped.npz and fermat_type_s.npz.
+  ``bend=True`` is opt-in and integrates the true Fermat equations the reference's notebooks specify
+  (notebooks/FermatClass.ipynb c0:60-96) with grad n from the ``kind`` interpolant ('linear' or
+  'cubic'; default 'cubic' when bending).
 The ODE is integrated on the GPU with fixed-step RK4 (``substeps`` steps per output sample)
 instead of per-ray LSODA calls.
 """
@@ -18,11 +23,10 @@ from .. import _lib
 
 
 class Fermat(object):
-    def __init__(self, ne_tci, frequency=120e6, type='z', straight_line_approx=True, bend=True, kind=None,
+    def __init__(self, ne_tci, frequency=120e6, type='z', straight_line_approx=True, bend=False, kind=None,
                  substeps=4):
-        if type != 'z':
-            raise NotImplementedError("only type='z' (z as independent variable) is built; no reference call site "
-                                      "uses type='s'")
+        if type not in ('z', 's'):
+            raise ValueError("type must be 'z' or 's'")
         self.type = type
         self.frequency = frequency
         self.straight_line_approx = straight_line_approx
@@ -42,11 +46,11 @@ class Fermat(object):
         o = np.asarray(origins, dtype=np.float64)
         ctx = _lib.default_context()
         if self.straight_line_approx:
-            rays = ctx.trace_straight(o, directions, tmax, N)
+            rays = ctx.trace_straight(o, directions, tmax, N, type=self.type)
         else:
             self.ne_tci.bind(ctx)
             rays = ctx.trace_fermat(o, directions, tmax, N, self.frequency, bend=self.bend, kind=self.kind,
-                                    substeps=self.substeps)
+                                    substeps=self.substeps, type=self.type)
         return rays.reshape(o.shape[:-1] + (4, int(N)))
 
     def integrate_ray(self, origin, direction, tmax, N=100):

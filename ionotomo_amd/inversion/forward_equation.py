@@ -5,9 +5,17 @@ integral of the interpolated ne along every ray, dTEC = TEC - TEC[i0].  One GPU 
 (exp at nodes) + one (all rays) + one (reference-antenna subtraction) instead of the reference's
 per-ray Python loop.
 
-``quad`` pins the quadrature rule (SURVEY.md surprise 3): 'avg' = reference-era
-``scipy.integrate.simps`` default (even='avg'); 'scipy' = scipy >= 1.11 ``simpson``.  For odd
-sample counts all Simpson variants coincide.
+``quad`` pins the quadrature rule for EVEN sample counts -- which is the reference's default, since
+``calc_rays`` takes ``N = ne_tci.nz`` (SURVEY.md surprise 3); for odd counts all Simpson variants
+coincide.
+* ``quad='avg'`` (DEFAULT): ``scipy.integrate.simps(y, s)`` as it behaved when the reference was
+  written (scipy <= 1.10: even='avg'), i.e. what the reference computes on the scipy it was
+  developed against.  Pinned by tests/golden/forward_tec_even_avg.npz (the reference module run with
+  that rule).
+* ``quad='scipy'``: what ``simps`` resolves to on a current scipy (>= 1.11 ``simpson``, Cartwright
+  end correction), i.e. what the unmodified reference computes when run TODAY.  Pinned by
+  tests/golden/forward_tec.npz.  The two differ by ~2e-6 relative at N = 64 on the cfg1 field.
+Pick 'scipy' to compare against a reference run on a modern stack.
 """
 import numpy as np
 

@@ -21,6 +21,17 @@ import torch
 FACTR, PGTOL, EPS = 1e7, 1e-2, 2.220446049250313e-16
 
 
+def reference_stop(S_prev, S, max_step, it, max_iter=20, min_iter=5, pgtol=PGTOL):
+    """The reference's loop condition (inversion/iterative_newton.py:959-962,993), negated:
+    ``while ((S_n - S_np1)/max(|S_n|, |S_np1|, 1) > factr*eps and max|m_n - m_np1| > pgtol and iter < max_iter)
+    or iter < 5`` with factr = 1e7, pgtol = 1e-2, max_iter = 20.  ``it`` = updates done so far, ``S_prev`` / ``S`` the
+    objective before / after the last update, ``max_step`` the largest change of a model value in it."""
+    if it < min_iter:
+        return False
+    going = ((S_prev - S) / max(abs(S_prev), abs(S), 1.0) > FACTR * EPS) and (max_step > pgtol) and (it < max_iter)
+    return not going
+
+
 def smooth_grid(eng, v, covariance):
     """C_m v on the engine's device (engines without a smoothing kernel -- the CPU test stand-in -- may
     provide ``smooth`` too)."""
@@ -36,9 +47,12 @@ def _set_x(problem, x):
     problem.engine.set_values(x.reshape(-1))
 
 
-def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None):
+def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=None, pgtol=PGTOL):
     """x_{k+1} = x_k + relax * C A^T L (d - A x_k),  A = differenced ray operator.
-    L, C from row / column sums of |A| bounded by the un-differenced sums (keeps rho <= 1)."""
+    L, C from row / column sums of |A| bounded by the un-differenced sums (keeps rho <= 1).
+    ``stop="reference"``: the reference's stopping rule (``reference_stop``; ``n_iter`` is its max_iter) on the
+    objective S = 1/2 sum r^2/CdCt and the largest model change per update -- one host read-back per iteration;
+    ``stop=None`` runs exactly ``n_iter`` updates without ever synchronising with the host."""
     eng = problem.engine
     x = x0.clone()
     ones = torch.ones(eng.shape, dtype=torch.float64, device=eng.device)
@@ -52,16 +66,31 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None):
     C = torch.where(col > 1e-9 * col.max(), 1.0 / col, torch.zeros_like(col))
     hist = []
     Wt = 1.0 / (problem.cdct + 1e-15)
-    for k in range(n_iter):
+    max_step = None
+    for k in range(n_iter + (1 if stop else 0)):
         _set_x(problem, x)
         r = problem.dobs - problem.forward()
         hist.append(0.5 * problem.dot_rays_t(r, r * Wt))        # stays on the device (see cgls)
         if callback:
             callback(k, x, float(hist[-1]))
-        x.addcmul_(C, problem.adjoint(L * r), value=relax)         # one pass
+        if stop and k > 0 and (k >= n_iter or _stop_now(hist, max_step, k, n_iter, pgtol)):
+            break
+        upd = problem.adjoint(L * r).mul_(C)
         if nonneg:
-            x.clamp_(min=0)
+            xn = torch.clamp(torch.add(x, upd, alpha=relax), min=0)
+            upd, x = xn - x, xn
+            max_step = upd.abs().max() if stop else None
+        else:
+            x.add_(upd, alpha=relax)
+            max_step = relax * upd.abs().max() if stop else None
     return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
+
+
+def _stop_now(hist, max_step, k, max_iter, pgtol):
+    """``reference_stop`` on device scalars (one read-back)."""
+    vals = torch.stack([hist[-2], hist[-1], max_step.reshape(())]).cpu()
+    S_prev, S, step = (float(v) for v in vals)
+    return reference_stop(S_prev, S, step, k, max_iter, pgtol=pgtol)
 
 
 def parallel_adjoint_raw(problem, w):
@@ -71,10 +100,11 @@ def parallel_adjoint_raw(problem, w):
                                                   order=problem.order))
 
 
-def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
+def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL):
     """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2 + damp/2 ||x||^2,  W = 1/(CdCt + 1e-15).
     All scalars (alpha, beta, objective) stay on the device; the history is read back once at the
-    end, so an iteration never waits for the host (``callback`` forces a read-back per iteration)."""
+    end, so an iteration never waits for the host (``callback`` forces a read-back per iteration).
+    ``stop="reference"``: the reference's stopping rule as in ``sirt`` (one read-back per iteration)."""
     eng = problem.engine
     x = x0.clone()
     Wh = torch.rsqrt(problem.cdct + 1e-15)
@@ -89,15 +119,20 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None):
     p = s.clone()
     gamma = torch.dot(s.reshape(-1), s.reshape(-1))
     hist = []
-    for k in range(n_iter):
+    max_step = None
+    for k in range(n_iter + (1 if stop else 0)):
         hist.append(0.5 * problem.dot_rays_t(r, r))
         if callback:
             callback(k, x, float(hist[-1]))
+        if stop and k > 0 and (k >= n_iter or _stop_now(hist, max_step, k, n_iter, pgtol)):
+            break
         _set_x(problem, p)
         q = Wh * problem.forward()
         qq = problem.dot_rays_t(q, q)
         den = qq + damp * torch.dot(p.reshape(-1), p.reshape(-1)) if damp != 0.0 else qq
         # alpha = gamma / den and beta = gnew / gamma are 0-dim device tensors: one fused pass per update
+        if stop:
+            max_step = p.abs().max() * (gamma / den).abs()            # max |alpha p|
         eng.axpby_(x, p, a_num=gamma, a_den=den)                      # x += alpha p
         eng.axpby_(r, q, a_num=gamma, a_den=den, a_sign=-1.0)         # r -= alpha q
         s = normal_residual(r)

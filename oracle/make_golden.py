@@ -264,8 +264,58 @@ def main():
         cases["m_" + tag] = C.c_stencil.shape[0]
         cases["stencil_" + tag] = C.c_stencil
     np.savez_compressed(os.path.join(OUT, "covariance_smooth.npz"), meta=meta(), **cases)
+    round2_fixtures(R, w, rays, m_tci, K_ne, ne_tci)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+def simps_even_avg(y, x=None, dx=1, axis=-1, even='avg'):
+    """scipy <= 1.10 ``simps(y, x)`` semantics for EVEN sample counts (its documented default
+    even='avg': "average two results: 1) use the first N-2 intervals with a trapezoidal rule on the last
+    interval and 2) use the last N-2 intervals with a trapezoidal rule on the first interval"), composed
+    from the installed scipy's own ``simpson`` on the two odd-count sub-ranges (where every Simpson variant
+    agrees) plus numpy trapezoids.  1-D, which is how inversion/forward_equation.py:28 calls it."""
+    y, x = np.asarray(y), np.asarray(x)
+    assert y.ndim == 1 and x.shape == y.shape
+    if y.size % 2 == 1:
+        return scipy.integrate.simpson(y, x=x)
+    first = scipy.integrate.simpson(y[:-1], x=x[:-1]) + 0.5 * (x[-1] - x[-2]) * (y[-1] + y[-2])
+    last = scipy.integrate.simpson(y[1:], x=x[1:]) + 0.5 * (x[1] - x[0]) * (y[1] + y[0])
+    return 0.5 * (first + last)
+
+
+def round2_fixtures(R, w, rays, m_tci, K_ne, ne_tci):
+    """Fixtures added in round 2; the sections above are untouched (their files reproduce bit for bit)."""
+    fe = R["inversion.forward_equation"]
+    Fermat = R["inversion.fermat"].Fermat
+    # ---- 11. even-N forward_equation with the reference-era quadrature ---------------------------------
+    # The reference module is run unchanged; only the name ``simps`` it imported is bound to the
+    # even='avg' composition above instead of the scipy-1.15 ``simpson`` alias the other fixtures use.
+    saved = fe.simps
+    fe.simps = simps_even_avg
+    try:
+        out = dict(K_ne=K_ne, i0=3, workload="cfg1")
+        out["dtec64"] = fe.forward_equation(rays[64], K_ne, m_tci, 3)
+        ne_t = m_tci.copy()
+        np.exp(ne_t.M, out=ne_t.M)
+        ne_t.M *= K_ne / fe.TECU
+        out["tec64"] = np.stack([fe.do_forward_equation(rays[64][i], ne_t) for i in range(8)], 0)
+    finally:
+        fe.simps = saved
+    m = json.loads(meta())
+    m["simps"] = ("reference-era scipy.integrate.simps(y, x) default even='avg', composed from scipy %s simpson on the two "
+                  "odd-count sub-ranges + trapezoids (oracle/make_golden.py:simps_even_avg)" % scipy.__version__)
+    np.savez_compressed(os.path.join(OUT, "forward_tec_even_avg.npz"), meta=json.dumps(m), **out)
+
+    # ---- 12. Fermat(type='s'): arc length as the independent variable (inversion/fermat.py:74-82,165-166)
+    o, d = w["origins"][:3, 0, :3], w["directions"][:3, 0, :3]
+    smax = 900.0                                     # arc length: stays below the grid top for these zenith angles
+    fs = Fermat(ne_tci, 120e6, 's', True)
+    straight = np.array([[np.stack(fs.integrate_ray(o[i, j], d[i, j], smax, 33)) for j in range(3)] for i in range(3)])
+    fc = Fermat(ne_tci, 120e6, 's', False)           # shipped 'curved' mode: grad n = 0, x' = p / n
+    shipped = np.array([[np.stack(fc.integrate_ray(o[i, j], d[i, j], smax, 33)) for j in range(3)] for i in range(3)])
+    np.savez_compressed(os.path.join(OUT, "fermat_type_s.npz"), origins=o, directions=d, smax=smax, N=33,
+                        frequency=120e6, workload="cfg1", straight=straight, shipped=shipped, meta=meta())
 
 
 if __name__ == "__main__":

@@ -251,6 +251,20 @@ def straight_rays(origins, directions, tmax, N):
     return rays
 
 
+def straight_rays_s(origins, directions, smax, N):
+    """type='s' (arc length as the independent variable, inversion/fermat.py:74-82,165-166) with
+    n = 1: s = linspace(0, smax, N), position = origin + p s."""
+    o = np.asarray(origins, float)
+    d = np.asarray(directions, float)
+    p = d / np.linalg.norm(d, axis=-1, keepdims=True)
+    s = np.linspace(0.0, smax, N)
+    rays = np.empty(o.shape[:-1] + (4, N))
+    for a in range(3):
+        rays[..., a, :] = o[..., a, None] + p[..., a, None] * s
+    rays[..., 3, :] = s
+    return rays
+
+
 # --------------------------------------------------------------------------- A5 forward dTEC
 def ne_from_log_model(m, K_ne):
     """ne = K_ne exp(m) / TECU at the NODES (inversion/forward_equation.py:41-43)."""
@@ -414,38 +428,42 @@ def ne_to_n(ne, frequency):
     return np.sqrt(1.0 + ne * (-PLASMA_CONST ** 2 / frequency ** 2))
 
 
-def fermat_rhs(state, field, bend):
+def fermat_rhs(state, field, bend, type='z'):
     """d/dz of (px,py,pz,x,y,s) for type='z' (inversion/fermat.py:64-72;
-    notebooks/FermatClass.ipynb c0:76-84): s' = n/pz, p' = grad(n) n/pz, x' = px/pz, y' = py/pz.
+    notebooks/FermatClass.ipynb c0:76-84): s' = n/pz, p' = grad(n) n/pz, x' = px/pz, y' = py/pz;
+    d/ds for type='s' (fermat.py:74-82): s' = 1, p' = grad(n), (x,y,z)' = p/n.
     ``field(x,y,z) -> n, nx, ny, nz``; with bend=False the gradient is dropped, which is what
     the shipped code does (fermat.py:54-55)."""
     px, py, pz, x, y, z, s = state
     n, nx, ny, nz = field(x, y, z)
     if not bend:
         nx = ny = nz = np.zeros_like(n)
+    if type == 's':
+        rn = 1.0 / n
+        return np.stack([nx, ny, nz, px * rn, py * rn, pz * rn, np.ones_like(pz)])
     f = n / pz
     return np.stack([nx * f, ny * f, nz * f, px / pz, py / pz, np.ones_like(pz), f])
 
 
-def fermat_trace(origins, directions, tmax, N, field, bend=True, substeps=4):
-    """Fixed-step RK4 in z from z0 to tmax, N output samples, ``substeps`` RK4 steps between
-    outputs; vectorised over rays.  Returns rays[...,4,N] (x,y,z,s).  The GPU kernel
-    (fermat_trace_kernel) performs the same arithmetic in the same order."""
+def fermat_trace(origins, directions, tmax, N, field, bend=True, substeps=4, type='z'):
+    """Fixed-step RK4 in z from z0 to tmax (type='z') or in arc length from 0 to tmax (type='s'),
+    N output samples, ``substeps`` RK4 steps between outputs; vectorised over rays.  Returns
+    rays[...,4,N] (x,y,z,s).  The GPU kernels perform the same arithmetic in the same order."""
     o = np.asarray(origins, float)
     d = np.asarray(directions, float)
     shp = o.shape[:-1]
     o, d = o.reshape(-1, 3), d.reshape(-1, 3)
     p = d / np.linalg.norm(d, axis=-1, keepdims=True)
     st = np.stack([p[:, 0], p[:, 1], p[:, 2], o[:, 0], o[:, 1], o[:, 2], np.zeros(len(o))])
-    h = (tmax - o[:, 2]) / ((N - 1) * substeps)
+    h = (tmax - o[:, 2]) / ((N - 1) * substeps) if type == 'z' else np.full(len(o), tmax / ((N - 1) * substeps))
     rays = np.empty((len(o), 4, N))
     rays[:, 0, 0], rays[:, 1, 0], rays[:, 2, 0], rays[:, 3, 0] = st[3], st[4], st[5], st[6]
     for kout in range(1, N):
         for _ in range(substeps):
-            k1 = fermat_rhs(st, field, bend)
-            k2 = fermat_rhs(st + 0.5 * h * k1, field, bend)
-            k3 = fermat_rhs(st + 0.5 * h * k2, field, bend)
-            k4 = fermat_rhs(st + h * k3, field, bend)
+            k1 = fermat_rhs(st, field, bend, type)
+            k2 = fermat_rhs(st + 0.5 * h * k1, field, bend, type)
+            k3 = fermat_rhs(st + 0.5 * h * k2, field, bend, type)
+            k4 = fermat_rhs(st + h * k3, field, bend, type)
             st = st + (h / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
         rays[:, 0, kout], rays[:, 1, kout], rays[:, 2, kout], rays[:, 3, kout] = st[3], st[4], st[5], st[6]
     return rays.reshape(shp + (4, N))

@@ -29,7 +29,17 @@ def dense_operator(rays, xvec, yvec, zvec, i0):
     return G, D @ G
 
 
-def sirt(G, A, d, cd, x0, Na, P, i0, n_iter, relax=1.0):
+FACTR, PGTOL, EPS = 1e7, 1e-2, np.finfo(float).eps
+
+
+def reference_stop(S_prev, S, max_step, it, max_iter=20, min_iter=5, pgtol=PGTOL):
+    """Negation of the reference's loop condition (inversion/iterative_newton.py:959-962,993)."""
+    if it < min_iter:
+        return False
+    return not ((S_prev - S) / max(abs(S_prev), abs(S), 1.0) > FACTR * EPS and max_step > pgtol and it < max_iter)
+
+
+def sirt(G, A, d, cd, x0, Na, P, i0, n_iter, relax=1.0, stop=False, pgtol=PGTOL):
     x = x0.copy()
     rows = G.sum(1).reshape(Na, P)
     L = 1.0 / (rows + rows[i0:i0 + 1]).ravel()
@@ -39,14 +49,19 @@ def sirt(G, A, d, cd, x0, Na, P, i0, n_iter, relax=1.0):
     live = col > 1e-9 * col.max()
     C = np.where(live, 1.0 / np.where(live, col, 1.0), 0.0)
     hist = []
-    for _ in range(n_iter):
+    step = 0.0
+    for k in range(n_iter + (1 if stop else 0)):
         r = d - A @ x
         hist.append(0.5 * np.sum(r * r / (cd + 1e-15)))
-        x = x + relax * C * (A.T @ (L * r))
+        if stop and k > 0 and (k >= n_iter or reference_stop(hist[-2], hist[-1], step, k, n_iter, pgtol=pgtol)):
+            break
+        upd = relax * C * (A.T @ (L * r))
+        step = np.max(np.abs(upd))
+        x = x + upd
     return x, hist
 
 
-def cgls(A, d, cd, x0, n_iter, damp=0.0):
+def cgls(A, d, cd, x0, n_iter, damp=0.0, stop=False, pgtol=PGTOL):
     x = x0.copy()
     Wh = 1.0 / np.sqrt(cd + 1e-15)
     r = Wh * (d - A @ x)
@@ -54,10 +69,14 @@ def cgls(A, d, cd, x0, n_iter, damp=0.0):
     p = s.copy()
     gamma = s @ s
     hist = []
-    for _ in range(n_iter):
+    step = 0.0
+    for k in range(n_iter + (1 if stop else 0)):
         hist.append(0.5 * (r @ r))
+        if stop and k > 0 and (k >= n_iter or reference_stop(hist[-2], hist[-1], step, k, n_iter, pgtol=pgtol)):
+            break
         q = Wh * (A @ p)
         alpha = gamma / (q @ q + damp * (p @ p))
+        step = np.max(np.abs(alpha * p))
         x = x + alpha * p
         r = r - alpha * q
         s = A.T @ (Wh * r) - damp * x

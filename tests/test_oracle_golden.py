@@ -64,6 +64,22 @@ def test_forward_equation_even_N_rules(golden):
     assert 1e-8 < d < 0.1
 
 
+def test_forward_equation_even_N_reference_era_avg_rule(golden):
+    """Second even-N fixture: the reference module run with ``simps`` bound to the reference-era
+    even='avg' composition (oracle/make_golden.py:simps_even_avg) -> QUAD_SIMPSON_AVG must reproduce it,
+    and QUAD_SIMPSON_SCIPY must not (the two rules differ at ~1e-6..1e-3 on this field)."""
+    g, c = golden("forward_tec_even_avg"), golden("cast_ray")
+    w = syn.make_workload("cfg1")
+    K_ne, i0 = float(g["K_ne"]), int(g["i0"])
+    ne = O.ne_from_log_model(w["m"], K_ne)
+    tec = O.forward_tec(c["rays64"], w["xvec"], w["yvec"], w["zvec"], ne, O.QUAD_SIMPSON_AVG)
+    assert rel(tec, g["tec64"]) < 1e-13
+    dtec = O.forward_equation(c["rays64"], K_ne, w["xvec"], w["yvec"], w["zvec"], w["m"], i0, O.QUAD_SIMPSON_AVG)
+    assert np.max(np.abs(dtec - g["dtec64"])) < 1e-13 * np.max(np.abs(g["tec64"]))
+    other = O.forward_tec(c["rays64"], w["xvec"], w["yvec"], w["zvec"], ne, O.QUAD_SIMPSON_SCIPY)
+    assert rel(other, g["tec64"]) > 1e-8
+
+
 def test_simpson_avg_rule_is_exact_for_quadratics_and_matches_definition():
     rng = np.random.default_rng(0)
     s = np.sort(rng.uniform(0, 3, size=(5, 10)), axis=-1)
@@ -159,6 +175,22 @@ def test_ne2n_and_shipped_curved_mode(golden):
     assert np.max(np.abs(rays[..., 3, :] - ref[..., 3, :])) < 2e-6 * np.max(ref[..., 3, :])
     straight = O.straight_rays(g["origins"], g["directions"], float(g["tmax"]), 65)
     assert np.max(np.abs(straight[..., 3, :] - ref[..., 3, :])) > 1e-3      # s really differs
+
+
+def test_fermat_type_s(golden):
+    """type='s' (arc length independent, inversion/fermat.py:74-82): closed form for n = 1 and the shipped
+    grad n = 0 mode (x' = p/n) against the reference's LSODA output."""
+    g = golden("fermat_type_s")
+    w = syn.make_workload("cfg1")
+    smax, N = float(g["smax"]), int(g["N"])
+    st = O.straight_rays_s(g["origins"], g["directions"], smax, N)
+    assert np.max(np.abs(st - g["straight"])) < 1e-9 * smax
+    nM = O.ne_to_n(w["ne"], float(g["frequency"]))
+    field = O.n_field_trilinear(w["xvec"], w["yvec"], w["zvec"], nM)
+    rays = O.fermat_trace(g["origins"], g["directions"], smax, N, field, bend=False, substeps=8, type='s')
+    ref = g["shipped"]
+    assert np.max(np.abs(rays - ref)) < 2e-6 * smax
+    assert np.max(np.abs(st[..., :3, :] - ref[..., :3, :])) > 1e-4          # the mode really differs from n = 1
 
 
 def test_matern_field_matches_reference_realisation(golden):
