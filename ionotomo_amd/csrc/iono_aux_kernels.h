@@ -310,8 +310,15 @@ __global__ __launch_bounds__(64) void k_trace_fermat(GridView g, const double *_
 // contracts its 6 x 6 (y, z) plane (z taps are 6 contiguous doubles per load group); the four partial
 // results (n, nx, ny, nz) are summed over the 8 lanes with three DPP steps (quad_perm xor 1, xor 2,
 // row_half_mirror).  Every lane keeps the full ray state, so no broadcast is needed.
+// The add must see the ROUNDED value of v on both sides of the exchange: with FP contraction on, `v + other` where
+// v = a * b in the caller became fma(a, b, other) -- the lane's own term unrounded, its partner's rounded -- so the
+// two lanes of a pair got sums that differ in the last bit.  Every lane of a group integrates its own copy of the
+// ray state, so the copies drifted apart (random walk, ~1e-12 km after 2,000 stages), the x-tap weights of the
+// lanes then belonged to slightly different positions and sum_a dw_a no longer cancelled: a spurious gradient
+// of ~1e-12 / km along the lane-split axis, 2e-7 km of bending error at config-3 size.  Contraction is off here.
 template <int CTRL>
 __device__ __forceinline__ double dpp_xadd(double v) {
+#pragma clang fp contract(off)
     const int lo = __double2loint(v), hi = __double2hiint(v);
     const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
     const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);

@@ -20,3 +20,13 @@ def golden():
     def load(name):
         return np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return load
+
+
+def pytest_collection_modifyitems(config, items):
+    """The two-process HIP-engine test starts fresh child processes that open the GPU themselves: run it before
+    any test of this process has initialised the GPU (children of a GPU-initialised parent work too on this
+    image -- tests/test_gpu_fuzz.py starts one -- but first is the conservative order)."""
+    first = [it for it in items if "test_two_process_hip_engine" in it.nodeid]
+    if first:
+        rest = [it for it in items if it not in first]
+        items[:] = first + rest

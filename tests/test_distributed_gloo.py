@@ -21,41 +21,50 @@ def _free_port():
     return p
 
 
-def _run(world, exchange="dense"):
-    """Executed by every rank (and with world == 1 in the parent for the reference result)."""
+def _run(world, exchange="dense", engine="oracle", size=None):
+    """Executed by every rank (and with world == 1 in the parent for the reference result).
+    ``engine="oracle"``: the CPU stand-in (this file's tests); ``engine="hip"``: the product's RayEngine on GPU 0
+    (tests/test_gpu_configs.py runs the same function in two fresh processes sharing the card)."""
     sys.path.insert(0, HERE)
     sys.path.insert(0, os.path.dirname(HERE))
     from ionotomo_amd import parallel, solvers
-    from cpu_engine import OracleEngine
     from problems import small_problem
-    pb = small_problem(na=4, nd=5, nt=2, n=12, Ns=13)
+    pb = small_problem(**(size or dict(na=4, nd=5, nt=2, n=12, Ns=13)))
     w = pb["w"]
     rng = np.random.default_rng(1)
     d = rng.normal(size=(pb["na"], pb["P"])) * 0.01
     cd = np.full((pb["na"], pb["P"]), 1e-4)
-    eng = OracleEngine(w["xvec"], w["yvec"], w["zvec"])
+    if engine == "hip":
+        from ionotomo_amd.engine import RayEngine
+        eng = RayEngine(0)
+        eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    else:
+        from cpu_engine import OracleEngine
+        eng = OracleEngine(w["xvec"], w["yvec"], w["zvec"])
+    dev = eng.device
+    host = lambda t: t.detach().cpu().numpy()
     prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d, cdct=cd, i0=pb["i0"], exchange=exchange)
-    x = torch.from_numpy(pb["x_true"].copy())
+    x = torch.from_numpy(pb["x_true"].copy()).to(dev)
     eng.set_values(x)
     fwd = prob.gather_rays(prob.forward()).numpy()
     y_full = torch.from_numpy(rng.normal(size=(pb["na"], pb["P"])))
-    adj = prob.adjoint(prob.slice(y_full)).numpy()
-    xc, hc = solvers.cgls(prob, torch.from_numpy(pb["x0"].copy()), n_iter=4)
-    xs, hs = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()), n_iter=3)
+    adj = host(prob.adjoint(prob.slice(y_full)))
+    xc, hc = solvers.cgls(prob, torch.from_numpy(pb["x0"].copy()).to(dev), n_iter=4)
+    xs, hs = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()).to(dev), n_iter=3)
     # float32 on the links (compact plan shared with the float64 exchange above)
     p32 = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], i0=pb["i0"], exchange=exchange,
                                reduce_dtype=torch.float32)
-    adj32 = p32.adjoint(p32.slice(y_full)).numpy()
-    return dict(fwd=fwd, adj=adj, xc=xc.numpy(), hc=np.array(hc), xs=xs.numpy(), hs=np.array(hs),
+    adj32 = host(p32.adjoint(p32.slice(y_full)))
+    return dict(fwd=fwd, adj=adj, xc=host(xc), hc=np.array(hc), xs=host(xs), hs=np.array(hs),
                 block=(prob.lo, prob.hi), adj32=adj32, active=prob.exchange.fraction,
-                compact=prob.exchange.index is not None)
+                compact=prob.exchange.index is not None, P=pb["P"])
 
 
-def _worker(rank, world, port, q, exchange):
+def _worker(rank, world, port, q, exchange, engine="oracle", size=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = _run(world, exchange)
+    out = _run(world, exchange, engine, size)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()

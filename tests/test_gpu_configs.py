@@ -1,0 +1,263 @@
+"""BASELINE.json configs 3, 4 and 5 at their stated sizes, and the sharded path on the HIP engine in two
+processes.  Needs a real MI355X: -m gpu.
+
+cfg3: 62 x 42 Fermat curved rays (bending) through 128^3, trilinear and tricubic n  -- all 2,604 rays traced, a
+      208-ray sample against the oracle's RK4, TEC along the traced rays against the oracle.
+cfg4: 62 x 100 x 100 = 620,000 rays through 256^3 (fits one GPU): properties, a 640-ray sample against the C
+      oracle, full-batch dot-product test, and the world-size-8 shards r = 0, 7 equal to slices of the full result.
+cfg5: 50 CGLS + 50 SIRT iterations at 256^3 (monotone objective, model error not above the prior's), and all 50
+      iterations against the dense restatement on a reduced problem.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from ionotomo_amd import parallel, solvers, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+@pytest.fixture(scope="module")
+def OC():
+    from oracle import oracle_c
+    return oracle_c
+
+
+def make_engine(w, **kw):
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0, **kw)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    return eng
+
+
+# --------------------------------------------------------------------------- two processes, one card (first: the
+# children are started before this process has touched the GPU when the file runs on its own)
+@pytest.mark.parametrize("exchange", ["dense", "auto"])
+def test_two_process_hip_engine_matches_single_rank(exchange):
+    """ShardedRays over the product's RayEngine in 2 fresh processes (gloo rendezvous, both on GPU 0) against the
+    single-rank run: forward without collective, adjoint + all-reduce, CGLS / SIRT iterates, float32 links."""
+    import torch.multiprocessing as mp
+    from test_distributed_gloo import _worker, _run, _free_port
+    size = dict(na=6, nd=7, nt=6, n=40, Ns=65)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, "hip", size)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref = _run(1, exchange, "hip", size)
+    P = ref["P"]
+    assert res[0]["block"] == (0, P // 2) and res[1]["block"] == (P // 2, P)
+    for r in range(2):
+        assert np.allclose(res[r]["fwd"], ref["fwd"], rtol=1e-13, atol=1e-15)
+        assert np.max(np.abs(res[r]["adj"] - ref["adj"])) < 1e-11 * np.max(np.abs(ref["adj"]))
+        assert np.allclose(res[r]["hc"], ref["hc"], rtol=1e-8)
+        assert np.max(np.abs(res[r]["xc"] - ref["xc"])) < 1e-8 * np.max(np.abs(ref["xc"]))
+        assert np.allclose(res[r]["hs"], ref["hs"], rtol=1e-10)
+        assert np.max(np.abs(res[r]["xs"] - ref["xs"])) < 1e-10 * np.max(np.abs(ref["xs"]))
+        assert np.array_equal(res[r]["xc"], res[0]["xc"])        # replicas stay bit-identical across ranks
+        assert np.max(np.abs(res[r]["adj32"] - ref["adj"])) < 3e-7 * np.abs(ref["adj"]).max()
+        if exchange == "auto":
+            assert 0.0 < res[r]["active"] < 1.0 and res[r]["active"] == res[0]["active"]
+
+
+# --------------------------------------------------------------------------- config 3
+@pytest.mark.parametrize("kind", ["linear", "cubic"])
+def test_config3_fermat_bending_128_cubed(kind, O):
+    w = syn.make_workload("cfg2", margin_cells=16)
+    assert w["ne"].shape == (128, 128, 128) and w["origins"].shape[:3] == (62, 1, 42)
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"]))                       # the tracer wants ne in m^-3
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    Ns, freq = w["Ns"], 120e6
+    rays_t = eng.trace_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=4)
+    assert not eng.check_oob()
+    rays = rays_t.cpu().numpy()
+    assert rays.shape == (2604, 4, Ns) and np.all(np.isfinite(rays))
+    straight = O.straight_rays(o, d, w["tmax"], Ns)
+    assert np.max(np.abs(rays[:, 2] - straight[:, 2])) < 1e-9                      # z is the independent variable
+    assert np.max(np.abs(rays[:, :2] - straight[:, :2])) > 1.0                     # the rays really bend (km)
+    assert np.all(np.diff(rays[:, 3], axis=1) > 0)                                 # s increases
+    idx = np.sort(np.random.default_rng(0).choice(len(o), 208, replace=False))
+    nM = O.ne_to_n(w["ne"], freq)
+    field = (O.n_field_trilinear if kind == "linear" else O.n_field_tricubic)(w["xvec"], w["yvec"], w["zvec"], nM)
+    ref = O.fermat_trace(o[idx], d[idx], w["tmax"], Ns, field, bend=True, substeps=4)
+    assert np.max(np.abs(rays[idx] - ref)) < 1e-8
+    # TEC along the traced rays (explicit-sample kernel, non-uniform Simpson in-kernel), both interpolants
+    for tk, ok in (("linear", O.INTERP_TRILINEAR), ("cubic", O.INTERP_TRICUBIC)):
+        tec = eng.forward_rays(rays_t, kind=tk).cpu().numpy()
+        tref = O.forward_tec(rays[idx], w["xvec"], w["yvec"], w["zvec"], w["ne"], kind=ok)
+        assert np.max(np.abs(tec[idx] - tref) / np.abs(tref)) < 1e-11
+    assert not eng.check_oob()
+
+
+# --------------------------------------------------------------------------- config 4
+@pytest.fixture(scope="module")
+def cfg4():
+    w = syn.make_workload("cfg4")
+    assert w["origins"].shape == (62, 100, 100, 3) and w["ne"].shape == (256, 256, 256) and w["Ns"] == 257
+    return w
+
+
+def test_config4_620k_rays_256_cubed(cfg4, OC, monkeypatch):
+    w = cfg4
+    na, P = 62, 10000
+    eng = make_engine(w)
+    M = w["ne"] / 1e13
+    eng.set_log_model(eng.tensor(w["m"]), w["K_ne"] / 1e13)
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    R, Ns, tmax = len(o), w["Ns"], w["tmax"]
+    assert R == 620000
+    tec_t = eng.forward(ot, dt, tmax, Ns)
+    assert not eng.check_oob()
+    tec = tec_t.cpu().numpy()
+    assert np.all(np.isfinite(tec)) and np.all(tec > 0)
+    # (1) a 640-ray sample against the C oracle (exact searchsorted cells, divisions, plain loops)
+    idx = np.sort(np.random.default_rng(1).choice(R, 640, replace=False))
+    ref = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], M, o[idx], d[idx], tmax, Ns)
+    assert np.max(np.abs(tec[idx] - ref) / ref) < 1e-12
+    # (2) linearity in the grid values
+    rng = np.random.default_rng(2)
+    B = rng.uniform(0.5, 1.5, size=M.shape)
+    eng.set_values(eng.tensor(B))
+    tB = eng.forward(ot, dt, tmax, Ns).cpu().numpy()
+    eng.set_values(eng.tensor(2.0 * M - 0.5 * B))
+    tC = eng.forward(ot, dt, tmax, Ns).cpu().numpy()
+    assert np.max(np.abs(tC - (2.0 * tec - 0.5 * tB))) < 1e-12 * np.max(np.abs(tec))
+    # (3) full-batch dot-product test <G x, y> = <x, G^T y> with and without the walk order, + adjoint sample
+    eng.set_values(eng.tensor(M))
+    y = rng.normal(size=R)
+    yt = eng.tensor(y)
+    order = eng.locality_order(ot, dt, tmax)
+    lhs = float(torch.dot(tec_t, yt))
+    for ordr in (order, None):
+        g = eng.adjoint(ot, dt, yt, tmax, Ns, order=ordr)
+        rhs = float((g * eng.tensor(M)).sum())
+        assert abs(lhs - rhs) < 1e-10 * np.linalg.norm(tec) * np.linalg.norm(y)
+    ys = np.zeros(R)
+    ys[idx] = y[idx]
+    gs = eng.adjoint(ot, dt, eng.tensor(ys), tmax, Ns, order=order).cpu().numpy()
+    gref = OC.adjoint_straight(w["xvec"], w["yvec"], w["zvec"], o[idx], d[idx], y[idx], tmax, Ns)
+    assert np.max(np.abs(gs - gref)) < 1e-11 * np.max(np.abs(gref))
+    # (4) the 8-GPU partition: shards r = 0 and r = 7 of pair_block(10000, 8, r) reproduce their slices of the full
+    #     differential TEC exactly (a ray's integral does not depend on which wave / GPU computes it), and the
+    #     8 partial gradients sum to the full one
+    o4, d4 = w["origins"].reshape(na, P, 3), w["directions"].reshape(na, P, 3)
+    t2 = eng.forward(ot, dt, tmax, Ns).cpu().numpy().reshape(na, P)      # same grid values (M) as the shards below
+    dtec = t2 - t2[0:1]
+    yfull = y.reshape(na, P)
+    full = parallel.ShardedRays(eng, o4, d4, tmax, Ns, i0=0, tune=False)
+    gfull = full.adjoint(full.slice(yfull)).cpu().numpy()
+    gsum = np.zeros_like(gfull)
+    for r in range(8):
+        monkeypatch.setattr(parallel, "world_info", lambda r=r: (8, r))
+        shard = parallel.ShardedRays(eng, o4, d4, tmax, Ns, i0=0, exchange="dense", tune=False)
+        lo, hi = parallel.pair_block(P, 8, r)
+        assert (shard.lo, shard.hi) == (lo, hi) == (1250 * r, 1250 * (r + 1)) and shard.R_local == 62 * 1250
+        if r in (0, 7):
+            assert np.array_equal(shard.forward().cpu().numpy().reshape(na, hi - lo), dtec[:, lo:hi])
+        gsum += shard.adjoint(shard.slice(yfull)).cpu().numpy()     # no process group: the "all-reduce" is this sum
+    monkeypatch.undo()
+    assert np.max(np.abs(gsum - gfull)) < 1e-11 * np.max(np.abs(gfull))
+    assert not eng.check_oob()
+
+
+# --------------------------------------------------------------------------- config 5
+def test_config5_fifty_iterations_256_cubed():
+    """50 CGLS and 50 SIRT iterations on the bench workload (260,400 rays, 256^3).  CGLS minimises ||W^1/2 (A x - d)||:
+    its objective decreases monotonically and so does ||x_k - x*||_2.  SIRT is a contraction in the norms its
+    row / column normalisation defines: the L-weighted residual and the C^-1-weighted (ray-coverage-weighted) model
+    error -- NOT the plain 2-norm.  Its update lies in C range(A^T), which is orthogonal to null(A) only in the
+    C^-1 inner product; with rays within 2 degrees of the vertical and differential data null(A) is huge, so in the
+    plain 2-norm the iterate can and does move AWAY from the truth while it fits the data (round 1 saw 1.32 x and did
+    not explain it; tests/test_solvers_cpu.py checks the contraction iteration by iteration on a dense problem)."""
+    import bench
+    wb = bench.build_workload(0)
+    eng = make_engine(wb)
+    na, P = bench.NA, bench.NT * bench.ND
+    oo, dd = wb["origins"].reshape(na, P, 3), wb["directions"].reshape(na, P, 3)
+    x0 = np.exp(wb["m"]) * (wb["K_ne"] / 1e13)
+    X, Y, Z = np.meshgrid(wb["xvec"], wb["yvec"], wb["zvec"], indexing="ij")
+    x_true = x0 * (1.0 + 0.3 * np.exp(-((X - 5) ** 2 + (Y + 8) ** 2) / 15.0 ** 2 - ((Z - 300) / 80.0) ** 2))
+    del X, Y, Z
+    prob = parallel.ShardedRays(eng, oo, dd, bench.TMAX, bench.NS, dobs=np.zeros((na, P)), cdct=np.full((na, P), 1e-6), i0=0)
+    xt, x0t = eng.tensor(x_true), eng.tensor(x0)
+    eng.set_values(xt)
+    clean = prob.forward()
+    prob.dobs = clean + eng.tensor(np.random.default_rng(3).normal(size=na * P) * 1e-3)
+    noise_floor = 0.5 * float(((prob.dobs - clean) ** 2).sum()) / 1e-6
+    # column sums of the SIRT normalisation (same construction as solvers.sirt)
+    wcol = torch.ones(na, P, dtype=torch.float64, device=eng.device)
+    wcol[0] += na
+    col = solvers.parallel_adjoint_raw(prob, wcol.reshape(-1))
+    e0 = x0t - xt
+    report = {}
+    xc, hc = solvers.cgls(prob, x0t, n_iter=50)
+    hc = np.array(hc)
+    assert len(hc) == 50 and np.all(np.diff(hc) <= 1e-9 * hc[:-1]), "CGLS objective must not increase"
+    assert hc[-1] < 1e-3 * hc[0] and hc[-1] > 0.5 * noise_floor
+    err_c = float((xc - xt).norm() / e0.norm())
+    assert err_c <= 1.0
+    report["cgls"] = (hc[0], hc[-1], err_c)
+    xs, hs = solvers.sirt(prob, x0t, n_iter=50)
+    hs = np.array(hs)
+    assert len(hs) == 50 and np.all(np.diff(hs) <= 1e-9 * hs[:-1]), "SIRT objective must not increase"
+    assert hs[-1] < 1e-2 * hs[0] and hs[-1] > 0.5 * noise_floor
+    es = xs - xt
+    err_s_weighted = float(torch.sqrt((col * es * es).sum() / (col * e0 * e0).sum()))
+    err_s_plain = float(es.norm() / e0.norm())
+    assert err_s_weighted <= 1.0
+    report["sirt"] = (hs[0], hs[-1], err_s_weighted, err_s_plain)
+    print("cfg5 report", report, "noise floor", noise_floor)
+    assert not eng.check_oob()
+
+
+def test_config5_fifty_iterations_match_dense_restatement():
+    """All 50 iterations of SIRT and CGLS against oracle/solvers.py on a problem small enough for a dense matrix."""
+    sys.path.insert(0, HERE)
+    from oracle import oracle as Or, solvers as OS
+    from problems import small_problem
+    pb = small_problem(na=6, nd=6, nt=4, n=18, Ns=19)
+    w = pb["w"]
+    rays = Or.straight_rays(pb["o"], pb["d"], pb["tmax"], pb["Ns"])
+    G, A = OS.dense_operator(rays, w["xvec"], w["yvec"], w["zvec"], pb["i0"])
+    d = A @ pb["x_true"].ravel() + pb["rng"].normal(size=A.shape[0]) * 1e-3
+    cd = np.full(A.shape[0], 1e-6)
+    eng = make_engine(w)
+    prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d.reshape(pb["na"], pb["P"]),
+                                cdct=cd.reshape(pb["na"], pb["P"]), i0=pb["i0"])
+    x0 = eng.tensor(pb["x0"])
+    xs, hs = solvers.sirt(prob, x0, n_iter=50)
+    xr, hr = OS.sirt(G, A, d, cd, pb["x0"].ravel(), pb["na"], pb["P"], pb["i0"], 50)
+    assert len(hs) == 50 and np.allclose(hs, hr, rtol=1e-8)
+    assert np.max(np.abs(xs.cpu().numpy().ravel() - xr)) < 1e-9 * np.max(np.abs(xr))
+    xc, hc = solvers.cgls(prob, x0, n_iter=50)
+    xr, hr = OS.cgls(A, d, cd, pb["x0"].ravel(), 50)
+    hc, hr = np.array(hc), np.array(hr)
+    # CG amplifies the rounding differences between two implementations of the same operator (1e-14 vs 1e-16 per
+    # product) by orders of magnitude once it has converged to the data noise: compare tightly while the objective
+    # is still falling, and to 1e-5 of the initial objective throughout
+    assert np.allclose(hc[:12], hr[:12], rtol=1e-6)
+    assert np.max(np.abs(hc - hr)) < 1e-5 * hr[0]
+    assert np.max(np.abs(xc.cpu().numpy().ravel() - xr)) < 1e-2 * np.max(np.abs(xr))
+    # the reference's stopping rule ends both at the same iteration as the restatement
+    for pgtol in (1e-2, 1e-6):
+        _, h1 = solvers.sirt(prob, x0, n_iter=20, stop="reference", pgtol=pgtol)
+        _, h2 = OS.sirt(G, A, d, cd, pb["x0"].ravel(), pb["na"], pb["P"], pb["i0"], 20, stop=True, pgtol=pgtol)
+        assert len(h1) == len(h2) and np.allclose(h1, h2, rtol=1e-8)

@@ -64,3 +64,55 @@ def test_sirt_cgls_sd_match_dense_restatement():
     assert len(hm) == len(hr) and np.allclose(hm, hr, rtol=1e-8)
     assert np.allclose(mm.numpy().ravel(), mr, rtol=1e-7, atol=1e-10)
     assert hm[-1] < hm[0]
+
+
+def test_reference_stop_rule_in_sirt_and_cgls():
+    """stop="reference" = the loop condition of inversion/iterative_newton.py:959-962,993: at least 5 updates, then
+    stop on a small relative decrease, a small model change (pgtol) or the iteration cap."""
+    pb, G, A, d, cd, prob = setup()
+    x0 = torch.from_numpy(pb["x0"].copy())
+    assert not solvers.reference_stop(10.0, 9.0, 1.0, 3)                      # fewer than 5 updates: go on
+    assert solvers.reference_stop(10.0, 9.0, 1.0, 20) and not solvers.reference_stop(10.0, 9.0, 1.0, 19)
+    assert solvers.reference_stop(10.0, 10.0 - 1e-10, 1.0, 7)                 # relative decrease <= 1e7 eps
+    assert solvers.reference_stop(10.0, 9.0, 5e-3, 7)                         # max |dm| <= pgtol
+    for pgtol, cap in ((1e-2, 20), (1e-7, 10), (1e-7, 8), (0.0, 6)):
+        xs, hs = solvers.sirt(prob, x0, n_iter=cap, stop="reference", pgtol=pgtol)
+        xr, hr = OS.sirt(G, A, d, cd, pb["x0"].ravel(), pb["na"], pb["P"], pb["i0"], cap, stop=True, pgtol=pgtol)
+        assert len(hs) == len(hr) and 6 <= len(hs) <= cap + 1
+        assert np.allclose(hs, hr, rtol=1e-9) and np.allclose(xs.numpy().ravel(), xr, rtol=1e-9, atol=1e-12)
+        xc, hc = solvers.cgls(prob, x0, n_iter=cap, stop="reference", pgtol=pgtol)
+        xr, hr = OS.cgls(A, d, cd, pb["x0"].ravel(), cap, stop=True, pgtol=pgtol)
+        assert len(hc) == len(hr) and 6 <= len(hc) <= cap + 1
+        assert np.allclose(hc, hr, rtol=1e-6, atol=1e-9 * hr[0])
+        assert np.max(np.abs(xc.numpy().ravel() - xr)) < 1e-4 * np.max(np.abs(xr))
+    # the default pgtol = 1e-2 ends both solvers right after the 5 mandatory updates on this problem (tiny steps)
+    _, h = solvers.sirt(prob, x0, n_iter=20, stop="reference")
+    assert len(h) == 6
+
+
+def test_sirt_is_a_contraction_in_its_own_norms():
+    """SIRT x += C A^T L (d - A x) with L, C from the row / column sums: for consistent data the C^-1-weighted model
+    error and the L-weighted residual decrease at EVERY iteration (rho(C A^T L A) <= 1); the plain 2-norm of the
+    model error carries no such guarantee -- the update C A^T(...) is orthogonal to null(A) only in the C^-1 inner
+    product (explains the config-5 observation: objective falls, plain model error grows)."""
+    pb, G, A, d, cd, prob = setup()
+    d = A @ pb["x_true"].ravel()                                   # consistent data
+    Na, P, i0 = pb["na"], pb["P"], pb["i0"]
+    rows = G.sum(1).reshape(Na, P)
+    L = 1.0 / (rows + rows[i0:i0 + 1]).ravel()
+    wcol = np.ones((Na, P))
+    wcol[i0] += Na
+    col = G.T @ wcol.ravel()
+    live = col > 1e-9 * col.max()
+    prob.dobs = torch.from_numpy(d.copy())
+    errs, res = [], []
+
+    def cb(k, x, S):
+        e = x.numpy().ravel() - pb["x_true"].ravel()
+        errs.append(np.sum(col[live] * e[live] ** 2))
+        r = d - A @ x.numpy().ravel()
+        res.append(np.sum(L * r * r))
+    solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()), n_iter=25, callback=cb)
+    errs, res = np.array(errs), np.array(res)
+    assert np.all(np.diff(errs) <= 1e-12 * errs[0]) and errs[-1] < errs[0]
+    assert np.all(np.diff(res) <= 1e-12 * res[0]) and res[-1] < 0.05 * res[0]
