@@ -111,11 +111,13 @@ int iono_forward_phase_rays(iono_ctx *ctx, const double *rays, int Na, int Nt, i
 /* ---- adjoint (exact transpose of the forward; SURVEY.md section 8a row A7') ------------------- */
 /* grad[v] (+)= sum_r w[r] sum_k c_{r,k} W_{k,v}; if scale_by_grid, grad[v] *= M[v] afterwards
  * (gradient w.r.t. the log-model, cf. inversion/gradient.py:19).  grad_out: float64[nx*ny*nz]. */
+/* interp_kind selects WHICH forward is transposed: IONO_INTERP_TRILINEAR (8 weights per sample) or
+ * IONO_INTERP_TRICUBIC (the 216-tap tensor-product form; notebooks/TricubicInterpolation.ipynb c0:165-299). */
 int iono_adjoint_straight(iono_ctx *ctx, const double *origins, const double *directions,
-                          const double *w, int64_t R, double tmax, int Ns, int quad_rule,
+                          const double *w, int64_t R, double tmax, int Ns, int interp_kind, int quad_rule,
                           int scale_by_grid, double *grad_out);
 int iono_adjoint_rays(iono_ctx *ctx, const double *rays, const double *w, int64_t R, int Ns,
-                      int quad_rule, int scale_by_grid, double *grad_out);
+                      int interp_kind, int quad_rule, int scale_by_grid, double *grad_out);
 
 /* ---- device-pointer (asynchronous) variants used by the inversion loop, bench.py and the
  *      multi-GPU driver.  Out-of-grid samples set a sticky device flag read by iono_check_oob. ---- */
@@ -134,17 +136,25 @@ int iono_forward_tec_rays_dev(iono_ctx *ctx, const double *rays_dev, int64_t R, 
  * puts spatially neighbouring rays next to each other cuts global atomics by an order of magnitude. */
 int iono_adjoint_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
                               const int *order_dev, const double *w_dev, int64_t R, double tmax, int Ns,
-                              int quad_rule, void *grad_dev, int accum_dtype);
+                              int interp_kind, int quad_rule, void *grad_dev, int accum_dtype);
 int iono_adjoint_rays_dev(iono_ctx *ctx, const double *rays_dev, const double *w_dev, int64_t R,
-                          int Ns, int quad_rule, void *grad_dev, int accum_dtype);
+                          int Ns, int interp_kind, int quad_rule, void *grad_dev, int accum_dtype);
 /* fused residual -> differential weights -> back-projection for layout [Na][Nt*Nd]:
  *   dd = (tec[a,p] - tec[i0,p] - dobs[a,p]) / (CdCt[a,p] + 1e-15)      (inversion/gradient.py:77-81)
  *   w[a,p] = dd[a,p] - [a == i0] sum_a' dd[a',p]                        (transpose of the i0 differencing)
  * then the adjoint of the straight-ray forward, in ONE launch. */
 int iono_adjoint_residual_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
                                        const int *order_dev, const double *tec_dev, const double *dobs_dev, const double *cdct_dev,
-                                       int Na, int64_t NtNd, int i0, double tmax, int Ns, int quad_rule,
+                                       int Na, int64_t NtNd, int i0, double tmax, int Ns, int interp_kind, int quad_rule,
                                        void *grad_dev, int accum_dtype);
+/* the same fused launch for the LINEAR solvers: back-projection of the differential weights of v * scale,
+ *   w[a,p] = y[a,p] - [a == i0] sum_a' y[a',p],  y = v * scale  (scale_dev nullable = 1)
+ * i.e. A^T (scale o v) for the differenced operator A x = G x - (G x)[i0] -- CGLS needs A^T (W^1/2 r), SIRT
+ * A^T (L r) (row-sum normalisation, geometry/oct_trees/Inversion.py:559) -- without forming y or w in memory. */
+int iono_adjoint_differential_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
+                                           const int *order_dev, const double *v_dev, const double *scale_dev,
+                                           int Na, int64_t NtNd, int i0, double tmax, int Ns, int interp_kind,
+                                           int quad_rule, void *grad_dev, int accum_dtype);
 int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);
 /* Measured load balance of the two chunked kernels.  The straight-ray forward gives every resident wave one
  * contiguous chunk of the ray walk, the LDS-tiled adjoint every resident workgroup; the cost per ray varies with where

@@ -62,13 +62,14 @@ _SIGNATURES = {
     "iono_forward_tec_rays": [_P, _L, _I, _I, _I, _P],
     "iono_subtract_reference": [_P, _I, _L, _I],
     "iono_forward_phase_rays": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P],
-    "iono_adjoint_straight": [_P, _P, _P, _L, _D, _I, _I, _I, _P],
-    "iono_adjoint_rays": [_P, _P, _L, _I, _I, _I, _P],
+    "iono_adjoint_straight": [_P, _P, _P, _L, _D, _I, _I, _I, _I, _P],
+    "iono_adjoint_rays": [_P, _P, _L, _I, _I, _I, _I, _P],
     "iono_forward_tec_straight_dev": [_V, _V, _V, _L, _D, _I, _I, _I, _V],
     "iono_forward_tec_rays_dev": [_V, _L, _I, _I, _I, _V],
-    "iono_adjoint_straight_dev": [_V, _V, _V, _V, _L, _D, _I, _I, _V, _I],
-    "iono_adjoint_rays_dev": [_V, _V, _L, _I, _I, _V, _I],
-    "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _V, _I],
+    "iono_adjoint_straight_dev": [_V, _V, _V, _V, _L, _D, _I, _I, _I, _V, _I],
+    "iono_adjoint_rays_dev": [_V, _V, _L, _I, _I, _I, _V, _I],
+    "iono_adjoint_residual_straight_dev": [_V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _I, _V, _I],
+    "iono_adjoint_differential_straight_dev": [_V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _I, _V, _I],
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
     "iono_vec_axpby_dev": [_V, _V, _L, _V, _V, _D, _V, _V],
     "iono_walk_cycles": [_I, _V, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
@@ -302,13 +303,13 @@ class Context(object):
                   int(i0), quad_rule(rule), _dp(out))
         return out
 
-    def adjoint_straight(self, origins, directions, w, tmax, Ns, rule="avg", scale_by_grid=False):
+    def adjoint_straight(self, origins, directions, w, tmax, Ns, rule="avg", scale_by_grid=False, kind="linear"):
         o, d, R = _rays_in(origins, directions)
         w = as_f64(w).ravel()
         if w.size != R:
             raise ValueError("one weight per ray expected")
         out = np.empty(self.grid_shape, dtype=np.float64)
-        self.call("iono_adjoint_straight", _dp(o), _dp(d), _dp(w), R, float(tmax), int(Ns), quad_rule(rule),
+        self.call("iono_adjoint_straight", _dp(o), _dp(d), _dp(w), R, float(tmax), int(Ns), interp_kind(kind), quad_rule(rule),
                   int(bool(scale_by_grid)), _dp(out))
         return out
 
@@ -320,7 +321,7 @@ class Context(object):
         self.call("iono_smooth_separable", _dp(phi), _dp(out), _dp(kx), _dp(ky), _dp(kz), h)
         return out
 
-    def adjoint_rays(self, rays, w, rule="avg", scale_by_grid=False):
+    def adjoint_rays(self, rays, w, rule="avg", scale_by_grid=False, kind="linear"):
         rays = as_f64(rays)
         Ns = rays.shape[-1]
         R = int(np.prod(rays.shape[:-2], dtype=np.int64))
@@ -328,7 +329,8 @@ class Context(object):
         if w.size != R:
             raise ValueError("one weight per ray expected")
         out = np.empty(self.grid_shape, dtype=np.float64)
-        self.call("iono_adjoint_rays", _dp(rays), _dp(w), R, int(Ns), quad_rule(rule), int(bool(scale_by_grid)), _dp(out))
+        self.call("iono_adjoint_rays", _dp(rays), _dp(w), R, int(Ns), interp_kind(kind), quad_rule(rule),
+                  int(bool(scale_by_grid)), _dp(out))
         return out
 
 

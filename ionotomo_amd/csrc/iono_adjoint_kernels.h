@@ -33,7 +33,13 @@ __device__ __forceinline__ void scatter_trilinear(const GridView &g, const Axes 
 // MODE 0: weights given (w[R]);  MODE 1: fused residual -> differential weights for layout
 // [Na][NtNd]: dd = (tec - tec[i0] - dobs)/(CdCt + 1e-15) (inversion/gradient.py:77-81),
 // w = dd - [a == i0] sum_a' dd[a']  (transpose of "tec - tec[i0]", forward_equation.py:50)
-template <typename AT, int MODE>
+template <typename AT>
+__device__ __forceinline__ void scatter_tricubic(const GridView &g, const Axes &ax, AT *__restrict__ G, double x, double y,
+                                                 double z, double c);
+template <int MODE>
+__device__ __forceinline__ double dd_of(const double *__restrict__ tec, const double *__restrict__ dobs,
+                                        const double *__restrict__ cdct, double tref, int64_t r);
+template <typename AT, int MODE, int KIND = IONO_INTERP_TRILINEAR>
 __global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const double *__restrict__ origins,
                                                           const double *__restrict__ dirs, const double *__restrict__ wray,
                                                           const double *__restrict__ tec, const double *__restrict__ dobs,
@@ -51,14 +57,11 @@ __global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const doub
         } else {
             const int a = (int)(w.r / NtNd);
             const int64_t p = w.r % NtNd;
-            const double tref = tec[(int64_t)i0 * NtNd + p];
-            wr = (tec[w.r] - tref - dobs[w.r]) / (cdct[w.r] + 1e-15);
+            const double tref = MODE == 2 ? 0.0 : tec[(int64_t)i0 * NtNd + p];
+            wr = dd_of<MODE>(tec, dobs, cdct, tref, w.r);
             if (a == i0) {
                 double s = 0.0;
-                for (int a2 = lane; a2 < Na; a2 += 64) {
-                    const int64_t r2 = (int64_t)a2 * NtNd + p;
-                    s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
-                }
+                for (int a2 = lane; a2 < Na; a2 += 64) s += dd_of<MODE>(tec, dobs, cdct, tref, (int64_t)a2 * NtNd + p);
                 wr -= wave_sum(s);
             }
         }
@@ -68,11 +71,12 @@ __global__ __launch_bounds__(256) void k_adjoint_straight(GridView g, const doub
         for (int k = lane; k < Ns; k += 64) {
             double x, y, z;
             straight_point(q, k, Ns, x, y, z);
-            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+            if (sample_outside<KIND>(ax, x, y, z)) {
                 oob = true;
                 continue;
             }
-            scatter_trilinear<AT>(g, ax, G, x, y, z, scale * unitw[k]);
+            if (KIND == IONO_INTERP_TRILINEAR) scatter_trilinear<AT>(g, ax, G, x, y, z, scale * unitw[k]);
+            else scatter_tricubic<AT>(g, ax, G, x, y, z, scale * unitw[k]);
         }
     }
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
@@ -127,18 +131,34 @@ __device__ __forceinline__ void global_add4(AT *__restrict__ G, int i, int j, in
 // A 2x2 patch goes to the tile when it lies inside that level's window, to global memory otherwise.  The common case
 // -- every lane of the wave inside on both levels, which the bundle selection guarantees for bundles that fit -- is
 // a branch-free straight line.
-template <typename AT>
+// `field` < 0: trilinear weights (1 - t, t).  `field` = p + 2 q + 4 r >= 0: channel (p, q, r) of the tricubic transpose
+// (iono_cubic_kernels.h): per axis the cubic Hermite VALUE weights of the two nodes (bit 0) or their SLOPE weights (1).
+__device__ __forceinline__ void axis_pair(double t, int field_bit, bool cubic, double &w0, double &w1) {
+    if (!cubic) {
+        w0 = 1 - t, w1 = t;
+        return;
+    }
+    const double t2 = t * t, t3 = t2 * t;
+    if (field_bit) {
+        w0 = t3 - 2.0 * t2 + t, w1 = t3 - t2;
+    } else {
+        w1 = 3.0 * t2 - 2.0 * t3, w0 = 1.0 - w1;
+    }
+}
+template <typename AT, bool CUBIC>
 __device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
-                                                     int kz0, double fx, double fy, double fz, double c, int dbg = 0) {
+                                                     int kz0, double fx, double fy, double fz, double c, int dbg = 0, int field = -1) {
     // floor(|f|): see load_corners (a validated ray may graze a low face at f = -1e-14; never cell -1)
     const double fi = fmin(__builtin_floor(__builtin_fabs(fx)), (double)(g.nx - 2)),
                  fj = fmin(__builtin_floor(__builtin_fabs(fy)), (double)(g.ny - 2));
     const double fk = fmin(__builtin_floor(__builtin_fabs(fz)), (double)(g.nz - 2));
     const int i = (int)fi, j = (int)fj, k = (int)fk;
-    const double tx = fx - fi, ty = fy - fj, tz = fz - fk;
-    const double w0 = c * (1 - tx), w1 = c * tx;
-    const double w00 = w0 * (1 - ty), w01 = w0 * ty, w10 = w1 * (1 - ty), w11 = w1 * ty;
-    const double uz = 1 - tz;
+    double ax0, ax1, ay0, ay1, uz, tz;
+    axis_pair(fx - fi, field & 1, CUBIC, ax0, ax1);
+    axis_pair(fy - fj, field & 2, CUBIC, ay0, ay1);
+    axis_pair(fz - fk, field & 4, CUBIC, uz, tz);
+    const double w0 = c * ax0, w1 = c * ax1;
+    const double w00 = w0 * ay0, w01 = w0 * ay1, w10 = w1 * ay0, w11 = w1 * ay1;
     const int m = k - kz0;
     const int m0 = min(max(m, 0), T_TK - 1), m1 = min(max(m + 1, 0), T_TK - 1);      // clamped for the window look-up only
     const unsigned a0 = (unsigned)(i - I0[m0]), b0 = (unsigned)(j - J0[m0]);
@@ -156,19 +176,26 @@ __device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile
     else if (!ADJ_ABLATE(dbg, 4)) global_add4<AT>(G, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz);
 }
 
-// residual -> differential weight of ray r = (a, p) in layout [Na][NtNd] (see k_adjoint_straight MODE 1)
+// differential weight of ray r = (a, p) in layout [Na][NtNd]:  w = dd(r) - [a == i0] sum_a' dd(a', p)  (the transpose of
+// "tec - tec[i0]", inversion/forward_equation.py:50), with
+//   MODE 1: dd = (tec - tec[i0] - dobs) / (cdct + 1e-15)     (fused residual, inversion/gradient.py:77-81)
+//   MODE 2: dd = v * scale   (v passed as `tec`, scale as `cdct`, null = 1): A^T (scale o v) for the linear solvers
+template <int MODE>
+__device__ __forceinline__ double dd_of(const double *__restrict__ tec, const double *__restrict__ dobs,
+                                        const double *__restrict__ cdct, double tref, int64_t r) {
+    if (MODE == 2) return cdct ? tec[r] * cdct[r] : tec[r];
+    return (tec[r] - tref - dobs[r]) / (cdct[r] + 1e-15);
+}
+template <int MODE>
 __device__ __forceinline__ double residual_weight(const double *__restrict__ tec, const double *__restrict__ dobs,
                                                   const double *__restrict__ cdct, int Na, int64_t NtNd, int i0, int64_t r) {
     const int a = (int)(r / NtNd);
     const int64_t p = r % NtNd;
-    const double tref = tec[(int64_t)i0 * NtNd + p];
-    double wr = (tec[r] - tref - dobs[r]) / (cdct[r] + 1e-15);
+    const double tref = MODE == 2 ? 0.0 : tec[(int64_t)i0 * NtNd + p];
+    double wr = dd_of<MODE>(tec, dobs, cdct, tref, r);
     if (a == i0) {
         double s = 0.0;
-        for (int a2 = 0; a2 < Na; ++a2) {
-            const int64_t r2 = (int64_t)a2 * NtNd + p;
-            s += (tec[r2] - tref - dobs[r2]) / (cdct[r2] + 1e-15);
-        }
+        for (int a2 = 0; a2 < Na; ++a2) s += dd_of<MODE>(tec, dobs, cdct, tref, (int64_t)a2 * NtNd + p);
         wr -= s;
     }
     return wr;
@@ -216,7 +243,9 @@ struct AdjRay {
     double scale;
 };
 // lane-parallel load of `q` rays per wave starting at walk position qw (lanes >= cnt idle)
-template <int MODE>
+__device__ __forceinline__ URay load_uray_cubic(const GridView &g, const double *origins, const double *dirs, int64_t r,
+                                                double tmax, int Ns);
+template <int MODE, bool CUBIC = false>
 __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *origins, const double *dirs, const int *order,
                                                const double *wray, const double *tec, const double *dobs, const double *cdct,
                                                int Na, int64_t NtNd, int i0, int64_t q, bool active, double tmax, int Ns,
@@ -226,8 +255,8 @@ __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *
     a.scale = 0.0;
     if (active) {
         const int64_t r = order ? (int64_t)order[q] : q;
-        a.u = load_uray(g, origins, dirs, r, tmax, Ns);
-        const double wr = MODE == 0 ? wray[r] : residual_weight(tec, dobs, cdct, Na, NtNd, i0, r);
+        a.u = CUBIC ? load_uray_cubic(g, origins, dirs, r, tmax, Ns) : load_uray(g, origins, dirs, r, tmax, Ns);
+        const double wr = MODE == 0 ? wray[r] : residual_weight<MODE>(tec, dobs, cdct, Na, NtNd, i0, r);
         if (a.u.valid) a.scale = wr * a.u.h; else oob = true;
     }
     return a;
@@ -244,7 +273,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename AT, int MODE, int NW>
+template <typename AT, int MODE, int NW, bool CUBIC = false>
 __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
                                                                const double *__restrict__ dirs, const int *__restrict__ order,
                                                                const double *__restrict__ wray, const double *__restrict__ tec,
@@ -253,7 +282,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                                                                int dbg, const double *__restrict__ unitw, AT *__restrict__ G,
                                                                int *oob_flag, const int64_t *__restrict__ part, int n_chunks,
                                                                unsigned int *__restrict__ chunk_counter,
-                                                               unsigned long long *__restrict__ blk_cycles) {
+                                                               unsigned long long *__restrict__ blk_cycles, int field = -1) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][ADJ_REF] per-wave sums and bounding boxes
@@ -291,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
         int q = 64;                                     // rays per wave
         int64_t qw = q0 + (int64_t)q * wid;
         int cnt = (int)max((int64_t)0, min((int64_t)q, min(hi, q0 + (int64_t)cw) - qw));
-        AdjRay a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
+        AdjRay a = load_adj_ray<MODE, CUBIC>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
                                       Ns, oob);
         int c = 64 * NW;
         for (int round = 0; round < 2; ++round) {
@@ -354,15 +383,15 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
             q = c / NW;
             qw = q0 + (int64_t)q * wid;
             cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
-            a = load_adj_ray<MODE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax, Ns,
+            a = load_adj_ray<MODE, CUBIC>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax, Ns,
                                    oob);
         }
         q0 += c;
         if (a.scale != 0.0 && tail_by_lane && nslab == 0) {  // fewer than 9 samples in all: straight to global memory
             for (int k = ntail0; k < Ns; ++k) {
                 const double kd = (double)k;
-                scatter_sample_tiled<AT>(g, tile, G, I0, J0, -(1 << 28), fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
-                                         fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k]);
+                scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, -(1 << 28), fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
+                                                fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k], dbg, field);
             }
         }
         double nlive = 0.0, sz0 = 0.0, sdz = 0.0;
@@ -398,9 +427,9 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                 const int k = k0 + lane;
                 if (k < Ns && (tail_by_lane ? k < ntail0 : true)) {
                     const double kd = (double)k;
-                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
-                                             fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
-                                             fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi)), sc * wlds[k], dbg);
+                    scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
+                                                    fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
+                                                    fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi)), sc * wlds[k], dbg, field);
                 }
             }
             if (tail_by_lane && it == nslab - 1 && a.scale != 0.0) {
@@ -408,8 +437,8 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                 // (anything that still falls outside goes to global memory as everywhere else)
                 for (int k = ntail0; k < Ns; ++k) {
                     const double kd = (double)k;
-                    scatter_sample_tiled<AT>(g, tile, G, I0, J0, kz0, fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
-                                             fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k], dbg);
+                    scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, kz0, fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
+                                                    fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k], dbg, field);
                 }
             }
             lds_barrier();
@@ -438,7 +467,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
-template <typename AT>
+template <typename AT, int KIND = IONO_INTERP_TRILINEAR>
 __global__ __launch_bounds__(256) void k_adjoint_rays(GridView g, const double *__restrict__ rays,
                                                       const double *__restrict__ wray, int64_t R, int Ns, int rule,
                                                       AT *__restrict__ G, int *oob_flag) {
@@ -452,11 +481,12 @@ __global__ __launch_bounds__(256) void k_adjoint_rays(GridView g, const double *
         if (wr == 0.0) continue;
         for (int k = lane; k < Ns; k += 64) {
             const double x = rx[k], y = ry[k], z = rz[k];
-            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+            if (sample_outside<KIND>(ax, x, y, z)) {
                 oob = true;
                 continue;
             }
-            scatter_trilinear<AT>(g, ax, G, x, y, z, wr * quad_weight(rs, Ns, k, rule));
+            if (KIND == IONO_INTERP_TRILINEAR) scatter_trilinear<AT>(g, ax, G, x, y, z, wr * quad_weight(rs, Ns, k, rule));
+            else scatter_tricubic<AT>(g, ax, G, x, y, z, wr * quad_weight(rs, Ns, k, rule));
         }
     }
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);

@@ -1,0 +1,257 @@
+// tricubic on the hot path (ideal-uniform grids): Lekien-Marsden derivative fields, fast forward, channel scatter + fold
+#ifndef IONO_CUBIC_KERNELS_H
+#define IONO_CUBIC_KERNELS_H
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// The tricubic of this build (notebooks/TricubicInterpolation.ipynb c0:138-1257: Lekien-Marsden with 4th-order
+// central-difference derivative data) is the tensor product of 1-D cubic Hermite splines whose node slopes are
+//   D f_i = (f[i-2] - 8 f[i-1] + 8 f[i+1] - f[i+2]) / 12      (cell units, uniform axis; 2 <= i <= n-3)
+// (iono_device_common.h:cubic_axis spells out the equivalent 6-tap form).  Evaluating the 6 x 6 x 6 taps per sample
+// costs 216 gathered values and 258 FMAs.  Lekien-Marsden's own formulation keeps, per NODE, the 8 derivative data
+//   F[p + 2 q + 4 r] = Dx^p Dy^q Dz^r f,   p, q, r in {0, 1}
+// (what the notebook calls bVec and caches per cell, c0:165-299) and evaluates in the cell's 8 corners:
+//   f(x, y, z) = sum_{a,b,c in {0,1}} sum_{p,q,r} Hx[a][p](tx) Hy[b][q](ty) Hz[c][r](tz) F[p,q,r](i+a, j+b, k+c),
+//   H[0][0] = 2t^3 - 3t^2 + 1,  H[1][0] = -2t^3 + 3t^2,  H[0][1] = t^3 - 2t^2 + t,  H[1][1] = t^3 - t^2
+// -- 64 values (4 corner columns x one contiguous 128-B run of two nodes) and 84 FMAs per sample, the same
+// arithmetic to rounding.  The fields are rebuilt (one kernel) whenever the grid values change; 8 doubles per node:
+// 1 GiB at 256^3, which is what 288 GB of HBM is for.
+//
+// Transpose: each of the 8 channels is a trilinear-shaped scatter with the Hermite weights in place of (1-t, t), so
+// the LDS-tiled back-projection kernel is reused per channel (field-major buffer G8[8][nx ny nz]); one fold kernel
+// then applies the transposed difference stencils:  grad = sum_{pqr} (Dx^p Dy^q Dz^r)^T G8[pqr].
+// ------------------------------------------------------------------------------------------------
+#define LM_NF 8
+
+// forward difference coefficient of tap offset d (-2..2), x 1/12
+__device__ __forceinline__ double fd_coef(int d) {
+    return d == -2 ? 1.0 / 12.0 : d == -1 ? -8.0 / 12.0 : d == 1 ? 8.0 / 12.0 : d == 2 ? -1.0 / 12.0 : 0.0;
+}
+
+// F8[node][8] from the stored values.  One thread per node, lanes along z.  Nodes within 2 of a face have no slope
+// along that axis (no valid sample ever weighs them: tricubic samples live in g[2] <= x <= g[n-3]): 0.
+template <typename GT>
+__global__ __launch_bounds__(256) void k_lm_fields(const GT *__restrict__ M, double *__restrict__ F8, int nx, int ny, int nz) {
+    const int64_t n = (int64_t)nx * ny * nz;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % nz);
+        const int j = (int)((idx / nz) % ny);
+        const int i = (int)(idx / ((int64_t)nz * ny));
+        const bool vx = i >= 2 && i <= nx - 3, vy = j >= 2 && j <= ny - 3, vz = k >= 2 && k <= nz - 3;
+        double out[LM_NF];
+#pragma unroll
+        for (int f = 0; f < LM_NF; ++f) out[f] = 0.0;
+        // accumulate in the nesting order x (outer), y, z (inner) so that every field is a plain nested sum
+        for (int da = -2; da <= 2; ++da) {
+            if (da != 0 && !vx) continue;
+            const double cx = fd_coef(da);
+            double sy[4] = {0.0, 0.0, 0.0, 0.0};         // [q + 2 r] partial sums over (db, dc) for this da
+            for (int db = -2; db <= 2; ++db) {
+                if (db != 0 && !vy) continue;
+                const double cy = fd_coef(db);
+                const GT *row = M + ((int64_t)(i + da) * ny + (j + db)) * nz + k;
+                const double v0 = (double)row[0];
+                double dz = 0.0;
+                if (vz) dz = fd_coef(-2) * (double)row[-2] + fd_coef(-1) * (double)row[-1] + fd_coef(1) * (double)row[1] +
+                             fd_coef(2) * (double)row[2];
+                if (db == 0) {
+                    sy[0] += v0;
+                    sy[2] += dz;
+                } else {
+                    sy[1] += cy * v0;
+                    sy[3] += cy * dz;
+                }
+            }
+            if (da == 0) {
+                out[0] += sy[0], out[2] += sy[1], out[4] += sy[2], out[6] += sy[3];
+            } else {
+                out[1] += cx * sy[0], out[3] += cx * sy[1], out[5] += cx * sy[2], out[7] += cx * sy[3];
+            }
+        }
+        double2 *o = (double2 *)(F8 + idx * LM_NF);
+        o[0] = make_double2(out[0], out[1]);
+        o[1] = make_double2(out[2], out[3]);
+        o[2] = make_double2(out[4], out[5]);
+        o[3] = make_double2(out[6], out[7]);
+    }
+}
+
+// grad[m] += sum_{pqr} sum_{offsets} ct_x^p ct_y^q ct_z^r G8[pqr][m + offset]: the transposed stencils.  The source node
+// of a slope must itself be a valid slope node (2 <= i <= n-3 along that axis); transposed coefficient = fd_coef(-d).
+template <typename AT>
+__global__ __launch_bounds__(256) void k_lm_fold(const double *__restrict__ G8, AT *__restrict__ grad, int nx, int ny, int nz) {
+    const int64_t n = (int64_t)nx * ny * nz;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int k = (int)(idx % nz);
+        const int j = (int)((idx / nz) % ny);
+        const int i = (int)(idx / ((int64_t)nz * ny));
+        double acc = 0.0;
+        for (int da = -2; da <= 2; ++da) {
+            const int si = i + da;
+            if (da != 0 && !(si >= 2 && si <= nx - 3)) continue;
+            const double cx = da == 0 ? 1.0 : fd_coef(-da);
+            const int p = da != 0;
+            for (int db = -2; db <= 2; ++db) {
+                const int sj = j + db;
+                if (db != 0 && !(sj >= 2 && sj <= ny - 3)) continue;
+                const double cxy = cx * (db == 0 ? 1.0 : fd_coef(-db));
+                const int q = db != 0;
+                const double *row = G8 + ((int64_t)si * ny + sj) * nz + k;
+                const double *r0 = row + (int64_t)(p + 2 * q) * n, *r1 = row + (int64_t)(p + 2 * q + 4) * n;
+                double s = r0[0];
+#pragma unroll
+                for (int dc = -2; dc <= 2; ++dc) {
+                    if (dc == 0) continue;
+                    const int sk = k + dc;
+                    if (sk >= 2 && sk <= nz - 3) s += fd_coef(-dc) * r1[dc];
+                }
+                acc += cxy * s;
+            }
+        }
+        grad[idx] = (AT)((double)grad[idx] + acc);
+    }
+}
+
+struct Herm {
+    double h0, h1, s0, s1;        // value weights of nodes 0 / 1, slope weights of nodes 0 / 1
+};
+__device__ __forceinline__ Herm hermite(double t) {
+    const double t2 = t * t, t3 = t2 * t;
+    Herm h;
+    h.h1 = 3.0 * t2 - 2.0 * t3;
+    h.h0 = 1.0 - h.h1;
+    h.s0 = t3 - 2.0 * t2 + t;
+    h.s1 = t3 - t2;
+    return h;
+}
+
+// one sample: 4 corner columns x (2 nodes x 8 fields = 128 contiguous bytes)
+__device__ __forceinline__ double tricubic_lm(const double *__restrict__ F8, int ny, int nz, double fx, double fy, double fz) {
+    const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)),
+                 fk = __builtin_floor(__builtin_fabs(fz));
+    const Herm hx = hermite(fx - fi), hy = hermite(fy - fj), hz = hermite(fz - fk);
+    const double lin = __builtin_fma(fi, (double)ny * (double)nz, __builtin_fma(fj, (double)nz, fk));
+    const double2 *base = (const double2 *)(F8 + (size_t)lin * LM_NF);
+    const size_t sj = (size_t)nz * (LM_NF / 2), si = (size_t)ny * sj;      // strides in double2
+    double ux[2][2];                          // [a][p]: after the z and y contractions
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        ux[a][0] = ux[a][1] = 0.0;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const double2 *col = base + a * si + b * sj;
+            double2 n0[4], n1[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) n0[t] = col[t], n1[t] = col[4 + t];
+            // z: value fields (r = 0) sit in n?[0..1], their z-slopes (r = 1) in n?[2..3]; component .x = p 0, .y = p 1
+            const double v00 = hz.h0 * n0[0].x + hz.h1 * n1[0].x + hz.s0 * n0[2].x + hz.s1 * n1[2].x;     // p 0, q 0
+            const double v10 = hz.h0 * n0[0].y + hz.h1 * n1[0].y + hz.s0 * n0[2].y + hz.s1 * n1[2].y;     // p 1, q 0
+            const double v01 = hz.h0 * n0[1].x + hz.h1 * n1[1].x + hz.s0 * n0[3].x + hz.s1 * n1[3].x;     // p 0, q 1
+            const double v11 = hz.h0 * n0[1].y + hz.h1 * n1[1].y + hz.s0 * n0[3].y + hz.s1 * n1[3].y;     // p 1, q 1
+            const double wy = b ? hy.h1 : hy.h0, wys = b ? hy.s1 : hy.s0;
+            ux[a][0] += wy * v00 + wys * v01;
+            ux[a][1] += wy * v10 + wys * v11;
+        }
+    }
+    return hx.h0 * ux[0][0] + hx.s0 * ux[0][1] + hx.h1 * ux[1][0] + hx.s1 * ux[1][1];
+}
+
+// straight ray in ideal grid coordinates, valid when both end points lie in the tricubic domain g[2] .. g[n-3]
+__device__ __forceinline__ URay load_uray_cubic(const GridView &g, const double *origins, const double *dirs, int64_t r,
+                                                double tmax, int Ns) {
+    URay u = load_uray(g, origins, dirs, r, tmax, Ns);
+    const double ox = origins[3 * r], oy = origins[3 * r + 1], oz = origins[3 * r + 2];
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    const double pz = dz / nrm, sx = dx / nrm / pz, sy = dy / nrm / pz, L = tmax - oz;
+    const double xe = ox + sx * L, ye = oy + sy * L, ze = oz + L;
+    u.valid = (ox >= g.c0[0]) & (ox <= g.clast[0]) & (xe >= g.c0[0]) & (xe <= g.clast[0]) & (oy >= g.c0[1]) &
+              (oy <= g.clast[1]) & (ye >= g.c0[1]) & (ye <= g.clast[1]) & (oz >= g.c0[2]) & (oz <= g.clast[2]) &
+              (ze >= g.c0[2]) & (ze <= g.clast[2]);
+    return u;
+}
+
+// Same wave / chunk structure as k_forward_straight_u (iono_forward_kernels.h): one wave per ray, lanes = samples,
+// lane-parallel ray set-up for groups of 16 rays, DPP Simpson reduction, quadrature weights in LDS.
+__global__ __launch_bounds__(256, 4) void k_forward_straight_lm(GridView g, const double *__restrict__ F8,
+                                                             const double *__restrict__ origins,
+                                                             const double *__restrict__ dirs, const int *__restrict__ order,
+                                                             int64_t R, double tmax, int Ns, int walk_mode,
+                                                             const double *__restrict__ unitw, double *__restrict__ tec,
+                                                             int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double wlds[];
+    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nfull = Ns >> 6, ntail0 = nfull << 6;
+    const bool tail_by_lane = (Ns - ntail0) <= 8;
+    const Chunk ch = wave_chunk(R, walk_mode, nullptr);
+    const double dlane = (double)lane;
+    const double *wp = wlds + lane;
+    bool oob = false;
+    for (int64_t q0 = ch.lo; q0 < ch.hi; q0 += U_MAXG * ch.stride) {
+        const int cnt = (int)min((int64_t)U_MAXG, (ch.hi - q0 + ch.stride - 1) / ch.stride);
+        URay u = {};
+        int64_t r = 0;
+        double tail = 0.0;
+        if (lane < cnt) {
+            const int64_t q = q0 + lane * ch.stride;
+            r = order ? (int64_t)order[q] : q;
+            u = load_uray_cubic(g, origins, dirs, r, tmax, Ns);
+            if (u.valid && tail_by_lane) {
+                for (int k = ntail0; k < Ns; ++k) {
+                    const double kd = (double)k;
+                    tail += wlds[k] * tricubic_lm(F8, g.ny, g.nz, fma(kd, u.dfx, u.fx0), fma(kd, u.dfy, u.fy0), fma(kd, u.dfz, u.fz0));
+                }
+            }
+            if (!u.valid) oob = true;
+        }
+        double res = 0.0;
+        for (int gi = 0; gi < cnt; ++gi) {
+            const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
+            if (!ok) continue;
+            const double dfx = bcast_lane(u.dfx, gi), dfy = bcast_lane(u.dfy, gi), dfz = bcast_lane(u.dfz, gi);
+            double fx = fma(dlane, dfx, bcast_lane(u.fx0, gi));
+            double fy = fma(dlane, dfy, bcast_lane(u.fy0, gi));
+            double fz = fma(dlane, dfz, bcast_lane(u.fz0, gi));
+            const double sx64 = 64.0 * dfx, sy64 = 64.0 * dfy, sz64 = 64.0 * dfz;
+            double acc = 0.0;
+            for (int it = 0; it < nfull; ++it) {
+                acc = fma(wp[it << 6], tricubic_lm(F8, g.ny, g.nz, fx, fy, fz), acc);
+                fx += sx64;
+                fy += sy64;
+                fz += sz64;
+            }
+            if (!tail_by_lane && lane + ntail0 < Ns) acc = fma(wp[ntail0], tricubic_lm(F8, g.ny, g.nz, fx, fy, fz), acc);
+            const double total = wave_sum_dpp(acc);
+            if (lane == gi) res = total;
+        }
+        if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- general tier of the tricubic transpose: 216 hardware atomics per sample (any grid; explicit or straight rays) ----
+template <typename AT>
+__device__ __forceinline__ void scatter_tricubic(const GridView &g, const Axes &ax, AT *__restrict__ G, double x, double y,
+                                                 double z, double c) {
+    double wx[6], wy[6], wz[6], dd[6];
+    const int i = cubic_axis(ax.x, g.nx, x, g.inv_h[0], g.uniform[0], wx, dd, false);
+    const int j = cubic_axis(ax.y, g.ny, y, g.inv_h[1], g.uniform[1], wy, dd, false);
+    const int k = cubic_axis(ax.z, g.nz, z, g.inv_h[2], g.uniform[2], wz, dd, false);
+    AT *base = G + ((size_t)(i - 2) * g.ny + (j - 2)) * g.nz + (k - 2);
+    for (int a = 0; a < 6; ++a) {
+        const double wa = c * wx[a];
+        for (int b = 0; b < 6; ++b) {
+            const double wab = wa * wy[b];
+            AT *p = base + ((size_t)a * g.ny + b) * g.nz;
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) atomicAdd(p + cc, (AT)(wab * wz[cc]));
+        }
+    }
+}
+
+}  // namespace
+
+#endif

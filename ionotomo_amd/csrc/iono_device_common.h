@@ -15,6 +15,7 @@ struct GridView {
     double inv_h[3];      // 1/(mean spacing) per axis: first guess of the cell index
     int uniform[3];       // axis is (numerically) uniform -> guess + fix-up; else binary search
     double g0[3], glast[3];   // first / last node per axis (host copies)
+    double c0[3], clast[3];   // tricubic domain: nodes 2 and n-3 per axis (host copies)
 };
 
 struct Axes {             // axis tables staged in LDS

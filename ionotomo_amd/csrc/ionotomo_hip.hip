@@ -32,6 +32,7 @@
 #include "iono_device_common.h"
 #include "iono_forward_kernels.h"
 #include "iono_adjoint_kernels.h"
+#include "iono_cubic_kernels.h"
 #include "iono_aux_kernels.h"
 
 namespace {
@@ -83,6 +84,10 @@ struct iono_ctx {
     int fermat_lin4_rpw = 0;            // rays per wave of that kernel: 0 = by batch size (env IONOTOMO_FERMAT_LIN4_RPW)
     int ideal = 0;                   // every axis is g0 + i*h to within 2.5e-13 h (np.linspace)
     double g0[3] = {0, 0, 0}, glast[3] = {0, 0, 0};
+    double c0[3] = {0, 0, 0}, clast[3] = {0, 0, 0};     // tricubic domain g[2] .. g[n-3] (n >= 6)
+    double *d_F8 = nullptr;          // Lekien-Marsden derivative fields [node][8] of the current values (lazily built)
+    bool F8_valid = false;
+    double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
 };
 
 namespace {
@@ -122,6 +127,8 @@ GridView view(const iono_ctx *c) {
         g.uniform[a] = c->uniform[a];
         g.g0[a] = c->g0[a];
         g.glast[a] = c->glast[a];
+        g.c0[a] = c->c0[a];
+        g.clast[a] = c->clast[a];
     }
     return g;
 }
@@ -376,6 +383,8 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_flags) (void)hipFree(c->d_flags);
     if (c->d_unitw) (void)hipFree(c->d_unitw);
     if (c->d_nM) (void)hipFree(c->d_nM);
+    if (c->d_F8) (void)hipFree(c->d_F8);
+    if (c->d_G8) (void)hipFree(c->d_G8);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
     for (auto &wp : c->walk) {
@@ -446,16 +455,24 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     if (c->d_axes) HIP_TRY(c, hipFree(c->d_axes));
     if (c->d_M) HIP_TRY(c, hipFree(c->d_M));
     if (c->d_nM) HIP_TRY(c, hipFree(c->d_nM));
+    if (c->d_F8) HIP_TRY(c, hipFree(c->d_F8));
+    if (c->d_G8) HIP_TRY(c, hipFree(c->d_G8));
     c->d_axes = nullptr;
     c->d_M = nullptr;
     c->d_nM = nullptr;
+    c->d_F8 = c->d_G8 = nullptr;
+    c->F8_valid = false;
     c->nM_freq = -1.0;
     c->nx = nx;
     c->ny = ny;
     c->nz = nz;
     c->storage = storage;
     c->ideal = ideal ? 1 : 0;
-    for (int a = 0; a < 3; ++a) c->uniform[a] = uniform[a], c->inv_h[a] = inv_h[a], c->g0[a] = g0[a], c->glast[a] = glast[a];
+    for (int a = 0; a < 3; ++a) {
+        c->uniform[a] = uniform[a], c->inv_h[a] = inv_h[a], c->g0[a] = g0[a], c->glast[a] = glast[a];
+        c->c0[a] = n[a] >= 6 ? ax[a][2] : g0[a];
+        c->clast[a] = n[a] >= 6 ? ax[a][n[a] - 3] : glast[a];
+    }
     std::vector<double> cat;
     cat.insert(cat.end(), xv, xv + nx);
     cat.insert(cat.end(), yv, yv + ny);
@@ -474,6 +491,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
 static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, double scale) {
     const int64_t n = ncells(c);
     c->nM_freq = -1.0;
+    c->F8_valid = false;
     int rc = dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
         hipLaunchKernelGGL((k_set_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, src_dev, (GT *)c->d_M, n,
@@ -575,6 +593,27 @@ static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks
     return IONO_OK;
 }
 
+// Lekien-Marsden derivative fields of the current grid values (iono_cubic_kernels.h): rebuilt after every change
+static int ensure_lm_fields(iono_ctx *c) {
+    const int64_t n = ncells(c);
+    if (!c->d_F8) HIP_TRY(c, hipMalloc((void **)&c->d_F8, (size_t)n * LM_NF * sizeof(double)));
+    if (!c->F8_valid) {
+        dispatch_storage(c, [&](auto *tag) {
+            using GT = std::remove_pointer_t<decltype(tag)>;
+            hipLaunchKernelGGL((k_lm_fields<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M, c->d_F8, c->nx,
+                               c->ny, c->nz);
+            return IONO_OK;
+        });
+        HIP_TRY(c, hipGetLastError());
+        c->F8_valid = true;
+    }
+    return IONO_OK;
+}
+// fast tricubic tier: ideal-uniform axes, weights in LDS, 32-bit-safe field array (IONOTOMO_VARIANT=4 forces the general tier)
+static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
+    return ideal_path_ok(c, Ns) && c->variant != 4 && c->nx >= 6 && c->ny >= 6 && c->nz >= 6;
+}
+
 // ---- forward (device pointers) ---------------------------------------------------------------
 int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, int64_t R, double tmax,
                                   int Ns, int kind, int rule, double *tec) {
@@ -598,6 +637,13 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             if (rc2) return rc2;
             hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
                                c->walk_mode, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
+        } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
+            const int rc2 = ensure_lm_fields(c);
+            if (rc2) return rc2;
+            const size_t wl = sizeof(double) * Ns;
+            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_lm, wl), R);
+            hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, c->stream, g, c->d_F8, o, d, order, R, tmax, Ns,
+                               c->walk_mode, c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))      // (`order` is a speed hint: ignored here)
             hipLaunchKernelGGL((k_forward_straight_fast<GT>), grid, block, 2 * lds, c->stream, g, o, d, R, tmax, Ns,
                                c->d_unitw, tec, c->d_flags);
@@ -690,93 +736,127 @@ int iono_walk_partition_set(iono_ctx *c, int which, const int64_t *starts, int n
 }
 
 // ---- adjoint (device pointers) ----------------------------------------------------------------
+}  // extern "C"  (templates below need C++ linkage)
+
+// One launch of the LDS-tiled back-projection (ideal-uniform grids).  CUBIC: channel `field` of the tricubic transpose.
+template <typename AT, int MODE, bool CUBIC>
+static int launch_adjoint_tile(iono_ctx *c, const GridView &g, const double *o, const double *d, const int *order, const double *w,
+                               const double *tec, const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0, int64_t R,
+                               double tmax, int Ns, AT *grad, int field) {
+    constexpr int NW = 4;    // waves per workgroup (8 waves sharing one tile, bundles of 128: measured 8 % slower)
+    const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + (ADJ_REF * NW + ADJ_SUB) * sizeof(double) +
+                      sizeof(AT) * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
+    const int per_cu = blocks_per_cu(k_adjoint_straight_tile<AT, MODE, NW, CUBIC>, 64 * NW, tl, 1);
+    int nb = per_cu * c->num_cus;
+    const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);   // at least ~64 rays per workgroup
+    if (nb > nbund) nb = (int)nbund;
+    if (nb >= 8) nb = nb / 8 * 8;
+    iono_ctx::WalkPart &wp = c->walk[1];
+    const bool use_part = wp.n >= nb && wp.R == R;
+    const int nchunks = use_part ? wp.n : nb;
+    const int rc = walk_cycles_reserve(c, wp, nchunks, nb);
+    if (rc) return rc;
+    if (!c->d_chunk_counter) HIP_TRY(c, hipMalloc((void **)&c->d_chunk_counter, 4));
+    if (use_part) HIP_TRY(c, hipMemsetAsync(c->d_chunk_counter, 0, 4, c->stream));
+    hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE, NW, CUBIC>), dim3(nb), dim3(64 * NW), tl, c->stream, g, o, d, order, w,
+                       tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->adj_mode, c->d_unitw, grad, c->d_flags,
+                       use_part ? wp.d_starts : nullptr, nchunks, c->d_chunk_counter, wp.d_cyc, field);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+// mode 0: weights w[R];  1: fused residual (tec, dobs, cdct);  2: differential weights of v[R] * scale[R] (tec = v,
+// cdct = scale or null).  kind: trilinear or tricubic transpose.
+template <typename AT, int MODE>
+static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *o, const double *d, const int *order,
+                                  const double *w, const double *tec, const double *dobs, const double *cdct, int Na,
+                                  int64_t NtNd, int i0, int64_t R, double tmax, int Ns, int kind, AT *grad) {
+    if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
+        return launch_adjoint_tile<AT, MODE, false>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, grad, -1);
+    if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2) {
+        // 8 channel scatters (cubic Hermite value / slope weights per axis) into G8[8][nodes], then the transposed
+        // difference stencils fold them into the node gradient (iono_cubic_kernels.h)
+        const int64_t n = ncells(c);
+        if (!c->d_G8) HIP_TRY(c, hipMalloc((void **)&c->d_G8, (size_t)n * LM_NF * sizeof(double)));
+        HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
+        for (int f = 0; f < LM_NF; ++f) {
+            const int rc = launch_adjoint_tile<double, MODE, true>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns,
+                                                                   c->d_G8 + (size_t)f * n, f);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL((k_lm_fold<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_G8, grad, c->nx, c->ny, c->nz);
+        HIP_TRY(c, hipGetLastError());
+        return IONO_OK;
+    }
+    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    const size_t lds = lds_bytes(c);
+    if (kind == IONO_INTERP_TRILINEAR)
+        hipLaunchKernelGGL((k_adjoint_straight<AT, MODE, IONO_INTERP_TRILINEAR>), grid, block, lds, c->stream, g, o, d, w, tec, dobs,
+                           cdct, Na, NtNd, i0, R, tmax, Ns, c->d_unitw, grad, c->d_flags);
+    else
+        hipLaunchKernelGGL((k_adjoint_straight<AT, MODE, IONO_INTERP_TRICUBIC>), grid, block, lds, c->stream, g, o, d, w, tec, dobs,
+                           cdct, Na, NtNd, i0, R, tmax, Ns, c->d_unitw, grad, c->d_flags);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+extern "C" {
+
 static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const double *d, const int *order, const double *w,
                                    const double *tec, const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0,
-                                   int64_t R, double tmax, int Ns, int rule, void *grad, int accum) {
-    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+                                   int64_t R, double tmax, int Ns, int kind, int rule, void *grad, int accum) {
+    int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (accum != IONO_F64 && accum != IONO_F32) return fail(c, IONO_ERR_ARG, "bad accum_dtype");
     if (R == 0) return IONO_OK;
     rc = ensure_unitw(c, Ns, rule);
     if (rc) return rc;
     const GridView g = view(c);
-    const dim3 block(256);
-    if (ideal_path_ok(c, Ns) && c->variant != 2) {
-        const size_t esz = accum == IONO_F64 ? 8 : 4;
-        constexpr int NWv = 4;    // waves per workgroup (8 waves sharing one tile, bundles of 128: measured 8 % slower)
-        const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + (ADJ_REF * NWv + ADJ_SUB) * sizeof(double) +
-                          esz * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
-#define LAUNCH_ADJT(AT, MODE, NW)                                                                                          \
-    do {                                                                                                                   \
-        const int per_cu = blocks_per_cu(k_adjoint_straight_tile<AT, MODE, NW>, 64 * NW, tl, 1);                           \
-        int nb = per_cu * c->num_cus;                                                                                      \
-        const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);   /* at least ~64 rays per workgroup */                       \
-        if (nb > nbund) nb = (int)nbund;                                                                                   \
-        if (nb >= 8) nb = nb / 8 * 8;                                                                                      \
-        iono_ctx::WalkPart &wp = c->walk[1];                                                                               \
-        const bool use_part = wp.n >= nb && wp.R == R;                                                                     \
-        const int nchunks = use_part ? wp.n : nb;                                                                          \
-        { const int rc2 = walk_cycles_reserve(c, wp, nchunks, nb); if (rc2) return rc2; }                                  \
-        if (!c->d_chunk_counter) HIP_TRY(c, hipMalloc((void **)&c->d_chunk_counter, 4));                                   \
-        if (use_part) HIP_TRY(c, hipMemsetAsync(c->d_chunk_counter, 0, 4, c->stream));                                     \
-        hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE, NW>), dim3(nb), dim3(64 * NW), tl, c->stream, g, o, d,      \
-                           order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->adj_mode, c->d_unitw, (AT *)grad,      \
-                           c->d_flags, use_part ? wp.d_starts : nullptr, nchunks, c->d_chunk_counter, wp.d_cyc);                                                                 \
-    } while (0)
-#define LAUNCH_ADJT_NW(AT, MODE) LAUNCH_ADJT(AT, MODE, NWv)
-        if (accum == IONO_F64) {
-            if (mode == 0) LAUNCH_ADJT_NW(double, 0); else LAUNCH_ADJT_NW(double, 1);
-        } else {
-            if (mode == 0) LAUNCH_ADJT_NW(float, 0); else LAUNCH_ADJT_NW(float, 1);
-        }
-#undef LAUNCH_ADJT_NW
-#undef LAUNCH_ADJT
-        HIP_TRY(c, hipGetLastError());
-        return IONO_OK;
-    }
-    const dim3 grid(ray_grid_blocks(c, R));
-    const size_t lds = lds_bytes(c);
-#define LAUNCH_ADJ(AT, MODE)                                                                                          \
-    hipLaunchKernelGGL((k_adjoint_straight<AT, MODE>), grid, block, lds, c->stream, g, o, d, w, tec, dobs, cdct, Na, \
-                       NtNd, i0, R, tmax, Ns, c->d_unitw, (AT *)grad, c->d_flags)
-    if (accum == IONO_F64) {
-        if (mode == 0) LAUNCH_ADJ(double, 0); else LAUNCH_ADJ(double, 1);
-    } else {
-        if (mode == 0) LAUNCH_ADJ(float, 0); else LAUNCH_ADJ(float, 1);
-    }
-#undef LAUNCH_ADJ
-    HIP_TRY(c, hipGetLastError());
-    return IONO_OK;
+#define ADJ_CALL(AT, MODE) \
+    adjoint_straight_typed<AT, MODE>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, kind, (AT *)grad)
+    if (accum == IONO_F64) return mode == 0 ? ADJ_CALL(double, 0) : mode == 1 ? ADJ_CALL(double, 1) : ADJ_CALL(double, 2);
+    return mode == 0 ? ADJ_CALL(float, 0) : mode == 1 ? ADJ_CALL(float, 1) : ADJ_CALL(float, 2);
+#undef ADJ_CALL
 }
 
 int iono_adjoint_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, const double *w, int64_t R,
-                              double tmax, int Ns, int rule, void *grad, int accum) {
-    return adjoint_straight_launch(c, 0, o, d, order, w, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, rule, grad, accum);
+                              double tmax, int Ns, int kind, int rule, void *grad, int accum) {
+    return adjoint_straight_launch(c, 0, o, d, order, w, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, kind, rule, grad, accum);
 }
 
 int iono_adjoint_residual_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, const double *tec,
                                        const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0, double tmax, int Ns,
-                                       int rule, void *grad, int accum) {
+                                       int kind, int rule, void *grad, int accum) {
     if (Na < 1 || NtNd < 0 || i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "bad [Na][NtNd]/i0");
     return adjoint_straight_launch(c, 1, o, d, order, nullptr, tec, dobs, cdct, Na, NtNd, i0, (int64_t)Na * NtNd, tmax, Ns,
-                                   rule, grad, accum);
+                                   kind, rule, grad, accum);
 }
 
-int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int rule, void *grad,
+int iono_adjoint_differential_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, const double *v,
+                                           const double *scale, int Na, int64_t NtNd, int i0, double tmax, int Ns, int kind,
+                                           int rule, void *grad, int accum) {
+    if (Na < 1 || NtNd < 0 || i0 < 0 || i0 >= Na || !v) return fail(c, IONO_ERR_ARG, "bad [Na][NtNd]/i0/v");
+    return adjoint_straight_launch(c, 2, o, d, order, nullptr, v, nullptr, scale, Na, NtNd, i0, (int64_t)Na * NtNd, tmax, Ns,
+                                   kind, rule, grad, accum);
+}
+
+int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int kind, int rule, void *grad,
                           int accum) {
-    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (accum != IONO_F64 && accum != IONO_F32) return fail(c, IONO_ERR_ARG, "bad accum_dtype");
     if (R == 0) return IONO_OK;
     const GridView g = view(c);
     const dim3 grid(ray_grid_blocks(c, R)), block(256);
     const size_t lds = lds_bytes(c);
-    if (accum == IONO_F64)
-        hipLaunchKernelGGL((k_adjoint_rays<double>), grid, block, lds, c->stream, g, rays, w, R, Ns, rule, (double *)grad,
-                           c->d_flags);
-    else
-        hipLaunchKernelGGL((k_adjoint_rays<float>), grid, block, lds, c->stream, g, rays, w, R, Ns, rule, (float *)grad,
-                           c->d_flags);
+#define LAUNCH_AR(AT, K) \
+    hipLaunchKernelGGL((k_adjoint_rays<AT, K>), grid, block, lds, c->stream, g, rays, w, R, Ns, rule, (AT *)grad, c->d_flags)
+    if (accum == IONO_F64) {
+        if (kind == IONO_INTERP_TRILINEAR) LAUNCH_AR(double, IONO_INTERP_TRILINEAR); else LAUNCH_AR(double, IONO_INTERP_TRICUBIC);
+    } else {
+        if (kind == IONO_INTERP_TRILINEAR) LAUNCH_AR(float, IONO_INTERP_TRILINEAR); else LAUNCH_AR(float, IONO_INTERP_TRICUBIC);
+    }
+#undef LAUNCH_AR
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
 }
@@ -891,8 +971,8 @@ int iono_walk_order(iono_ctx *c, const double *o, const double *d, int64_t R, do
 }
 
 int iono_adjoint_straight(iono_ctx *c, const double *o, const double *d, const double *w, int64_t R, double tmax, int Ns,
-                          int rule, int scale_by_grid, double *grad_out) {
-    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+                          int kind, int rule, int scale_by_grid, double *grad_out) {
+    int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     const int64_t n = ncells(c);
     DevBuf b(c);
@@ -912,14 +992,14 @@ int iono_adjoint_straight(iono_ctx *c, const double *o, const double *d, const d
     HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dW, w, R * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(dG, 0, n * 8, c->stream));
-    rc = iono_adjoint_straight_dev(c, dO, dD, dOrder, dW, R, tmax, Ns, rule, dG, IONO_F64);
+    rc = iono_adjoint_straight_dev(c, dO, dD, dOrder, dW, R, tmax, Ns, kind, rule, dG, IONO_F64);
     if (rc) return rc;
     return adjoint_host_finish(c, dG, scale_by_grid, grad_out, "iono_adjoint_straight");
 }
 
-int iono_adjoint_rays(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int rule, int scale_by_grid,
+int iono_adjoint_rays(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int kind, int rule, int scale_by_grid,
                       double *grad_out) {
-    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     const int64_t n = ncells(c);
     DevBuf b(c);
@@ -929,7 +1009,7 @@ int iono_adjoint_rays(iono_ctx *c, const double *rays, const double *w, int64_t 
     HIP_TRY(c, hipMemcpyAsync(dR, rays, nr * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dW, w, R * 8, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(dG, 0, n * 8, c->stream));
-    rc = iono_adjoint_rays_dev(c, dR, dW, R, Ns, rule, dG, IONO_F64);
+    rc = iono_adjoint_rays_dev(c, dR, dW, R, Ns, kind, rule, dG, IONO_F64);
     if (rc) return rc;
     return adjoint_host_finish(c, dG, scale_by_grid, grad_out, "iono_adjoint_rays");
 }

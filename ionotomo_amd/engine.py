@@ -101,7 +101,23 @@ class RayEngine(object):
             out = torch.zeros(self.shape, dtype=accum, device=self.device)
         op = _lib._V(0) if order is None else _ptr(order)
         self.ctx.call("iono_adjoint_straight_dev", _ptr(origins_t), _ptr(dirs_t), op, _ptr(w_t), R, float(tmax), int(Ns),
-                      self.rule, _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+                      self.kind, self.rule, _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+        return out
+
+    def adjoint_differential(self, origins_t, dirs_t, v_t, scale_t, Na, i0, tmax, Ns, out=None, accum=torch.float64,
+                             order=None):
+        """One launch: out += A^T (scale o v) for the differenced operator A x = G x - (G x)[i0], ray layout [Na][NtNd]
+        (``scale_t`` may be None).  What CGLS (scale = W^1/2) and SIRT (scale = row normalisation) back-project."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        assert R % Na == 0 and v_t.numel() == R and (scale_t is None or scale_t.numel() == R)
+        if out is None:
+            out = torch.zeros(self.shape, dtype=accum, device=self.device)
+        op = _lib._V(0) if order is None else _ptr(order)
+        sp = _lib._V(0) if scale_t is None else _ptr(scale_t)
+        self.ctx.call("iono_adjoint_differential_straight_dev", _ptr(origins_t), _ptr(dirs_t), op, _ptr(v_t), sp, int(Na),
+                      R // Na, int(i0), float(tmax), int(Ns), self.kind, self.rule, _ptr(out),
+                      _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 
     def adjoint_residual(self, origins_t, dirs_t, tec_t, dobs_t, cdct_t, Na, i0, tmax, Ns, out=None,
@@ -115,7 +131,7 @@ class RayEngine(object):
             out = torch.zeros(self.shape, dtype=accum, device=self.device)
         op = _lib._V(0) if order is None else _ptr(order)
         self.ctx.call("iono_adjoint_residual_straight_dev", _ptr(origins_t), _ptr(dirs_t), op, _ptr(tec_t), _ptr(dobs_t),
-                      _ptr(cdct_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.rule, _ptr(out),
+                      _ptr(cdct_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.kind, self.rule, _ptr(out),
                       _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 

@@ -30,7 +30,7 @@ def compute_gradient(rays, g, dobs, i0, K_ne, m_tci, m_prior, CdCt, sigma_m, Nke
     ctx = _lib.default_context()
     ctx.set_grid(m_tci.xvec, m_tci.yvec, m_tci.zvec, None, storage=m_tci.storage)
     ctx.set_values_exp(m_tci.M, K_ne / TECU)
-    return ctx.adjoint_rays(rays, differential_weights(dd, i0), rule=quad, scale_by_grid=True)
+    return ctx.adjoint_rays(rays, differential_weights(dd, i0), rule=quad, scale_by_grid=True, kind=m_tci.kind)
 
 
 compute_gradient_dask = compute_gradient

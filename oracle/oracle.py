@@ -331,16 +331,28 @@ def neg_log_like(g, dobs, CdCt):
 
 
 # --------------------------------------------------------------------------- A7' exact adjoint
-def adjoint_tec(rays, xvec, yvec, zvec, w_ray, rule=QUAD_SIMPSON_AVG):
+def adjoint_tec(rays, xvec, yvec, zvec, w_ray, rule=QUAD_SIMPSON_AVG, kind=INTERP_TRILINEAR):
     """(G^T w)[v] = sum_r w_r sum_k c_{r,k} W_{k,v}: the exact transpose of forward_tec
-    (trilinear + quadrature weights).  Not in the reference (its gradient.py:15-20 uses
-    voxel chord lengths instead -- a different discretisation); defined by A2a + A5'."""
+    (interpolation weights x quadrature weights).  Not in the reference (its gradient.py:15-20 uses
+    voxel chord lengths instead -- a different discretisation); defined by A2a / A2b + A5'.
+    ``kind``: trilinear (8 weights per sample) or the tricubic's 6 x 6 x 6 tensor-product taps."""
     nx, ny, nz = len(xvec), len(yvec), len(zvec)
     c = quadrature_weights(rays[..., 3, :], rule) * np.asarray(w_ray)[..., None]
+    out = np.zeros(nx * ny * nz)
+    if kind == INTERP_TRICUBIC:
+        i, wx = tricubic_axis_weights(xvec, rays[..., 0, :])
+        j, wy = tricubic_axis_weights(yvec, rays[..., 1, :])
+        k, wz = tricubic_axis_weights(zvec, rays[..., 2, :])
+        for a in range(6):
+            for b in range(6):
+                wab = c * wx[a] * wy[b]
+                for cc in range(6):
+                    idx = (k + cc - 2) + nz * ((j + b - 2) + ny * (i + a - 2))
+                    out += np.bincount(idx.ravel(), weights=(wab * wz[cc]).ravel(), minlength=out.size)
+        return out.reshape(nx, ny, nz)
     i, tx = find_cell(xvec, rays[..., 0, :])
     j, ty = find_cell(yvec, rays[..., 1, :])
     k, tz = find_cell(zvec, rays[..., 2, :])
-    out = np.zeros(nx * ny * nz)
     for di, wx in ((0, 1 - tx), (1, tx)):
         for dj, wy in ((0, 1 - ty), (1, ty)):
             for dk, wz in ((0, 1 - tz), (1, tz)):

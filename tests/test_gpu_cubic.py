@@ -1,0 +1,192 @@
+"""Tricubic on the hot path (round 2): the Lekien-Marsden derivative-field forward and the channel-scatter + fold
+transpose (ionotomo_amd/csrc/iono_cubic_kernels.h) against the oracle's 6 x 6 x 6 tensor-product form
+(oracle.tricubic: notebooks/TricubicInterpolation.ipynb c0:138-1257), through the C-ABI.  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from ionotomo_amd import _lib, parallel, synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def rel(a, b):
+    return np.max(np.abs(a - b)) / np.max(np.abs(b))
+
+
+def engine(w, **kw):
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0, interp="cubic", **kw)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    return eng
+
+
+@pytest.fixture(scope="module")
+def cfg2():
+    # config 2: 62 LOFAR stations x 42 directions x 1 time, 128^3, TriCubic interpolation
+    return syn.make_workload("cfg2")
+
+
+def test_config2_tricubic_forward_all_rays(cfg2, O, monkeypatch):
+    w = cfg2
+    M = w["ne"] / 1e13
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    eng = engine(w)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    for Ns, rule in ((129, "avg"), (128, "avg"), (128, "scipy"), (200, "avg"), (70, "trapz")):
+        eng.rule = _lib.quad_rule(rule)
+        tec = eng.forward(ot, dt, w["tmax"], Ns).cpu().numpy()
+        assert not eng.check_oob()
+        rays = O.straight_rays(o, d, w["tmax"], Ns)
+        ref = O.forward_tec(rays, w["xvec"], w["yvec"], w["zvec"], M, rule=_lib.quad_rule(rule), kind=O.INTERP_TRICUBIC)
+        assert rel(tec, ref) < 1e-11, (Ns, rule)
+    # the general tier (216 taps per sample, any grid) agrees with the fast one
+    monkeypatch.setenv("IONOTOMO_VARIANT", "4")
+    gen = engine(w)
+    gen.set_values(gen.tensor(M))
+    eng.rule = gen.rule = _lib.quad_rule("avg")
+    a = eng.forward(ot, dt, w["tmax"], 129).cpu().numpy()
+    b = gen.forward(gen.tensor(o), gen.tensor(d), w["tmax"], 129).cpu().numpy()
+    assert rel(a, b) < 1e-12
+    # values change -> the derivative fields are rebuilt
+    eng.set_values(eng.tensor(2.0 * M))
+    assert rel(eng.forward(ot, dt, w["tmax"], 129).cpu().numpy(), 2.0 * a) < 1e-13
+    # float32 storage of the node values (the fields themselves stay float64)
+    e32 = engine(w, storage="f32")
+    e32.set_values(e32.tensor(M))
+    c = e32.forward(e32.tensor(o), e32.tensor(d), w["tmax"], 129).cpu().numpy()
+    assert rel(c, a) < 2e-6
+    # rays that leave the tricubic domain g[2] .. g[n-3] set the flag (scipy-style bounds error in the facade)
+    eng.forward(ot, dt, w["zvec"][-2], 129)
+    assert eng.check_oob() and not eng.check_oob()
+
+
+def test_lm_fields_reproduce_a_cubic_polynomial_exactly(O):
+    """The interpolant is exact for tri-quadratic fields (cubic Hermite with 4th-order slopes differentiates
+    polynomials up to degree 4 exactly and reproduces cubics): TEC = the analytic line integral, Simpson exact."""
+    xv, yv, zv = np.linspace(-30, 30, 41), np.linspace(-25, 35, 37), np.linspace(0, 100, 51)
+    X, Y, Z = np.meshgrid(xv, yv, zv, indexing="ij")
+    M = 1.0 + 0.01 * X - 0.02 * Y + 0.003 * Z + 1e-3 * X * Y - 2e-4 * Y * Z + 3e-4 * X * Z + 1e-5 * X * Y * Z
+    w = dict(xvec=xv, yvec=yv, zvec=zv)
+    eng = engine(w)
+    eng.set_values(eng.tensor(M))
+    rng = np.random.default_rng(0)
+    R = 300
+    o = np.stack([rng.uniform(-10, 10, R), rng.uniform(-10, 10, R), np.full(R, zv[2])], 1)
+    d = np.stack([rng.uniform(-0.1, 0.1, R), rng.uniform(-0.1, 0.1, R), np.ones(R)], 1)
+    tmax, Ns = zv[-3], 97
+    tec = eng.forward(eng.tensor(o), eng.tensor(d), tmax, Ns).cpu().numpy()
+    # the field restricted to a straight ray is a cubic in the path parameter: Simpson integrates it exactly
+    rays = O.straight_rays(o, d, tmax, Ns)
+    f = lambda x, y, z: 1.0 + 0.01 * x - 0.02 * y + 0.003 * z + 1e-3 * x * y - 2e-4 * y * z + 3e-4 * x * z + 1e-5 * x * y * z
+    vals = f(rays[:, 0], rays[:, 1], rays[:, 2])
+    ref = O.simps(vals, rays[:, 3])
+    assert rel(tec, ref) < 1e-12
+
+
+def test_tricubic_adjoint_general_tier_small(O):
+    """Explicit-sample and straight-ray transposes on a NON-uniform grid (216 atomics per sample) vs the oracle."""
+    rng = np.random.default_rng(1)
+    xv = np.cumsum(rng.uniform(0.5, 1.5, 16))
+    yv = np.cumsum(rng.uniform(0.5, 1.5, 15))
+    zv = np.cumsum(rng.uniform(0.5, 1.5, 18))
+    M = rng.normal(size=(16, 15, 18))
+    R = 40
+    o = np.stack([rng.uniform(xv[4], xv[10], R), rng.uniform(yv[4], yv[9], R), np.full(R, zv[2])], 1)
+    d = np.stack([rng.uniform(-0.05, 0.05, R), rng.uniform(-0.05, 0.05, R), np.ones(R)], 1)
+    c = _lib.Context(0)
+    c.set_grid(xv, yv, zv, M)
+    y = rng.normal(size=R)
+    for Ns in (9, 12):
+        rays = O.straight_rays(o, d, zv[-3], Ns)
+        ref = O.adjoint_tec(rays, xv, yv, zv, y, kind=O.INTERP_TRICUBIC)
+        g1 = c.adjoint_rays(rays, y, kind="cubic")
+        g2 = c.adjoint_straight(o, d, y, zv[-3], Ns, kind="cubic")
+        assert rel(g1, ref) < 1e-11 and rel(g2, ref) < 1e-11
+        t = c.forward_tec_rays(rays, kind="cubic")
+        assert abs(np.dot(t.ravel(), y) - np.sum(g1 * M)) < 1e-11 * np.linalg.norm(t) * np.linalg.norm(y)
+    gs = c.adjoint_straight(o, d, y, zv[-3], 9, kind="cubic", scale_by_grid=True)
+    assert rel(gs, O.adjoint_tec(O.straight_rays(o, d, zv[-3], 9), xv, yv, zv, y, kind=O.INTERP_TRICUBIC) * M) < 1e-11
+    c.close()
+
+
+def test_config2_tricubic_adjoint_fast_tier(cfg2, O, monkeypatch):
+    """Channel scatter (LDS-tiled) + fold vs the oracle's 216-tap transpose, a 400-ray sample of config 2 at 128^3;
+    with / without walk order; fused-residual and differential-weight modes; float32 accumulation; general tier."""
+    w = cfg2
+    M = w["ne"] / 1e13
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    idx = np.sort(np.random.default_rng(2).choice(len(o), 400, replace=False))
+    Ns = 129
+    rays = O.straight_rays(o[idx], d[idx], w["tmax"], Ns)
+    y = np.random.default_rng(3).normal(size=len(idx))
+    ref = O.adjoint_tec(rays, w["xvec"], w["yvec"], w["zvec"], y, kind=O.INTERP_TRICUBIC)
+    eng = engine(w)
+    eng.set_values(eng.tensor(M))
+    ot, dt, yt = eng.tensor(o[idx]), eng.tensor(d[idx]), eng.tensor(y)
+    order = eng.locality_order(ot, dt, w["tmax"])
+    for ordr in (None, order):
+        g = eng.adjoint(ot, dt, yt, w["tmax"], Ns, order=ordr).cpu().numpy()
+        assert rel(g, ref) < 1e-11
+    g32 = eng.adjoint(ot, dt, yt, w["tmax"], Ns, order=order, accum=torch.float32).cpu().numpy()
+    assert rel(g32, ref) < 1e-6
+    monkeypatch.setenv("IONOTOMO_VARIANT", "4")
+    gen = engine(w)
+    gen.set_values(gen.tensor(M))
+    gg = gen.adjoint(gen.tensor(o[idx]), gen.tensor(d[idx]), gen.tensor(y), w["tmax"], Ns).cpu().numpy()
+    assert rel(gg, ref) < 1e-11
+    monkeypatch.delenv("IONOTOMO_VARIANT")
+    # all 2,604 rays in layout [Na][P]: fused residual and differential modes against the separate steps
+    na, P = 62, 42
+    rng = np.random.default_rng(4)
+    dobs, cdct = rng.normal(size=(na, P)) * 0.1, rng.uniform(0.5, 2.0, size=(na, P))
+    O4, D4 = w["origins"].reshape(na, P, 3), w["directions"].reshape(na, P, 3)
+    for i0 in (0, 7):
+        prob = parallel.ShardedRays(eng, O4, D4, w["tmax"], Ns, dobs=dobs, cdct=cdct, i0=i0, tune=False)
+        tec = prob.forward_tec()
+        t = tec.cpu().numpy().reshape(na, P)
+        dd = (t - t[i0] - dobs) / (cdct + 1e-15)
+        wd = O.differential_weights(dd, i0)
+        sep = eng.adjoint(prob.origins, prob.dirs, eng.tensor(wd.ravel()), w["tmax"], Ns, order=prob.order).cpu().numpy()
+        fused = prob.gradient_from_tec(tec).cpu().numpy()
+        assert rel(fused, sep) < 1e-11
+        v, sc = rng.normal(size=(na, P)), rng.uniform(0.5, 2.0, size=(na, P))
+        wd2 = O.differential_weights(v * sc, i0)
+        sep2 = eng.adjoint(prob.origins, prob.dirs, eng.tensor(wd2.ravel()), w["tmax"], Ns, order=prob.order).cpu().numpy()
+        dif = eng.adjoint_differential(prob.origins, prob.dirs, eng.tensor(v.ravel()), eng.tensor(sc.ravel()), na, i0, w["tmax"],
+                                       Ns, order=prob.order).cpu().numpy()
+        assert rel(dif, sep2) < 1e-11
+    assert not eng.check_oob()
+
+
+def test_full_batch_tricubic_dot_product_256_cubed():
+    """BASELINE size: 260,400 rays through 256^3 with the tricubic -- <G x, y> = <x, G^T y> and linearity."""
+    import bench
+    w = bench.build_workload(0)
+    eng = engine(w)
+    rng = np.random.default_rng(5)
+    x = np.exp(w["m"])
+    eng.set_values(eng.tensor(x))
+    ot, dt = eng.tensor(w["origins"]), eng.tensor(w["directions"])
+    tec = eng.forward(ot, dt, bench.TMAX, bench.NS)
+    assert not eng.check_oob()
+    yt = eng.tensor(rng.normal(size=ot.shape[0]))
+    order = eng.locality_order(ot, dt, bench.TMAX)
+    g = eng.adjoint(ot, dt, yt, bench.TMAX, bench.NS, order=order)
+    lhs, rhs = float(torch.dot(tec, yt)), float((g * eng.tensor(x)).sum())
+    assert abs(lhs - rhs) < 1e-10 * float(tec.norm()) * float(yt.norm())
+    # trilinear and tricubic TEC of a smooth field agree to the interpolation error, not to rounding
+    lin = engine(w)
+    lin.kind = _lib.interp_kind("linear")
+    lin.set_values(lin.tensor(x))
+    tl = lin.forward(ot, dt, bench.TMAX, bench.NS)
+    dev = float(((tl - tec).abs() / tec.abs()).max())
+    assert 1e-9 < dev < 5e-2
+    assert not eng.check_oob()
