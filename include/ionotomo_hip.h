@@ -187,6 +187,43 @@ int iono_walk_partition_set(iono_ctx *ctx, int which, const int64_t *starts, int
  * model update m <- m - eps (...), geometry/oct_trees/Inversion.py:533 -- never visit the host. */
 int iono_vec_axpby_dev(iono_ctx *ctx, double *y_dev, const double *x_dev, int64_t n, const double *a_num_dev,
                        const double *a_den_dev, double a_sign, const double *b_num_dev, const double *b_den_dev);
+/* ---- fused vector passes of the inversion loop (ionotomo_amd/csrc/iono_solver_kernels.h).  A CGLS / SIRT iteration
+ *      (objective / step lengths: inversion/iterative_newton.py:32-38,542-554; normalisations:
+ *      geometry/oct_trees/Inversion.py:533,559,564) is the two ray kernels + these.  Device scalars are passed as
+ *      (pointer, count): NULL = 1.0; count 1 = a plain scalar (e.g. after an all-reduce); count IONO_NPART = the
+ *      per-workgroup partial sums a dot-producing pass wrote (summed in a fixed order by the consumer: no atomics,
+ *      identical bits in every workgroup and on every rank). ------------------------------------------------------- */
+enum { IONO_NPART = 512 };
+/* Grid values owned by the caller: a float64 device buffer of iono_grid_padded_size() elements (the tail beyond
+ * nx*ny*nz must stay zero: unclamped far-corner reads) that the kernels read IN PLACE -- the solver updates it through
+ * the compact index instead of copying a model vector into the library every iteration.  NULL unbinds.  Tell the
+ * library with iono_grid_values_changed() when the buffer was modified (cached refractive-index nodes / tricubic
+ * derivative fields are then rebuilt on next use). */
+int iono_grid_padded_size(iono_ctx *ctx, int64_t *count_out);
+int iono_grid_bind_values_dev(iono_ctx *ctx, double *values_dev);
+int iono_grid_values_changed(iono_ctx *ctx);
+/* out[a,p] = s1[a,p] * (a_coef * (tec[a,p] - tec[i0,p]) + b_coef * dobs[a,p]);  partial[blk] = sum out^2 * s2
+ * (dobs, s1, s2, partial nullable): the differenced forward (inversion/forward_equation.py:50), the residual and its
+ * weighted norm in ONE pass over the rays. */
+int iono_rays_combine_dev(iono_ctx *ctx, const double *tec_dev, const double *dobs_dev, const double *s1_dev,
+                          const double *s2_dev, int Na, int64_t NtNd, int i0, double a_coef, double b_coef,
+                          double *out_dev, double *partial_dev);
+/* y = (a_sign an / ad) x + (bn / bd) y;  partial[blk] = sum y^2 */
+int iono_vec_axpby_dot_dev(iono_ctx *ctx, double *y_dev, const double *x_dev, int64_t n, const double *an, int an_count,
+                           const double *ad, int ad_count, double a_sign, const double *bn, int bn_count,
+                           const double *bd, int bd_count, double *partial_dev);
+/* active-set (compact) grid vectors: idx_dev = sorted int32 node indices the rays reach, n of them */
+int iono_compact_gather_dev(iono_ctx *ctx, double *full_dev, const int *idx_dev, int64_t n, double *out_dev,
+                            int zero_source, double *partial_dev);          /* out = full[idx] (re-zeroed); sum out^2 */
+int iono_compact_scatter_dev(iono_ctx *ctx, double *full_dev, const int *idx_dev, int64_t n, const double *src_dev);
+/* x += (an/ad) p;  p = s + (bn/bd) p;  full_p[idx] = p   (the tail of a CGLS iteration in one pass) */
+int iono_compact_cg_update_dev(iono_ctx *ctx, double *x_dev, double *p_dev, const double *s_dev, const int *idx_dev,
+                               int64_t n, double *full_p_dev, const double *an, int an_count, const double *ad,
+                               int ad_count, const double *bn, int bn_count, const double *bd, int bd_count);
+/* s = full_s[idx] (re-zeroed);  x += relax C s (>= 0 if nonneg);  full_x[idx] = x;  partial_max[blk] = max |dx| */
+int iono_compact_sirt_update_dev(iono_ctx *ctx, double *x_dev, const double *C_dev, double *full_s_dev,
+                                 const int *idx_dev, int64_t n, double *full_x_dev, double relax, int nonneg,
+                                 double *partial_max_dev);
 /* Fermat tracer with device buffers (rays_dev[R][4][Ns]); the refractive-index nodes are cached in the
  * ctx and rebuilt when the grid values or the frequency change.  Feed rays_dev to
  * iono_forward_tec_rays_dev for the curved-ray TEC (BASELINE config 3) without leaving the GPU. */

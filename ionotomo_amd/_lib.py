@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libionotomo_hip.so")
 
 OK, ERR_OOB, ERR_NONFINITE, ERR_SHAPE, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 WALK_FORWARD, WALK_ADJOINT = 0, 1          # iono_walk_cycles / iono_walk_partition_set
+NPART = 512                                # IONO_NPART: partial sums per dot-producing pass
 F64, F32 = 0, 1
 INTERP_TRILINEAR, INTERP_TRICUBIC = 0, 1
 RAY_Z, RAY_S = 0, 1                        # independent variable of a ray: Fermat(type='z' | 's')
@@ -72,6 +73,15 @@ _SIGNATURES = {
     "iono_adjoint_differential_straight_dev": [_V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _I, _V, _I],
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
     "iono_vec_axpby_dev": [_V, _V, _L, _V, _V, _D, _V, _V],
+    "iono_grid_padded_size": [ctypes.POINTER(ctypes.c_int64)],
+    "iono_grid_bind_values_dev": [_V],
+    "iono_grid_values_changed": [],
+    "iono_rays_combine_dev": [_V, _V, _V, _V, _I, _L, _I, _D, _D, _V, _V],
+    "iono_vec_axpby_dot_dev": [_V, _V, _L, _V, _I, _V, _I, _D, _V, _I, _V, _I, _V],
+    "iono_compact_gather_dev": [_V, _V, _L, _V, _I, _V],
+    "iono_compact_scatter_dev": [_V, _V, _L, _V],
+    "iono_compact_cg_update_dev": [_V, _V, _V, _V, _L, _V, _V, _I, _V, _I, _V, _I, _V, _I],
+    "iono_compact_sirt_update_dev": [_V, _V, _V, _V, _L, _V, _D, _I, _V],
     "iono_walk_cycles": [_I, _V, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "iono_walk_partition_set": [_I, _V, _I, _L],
     "iono_walk_order": [_P, _P, _L, _D, ctypes.POINTER(ctypes.c_int)],

@@ -33,6 +33,7 @@
 #include "iono_forward_kernels.h"
 #include "iono_adjoint_kernels.h"
 #include "iono_cubic_kernels.h"
+#include "iono_solver_kernels.h"
 #include "iono_aux_kernels.h"
 
 namespace {
@@ -47,7 +48,8 @@ struct iono_ctx {
     hipStream_t own_stream = nullptr, stream = nullptr;
     int nx = 0, ny = 0, nz = 0, storage = IONO_F64;
     double *d_axes = nullptr;
-    void *d_M = nullptr;
+    void *d_M = nullptr;             // library-owned node values (storage type)
+    double *d_M_ext = nullptr;       // caller-owned float64 values bound with iono_grid_bind_values_dev (takes precedence)
     double inv_h[3] = {0, 0, 0};
     int uniform[3] = {0, 0, 0};
     int *d_flags = nullptr;          // [0] out-of-bounds, [1] non-finite
@@ -75,6 +77,7 @@ struct iono_ctx {
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     int walk_mode = 0;               // env IONOTOMO_WALK: forward walk A/B (see wave_chunk); never changes results
+    bool walk_mode_set = false;
     int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
                                            // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
@@ -115,10 +118,12 @@ struct DevBuf {
     template <typename T> T *as() { return (T *)p; }
 };
 
+void *cur_values(const iono_ctx *c) { return c->d_M_ext ? (void *)c->d_M_ext : c->d_M; }
+
 GridView view(const iono_ctx *c) {
     GridView g;
     g.axes = c->d_axes;
-    g.M = c->d_M;
+    g.M = cur_values(c);
     g.nx = c->nx;
     g.ny = c->ny;
     g.nz = c->nz;
@@ -361,7 +366,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_FORCE_GENERAL")) c->force_general = atoi(e);
     if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
-    if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 4);
+    if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 4), c->walk_mode_set = true;
     if (const char *e = getenv("IONOTOMO_ADJ_BUNDLE")) c->adj_mode = atoi(e) & (32 | 64 | 128);
 #ifdef IONO_ABLATION
     if (const char *e = getenv("IONOTOMO_ADJ_ABLATE")) c->adj_mode |= atoi(e) & (4 | 8);     // timing only: WRONG results
@@ -461,6 +466,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     c->d_M = nullptr;
     c->d_nM = nullptr;
     c->d_F8 = c->d_G8 = nullptr;
+    c->d_M_ext = nullptr;
     c->F8_valid = false;
     c->nM_freq = -1.0;
     c->nx = nx;
@@ -494,7 +500,7 @@ static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, d
     c->F8_valid = false;
     int rc = dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL((k_set_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, src_dev, (GT *)c->d_M, n,
+        hipLaunchKernelGGL((k_set_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, src_dev, (GT *)cur_values(c), n,
                            do_exp, scale, c->d_flags + 1);
         return IONO_OK;
     });
@@ -528,7 +534,7 @@ int iono_grid_set_exp_dev(iono_ctx *c, const double *m_dev, double scale) {
     int rc = need_grid(c);
     return rc ? rc : set_values_dev_impl(c, m_dev, 1, scale);
 }
-void *iono_grid_values_ptr(iono_ctx *c) { return c ? c->d_M : nullptr; }
+void *iono_grid_values_ptr(iono_ctx *c) { return c ? cur_values(c) : nullptr; }
 
 int iono_grid_get_values(iono_ctx *c, double *out) {
     int rc = need_grid(c);
@@ -538,7 +544,7 @@ int iono_grid_get_values(iono_ctx *c, double *out) {
     HIP_TRY(c, tmp.alloc((size_t)n * 8));
     dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL((k_get_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M,
+        hipLaunchKernelGGL((k_get_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c),
                            tmp.as<double>(), n);
         return IONO_OK;
     });
@@ -600,7 +606,7 @@ static int ensure_lm_fields(iono_ctx *c) {
     if (!c->F8_valid) {
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_lm_fields<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M, c->d_F8, c->nx,
+            hipLaunchKernelGGL((k_lm_fields<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c), c->d_F8, c->nx,
                                c->ny, c->nz);
             return IONO_OK;
         });
@@ -641,9 +647,12 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
             const size_t wl = sizeof(double) * Ns;
-            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_lm, wl), R);
-            hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, c->stream, g, c->d_F8, o, d, order, R, tmax, Ns,
-                               c->walk_mode, c->d_unitw, tec, c->d_flags);
+const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_lm, wl), R);
+            // default walk for this kernel: one contiguous chunk per workgroup with its 4 waves interleaved (neighbouring
+            // rays of an ordered walk then share the 64-B field records in L1): measured 1.89 vs 1.97 ms per-wave chunks
+            const int wm = c->walk_mode_set ? c->walk_mode : 1;
+            hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, c->stream, g, c->d_F8, o, d, order, R, tmax, Ns, wm,
+                               c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))      // (`order` is a speed hint: ignored here)
             hipLaunchKernelGGL((k_forward_straight_fast<GT>), grid, block, 2 * lds, c->stream, g, o, d, R, tmax, Ns,
                                c->d_unitw, tec, c->d_flags);
@@ -698,6 +707,96 @@ int iono_vec_axpby_dev(iono_ctx *c, double *y, const double *x, int64_t n, const
     HIP_TRY(c, hipSetDevice(c->device));
     hipLaunchKernelGGL(k_axpby, dim3(ew_blocks(c, (n + 1) / 2)), dim3(256), 0, c->stream, y, x, n, a_num, a_den, a_sign, b_num,
                        b_den);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+// ---- caller-owned grid values + fused solver passes (iono_solver_kernels.h) ---------------------------------------
+int iono_grid_padded_size(iono_ctx *c, int64_t *count) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    if (!count) return fail(c, IONO_ERR_ARG, "null count");
+    *count = ncells(c) + (int64_t)c->ny * c->nz + c->nz + 2;
+    return IONO_OK;
+}
+
+int iono_grid_bind_values_dev(iono_ctx *c, double *values_dev) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    if (values_dev && c->storage != IONO_F64) return fail(c, IONO_ERR_ARG, "caller-owned values need float64 storage");
+    if (values_dev && (((uintptr_t)values_dev) & 15)) return fail(c, IONO_ERR_ARG, "values must be 16-byte aligned");
+    c->d_M_ext = values_dev;
+    c->nM_freq = -1.0;
+    c->F8_valid = false;
+    return IONO_OK;
+}
+
+int iono_grid_values_changed(iono_ctx *c) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    c->nM_freq = -1.0;
+    c->F8_valid = false;
+    return IONO_OK;
+}
+
+int iono_rays_combine_dev(iono_ctx *c, const double *tec, const double *dobs, const double *s1, const double *s2, int Na,
+                          int64_t NtNd, int i0, double a, double b, double *out, double *partial) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (Na < 1 || NtNd < 0 || i0 < 0 || i0 >= Na || !tec || !out) return fail(c, IONO_ERR_ARG, "iono_rays_combine_dev: bad argument");
+    hipLaunchKernelGGL(k_rays_combine, dim3(IONO_NPART), dim3(256), 0, c->stream, tec, dobs, s1, s2, Na, NtNd, i0, a, b, out, partial);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_vec_axpby_dot_dev(iono_ctx *c, double *y, const double *x, int64_t n, const double *an, int ann, const double *ad, int adn,
+                           double a_sign, const double *bn, int bnn, const double *bd, int bdn, double *partial) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (n < 0 || (n > 0 && (!y || !x))) return fail(c, IONO_ERR_ARG, "iono_vec_axpby_dot_dev: null vector");
+    if (ann > IONO_NPART || adn > IONO_NPART || bnn > IONO_NPART || bdn > IONO_NPART) return fail(c, IONO_ERR_ARG, "scalar count too large");
+    hipLaunchKernelGGL(k_axpby_dot, dim3(IONO_NPART), dim3(256), 0, c->stream, y, x, n, an, ann, ad, adn, a_sign, bn, bnn, bd, bdn,
+                       partial);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+static int compact_args_ok(iono_ctx *c, const int *idx, int64_t n) {
+    if (n < 0 || (n > 0 && !idx)) return fail(c, IONO_ERR_ARG, "compact op: bad index");
+    return IONO_OK;
+}
+
+int iono_compact_gather_dev(iono_ctx *c, double *full, const int *idx, int64_t n, double *out, int zero, double *partial) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    { const int rc = compact_args_ok(c, idx, n); if (rc) return rc; }
+    hipLaunchKernelGGL(k_compact_gather, dim3(IONO_NPART), dim3(256), 0, c->stream, full, idx, n, out, zero, partial);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_compact_scatter_dev(iono_ctx *c, double *full, const int *idx, int64_t n, const double *src) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    { const int rc = compact_args_ok(c, idx, n); if (rc) return rc; }
+    hipLaunchKernelGGL(k_compact_scatter, dim3(IONO_NPART), dim3(256), 0, c->stream, full, idx, n, src);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_compact_cg_update_dev(iono_ctx *c, double *x, double *p, const double *s, const int *idx, int64_t n, double *full_p,
+                               const double *an, int ann, const double *ad, int adn, const double *bn, int bnn, const double *bd,
+                               int bdn) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    { const int rc = compact_args_ok(c, idx, n); if (rc) return rc; }
+    hipLaunchKernelGGL(k_compact_cg_update, dim3(IONO_NPART), dim3(256), 0, c->stream, x, p, s, idx, n, full_p, an, ann, ad, adn, bn,
+                       bnn, bd, bdn);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_compact_sirt_update_dev(iono_ctx *c, double *x, const double *C, double *full_s, const int *idx, int64_t n, double *full_x,
+                                 double relax, int nonneg, double *partial_max) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    { const int rc = compact_args_ok(c, idx, n); if (rc) return rc; }
+    hipLaunchKernelGGL(k_compact_sirt_update, dim3(IONO_NPART), dim3(256), 0, c->stream, x, C, full_s, idx, n, full_x, relax, nonneg,
+                       partial_max);
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
 }
@@ -954,7 +1053,7 @@ static int adjoint_host_finish(iono_ctx *c, double *dG, int scale_by_grid, doubl
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
             hipLaunchKernelGGL((k_scale_by_grid<double, GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, dG,
-                               (const GT *)c->d_M, n);
+                               (const GT *)cur_values(c), n);
             return IONO_OK;
         });
     HIP_TRY(c, hipGetLastError());
@@ -1098,7 +1197,7 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
     if (c->nM_freq != frequency) {       // n = sqrt(1 - 8.98^2 ne / nu^2) at the nodes, rebuilt when ne or nu changed
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_ne_to_n<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)c->d_M, c->d_nM, n,
+            hipLaunchKernelGGL((k_ne_to_n<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c), c->d_nM, n,
                                frequency);
             return IONO_OK;
         });

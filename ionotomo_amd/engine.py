@@ -18,6 +18,16 @@ def _ptr(t):
     return _lib._V(t.data_ptr())
 
 
+def ctypes_int64():
+    import ctypes
+    return ctypes.c_int64(0)
+
+
+def _byref(v):
+    import ctypes
+    return ctypes.byref(v)
+
+
 class RayEngine(object):
     """One GPU, one grid, straight z-parametrised rays generated in-kernel (rays[R,4,Ns] is never
     materialised: at config 4 it would be 5.1 GB)."""
@@ -254,6 +264,77 @@ class RayEngine(object):
         self.ctx.call("iono_vec_axpby_dev", _ptr(y), _ptr(x), y.numel(), *[0 if t is None else _ptr(t) for t in sc[:2]],
                       float(a_sign), *[0 if t is None else _ptr(t) for t in sc[2:]])
         return y
+
+    # -- fused solver passes (csrc/iono_solver_kernels.h): dot products as per-workgroup partials, compact grid vectors ----
+    def new_grid_buffer(self):
+        """(padded, view): a zeroed float64 buffer the kernels can read IN PLACE as grid values (``bind_values``) and its
+        [nx,ny,nz] view; the tail beyond the grid stays zero (unclamped far-corner reads)."""
+        n = ctypes_int64()
+        self.ctx.call("iono_grid_padded_size", _byref(n))
+        padded = torch.zeros(n.value, dtype=torch.float64, device=self.device)
+        return padded, padded[:self.ncells].view(self.shape)
+
+    def bind_values(self, padded):
+        """Kernels read ``padded`` (from ``new_grid_buffer``) as the grid values from now on; None: back to the
+        library's own storage.  Call ``values_changed`` after modifying the buffer."""
+        self._sync_stream()
+        self.ctx.call("iono_grid_bind_values_dev", _lib._V(0) if padded is None else _ptr(padded))
+        self._bound = padded                                  # keep it alive
+
+    def values_changed(self):
+        self.ctx.call("iono_grid_values_changed")
+
+    def _partial(self, want):
+        return torch.empty(_lib.NPART, dtype=torch.float64, device=self.device) if want else None
+
+    @staticmethod
+    def _sc(t):
+        """device scalar -> (pointer, count): None = 1.0, 1 element, or NPART partial sums"""
+        return (_lib._V(0), 0) if t is None else (_ptr(t), int(t.numel()))
+
+    def rays_combine(self, tec, Na, i0, a, b, dobs=None, s1=None, s2=None, out=None, want_dot=True):
+        """out = s1 * (a * (tec - tec[i0]) + b * dobs) over rays [Na][NtNd]; partials of sum out^2 * s2."""
+        self._sync_stream()
+        out = torch.empty_like(tec) if out is None else out
+        part = self._partial(want_dot)
+        opt = lambda t: _lib._V(0) if t is None else _ptr(t)
+        self.ctx.call("iono_rays_combine_dev", _ptr(tec), opt(dobs), opt(s1), opt(s2), int(Na), tec.numel() // Na, int(i0),
+                      float(a), float(b), _ptr(out), opt(part))
+        return out, part
+
+    def axpby_dot_(self, y, x, an=None, ad=None, a_sign=1.0, bn=None, bd=None, want_dot=True):
+        """y = (a_sign an / ad) x + (bn / bd) y in place; returns the partials of sum y^2 (or None)."""
+        self._sync_stream()
+        part = self._partial(want_dot)
+        (anp, ann), (adp, adn), (bnp, bnn), (bdp, bdn) = (self._sc(t) for t in (an, ad, bn, bd))
+        self.ctx.call("iono_vec_axpby_dot_dev", _ptr(y), _ptr(x), y.numel(), anp, ann, adp, adn, float(a_sign), bnp, bnn, bdp, bdn,
+                      _lib._V(0) if part is None else _ptr(part))
+        return part
+
+    def compact_gather(self, full, idx, out=None, zero=True, want_dot=True):
+        self._sync_stream()
+        out = torch.empty(idx.numel(), dtype=torch.float64, device=self.device) if out is None else out
+        part = self._partial(want_dot)
+        self.ctx.call("iono_compact_gather_dev", _ptr(full), _ptr(idx), idx.numel(), _ptr(out), int(bool(zero)),
+                      _lib._V(0) if part is None else _ptr(part))
+        return out, part
+
+    def compact_scatter(self, full, idx, src):
+        self._sync_stream()
+        self.ctx.call("iono_compact_scatter_dev", _ptr(full), _ptr(idx), idx.numel(), _ptr(src))
+
+    def compact_cg_update(self, x, p, s, idx, full_p, an, ad, bn, bd):
+        self._sync_stream()
+        (anp, ann), (adp, adn), (bnp, bnn), (bdp, bdn) = (self._sc(t) for t in (an, ad, bn, bd))
+        self.ctx.call("iono_compact_cg_update_dev", _ptr(x), _ptr(p), _ptr(s), _ptr(idx), idx.numel(), _ptr(full_p), anp, ann, adp,
+                      adn, bnp, bnn, bdp, bdn)
+
+    def compact_sirt_update(self, x, C, full_s, idx, full_x, relax=1.0, nonneg=False, want_max=False):
+        self._sync_stream()
+        part = self._partial(want_max)
+        self.ctx.call("iono_compact_sirt_update_dev", _ptr(x), _ptr(C), _ptr(full_s), _ptr(idx), idx.numel(), _ptr(full_x),
+                      float(relax), int(bool(nonneg)), _lib._V(0) if part is None else _ptr(part))
+        return part
 
     def check_oob(self):
         return self.ctx.check_oob()

@@ -130,9 +130,50 @@ class ShardedRays(object):
             self.partition = engine.tune_adjoint_partition(launch, self.R_local)
             del scratch
         self.exchange = GradientExchange(exchange, reduce_dtype)
+        self._active = None
         if self.world > 1 and exchange != "dense":
-            ones = torch.ones(self.R_local, dtype=torch.float64, device=dev)
-            self.exchange.plan(engine.adjoint(self.origins, self.dirs, ones, self.tmax, self.Ns, order=self.order))
+            self.exchange.plan(self._touched())
+
+    def _touched(self):
+        """this rank's back-projection of unit ray weights: non-zero exactly at the nodes its rays reach"""
+        ones = torch.ones(self.R_local, dtype=torch.float64, device=self.engine.device)
+        return self.engine.adjoint(self.origins, self.dirs, ones, self.tmax, self.Ns, order=self.order)
+
+    def active_index(self):
+        """Sorted int32 indices of the grid nodes ANY rank's rays reach (identical on every rank; computed once per
+        geometry).  The solvers keep their grid-sized vectors compact over this set."""
+        if self._active is None:
+            mask = (self._touched().reshape(-1) != 0).to(torch.int32)
+            if self.world > 1:
+                dist.all_reduce(mask, op=dist.ReduceOp.MAX)
+            self._active = mask.nonzero().reshape(-1).to(torch.int32).contiguous()
+        return self._active
+
+    def scalar(self, partial):
+        """A device scalar from the per-workgroup partial sums of a fused pass: used as is on one rank (the consuming
+        kernel sums it in a fixed order), summed and all-reduced to ONE value when rays are sharded."""
+        if self.world == 1:
+            return partial
+        t = partial.sum().reshape(1)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def backproject_differential(self, v, scale, out_full):
+        """out_full += (local rays) A^T (scale o v): fused differential weights + back-projection, no exchange."""
+        return self.engine.adjoint_differential(self.origins, self.dirs, v, scale, self.Na, self.i0, self.tmax, self.Ns,
+                                                out=out_full, order=self.order)
+
+    def reduce_compact_(self, s_c):
+        """In-place sum over ranks of a compact (active-set) vector."""
+        if self.world > 1:
+            rd = self.exchange.reduce_dtype
+            if rd is not None and rd != s_c.dtype:
+                buf = s_c.to(rd)
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+                s_c.copy_(buf)
+            else:
+                dist.all_reduce(s_c, op=dist.ReduceOp.SUM)
+        return s_c
 
     def slice(self, full):
         """[Na,P] (full problem) -> this rank's [Na*P_local] device vector."""
@@ -141,8 +182,10 @@ class ShardedRays(object):
 
     # -- operators ---------------------------------------------------------------------------------
     def forward_tec(self):
-        # no walk order here: the forward reads only, and its plain XCD-major walk measured faster
-        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns)
+        # trilinear: no walk order -- the forward reads only and its plain XCD-major walk measured faster;
+        # tricubic: the 64-B-per-node derivative fields overflow L2, neighbouring rays back to back help (2.2 -> 1.9 ms)
+        cubic = getattr(self.engine, "kind", 0) == 1
+        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns, order=self.order if cubic else None)
 
     def forward(self):
         """differential TEC of the current grid values, local rays: A x = G x - (G x)[i0]."""

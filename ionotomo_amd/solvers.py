@@ -47,7 +47,7 @@ def _set_x(problem, x):
     problem.engine.set_values(x.reshape(-1))
 
 
-def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=None, pgtol=PGTOL):
+def _sirt_dense(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=None, pgtol=PGTOL):
     """x_{k+1} = x_k + relax * C A^T L (d - A x_k),  A = differenced ray operator.
     L, C from row / column sums of |A| bounded by the un-differenced sums (keeps rho <= 1).
     ``stop="reference"``: the reference's stopping rule (``reference_stop``; ``n_iter`` is its max_iter) on the
@@ -100,7 +100,7 @@ def parallel_adjoint_raw(problem, w):
                                                   order=problem.order))
 
 
-def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL):
+def _cgls_dense(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL):
     """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2 + damp/2 ||x||^2,  W = 1/(CdCt + 1e-15).
     All scalars (alpha, beta, objective) stay on the device; the history is read back once at the
     end, so an iteration never waits for the host (``callback`` forces a read-back per iteration).
@@ -140,6 +140,128 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
         eng.axpby_(p, s, b_num=gnew, b_den=gamma)                     # p = s + beta p
         gamma = gnew
     return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
+
+
+def _history(hist):
+    """list of device scalars (1 element or per-workgroup partials) -> list of floats, one read-back"""
+    if not hist:
+        return []
+    return [0.5 * float(v) for v in torch.stack([h.sum() for h in hist]).cpu()]
+
+
+def _fused_ok(problem, callback):
+    eng = problem.engine
+    return (callback is None and hasattr(eng, "compact_gather") and problem.dobs is not None and
+            getattr(eng, "storage", "f64") in ("f64", "float64"))
+
+
+def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=None, pgtol=PGTOL):
+    """x_{k+1} = x_k + relax * C A^T L (d - A x_k),  A = differenced ray operator; L, C from row / column sums of |A|
+    bounded by the un-differenced sums (keeps rho <= 1; geometry/oct_trees/Inversion.py:559,564).
+    One iteration = forward launch, ONE pass over the rays (residual + objective), fused differential back-projection,
+    ONE pass over the active nodes (update + re-zero + refresh of the grid the forward reads): 4 launches
+    (``_sirt_dense`` is the same arithmetic with full-grid torch vectors; used when a ``callback`` wants the iterate).
+    ``stop="reference"``: the reference's stopping rule (``reference_stop``; ``n_iter`` is its max_iter) on the
+    objective S = 1/2 sum r^2/CdCt and the largest model change per update -- one host read-back per iteration;
+    ``stop=None`` runs exactly ``n_iter`` updates without ever synchronising with the host."""
+    if not _fused_ok(problem, callback):
+        return _sirt_dense(problem, x0, n_iter, relax, nonneg, callback, stop, pgtol)
+    eng = problem.engine
+    idx = problem.active_index()
+    il = idx.long()
+    ones = torch.ones(eng.shape, dtype=torch.float64, device=eng.device)
+    eng.bind_values(None)
+    _set_x(problem, ones)
+    rows = problem.forward_tec().view(problem.Na, problem.P_local)          # path lengths
+    L = (1.0 / (rows + rows[problem.i0:problem.i0 + 1])).reshape(-1).contiguous()
+    wcol = torch.ones(problem.Na, problem.P_local, dtype=torch.float64, device=eng.device)
+    wcol[problem.i0] += problem.Na
+    col = parallel_adjoint_raw(problem, wcol.reshape(-1)).reshape(-1)
+    C = torch.where(col > 1e-9 * col.max(), 1.0 / col, torch.zeros_like(col))
+    C_c = C.index_select(0, il).contiguous()
+    del ones, col, C
+    Wt = (1.0 / (problem.cdct + 1e-15)).contiguous()
+    x_pad, x_full = eng.new_grid_buffer()
+    x_full.copy_(x0)
+    x_c = x0.reshape(-1).index_select(0, il).contiguous()
+    s_full = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
+    s_c = torch.empty_like(x_c) if problem.world > 1 else None
+    eng.bind_values(x_pad)
+    hist, r, step = [], None, None
+    try:
+        for k in range(n_iter + (1 if stop else 0)):
+            eng.values_changed()
+            tec = problem.forward_tec()
+            r, S2 = eng.rays_combine(tec, problem.Na, problem.i0, -1.0, 1.0, dobs=problem.dobs, s2=Wt, out=r)   # r = d - A x
+            hist.append(problem.scalar(S2))
+            if stop and k > 0 and (k >= n_iter or _stop_fused(hist, step, k, n_iter, pgtol)):
+                break
+            problem.backproject_differential(r, L, s_full)
+            if problem.world > 1:                # sum the partial updates over ranks on the active nodes only
+                eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=False)
+                problem.reduce_compact_(s_c)
+                eng.compact_scatter(s_full, idx, s_c)
+            step = eng.compact_sirt_update(x_c, C_c, s_full, idx, x_full, relax, nonneg, want_max=bool(stop))
+    finally:
+        eng.bind_values(None)
+    return x_full.clone(), _history(hist)
+
+
+def _stop_fused(hist, step_partial, k, max_iter, pgtol):
+    vals = torch.stack([hist[-2].sum() * 0.5, hist[-1].sum() * 0.5, step_partial.max()]).cpu()
+    return reference_stop(float(vals[0]), float(vals[1]), float(vals[2]), k, max_iter, pgtol=pgtol)
+
+
+def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL):
+    """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2,  W = 1/(CdCt + 1e-15).
+    One iteration = forward launch (reads the search direction IN PLACE), one pass over the rays (q = W^1/2 A p and
+    <q, q>), one (r -= alpha q and <r, r>), the fused differential back-projection, one gather over the active nodes
+    (s and <s, s>, re-zeroing the back-projection buffer) and one update (x += alpha p, p = s + beta p, refresh of the
+    grid the forward reads): 6 launches, all scalars on the device as per-workgroup partial sums.
+    ``damp`` > 0 (Tikhonov term: the gradient is then non-zero off the ray fan) or a ``callback`` use the dense-vector
+    form ``_cgls_dense``.  ``stop="reference"``: the reference's stopping rule as in ``sirt``."""
+    if damp != 0.0 or stop or not _fused_ok(problem, callback):
+        return _cgls_dense(problem, x0, n_iter, damp, callback, stop, pgtol)
+    eng = problem.engine
+    idx = problem.active_index()
+    il = idx.long()
+    Wh = torch.rsqrt(problem.cdct + 1e-15).contiguous()
+    multi = problem.world > 1
+    eng.bind_values(None)
+    _set_x(problem, x0)
+    r, rr = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, -1.0, 1.0, dobs=problem.dobs, s1=Wh)   # W^1/2 (d - A x0)
+    s_full = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
+    problem.backproject_differential(r, Wh, s_full)
+    s_c, gamma = eng.compact_gather(s_full, idx, zero=True, want_dot=not multi)
+    if multi:
+        problem.reduce_compact_(s_c)
+        gamma = eng.axpby_dot_(s_c, s_c, a_sign=0.0)                    # y = 0 x + 1 y: just the dot
+    p_c = s_c.clone()
+    x_c = x0.reshape(-1).index_select(0, il).contiguous()
+    p_pad, p_full = eng.new_grid_buffer()
+    eng.compact_scatter(p_full, idx, p_c)
+    eng.bind_values(p_pad)
+    hist, q = [problem.scalar(rr)], None
+    try:
+        for k in range(n_iter):
+            eng.values_changed()
+            q, qq = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, 1.0, 0.0, s1=Wh, out=q)      # W^1/2 A p
+            qq = problem.scalar(qq)
+            rr = eng.axpby_dot_(r, q, an=gamma, ad=qq, a_sign=-1.0)         # r -= alpha q
+            if k + 1 < n_iter:
+                hist.append(problem.scalar(rr))
+            problem.backproject_differential(r, Wh, s_full)
+            _, gnew = eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=not multi)
+            if multi:
+                problem.reduce_compact_(s_c)
+                gnew = eng.axpby_dot_(s_c, s_c, a_sign=0.0)
+            eng.compact_cg_update(x_c, p_c, s_c, idx, p_full, gamma, qq, gnew, gamma)
+            gamma = gnew
+    finally:
+        eng.bind_values(None)
+    x = x0.clone()
+    x.view(-1).index_copy_(0, il, x_c)
+    return x, _history(hist)
 
 
 def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=0.0, max_iter=20, min_iter=5,
