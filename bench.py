@@ -10,10 +10,17 @@ trilinear interpolation, Simpson quadrature, float64) over this rank's batch of 
 62 LOFAR-HBA stations x 42 directions x 100 timesteps = 260,400 rays, Ns = 257 samples each,
 through a 256^3 electron-density grid resident in HBM.  Weak scaling: every rank owns its own
 (time, direction) block of rays and a replica of the grid; the forward needs no collective.
-Rank 0 prints ONE JSON line.  Extra keys report the adjoint, a full forward+adjoint+all-reduce
-iteration, float32 grid storage and the single-timestep (2,604-ray) launch.
+Rank 0 prints ONE JSON line.  `roofline` prices the kernel against the roof that binds it (the
+per-CU vector-L1 / texture-address path: the 128 MiB grid is cache-resident, so HBM is not the
+limiter) and reports the HBM-side, L2-side and compulsory figures next to it (DESIGN.md section 4
+gives the formulas).  Extra keys report the adjoint, a forward + adjoint + all-reduce iteration,
+CGLS / SIRT iterations, the tricubic path, float32 storage and the single-timestep launch.
+
+    python bench.py --only forward|adjoint|cubic_forward|cubic_adjoint|cgls|sirt --steps K
+runs ONE leg alone (clean rocprofv3 --stats / --pmc averages) and prints a short JSON line.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,13 +33,30 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NA, ND, NT, NGRID, NS, TMAX = 62, 42, 100, 256, 257, 1000.0
-HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 achievable); L2 ~34.5 TB/s aggregate; vector L1 /
+# texture-address path 64 B/clk/CU x 256 CUs x 2.4 GHz; memory-side float atomics ~1.3 TB/s of added bytes
+HBM_PEAK_GBS = 8000.0
+L2_PEAK_GBS = 34500.0
+VL1D_PEAK_GBS = 64 * 256 * 2.4
+ATOMIC_PEAK_GBS = 1300.0
 MAX_RANKS_FOR_DOMAIN = 8
+PMC_JSON = os.path.join(ROOT, "profiles", "pmc_counters.json")
 
 
 def algorithmic_bytes_per_ray(ns, grid_elem_bytes, corners=8):
     """Ns * C * sizeof(T_grid) + 56 (origin + direction in, TEC out)."""
     return ns * corners * grid_elem_bytes + 56
+
+
+def csrc_sha():
+    """Hash of everything the kernels are built from: committed PMC counters are used only while it matches."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "ionotomo_amd", "csrc")
+    for f in sorted(os.listdir(d)) + ["../../include/ionotomo_hip.h"]:
+        p = os.path.normpath(os.path.join(d, f))
+        if os.path.isfile(p) and p.endswith((".h", ".hip")):
+            h.update(open(p, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def build_workload(rank):
@@ -96,8 +120,9 @@ def time_steps(fn, steps, warmup, torch, dist, world):
 
 
 def cpu_baseline(w, tec_gpu):
-    """The oracle's C/OpenMP restatement on this box's host cores, same workload (rank 0, N=1):
-    reported next to the GPU number, and used as the in-run parity gate."""
+    """The oracle's C/OpenMP restatement on this box's host cores (rank 0, N=1): reported next to the GPU number
+    and used as the in-run parity gate.  It is a straightforward, UNOPTIMISED port (binary search + three divisions
+    per sample, weights recomputed per ray), built on this box (``-march=native`` here, not in the build container)."""
     from oracle import oracle as O
     from oracle import oracle_c as OC
     ne = O.ne_from_log_model(w["m"], w["K_ne"])
@@ -117,9 +142,83 @@ def cpu_baseline(w, tec_gpu):
     O.forward_tec_loop(rays, w["xvec"], w["yvec"], w["zvec"], ne)
     numpy_rate = rays.shape[0] / (time.perf_counter() - t1)
     return dict(value=R / dt, unit="ray-integrals/s", cores=threads, kind="port",
-                sample="full per-GPU batch (%d rays x %d samples, 256^3 f64 grid) x %d repetitions, "
-                       "oracle/oracle_c.c with OpenMP on %d threads; numpy per-ray-loop port (1 thread, "
-                       "%d rays): %.3g ray-integrals/s" % (R, NS, reps, threads, rays.shape[0], numpy_rate)), rel
+                sample="full per-GPU batch (%d rays x %d samples, 256^3 f64 grid) x %d repetitions, unoptimised C/OpenMP "
+                       "port oracle/oracle_c.c on %d threads; numpy per-ray-loop port (1 thread, %d rays): %.3g "
+                       "ray-integrals/s" % (R, NS, reps, threads, rays.shape[0], numpy_rate)), rel
+
+
+def load_pmc(sha):
+    """Committed per-launch PMC counters (profiles/summarize.py) -- only if they were taken on THESE kernel sources."""
+    try:
+        p = json.load(open(PMC_JSON))
+    except Exception:
+        return None, "no profiles/pmc_counters.json"
+    if p.get("csrc_sha") != sha:
+        return None, "profiles/pmc_counters.json was taken on csrc %s, this build is %s: stale, dropped" % (p.get("csrc_sha"), sha)
+    return p, p.get("source", "")
+
+
+def fabric_bytes(c):
+    """L2 fabric-side read bytes from the request-size counters (exact), else FETCH_SIZE (KiB; counts 64 B per
+    request whatever its size -- MI355X_MICROARCH.md, HBM section) as a lower bound."""
+    if all(k in c for k in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_EA0_RDREQ_128B_sum")):
+        n32, n128 = c["TCC_EA0_RDREQ_32B_sum"], c["TCC_EA0_RDREQ_128B_sum"]
+        n64 = c.get("TCC_EA0_RDREQ_64B_sum", c["TCC_EA0_RDREQ_sum"] - n32 - n128)
+        return 32.0 * n32 + 64.0 * n64 + 128.0 * n128, "sum over request sizes 32/64/128 B of TCC_EA0_RDREQ_*"
+    if "FETCH_SIZE" in c:
+        return 1024.0 * c["FETCH_SIZE"], "FETCH_SIZE (64 B per request: lower bound)"
+    return None, None
+
+
+def forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes):
+    bytes_ray = algorithmic_bytes_per_ray(NS, 8)
+    achieved = R * bytes_ray / kern / 1e9
+    compulsory = (grid_bytes + R * 56) / kern / 1e9
+    rl = {"bound": "vl1d", "achieved": achieved, "peak": VL1D_PEAK_GBS, "unit": "GB/s", "frac": achieved / VL1D_PEAK_GBS,
+          "traffic": None, "kernel": "k_forward_straight_u<double>", "kernel_ms": kern * 1e3,
+          "algorithmic_bytes_per_ray": bytes_ray, "algorithmic_gbs": achieved,
+          "hbm": {"peak": HBM_PEAK_GBS, "algorithmic_over_peak": achieved / HBM_PEAK_GBS, "compulsory_gbs": compulsory,
+                  "compulsory_frac": compulsory / HBM_PEAK_GBS, "copy_gbs_measured": copy_gbs,
+                  "counter_gbs": None, "counter_frac": None},
+          "l2": {"peak": L2_PEAK_GBS, "request_gbs": None, "frac": None},
+          "pmc": pmc_note,
+          "note": "Every corner value a lane asks for crosses the per-CU vector L1 / texture-address path (64 B/clk/CU), so "
+                  "the ALGORITHMIC bytes (Ns x 8 corners x 8 B + 56 per ray, no credit for reuse) are that path's load and "
+                  "`frac` is its utilisation.  The 128 MiB grid is L2 / Infinity-Cache resident: the HBM side carries far "
+                  "less (`hbm.counter_gbs`: L2 fabric-side requests, Infinity-Cache hits included; `hbm.compulsory_gbs`: "
+                  "grid + ray I/O once per launch), which is why the algorithmic rate exceeds the HBM peak "
+                  "(`hbm.algorithmic_over_peak`) -- HBM is not the roof of this kernel."}
+    c = (pmc or {}).get("forward")
+    if c and c.get("rays") == R and c.get("Ns") == NS:
+        fb, how = fabric_bytes(c)
+        if fb is not None:
+            fb += 1024.0 * c.get("WRITE_SIZE", 0.0)
+            rl["traffic"] = fb
+            rl["traffic_source"] = how + " + WRITE_SIZE, per launch (L2 fabric side: includes Infinity-Cache hits)"
+            rl["hbm"]["counter_gbs"] = fb / kern / 1e9
+            rl["hbm"]["counter_frac"] = fb / kern / 1e9 / HBM_PEAK_GBS
+            rl["hbm"]["traffic_over_compulsory"] = fb / (grid_bytes + R * 56)
+        if "TCP_TCC_READ_REQ_sum" in c:
+            req = 128.0 * c["TCP_TCC_READ_REQ_sum"] / kern / 1e9          # L1 -> L2 read requests are 128-B lines
+            rl["l2"]["request_gbs"], rl["l2"]["frac"] = req, req / L2_PEAK_GBS
+        if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
+            rl["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        if "GRBM_GUI_ACTIVE" in c and "TA_TA_BUSY_sum" in c:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # per-XCD active cycles of the launch (profiled run)
+            rl["vl1d"] = {"ta_busy_frac": c["TA_TA_BUSY_sum"] / (256.0 * cyc),
+                          "ta_addr_stalled_by_tc_frac": c.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum", 0.0) / (256.0 * cyc),
+                          "tcp_tag_lookups_per_clk_per_cu": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (256.0 * cyc),
+                          "profiled_clock_ghz": cyc / (kern * 1e9)}
+        if "SQ_INSTS_VMEM_RD" in c:
+            # wave-level load instructions per launch and the cycles the 256 CUs had per instruction
+            rl["vmem"] = {"wave_loads_per_launch": c["SQ_INSTS_VMEM_RD"],
+                          "cu_cycles_per_wave_load_at_2p4GHz": kern * 2.4e9 * 256 / c["SQ_INSTS_VMEM_RD"]}
+            for k in ("TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum",
+                      "TCP_PENDING_STALL_CYCLES_sum", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
+                      "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
+                if k in c:
+                    rl["vmem"][k] = c[k]
+    return rl
 
 
 def main():
@@ -129,9 +228,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-order", dest="order", action="store_false", help="walk rays in [Na][Nt][Nd] memory order")
-    ap.add_argument("--main-only", action="store_true",
-                    help="only the timed headline launches (clean rocprofv3 --stats averages); implies --no-cpu")
+    ap.add_argument("--main-only", action="store_true", help="same as --only forward")
+    ap.add_argument("--only", default=None,
+                    choices=["forward", "adjoint", "cubic_forward", "cubic_adjoint", "cgls", "sirt"],
+                    help="time ONE leg alone (clean rocprofv3 --stats / --pmc averages); implies --no-cpu")
     args = ap.parse_args()
+    if args.main_only:
+        args.only = "forward"
 
     import torch
     import torch.distributed as dist
@@ -152,6 +255,7 @@ def main():
         else:
             dist.init_process_group(backend)
 
+    from ionotomo_amd import parallel, solvers
     from ionotomo_amd.engine import RayEngine
     w = build_workload(rank)
     R = w["origins"].shape[0]
@@ -161,6 +265,7 @@ def main():
     eng.set_log_model(m_t, w["K_ne"] / 1e13)
     o_t, d_t = eng.tensor(w["origins"]), eng.tensor(w["directions"])
     tec_t = torch.empty(R, dtype=torch.float64, device=eng.device)
+    grid_bytes = NGRID ** 3 * 8
 
     # walk order: rays whose paths nearly coincide run back to back (geometry only, computed once,
     # reused by every launch of an inversion; results are independent of it)
@@ -169,99 +274,188 @@ def main():
     def fwd():
         eng.forward(o_t, d_t, TMAX, NS, out=tec_t)          # the forward gains nothing from the order (measured)
 
-    wall, kern = time_steps(fwd, args.steps, args.warmup, torch, dist, world)
-    assert not eng.check_oob(), "rays left the grid"
-    value = world * R * args.steps / wall
-    bytes_ray = algorithmic_bytes_per_ray(NS, 8)
-    achieved = R * bytes_ray / kern / 1e9
-    tec_gpu = tec_t.cpu().numpy()
+    # ---- legs that can run alone under a profiler ---------------------------------------------------------------
+    def adjoint_leg():
+        fwd()
+        tec0 = tec_t.cpu().numpy().reshape(NA, -1)
+        dobs = eng.tensor(tec0 - tec0[0] + np.random.default_rng(2 + rank).normal(size=tec0.shape) * 1e-3)
+        cdct = torch.full((R,), 1e-6, dtype=torch.float64, device=eng.device)
+        grad = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
 
-    extra = {}
-    if args.main_only:
+        def adj():
+            grad.zero_()
+            eng.adjoint_residual(o_t, d_t, tec_t, dobs, cdct, NA, 0, TMAX, NS, out=grad, order=order_t)
+        return adj, grad, dobs, cdct
+
+    def cubic_legs():
+        ec = RayEngine(local, storage="f64", interp="cubic")
+        ec.set_grid(w["xvec"], w["yvec"], w["zvec"])
+        ec.set_log_model(m_t, w["K_ne"] / 1e13)
+        tc = torch.empty_like(tec_t)
+        gc = torch.zeros(ec.shape, dtype=torch.float64, device=ec.device)
+        yc = torch.randn(R, dtype=torch.float64, device=ec.device)
+
+        def cf():
+            ec.forward(o_t, d_t, TMAX, NS, out=tc, order=order_t)
+
+        def ca():
+            gc.zero_()
+            ec.adjoint(o_t, d_t, yc, TMAX, NS, out=gc, order=order_t)
+        return ec, cf, ca, tc
+
+    def solver_problem():
+        fwd()
+        oo, dd = w["origins"].reshape(NA, -1, 3), w["directions"].reshape(NA, -1, 3)
+        prob = parallel.ShardedRays(eng, oo, dd, TMAX, NS, dobs=np.zeros((NA, R // NA)), cdct=np.full((NA, R // NA), 1e-6), i0=0)
+        x0 = torch.exp(m_t).mul_(w["K_ne"] / 1e13).reshape(eng.shape)
+        eng.set_values((x0 * 1.1).reshape(-1))
+        prob.dobs = prob.forward().clone()
+        return prob, x0
+
+    if args.only:
+        k = args.steps
+        if args.only == "forward":
+            leg = fwd
+        elif args.only == "adjoint":
+            leg = adjoint_leg()[0]
+            if order_t is not None:
+                eng.tune_adjoint_partition(leg, R)
+        elif args.only in ("cubic_forward", "cubic_adjoint"):
+            ec, cf, ca, _ = cubic_legs()
+            leg = cf if args.only == "cubic_forward" else ca
+        else:
+            prob, x0 = solver_problem()
+            fn = getattr(solvers, args.only)
+            fn(prob, x0, n_iter=2)
+            leg = lambda: fn(prob, x0, n_iter=10)
+            k = max(1, args.steps // 10)
+        wall, kern = time_steps(leg, k, min(args.warmup, 2), torch, dist, world)
         if rank == 0:
-            print(json.dumps({"metric": "ray-integrals/sec through 256^3 ne grid", "value": value, "n_gpus": world,
-                              "steps": args.steps, "kernel_ms": kern * 1e3, "main_only": True}))
+            per = 10 if args.only in ("cgls", "sirt") else 1
+            print(json.dumps({"only": args.only, "n_gpus": world, "steps": k, "ms_per_launch_or_iteration": kern * 1e3 / per,
+                              "rays": R, "csrc_sha": csrc_sha()}))
         if world > 1:
             dist.destroy_process_group()
         return
-    # everything below is reported next to the headline number; a failure there (e.g. in the collective of the
-    # iteration leg) must not lose the headline line
+
+    wall, kern = time_steps(fwd, args.steps, args.warmup, torch, dist, world)
+    assert not eng.check_oob(), "rays left the grid"
+    value = world * R * args.steps / wall
+    tec_gpu = tec_t.cpu().numpy()
+
+    # everything below is reported next to the headline number.  Nothing in it may be able to lose the headline line or
+    # hang a multi-rank run: every rank allocates what the legs need FIRST, the ranks agree that all of them succeeded,
+    # and only then enter code with collectives (which is the same on every rank).
+    extra = {}
+    ok = 1
     try:
-        # ---- adjoint + one full iteration (forward, fused residual adjoint, all-reduce of the update)
-        rng = np.random.default_rng(2 + rank)
-        dobs_t = eng.tensor(tec_gpu.reshape(NA, -1) - tec_gpu.reshape(NA, -1)[0] + rng.normal(size=(NA, R // NA)) * 1e-3)
-        cdct_t = torch.full((R,), 1e-6, dtype=torch.float64, device=eng.device)
-        grad_t = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
-
-        def adj():
-            grad_t.zero_()
-            eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t, order=order_t)
-
-        def iteration():
-            fwd()
-            adj()
-            if world > 1:
-                dist.all_reduce(grad_t)
-
-        k2 = max(3, min(25, args.steps // 4))
-        # work partition of the back-projection balanced by measured cost: like the walk order it depends on the ray
-        # geometry only, is computed once per inversion and never changes results (engine.tune_adjoint_partition)
-        extra["adjoint_partition"] = eng.tune_adjoint_partition(adj, R) if args.order else None
-        awall, akern = time_steps(adj, k2, 1, torch, dist, world)
-        iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
-        extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
-        extra["adjoint_ms"] = akern * 1e3
-        extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
-        if world > 1:
-            # the same iteration with the update exchanged only over the nodes some rank's rays reach
-            # (ionotomo_amd/parallel.py:GradientExchange; the plan is built once per geometry)
-            from ionotomo_amd.parallel import GradientExchange
-            ones = torch.ones(R, dtype=torch.float64, device=eng.device)
-            xch = GradientExchange("compact").plan(eng.adjoint(o_t, d_t, ones, TMAX, NS, order=order_t))
-
-            def iteration_compact():
-                fwd()
-                adj()
-                xch.sum_(grad_t)
-            cwall, _ = time_steps(iteration_compact, k2, 1, torch, dist, world)
-            extra["iteration_ms_compact_exchange"] = cwall / k2 * 1e3
-            extra["exchange_active_node_fraction"] = xch.fraction
-            xch32 = GradientExchange("compact", reduce_dtype=torch.float32)
-            xch32.index, xch32.fraction = xch.index, xch.fraction
-
-            def iteration_compact32():
-                fwd()
-                adj()
-                xch32.sum_(grad_t)
-            c32wall, _ = time_steps(iteration_compact32, k2, 1, torch, dist, world)
-            extra["iteration_ms_compact_exchange_f32"] = c32wall / k2 * 1e3
-        if order_t is not None:
-            eng.ctx.walk_partition_set(1, None, R)       # the tuned partition belongs to the ordered walk
-
-            def adj_unordered():
-                grad_t.zero_()
-                eng.adjoint_residual(o_t, d_t, tec_t, dobs_t, cdct_t, NA, 0, TMAX, NS, out=grad_t)
-            wn, kn = time_steps(adj_unordered, k2, 1, torch, dist, world)
-            extra["adjoint_unordered_walk_ms"] = kn * 1e3
-        # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
+        adj, grad_t, dobs_t, cdct_t = adjoint_leg()
         eng32 = RayEngine(local, storage="f32")
         eng32.set_grid(w["xvec"], w["yvec"], w["zvec"])
         eng32.set_log_model(m_t, w["K_ne"] / 1e13)
         tec32 = torch.empty_like(tec_t)
-        w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32), k2, 1, torch, dist, world)
-        extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
-        extra["f32_grid_roofline_frac"] = R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9 / HBM_PEAK_GBS
-        extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
-        # one timestep's worth of rays, contiguous in [Na][Nt*Nd] order is not one timestep; build it explicitly
-        sel = torch.arange(R, device=eng.device).reshape(NA, NT, ND)[:, 0, :].reshape(-1)
-        o1, d1 = o_t[sel].contiguous(), d_t[sel].contiguous()
-        t1 = torch.empty(o1.shape[0], dtype=torch.float64, device=eng.device)
-        _, k1 = time_steps(lambda: eng.forward(o1, d1, TMAX, NS, out=t1), 50, 5, torch, dist, 1)
-        extra["single_timestep_rays"] = int(o1.shape[0])
-        extra["single_timestep_us"] = k1 * 1e6
+        big_a = torch.empty(1 << 27, dtype=torch.float64, device=eng.device)         # 1 GiB
+        big_b = torch.empty_like(big_a)
+        ec, cf, ca, tc = cubic_legs()
     except Exception as exc:                                    # noqa: BLE001
+        ok = 0
         extra["error"] = "%s: %s" % (type(exc).__name__, exc)
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = int(flag.item())
+    copy_gbs = None
+    if ok:
+        try:
+            k2 = max(3, min(25, args.steps // 4))
 
+            def iteration():
+                fwd()
+                adj()
+                if world > 1:
+                    dist.all_reduce(grad_t)
+
+            # work partition of the back-projection balanced by measured cost: like the walk order it depends on the ray
+            # geometry only, is computed once per inversion and never changes results (engine.tune_adjoint_partition)
+            extra["adjoint_partition"] = eng.tune_adjoint_partition(adj, R) if args.order else None
+            awall, akern = time_steps(adj, k2, 1, torch, dist, world)
+            iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
+            extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
+            extra["adjoint_ms"] = akern * 1e3
+            extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
+            if world > 1:
+                # the same iteration with the update exchanged only over the nodes some rank's rays reach
+                # (ionotomo_amd/parallel.py:GradientExchange; the plan is built once per geometry)
+                from ionotomo_amd.parallel import GradientExchange
+                ones = torch.ones(R, dtype=torch.float64, device=eng.device)
+                xch = GradientExchange("compact").plan(eng.adjoint(o_t, d_t, ones, TMAX, NS, order=order_t))
+
+                def iteration_compact():
+                    fwd()
+                    adj()
+                    xch.sum_(grad_t)
+                cwall, _ = time_steps(iteration_compact, k2, 1, torch, dist, world)
+                extra["iteration_ms_compact_exchange"] = cwall / k2 * 1e3
+                extra["exchange_active_node_fraction"] = xch.fraction
+                xch32 = GradientExchange("compact", reduce_dtype=torch.float32)
+                xch32.index, xch32.fraction = xch.index, xch.fraction
+
+                def iteration_compact32():
+                    fwd()
+                    adj()
+                    xch32.sum_(grad_t)
+                c32wall, _ = time_steps(iteration_compact32, k2, 1, torch, dist, world)
+                extra["iteration_ms_compact_exchange_f32"] = c32wall / k2 * 1e3
+            # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
+            w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32), k2, 1, torch, dist, world)
+            extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
+            extra["f32_grid_vl1d_frac"] = R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9 / VL1D_PEAK_GBS
+            extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
+            sel = torch.arange(R, device=eng.device).reshape(NA, NT, ND)[:, 0, :].reshape(-1)
+            o1, d1 = o_t[sel].contiguous(), d_t[sel].contiguous()
+            t1 = torch.empty(o1.shape[0], dtype=torch.float64, device=eng.device)
+            _, k1 = time_steps(lambda: eng.forward(o1, d1, TMAX, NS, out=t1), 50, 5, torch, dist, 1)
+            extra["single_timestep_rays"] = int(o1.shape[0])
+            extra["single_timestep_us"] = k1 * 1e6
+            # ---- measured device-to-device copy (1 GiB read + 1 GiB written): the achievable HBM rate on this box
+            _, kc = time_steps(lambda: big_b.copy_(big_a), 10, 2, torch, dist, 1)
+            copy_gbs = 2.0 * big_a.numel() * 8 / kc / 1e9
+            # ---- tricubic (Lekien-Marsden derivative fields; config 2's interpolant) at the same shape
+            _, kcf = time_steps(cf, k2, 1, torch, dist, 1)
+            _, kca = time_steps(ca, max(2, k2 // 4), 1, torch, dist, 1)
+            extra["tricubic_forward_ms"] = kcf * 1e3
+            extra["tricubic_forward_ray_integrals_per_s"] = R / kcf
+            extra["tricubic_forward_vl1d_frac"] = R * algorithmic_bytes_per_ray(NS, 8, 64) / kcf / 1e9 / VL1D_PEAK_GBS
+            extra["tricubic_adjoint_ms"] = kca * 1e3
+            extra["tricubic_vs_trilinear_max_rel_dev"] = float((tc - tec_t).abs().div(tec_t.abs()).max().item())
+            # ---- adjoint roofline: memory-side float atomics
+            extra["adjoint_roofline"] = {"bound": "atomic", "peak": ATOMIC_PEAK_GBS, "unit": "GB/s", "kernel_ms": akern * 1e3,
+                                         "kernel": "k_adjoint_straight_tile<double, 1, 4>"}
+        except Exception as exc:                                    # noqa: BLE001
+            extra["error"] = "%s: %s" % (type(exc).__name__, exc)
+        if world == 1:
+            try:                                               # single-rank only: the solvers at the bench shape
+                prob, x0 = solver_problem()
+                for name in ("cgls", "sirt"):
+                    fn = getattr(solvers, name)
+                    fn(prob, x0, n_iter=2)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    fn(prob, x0, n_iter=30)
+                    torch.cuda.synchronize()
+                    extra["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 30 * 1e3
+            except Exception as exc:                                    # noqa: BLE001
+                extra["solver_error"] = "%s: %s" % (type(exc).__name__, exc)
+
+    sha = csrc_sha()
+    pmc, pmc_note = load_pmc(sha)
+    rl = forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes)
+    ar = extra.get("adjoint_roofline")
+    ca_ = (pmc or {}).get("adjoint")
+    if ar and ca_ and ca_.get("rays") == R and "TCC_EA0_ATOMIC_sum" in ca_:
+        ab = 64.0 * ca_["TCC_EA0_ATOMIC_sum"]                      # 64-B atomic requests leaving L2 per launch
+        ar.update({"atomic_requests_per_launch": ca_["TCC_EA0_ATOMIC_sum"], "achieved": ab / (ar["kernel_ms"] * 1e-3) / 1e9,
+                   "frac": ab / (ar["kernel_ms"] * 1e-3) / 1e9 / ATOMIC_PEAK_GBS})
     line = {
         "metric": "ray-integrals/sec through 256^3 ne grid",
         "value": value, "unit": "ray-integrals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -271,24 +465,10 @@ def main():
                                "grid, trilinear + Simpson, forward TEC" % (R, NS),
                    "rays_per_gpu": R, "samples_per_ray": NS, "grid": [NGRID] * 3, "interp": "trilinear",
                    "quadrature": "simpson", "sharding": "rays by (time,direction) block, grid replicated"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_forward_straight_u<double>", "kernel_ms": kern * 1e3,
-                     "algorithmic_bytes_per_ray": bytes_ray,
-                     "note": "achieved = ALGORITHMIC bytes (Ns*8 corners*8 B + 56 per ray, no credit for reuse) / kernel "
-                             "time; it can exceed the HBM peak because the 128 MiB grid is served from L2 / Infinity "
-                             "Cache -- `traffic` is the PMC-measured HBM-side bytes per launch"},
+        "roofline": rl,
+        "csrc_sha": sha,
         "extra": extra,
     }
-    pmc = os.path.join(ROOT, "profiles", "pmc_forward.json")
-    if os.path.exists(pmc):
-        try:
-            p = json.load(open(pmc))
-            if p.get("rays_per_launch") == R and p.get("samples_per_ray") == NS:
-                line["roofline"]["traffic"] = p.get("hbm_bytes_per_launch")
-                line["roofline"]["traffic_source"] = p.get("source")
-        except Exception:
-            pass
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, relerr = cpu_baseline(w, tec_gpu)
         line["cpu_baseline"] = cb

@@ -5,7 +5,31 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(_HERE, "liboracle_c.so")
+LIB = os.path.join(_HERE, "liboracle_c.so")            # portable build (__graft_entry__.build), travels with the snapshot
+
+
+def _native_lib():
+    """A -march=native build for THIS host, compiled on first use (the timed CPU baseline must be tuned for the box it
+    runs on, not for the build container); falls back to the portable library if no compiler is there."""
+    import hashlib
+    import subprocess
+    try:
+        model = [l for l in open("/proc/cpuinfo") if l.startswith(("model name", "flags"))][:2]
+    except OSError:
+        model = []
+    tag = hashlib.md5("".join(model).encode()).hexdigest()[:10]
+    d = os.path.join(_HERE, "_native")
+    path = os.path.join(d, "liboracle_c.%s.so" % tag)
+    src = os.path.join(_HERE, "oracle_c.c")
+    if not os.path.exists(path) or os.path.getmtime(path) < os.path.getmtime(src):
+        try:
+            os.makedirs(d, exist_ok=True)
+            subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", path + ".tmp%d" % os.getpid(),
+                                   src, "-lm"])
+            os.replace(path + ".tmp%d" % os.getpid(), path)
+        except Exception:
+            return None
+    return path
 _P = ctypes.POINTER(ctypes.c_double)
 _lib = None
 
@@ -13,11 +37,13 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB):
-            import subprocess
-            subprocess.check_call(["gcc", "-O3", "-march=native", "-fopenmp", "-fPIC", "-shared", "-o", LIB,
-                                   os.path.join(_HERE, "oracle_c.c"), "-lm"])
-        lib = ctypes.CDLL(LIB)
+        path = _native_lib()
+        if path is None:
+            if not os.path.exists(LIB):
+                import subprocess
+                subprocess.check_call(["gcc", "-O3", "-fopenmp", "-fPIC", "-shared", "-o", LIB, os.path.join(_HERE, "oracle_c.c"), "-lm"])
+            path = LIB
+        lib = ctypes.CDLL(path)
         lib.oracle_forward_tec_straight.restype = ctypes.c_int64
         lib.oracle_forward_tec_straight.argtypes = [_P, ctypes.c_int, _P, ctypes.c_int, _P, ctypes.c_int, _P, _P, _P,
                                                     ctypes.c_int64, ctypes.c_double, ctypes.c_int, _P, ctypes.c_int]

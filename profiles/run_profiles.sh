@@ -1,23 +1,56 @@
 #!/bin/bash
-# Run on the GPU box through gpurun:  bash profiles/run_profiles.sh <tag>
+# Run on the GPU box through gpurun:  bash profiles/run_profiles.sh <tag> [part]
+#   part 1: bench line + rocprofv3 --kernel-trace --stats of every leg           (~5 min)
+#   part 2: PMC passes of the forward kernel, one counter set per run            (~5 min)
+#   part 3: PMC passes of the adjoint and the tricubic forward                   (~5 min)
 # Produces gpurun_out/<tag>_*; `python profiles/summarize.py <tag>` condenses them into profiles/.
-TAG=${1:-r01}
+# (--pmc runs carry --kernel-trace only: gpurun refuses PMC combined with other trace domains.)
+TAG=${1:-r02}
+PART=${2:-1}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-python3 $REPO/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
-echo "bench done" >> $OUT/${TAG}_progress.log
-# (a) headline kernel alone: the --stats average IS the per-launch duration of the timed launches
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_statsmain -- python3 $REPO/bench.py --main-only --steps 20 --warmup 3 > $OUT/${TAG}_statsmain_bench.json 2> $OUT/${TAG}_statsmain.err || echo "statsmain failed" >> $OUT/${TAG}_bench.err
-echo "statsmain done" >> $OUT/${TAG}_progress.log
-# (b) the whole bench (forward, adjoint, f32, single-timestep launches)
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats -- python3 $REPO/bench.py --no-cpu --steps 20 --warmup 3 > $OUT/${TAG}_stats_bench.json 2> $OUT/${TAG}_stats.err || echo "stats failed" >> $OUT/${TAG}_bench.err
-echo "stats done" >> $OUT/${TAG}_progress.log
-# (c) PMC passes, one counter set per run (TCC: FETCH_SIZE needs 3 of 4 slots)
-for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_ATOMIC_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; do
-  N=$(echo $C | tr ' ' '_' | cut -c1-40)
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_$N -- python3 $REPO/bench.py --no-cpu --steps 5 --warmup 1 > /dev/null 2> $OUT/${TAG}_pmc_$N.err || echo "pmc $C failed" >> $OUT/${TAG}_bench.err
-  echo "pmc $N done" >> $OUT/${TAG}_progress.log
-done
+note() { echo "$(date +%T) $1" >> $OUT/${TAG}_progress.log; }
+
+stats() {   # stats <name> <bench args...>
+  local N=$1; shift
+  timeout -k 5 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_stats_$N -- python3 $REPO/bench.py "$@" > $OUT/${TAG}_stats_$N.json 2> $OUT/${TAG}_stats_$N.err || note "stats $N FAILED"
+  note "stats $N done"
+}
+pmc() {     # pmc <leg> <set index> "<counters>"
+  local LEG=$1 I=$2 C=$3
+  # (a counter set the hardware cannot schedule aborts the profiled process, which can then hang in finalisation:
+  #  bound every run)
+  timeout -k 5 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_${LEG}_$I -- python3 $REPO/bench.py --only $LEG --steps 5 --warmup 1 > /dev/null 2> $OUT/${TAG}_pmc_${LEG}_$I.err || note "pmc $LEG set $I ($C) FAILED"
+  note "pmc $LEG $I done"
+}
+
+if [ "$PART" = "1" ]; then
+  python3 $REPO/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
+  note "bench done"
+  stats forward --only forward --steps 20 --warmup 3          # the average IS the per-launch duration of the timed launches
+  stats adjoint --only adjoint --steps 10 --warmup 2
+  stats cubic_forward --only cubic_forward --steps 10 --warmup 2
+  stats cubic_adjoint --only cubic_adjoint --steps 4 --warmup 1
+  stats cgls --only cgls --steps 30 --warmup 1
+  stats sirt --only sirt --steps 30 --warmup 1
+  stats all --no-cpu --steps 20 --warmup 3
+fi
+SETS=("FETCH_SIZE" "WRITE_SIZE"
+      "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"
+      "TCC_HIT_sum TCC_MISS_sum TCC_EA0_ATOMIC_sum TCC_EA0_RDREQ_DRAM_sum"
+      "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"
+      "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"
+      "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM"
+      "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE"
+      "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum")
+FIRST=${3:-1}
+if [ "$PART" = "2" ]; then
+  i=0; for C in "${SETS[@]}"; do i=$((i+1)); [ $i -ge $FIRST ] && pmc forward $i "$C"; done
+fi
+if [ "$PART" = "3" ]; then
+  i=0; for C in "${SETS[@]}"; do i=$((i+1)); [ $i -ge $FIRST ] && pmc adjoint $i "$C"; done
+  for i in 1 3 4 5 8; do pmc cubic_forward $i "${SETS[$((i-1))]}"; done
+fi

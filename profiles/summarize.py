@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 CSV output (gpurun_out/<tag>_*) into small committed summaries under profiles/.
 
-    python profiles/summarize.py r01a        # reads gpurun_out/r01a_*, writes profiles/r01a_*.{csv,json}
+    python profiles/summarize.py r02a        # reads gpurun_out/r02a_*, writes profiles/r02a_*.{csv,json} and
+                                             # profiles/pmc_counters.json (read by bench.py while csrc is unchanged)
 """
 import collections
 import csv
@@ -11,9 +12,12 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 tag = sys.argv[1]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
+LEG_KERNEL = {"forward": "k_forward_straight_u<double>", "adjoint": "k_adjoint_straight_tile<double, 1, 4, false>",
+              "cubic_forward": "k_forward_straight_lm"}
 
 
 def short(name):
@@ -22,7 +26,7 @@ def short(name):
 
 
 # kernel stats (rocprofv3 --kernel-trace --stats)
-for f in glob.glob(os.path.join(G, tag + "_stats*", "*", "*_kernel_stats.csv")):
+for f in sorted(glob.glob(os.path.join(G, tag + "_stats_*", "*", "*_kernel_stats.csv"))):
     rows = list(csv.DictReader(open(f)))
     out = os.path.join(P, "%s_kernel_stats.csv" % os.path.basename(os.path.dirname(os.path.dirname(f))))
     with open(out, "w") as fh:
@@ -31,34 +35,37 @@ for f in glob.glob(os.path.join(G, tag + "_stats*", "*", "*_kernel_stats.csv")):
             fh.write('"%s",%s,%s,%s,%s,%s,%s,%s\n' % (short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"],
                                                       r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]))
     print("wrote", out)
+for f in sorted(glob.glob(os.path.join(G, tag + "_stats_*.json")) + glob.glob(os.path.join(G, tag + "_bench.json"))):
+    try:
+        line = [l for l in open(f).read().splitlines() if l.startswith("{")][-1]
+        json.dump(json.loads(line), open(os.path.join(P, os.path.basename(f)), "w"), indent=1)
+    except Exception as exc:
+        print("skip", f, exc)
 
-# PMC passes: per kernel, per counter, split by grid size (large = the per-GPU batch launches)
-pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+# PMC passes: per leg, per kernel, per counter (mean over the launches of the pass, largest grid only)
+legs = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
 for f in glob.glob(os.path.join(G, tag + "_pmc_*", "*", "*_counter_collection.csv")):
+    leg = os.path.basename(os.path.dirname(os.path.dirname(f)))[len(tag) + 5:].rsplit("_", 1)[0]
     for r in csv.DictReader(open(f)):
         key = "%s|grid=%s" % (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
-        pmc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        legs[leg][key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 summary = {}
-for k, cs in sorted(pmc.items()):
-    if not k.startswith("k_"):
-        continue
-    summary[k] = {c: {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for c, v in cs.items()}
+for leg, ks in legs.items():
+    summary[leg] = {k: {c: {"launches": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for c, v in cs.items()}
+                    for k, cs in sorted(ks.items()) if k.startswith("k_")}
 if summary:
     out = os.path.join(P, "%s_pmc_summary.json" % tag)
     json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
     print("wrote", out)
-
-# HBM traffic of the headline forward launch for bench.py's roofline.traffic: FETCH_SIZE / WRITE_SIZE are in
-# KiB; on gfx950 FETCH_SIZE reports half the bytes of wide (16 B/lane) coalesced reads -> doubled
-# (MI355X_MICROARCH.md, HBM section).  Only the full-batch launches (largest grid) are used.
-fwd = [(k, v) for k, v in summary.items() if k.startswith("k_forward_straight_u<double>")]
-if fwd:
-    k, v = max(fwd, key=lambda kv: int(kv[0].split("grid=")[1]))
-    if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-        traffic = 2.0 * v["FETCH_SIZE"]["mean"] * 1024 + v["WRITE_SIZE"]["mean"] * 1024
-        out = os.path.join(P, "pmc_forward.json")
-        json.dump({"rays_per_launch": 260400, "samples_per_ray": 257, "hbm_bytes_per_launch": traffic,
-                   "fetch_size_kib": v["FETCH_SIZE"]["mean"], "write_size_kib": v["WRITE_SIZE"]["mean"],
-                   "kernel": k, "source": "profiles/%s_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
-                                          "FETCH_SIZE doubled per the gfx950 correction)" % tag}, open(out, "w"), indent=1)
-        print("wrote", out)
+    import bench
+    pc = {"csrc_sha": bench.csrc_sha(),
+          "source": "profiles/%s_pmc_summary.json: rocprofv3 --pmc, one counter set per run of `bench.py --only <leg>`, mean over the "
+                    "launches of the leg's kernel (largest grid)" % tag}
+    for leg, kname in LEG_KERNEL.items():
+        cand = [(k, v) for k, v in summary.get(leg, {}).items() if k.startswith(kname)]
+        if not cand:
+            continue
+        k, v = max(cand, key=lambda kv: int(kv[0].split("grid=")[1]))
+        pc[leg] = dict({c: x["mean"] for c, x in v.items()}, rays=bench.NA * bench.ND * bench.NT, Ns=bench.NS, kernel=k)
+    json.dump(pc, open(os.path.join(P, "pmc_counters.json"), "w"), indent=1, sort_keys=True)
+    print("wrote profiles/pmc_counters.json for csrc", pc["csrc_sha"])
