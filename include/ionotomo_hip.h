@@ -187,6 +187,24 @@ int iono_walk_partition_set(iono_ctx *ctx, int which, const int64_t *starts, int
  * model update m <- m - eps (...), geometry/oct_trees/Inversion.py:533 -- never visit the host. */
 int iono_vec_axpby_dev(iono_ctx *ctx, double *y_dev, const double *x_dev, int64_t n, const double *a_num_dev,
                        const double *a_den_dev, double a_sign, const double *b_num_dev, const double *b_den_dev);
+/* ---- the phase observable on the device (inversion/iterative_newton.py:86-127) and its adjoint ------------------------
+ * g[a,t,d,l] = const[a] + 2 pi nu_l clock[a,t] - (2 pi nu_l / c) (phi[a,t,d,l] - phi[i0,t,d,l]),
+ * phi = int (1 - sqrt(1 - ne / n_p)) ds along straight rays whose samples are generated in-kernel (the reference's
+ * rays[Na,Nt,Nd,4,Ns] never exists); grid holds ne = K exp(mu).  freqs is a HOST array (Nf), everything else device.
+ * phi_work_dev: R x Nf doubles of scratch. */
+int iono_forward_phase_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int Na, int Nt,
+                                    int Nd, double tmax, int Ns, const double *freqs_host, int Nf, const double *clock_dev,
+                                    const double *const_dev, int i0, int quad_rule, double *phi_work_dev, double *g_dev);
+/* grad (+)= d/d ne [ sum y[r,l] g[r,l] ]  for y = dS/dg (e.g. (g - dobs)/CdCt, iterative_newton.py:32-38): the trilinear
+ * transpose with the per-sample factor sum_l w_{r,l} / (2 n_p,l sqrt(1 - ne_k / n_p,l)), forward gather and scatter in ONE
+ * traversal; w = -(2 pi nu / c) x differential weights of y (reference-antenna differencing).  wrt_log_model: multiply by
+ * ne at the nodes afterwards (d/d mu; grad_dev must then have been zero).  grad_dev float64[nx ny nz];
+ * wrf_work_dev: R x Nf doubles of scratch. */
+int iono_adjoint_phase_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
+                                    const int *order_dev, const double *y_dev, int Na, int64_t NtNd, double tmax, int Ns,
+                                    const double *freqs_host, int Nf, int i0, int quad_rule, double *wrf_work_dev,
+                                    int wrt_log_model, double *grad_dev);
+
 /* ---- fused vector passes of the inversion loop (ionotomo_amd/csrc/iono_solver_kernels.h).  A CGLS / SIRT iteration
  *      (objective / step lengths: inversion/iterative_newton.py:32-38,542-554; normalisations:
  *      geometry/oct_trees/Inversion.py:533,559,564) is the two ray kernels + these.  Device scalars are passed as

@@ -238,25 +238,40 @@ __device__ __forceinline__ void wave_prefix_minmax(double v, double &p8, double 
 constexpr int ADJ_REF = 16;     // doubles per wave in the bundle scratch: [4,5,7] sums, [8..15] box of its 64 lanes
 constexpr int ADJ_SUB = 24;     // + wave 0's boxes of its first 32 / 16 / 8 lanes (kept small: 4 workgroups per CU)
 
+__device__ __forceinline__ double phase_factor(double ne, const double (&wl)[8], const PhaseFreqs &pf);
 struct AdjRay {
     URay u;
     double scale;
+    double pw[8];       // PHASE: per-frequency weights of the ray (wrf[r][l])
 };
 // lane-parallel load of `q` rays per wave starting at walk position qw (lanes >= cnt idle)
 __device__ __forceinline__ URay load_uray_cubic(const GridView &g, const double *origins, const double *dirs, int64_t r,
                                                 double tmax, int Ns);
-template <int MODE, bool CUBIC = false>
+template <int MODE, bool CUBIC = false, bool PHASE = false>
 __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *origins, const double *dirs, const int *order,
                                                const double *wray, const double *tec, const double *dobs, const double *cdct,
                                                int Na, int64_t NtNd, int i0, int64_t q, bool active, double tmax, int Ns,
-                                               bool &oob) {
+                                               bool &oob, int nf = 0, int ldw = 0) {
     AdjRay a;
     a.u = URay{};
     a.scale = 0.0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) a.pw[l] = 0.0;
     if (active) {
         const int64_t r = order ? (int64_t)order[q] : q;
         a.u = CUBIC ? load_uray_cubic(g, origins, dirs, r, tmax, Ns) : load_uray(g, origins, dirs, r, tmax, Ns);
-        const double wr = MODE == 0 ? wray[r] : residual_weight<MODE>(tec, dobs, cdct, Na, NtNd, i0, r);
+        double wr;
+        if (PHASE) {                 // `wray` is wrf[R][ldw]; the per-sample factor is applied at the scatter
+            bool any = false;
+#pragma unroll
+            for (int l = 0; l < 8; ++l) {
+                if (l < nf) a.pw[l] = wray[(size_t)r * ldw + l];
+                any |= a.pw[l] != 0.0;
+            }
+            wr = any ? 1.0 : 0.0;
+        } else {
+            wr = MODE == 0 ? wray[r] : residual_weight<MODE>(tec, dobs, cdct, Na, NtNd, i0, r);
+        }
         if (a.u.valid) a.scale = wr * a.u.h; else oob = true;
     }
     return a;
@@ -273,7 +288,7 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <typename AT, int MODE, int NW, bool CUBIC = false>
+template <typename AT, int MODE, int NW, bool CUBIC = false, bool PHASE = false, typename GT = double>
 __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, const double *__restrict__ origins,
                                                                const double *__restrict__ dirs, const int *__restrict__ order,
                                                                const double *__restrict__ wray, const double *__restrict__ tec,
@@ -282,7 +297,8 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                                                                int dbg, const double *__restrict__ unitw, AT *__restrict__ G,
                                                                int *oob_flag, const int64_t *__restrict__ part, int n_chunks,
                                                                unsigned int *__restrict__ chunk_counter,
-                                                               unsigned long long *__restrict__ blk_cycles, int field = -1) {
+                                                               unsigned long long *__restrict__ blk_cycles, int field = -1,
+                                                               PhaseFreqs pf = PhaseFreqs{}, int ldw = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][ADJ_REF] per-wave sums and bounding boxes
@@ -297,6 +313,8 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     const bool tail_by_lane = (Ns - ntail0) <= 8;
     const int nslab = tail_by_lane ? nfull : nfull + 1;
     const double klast = (double)(Ns - 1);
+    // PHASE: corner columns of the stored values (the per-sample factor needs the interpolated ne)
+    const GT *pb00 = (const GT *)g.M, *pb01 = pb00 + g.nz, *pb10 = pb00 + (size_t)g.ny * g.nz, *pb11 = pb10 + g.nz;
     // Contiguous chunks of the walk per workgroup.  Without `part`: one chunk of equal ray count each (XCD-major).
     // With `part` (n_chunks + 1 boundaries from iono_walk_partition_set, cost-balanced from measured cycles):
     // chunk b goes to workgroup b, and the remaining -- progressively smaller -- chunks are handed out through an
@@ -320,8 +338,8 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
         int q = 64;                                     // rays per wave
         int64_t qw = q0 + (int64_t)q * wid;
         int cnt = (int)max((int64_t)0, min((int64_t)q, min(hi, q0 + (int64_t)cw) - qw));
-        AdjRay a = load_adj_ray<MODE, CUBIC>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
-                                      Ns, oob);
+        AdjRay a = load_adj_ray<MODE, CUBIC, PHASE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt,
+                                             tmax, Ns, oob, pf.nf, ldw);
         int c = 64 * NW;
         for (int round = 0; round < 2; ++round) {
             // per-wave sums (for the mean ray) and bounding boxes at the bottom / top of the rays, for the wave's
@@ -383,15 +401,17 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
             q = c / NW;
             qw = q0 + (int64_t)q * wid;
             cnt = (int)max((int64_t)0, min((int64_t)q, hi - qw));
-            a = load_adj_ray<MODE, CUBIC>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax, Ns,
-                                   oob);
+            a = load_adj_ray<MODE, CUBIC, PHASE>(g, origins, dirs, order, wray, tec, dobs, cdct, Na, NtNd, i0, qw + lane, lane < cnt, tmax,
+                                                 Ns, oob, pf.nf, ldw);
         }
         q0 += c;
         if (a.scale != 0.0 && tail_by_lane && nslab == 0) {  // fewer than 9 samples in all: straight to global memory
             for (int k = ntail0; k < Ns; ++k) {
                 const double kd = (double)k;
-                scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, -(1 << 28), fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
-                                                fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k], dbg, field);
+                const double sfx = fma(kd, a.u.dfx, a.u.fx0), sfy = fma(kd, a.u.dfy, a.u.fy0), sfz = fma(kd, a.u.dfz, a.u.fz0);
+                double cw = a.scale * wlds[k];
+                if (PHASE) cw *= phase_factor(trilinear_u<GT>(pb00, pb01, pb10, pb11, g.ny, g.nz, sfx, sfy, sfz), a.pw, pf);
+                scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, -(1 << 28), sfx, sfy, sfz, cw, dbg, field);
             }
         }
         double nlive = 0.0, sz0 = 0.0, sdz = 0.0;
@@ -427,9 +447,17 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                 const int k = k0 + lane;
                 if (k < Ns && (tail_by_lane ? k < ntail0 : true)) {
                     const double kd = (double)k;
-                    scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, kz0, fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
-                                                    fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
-                                                    fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi)), sc * wlds[k], dbg, field);
+                    const double sfx = fma(kd, bcast_lane(a.u.dfx, gi), bcast_lane(a.u.fx0, gi)),
+                                 sfy = fma(kd, bcast_lane(a.u.dfy, gi), bcast_lane(a.u.fy0, gi)),
+                                 sfz = fma(kd, bcast_lane(a.u.dfz, gi), bcast_lane(a.u.fz0, gi));
+                    double cw = sc * wlds[k];
+                    if (PHASE) {
+                        double wl[8];
+#pragma unroll
+                        for (int l = 0; l < 8; ++l) wl[l] = bcast_lane(a.pw[l], gi);
+                        cw *= phase_factor(trilinear_u<GT>(pb00, pb01, pb10, pb11, g.ny, g.nz, sfx, sfy, sfz), wl, pf);
+                    }
+                    scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, kz0, sfx, sfy, sfz, cw, dbg, field);
                 }
             }
             if (tail_by_lane && it == nslab - 1 && a.scale != 0.0) {
@@ -437,8 +465,10 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                 // (anything that still falls outside goes to global memory as everywhere else)
                 for (int k = ntail0; k < Ns; ++k) {
                     const double kd = (double)k;
-                    scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, kz0, fma(kd, a.u.dfx, a.u.fx0), fma(kd, a.u.dfy, a.u.fy0),
-                                                    fma(kd, a.u.dfz, a.u.fz0), a.scale * wlds[k], dbg, field);
+                    const double sfx = fma(kd, a.u.dfx, a.u.fx0), sfy = fma(kd, a.u.dfy, a.u.fy0), sfz = fma(kd, a.u.dfz, a.u.fz0);
+                    double cw = a.scale * wlds[k];
+                    if (PHASE) cw *= phase_factor(trilinear_u<GT>(pb00, pb01, pb10, pb11, g.ny, g.nz, sfx, sfy, sfz), a.pw, pf);
+                    scatter_sample_tiled<AT, CUBIC>(g, tile, G, I0, J0, kz0, sfx, sfy, sfz, cw, dbg, field);
                 }
             }
             lds_barrier();
@@ -464,6 +494,50 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     chunk = *next_chunk;
     if (chunk >= n_chunks) break;
   }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- adjoint of the phase observable (inversion/iterative_newton.py:86-127) w.r.t. the node values ne ------------------
+// phi_{r,l} = sum_k c_k f_l(ne_k),  f_l(ne) = 1 - sqrt(1 - ne / n_p,l),  ne_k = sum_v W_kv ne_v   =>
+//   d/d ne_v  sum_{r,l} wrf_{r,l} phi_{r,l} = sum_r sum_k c_k q_{r,k} W_kv,   q_{r,k} = sum_l wrf_{r,l} / (2 n_p,l sqrt(1 - ne_k / n_p,l))
+// i.e. the trilinear scatter with a per-SAMPLE factor that needs the interpolated value: forward gather and transpose
+// scatter in one traversal.  General tier (any grid, plain hardware atomics).
+__device__ __forceinline__ double phase_factor(double ne, const double (&wl)[8], const PhaseFreqs &pf) {
+    double q = 0.0;
+#pragma unroll
+    for (int l = 0; l < 8; ++l) q += wl[l] * (0.5 * pf.inv_np[l]) * rsqrt(1.0 - ne * pf.inv_np[l]);
+    return q;
+}
+template <typename GT, typename AT>
+__global__ __launch_bounds__(256) void k_adjoint_phase_straight(GridView g, const double *__restrict__ origins,
+                                                                const double *__restrict__ dirs, const double *__restrict__ wrf,
+                                                                int ldw, PhaseFreqs pf, int64_t R, double tmax, int Ns,
+                                                                const double *__restrict__ unitw, AT *__restrict__ G, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        double wl[8];
+        bool any = false;
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            wl[l] = l < pf.nf ? wrf[(size_t)w.r * ldw + l] : 0.0;
+            any |= wl[l] != 0.0;
+        }
+        if (!any) continue;
+        const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+        for (int k = lane; k < Ns; k += 64) {
+            double x, y, z;
+            straight_point(q, k, Ns, x, y, z);
+            if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                oob = true;
+                continue;
+            }
+            const double ne = trilinear_at<GT>(g, ax, x, y, z);
+            scatter_trilinear<AT>(g, ax, G, x, y, z, q.h * unitw[k] * phase_factor(ne, wl, pf));
+        }
+    }
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 

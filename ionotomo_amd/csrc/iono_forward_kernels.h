@@ -430,6 +430,90 @@ __global__ __launch_bounds__(256) void k_forward_phase_rays(GridView g, const do
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
+// The same observable with the samples generated in-kernel on straight z-parametrised rays (rays[R,4,Ns] never
+// exists): phi[r][l] = h_r sum_k w_k (1 - sqrt(1 - ne_k / n_p,l)).  IDEAL: ideal-uniform grid coordinates (one fma per
+// axis, unclamped corner loads); otherwise axis tables in LDS and the exact searchsorted cell rule.
+struct PhaseFreqs {
+    double inv_np[8];      // 1 / (1.2404e-2 nu^2)  (iterative_newton.py:112)
+    int nf;
+};
+template <typename GT, bool IDEAL>
+__global__ __launch_bounds__(256) void k_forward_phase_straight(GridView g, const double *__restrict__ origins,
+                                                                const double *__restrict__ dirs, int64_t R, double tmax, int Ns,
+                                                                const double *__restrict__ unitw, PhaseFreqs pf, int ldf,
+                                                                double *__restrict__ phi, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    Axes ax = {};
+    if (!IDEAL) ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
+    bool oob = false;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        double acc[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) acc[l] = 0.0;
+        double h;
+        if (IDEAL) {
+            const URay u = load_uray(g, origins, dirs, w.r, tmax, Ns);
+            h = u.h;
+            if (!u.valid) {
+                oob = true;
+                if (lane < pf.nf) phi[(size_t)w.r * ldf + lane] = nan("");
+                continue;
+            }
+            for (int k = lane; k < Ns; k += 64) {
+                const double kd = (double)k;
+                const double ne = trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fma(kd, u.dfx, u.fx0), fma(kd, u.dfy, u.fy0),
+                                                  fma(kd, u.dfz, u.fz0));
+                const double c = unitw[k];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] += c * (1.0 - sqrt(1.0 - ne * pf.inv_np[l]));
+            }
+        } else {
+            const StraightRay q = load_straight(origins, dirs, w.r, tmax, Ns);
+            h = q.h;
+            for (int k = lane; k < Ns; k += 64) {
+                double x, y, z;
+                straight_point(q, k, Ns, x, y, z);
+                if (sample_outside<IONO_INTERP_TRILINEAR>(ax, x, y, z)) {
+                    oob = true;
+                    continue;
+                }
+                const double ne = trilinear_at<GT>(g, ax, x, y, z);
+                const double c = unitw[k];
+#pragma unroll
+                for (int l = 0; l < 8; ++l) acc[l] += c * (1.0 - sqrt(1.0 - ne * pf.inv_np[l]));
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < 8; ++l) {
+            const double v = wave_sum(acc[l]);
+            if (lane == 0 && l < pf.nf) phi[(size_t)w.r * ldf + l] = v * h;
+        }
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// transpose of k_phase_finish w.r.t. phi: per-ray, per-frequency weights of the phase adjoint
+//   wrf[r][l] = -(2 pi nu_l / c) (y[r][l] - [a == i0] sum_a' y[a', p][l]),   y = dS/dg
+__global__ void k_phase_weights(const double *__restrict__ y, const double *__restrict__ freqs, int Na, int64_t NtNd, int Nf, int i0,
+                                double *__restrict__ wrf) {
+    const int64_t n = (int64_t)Na * NtNd * Nf;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int l = idx % Nf;
+        const int64_t r = idx / Nf;
+        const int64_t p = r % NtNd;
+        const int a = (int)(r / NtNd);
+        double v = y[idx];
+        if (a == i0) {
+            double s = 0.0;
+            for (int a2 = 0; a2 < Na; ++a2) s += y[((int64_t)a2 * NtNd + p) * Nf + l];
+            v -= s;
+        }
+        wrf[idx] = -(2.0 * M_PI * freqs[l] / SPEED_OF_LIGHT) * v;
+    }
+}
+
 // g = const_i + 2 pi nu clock_ij - (phi - phi[i0]) 2 pi nu / c   (inversion/iterative_newton.py:107-123)
 __global__ void k_phase_finish(const double *__restrict__ phi, const double *__restrict__ freqs,
                                const double *__restrict__ clock, const double *__restrict__ cst, int Na, int Nt, int Nd,

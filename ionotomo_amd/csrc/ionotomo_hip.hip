@@ -91,6 +91,8 @@ struct iono_ctx {
     double *d_F8 = nullptr;          // Lekien-Marsden derivative fields [node][8] of the current values (lazily built)
     bool F8_valid = false;
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
+    double *d_freqs = nullptr;       // frequencies of the phase observable on the device (cached copy of h_freqs)
+    std::vector<double> h_freqs;
 };
 
 namespace {
@@ -390,6 +392,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->d_F8) (void)hipFree(c->d_F8);
     if (c->d_G8) (void)hipFree(c->d_G8);
+    if (c->d_freqs) (void)hipFree(c->d_freqs);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
     for (auto &wp : c->walk) {
@@ -838,14 +841,14 @@ int iono_walk_partition_set(iono_ctx *c, int which, const int64_t *starts, int n
 }  // extern "C"  (templates below need C++ linkage)
 
 // One launch of the LDS-tiled back-projection (ideal-uniform grids).  CUBIC: channel `field` of the tricubic transpose.
-template <typename AT, int MODE, bool CUBIC>
+template <typename AT, int MODE, bool CUBIC, bool PHASE = false, typename GT = double>
 static int launch_adjoint_tile(iono_ctx *c, const GridView &g, const double *o, const double *d, const int *order, const double *w,
                                const double *tec, const double *dobs, const double *cdct, int Na, int64_t NtNd, int i0, int64_t R,
-                               double tmax, int Ns, AT *grad, int field) {
+                               double tmax, int Ns, AT *grad, int field, PhaseFreqs pf = PhaseFreqs{}, int ldw = 0) {
     constexpr int NW = 4;    // waves per workgroup (8 waves sharing one tile, bundles of 128: measured 8 % slower)
     const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + (ADJ_REF * NW + ADJ_SUB) * sizeof(double) +
                       sizeof(AT) * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
-    const int per_cu = blocks_per_cu(k_adjoint_straight_tile<AT, MODE, NW, CUBIC>, 64 * NW, tl, 1);
+    const int per_cu = blocks_per_cu(k_adjoint_straight_tile<AT, MODE, NW, CUBIC, PHASE, GT>, 64 * NW, tl, 1);
     int nb = per_cu * c->num_cus;
     const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);   // at least ~64 rays per workgroup
     if (nb > nbund) nb = (int)nbund;
@@ -857,9 +860,9 @@ static int launch_adjoint_tile(iono_ctx *c, const GridView &g, const double *o, 
     if (rc) return rc;
     if (!c->d_chunk_counter) HIP_TRY(c, hipMalloc((void **)&c->d_chunk_counter, 4));
     if (use_part) HIP_TRY(c, hipMemsetAsync(c->d_chunk_counter, 0, 4, c->stream));
-    hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE, NW, CUBIC>), dim3(nb), dim3(64 * NW), tl, c->stream, g, o, d, order, w,
-                       tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->adj_mode, c->d_unitw, grad, c->d_flags,
-                       use_part ? wp.d_starts : nullptr, nchunks, c->d_chunk_counter, wp.d_cyc, field);
+    hipLaunchKernelGGL((k_adjoint_straight_tile<AT, MODE, NW, CUBIC, PHASE, GT>), dim3(nb), dim3(64 * NW), tl, c->stream, g, o, d,
+                       order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, c->adj_mode, c->d_unitw, grad, c->d_flags,
+                       use_part ? wp.d_starts : nullptr, nchunks, c->d_chunk_counter, wp.d_cyc, field, pf, ldw);
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
 }
@@ -956,6 +959,102 @@ int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int6
         if (kind == IONO_INTERP_TRILINEAR) LAUNCH_AR(float, IONO_INTERP_TRILINEAR); else LAUNCH_AR(float, IONO_INTERP_TRICUBIC);
     }
 #undef LAUNCH_AR
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+// ---- phase observable on the device (inversion/iterative_newton.py:86-127) and its adjoint -------------------------------
+static int phase_freqs_dev(iono_ctx *c, const double *freqs, int Nf) {
+    if (!freqs || Nf < 1 || Nf > 4096) return fail(c, IONO_ERR_ARG, "bad frequency list");
+    for (int l = 0; l < Nf; ++l)
+        if (!(freqs[l] > 0)) return fail(c, IONO_ERR_ARG, "frequencies must be positive");
+    if (c->d_freqs && (int)c->h_freqs.size() == Nf && std::equal(freqs, freqs + Nf, c->h_freqs.begin())) return IONO_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->d_freqs) (void)hipFree(c->d_freqs);
+    c->d_freqs = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&c->d_freqs, sizeof(double) * Nf));
+    HIP_TRY(c, hipMemcpy(c->d_freqs, freqs, sizeof(double) * Nf, hipMemcpyHostToDevice));
+    c->h_freqs.assign(freqs, freqs + Nf);
+    return IONO_OK;
+}
+static PhaseFreqs phase_chunk(const double *freqs, int f0, int Nf) {
+    PhaseFreqs pf;
+    pf.nf = std::min(8, Nf - f0);
+    for (int l = 0; l < 8; ++l) pf.inv_np[l] = l < pf.nf ? 1.0 / (1.2404e-2 * freqs[f0 + l] * freqs[f0 + l]) : 0.0;     // iterative_newton.py:112
+    return pf;
+}
+
+int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *d, int Na, int Nt, int Nd, double tmax, int Ns,
+                                    const double *freqs, int Nf, const double *clock, const double *cst, int i0, int rule,
+                                    double *phi_work, double *gout) {
+    const int64_t R = (int64_t)Na * Nt * Nd;
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    if (rc) return rc;
+    if (i0 < 0 || i0 >= Na || !clock || !cst || !phi_work || !gout) return fail(c, IONO_ERR_ARG, "iono_forward_phase_straight_dev: bad argument");
+    rc = phase_freqs_dev(c, freqs, Nf);
+    if (rc) return rc;
+    if (R == 0) return IONO_OK;
+    rc = ensure_unitw(c, Ns, rule);
+    if (rc) return rc;
+    const GridView g = view(c);
+    const dim3 grid(ray_grid_blocks(c, R)), block(256);
+    const bool ideal = ideal_path_ok(c, Ns);
+    for (int f0 = 0; f0 < Nf; f0 += 8) {
+        const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
+        dispatch_storage(c, [&](auto *tag) {
+            using GT = std::remove_pointer_t<decltype(tag)>;
+            if (ideal)
+                hipLaunchKernelGGL((k_forward_phase_straight<GT, true>), grid, block, 0, c->stream, g, o, d, R, tmax, Ns, c->d_unitw, pf,
+                                   Nf, phi_work + f0, c->d_flags);
+            else
+                hipLaunchKernelGGL((k_forward_phase_straight<GT, false>), grid, block, lds_bytes(c), c->stream, g, o, d, R, tmax, Ns,
+                                   c->d_unitw, pf, Nf, phi_work + f0, c->d_flags);
+            return IONO_OK;
+        });
+    }
+    hipLaunchKernelGGL(k_phase_finish, dim3(ew_blocks(c, R * Nf)), dim3(256), 0, c->stream, phi_work, c->d_freqs, clock, cst, Na, Nt,
+                       Nd, Nf, i0, gout);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, const double *y, int Na,
+                                    int64_t NtNd, double tmax, int Ns, const double *freqs, int Nf, int i0, int rule,
+                                    double *wrf_work, int wrt_log_model, double *grad) {
+    const int64_t R = (int64_t)Na * NtNd;
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
+    if (rc) return rc;
+    if (i0 < 0 || i0 >= Na || !y || !wrf_work || !grad) return fail(c, IONO_ERR_ARG, "iono_adjoint_phase_straight_dev: bad argument");
+    rc = phase_freqs_dev(c, freqs, Nf);
+    if (rc) return rc;
+    if (R == 0) return IONO_OK;
+    rc = ensure_unitw(c, Ns, rule);
+    if (rc) return rc;
+    const GridView g = view(c);
+    hipLaunchKernelGGL(k_phase_weights, dim3(ew_blocks(c, R * Nf)), dim3(256), 0, c->stream, y, c->d_freqs, Na, NtNd, Nf, i0, wrf_work);
+    const bool tiled = ideal_path_ok(c, Ns) && c->variant != 2;
+    for (int f0 = 0; f0 < Nf; f0 += 8) {
+        const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
+        rc = dispatch_storage(c, [&](auto *tag) -> int {
+            using GT = std::remove_pointer_t<decltype(tag)>;
+            if (tiled)
+                return launch_adjoint_tile<double, 0, false, true, GT>(c, g, o, d, order, wrf_work + f0, nullptr, nullptr, nullptr, Na,
+                                                                       NtNd, i0, R, tmax, Ns, grad, -1, pf, Nf);
+            hipLaunchKernelGGL((k_adjoint_phase_straight<GT, double>), dim3(ray_grid_blocks(c, R)), dim3(256), lds_bytes(c), c->stream,
+                               g, o, d, wrf_work + f0, Nf, pf, R, tmax, Ns, c->d_unitw, grad, c->d_flags);
+            return IONO_OK;
+        });
+        if (rc) return rc;
+    }
+    if (wrt_log_model) {
+        const int64_t n = ncells(c);
+        dispatch_storage(c, [&](auto *tag) {
+            using GT = std::remove_pointer_t<decltype(tag)>;
+            hipLaunchKernelGGL((k_scale_by_grid<double, GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, grad,
+                               (const GT *)cur_values(c), n);
+            return IONO_OK;
+        });
+    }
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
 }

@@ -145,6 +145,35 @@ class RayEngine(object):
                       _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 
+    def forward_phase(self, origins_t, dirs_t, Na, Nt, Nd, tmax, Ns, freqs, clock_t, const_t, i0, out=None):
+        """g[Na,Nt,Nd,Nf] of inversion/iterative_newton.py:86-127 for straight rays (samples in-kernel); the grid must hold
+        ne = K exp(mu).  ``freqs``: host array; ``clock_t`` [Na,Nt], ``const_t`` [Na]: device tensors."""
+        self._sync_stream()
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        R = origins_t.shape[0]
+        assert R == Na * Nt * Nd
+        if out is None:
+            out = torch.empty((Na, Nt, Nd, freqs.size), dtype=torch.float64, device=self.device)
+        work = torch.empty(R * freqs.size, dtype=torch.float64, device=self.device)
+        self.ctx.call("iono_forward_phase_straight_dev", _ptr(origins_t), _ptr(dirs_t), int(Na), int(Nt), int(Nd), float(tmax),
+                      int(Ns), _lib._dp(freqs), freqs.size, _ptr(clock_t), _ptr(const_t), int(i0), self.rule, _ptr(work), _ptr(out))
+        return out
+
+    def adjoint_phase(self, origins_t, dirs_t, y_t, Na, tmax, Ns, freqs, i0, order=None, wrt_log_model=True, out=None):
+        """d/d mu (``wrt_log_model``) or d/d ne of sum y g for the phase observable: one traversal per 8 frequencies that
+        gathers ne at every sample and scatters the transpose.  ``y_t``: [Na, Nt*Nd, Nf] (= dS/dg)."""
+        self._sync_stream()
+        freqs = np.ascontiguousarray(freqs, dtype=np.float64)
+        R = origins_t.shape[0]
+        assert y_t.numel() == R * freqs.size and y_t.is_contiguous()
+        if out is None:
+            out = torch.zeros(self.shape, dtype=torch.float64, device=self.device)
+        work = torch.empty(R * freqs.size, dtype=torch.float64, device=self.device)
+        op = _lib._V(0) if order is None else _ptr(order)
+        self.ctx.call("iono_adjoint_phase_straight_dev", _ptr(origins_t), _ptr(dirs_t), op, _ptr(y_t), int(Na), R // Na, float(tmax),
+                      int(Ns), _lib._dp(freqs), freqs.size, int(i0), self.rule, _ptr(work), int(bool(wrt_log_model)), _ptr(out))
+        return out
+
     def trace_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=False, kind="linear", substeps=4, out=None, type="z"):
         """rays[R,4,Ns] (x,y,z,s) of the Fermat ray ODE, on the device; the grid must hold ne [m^-3]."""
         self._sync_stream()

@@ -361,6 +361,38 @@ def adjoint_tec(rays, xvec, yvec, zvec, w_ray, rule=QUAD_SIMPSON_AVG, kind=INTER
     return out.reshape(nx, ny, nz)
 
 
+def scatter_trilinear(rays, xvec, yvec, zvec, c):
+    """sum_{r,k} c[r,k] W_{k,v}: the trilinear transpose with arbitrary per-SAMPLE weights c[..., Ns]."""
+    nx, ny, nz = len(xvec), len(yvec), len(zvec)
+    i, tx = find_cell(xvec, rays[..., 0, :])
+    j, ty = find_cell(yvec, rays[..., 1, :])
+    k, tz = find_cell(zvec, rays[..., 2, :])
+    out = np.zeros(nx * ny * nz)
+    for di, wx in ((0, 1 - tx), (1, tx)):
+        for dj, wy in ((0, 1 - ty), (1, ty)):
+            for dk, wz in ((0, 1 - tz), (1, tz)):
+                idx = (k + dk) + nz * ((j + dj) + ny * (i + di))
+                out += np.bincount(idx.ravel(), weights=(c * wx * wy * wz).ravel(), minlength=out.size)
+    return out.reshape(nx, ny, nz)
+
+
+def gradient_phase(mu, xvec, yvec, zvec, rays, freqs, y, K=1e11, i0=0, rule=QUAD_SIMPSON_AVG, wrt_log_model=True):
+    """d/d mu (or d/d ne) of sum y[a,t,d,l] g[a,t,d,l] for the phase observable (forward_phase;
+    inversion/iterative_newton.py:86-127), y = dS/dg:
+      g = const + a_l clock - (a_l / c) (phi - phi[i0]),  phi_l = sum_k c_k (1 - sqrt(1 - ne_k / n_p,l))
+      d phi_l / d ne_v = sum_k c_k W_kv / (2 n_p,l sqrt(1 - ne_k / n_p,l))."""
+    ne = np.exp(mu) * K
+    ne_rays = trilinear(xvec, yvec, zvec, ne, rays[..., 0, :], rays[..., 1, :], rays[..., 2, :])
+    cq = quadrature_weights(rays[..., 3, :], rule)
+    q = np.zeros_like(ne_rays)
+    for l, nu in enumerate(freqs):
+        n_p = 1.2404e-2 * nu ** 2
+        wl = -(2 * np.pi * nu / SPEED_OF_LIGHT) * differential_weights(y[..., l], i0)
+        q += wl[..., None] * (0.5 / n_p) / np.sqrt(1.0 - ne_rays / n_p)
+    g = scatter_trilinear(rays, xvec, yvec, zvec, cq * q)
+    return g * ne if wrt_log_model else g
+
+
 def differential_weights(w, i0):
     """Transpose of ``tec - tec[i0]``:  w_r -> w_r - [a(r) == i0] sum_a w[a,t,d]."""
     w = np.array(w, float)

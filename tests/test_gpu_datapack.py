@@ -58,3 +58,57 @@ def test_device_realisation_equals_host_realisation():
     assert np.max(np.abs(dev.cpu().numpy() - host)) < 1e-10 * np.max(np.abs(host))
     fast = sim.realization_device(seed=123, host_draws=False)
     assert abs(float(fast.std(unbiased=False)) - 0.7) < 1e-12 and not torch.allclose(fast, dev)
+
+
+def test_phase_observable_on_the_device_and_its_adjoint():
+    """iono_forward_phase_straight_dev / iono_adjoint_phase_straight_dev (samples generated in-kernel, the reference's
+    rays[Na,Nt,Nd,4,Ns] never exists) against oracle.forward_phase / oracle.gradient_phase
+    (inversion/iterative_newton.py:86-127): ideal-uniform grid (LDS-tiled transpose) and a non-uniform one (general
+    tier), 3 and 10 frequencies (two passes of 8), with / without walk order, plus a finite-difference check."""
+    import torch
+    from oracle import oracle as O
+    from ionotomo_amd.engine import RayEngine
+    from ionotomo_amd import synthetic as syn
+    rng = np.random.default_rng(0)
+    w = syn.make_workload(antennas="lofar", na=12, nd=5, nt=3, n=40)
+    na, nt, nd = 12, 3, 5
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    xv_nu = w["xvec"] + 0.2 * (w["xvec"][1] - w["xvec"][0]) * np.sin(np.arange(40))        # a non-uniform variant of the x axis
+    for xv, Ns in ((w["xvec"], 65), (w["xvec"], 70), (xv_nu, 33)):
+        for freqs in (np.array([120e6, 150e6, 180e6]), np.linspace(110e6, 190e6, 10)):
+            eng = RayEngine(0)
+            eng.set_grid(xv, w["yvec"], w["zvec"])
+            mu = np.log(w["ne"] / 1e11) + 0.05 * rng.normal(size=w["ne"].shape)
+            eng.set_log_model(eng.tensor(mu), 1e11)
+            clock, const = rng.normal(size=(na, nt)) * 1e-9, rng.normal(size=na)
+            ot, dt = eng.tensor(o), eng.tensor(d)
+            g = eng.forward_phase(ot, dt, na, nt, nd, w["tmax"], Ns, freqs, eng.tensor(clock), eng.tensor(const), 2).cpu().numpy()
+            assert not eng.check_oob()
+            rays = O.straight_rays(w["origins"], w["directions"], w["tmax"], Ns)
+            ref = O.forward_phase(mu, clock, const, xv, w["yvec"], w["zvec"], rays, freqs, K=1e11, i0=2)
+            assert np.max(np.abs(g - ref)) < 1e-11 * np.max(np.abs(ref))
+            y = rng.normal(size=ref.shape)
+            gref = O.gradient_phase(mu, xv, w["yvec"], w["zvec"], rays, freqs, y, K=1e11, i0=2)
+            yt = eng.tensor(y.reshape(na, nt * nd, freqs.size))
+            order = eng.locality_order(ot, dt, w["tmax"])
+            for ordr in (None, order):
+                gg = eng.adjoint_phase(ot, dt, yt, na, w["tmax"], Ns, freqs, 2, order=ordr).cpu().numpy()
+                assert np.max(np.abs(gg - gref)) < 1e-10 * np.max(np.abs(gref))
+            gne = eng.adjoint_phase(ot, dt, yt, na, w["tmax"], Ns, freqs, 2, wrt_log_model=False).cpu().numpy()
+            assert np.max(np.abs(gne * np.exp(mu) * 1e11 - gref)) < 1e-10 * np.max(np.abs(gref))
+    # finite difference of S = 1/2 sum (g - dobs)^2 / CdCt through the device path
+    dobs, CdCt = ref + rng.normal(size=ref.shape) * 0.1, rng.uniform(0.5, 2.0, size=ref.shape) * 0.01
+    ct, kt = eng.tensor(clock), eng.tensor(const)
+
+    def S(m):
+        eng.set_log_model(eng.tensor(m), 1e11)
+        gm = eng.forward_phase(ot, dt, na, nt, nd, w["tmax"], Ns, freqs, ct, kt, 2).cpu().numpy()
+        return 0.5 * np.sum((gm - dobs) ** 2 / CdCt), gm
+    S0, g0 = S(mu)
+    grad = eng.adjoint_phase(ot, dt, eng.tensor(((g0 - dobs) / CdCt).reshape(na, nt * nd, freqs.size)), na, w["tmax"], Ns, freqs,
+                             2).cpu().numpy()
+    for f in np.argsort(-np.abs(grad.ravel()))[:4]:
+        e = np.zeros(mu.size)
+        e[f] = 1e-5
+        fd = (S(mu + e.reshape(mu.shape))[0] - S(mu - e.reshape(mu.shape))[0]) / 2e-5
+        assert abs(fd - grad.ravel()[f]) < 1e-4 * abs(grad.ravel()[f]) + 1e-8

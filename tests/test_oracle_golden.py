@@ -118,6 +118,27 @@ def test_phase_forward_and_objective(golden):
     assert abs(S - float(g["S"])) < 1e-12 * abs(float(g["S"]))
 
 
+def test_phase_gradient_finite_difference():
+    """oracle.gradient_phase = d/d mu of S = 1/2 sum (g - dobs)^2 / CdCt for the phase observable."""
+    w = syn.make_workload(antennas="example", na=4, nd=3, nt=2, n=10)
+    rays = O.straight_rays(w["origins"], w["directions"], w["tmax"], 11)
+    rng = np.random.default_rng(0)
+    freqs = np.array([120e6, 150e6, 180e6])
+    clock, const = rng.normal(size=(4, 2)) * 1e-9, rng.normal(size=4)
+    mu = np.log(w["ne"] / 1e11)
+    g0 = O.forward_phase(mu, clock, const, w["xvec"], w["yvec"], w["zvec"], rays, freqs, K=1e11, i0=1)
+    dobs = g0 + rng.normal(size=g0.shape) * 0.1
+    CdCt = rng.uniform(0.5, 2.0, size=g0.shape) * 0.01
+    S = lambda m: O.neg_log_like(O.forward_phase(m, clock, const, w["xvec"], w["yvec"], w["zvec"], rays, freqs, K=1e11, i0=1), dobs, CdCt)
+    grad = O.gradient_phase(mu, w["xvec"], w["yvec"], w["zvec"], rays, freqs, (g0 - dobs) / CdCt, K=1e11, i0=1)
+    flat = np.argsort(-np.abs(grad.ravel()))[:6]
+    for f in flat:
+        e = np.zeros(mu.size)
+        e[f] = 1e-5
+        fd = (S(mu + e.reshape(mu.shape)) - S(mu - e.reshape(mu.shape))) / 2e-5
+        assert abs(fd - grad.ravel()[f]) < 5e-5 * abs(grad.ravel()[f]) + 1e-9      # central difference of a 1e4-sized objective
+
+
 def test_shipped_chord_gradient(golden):
     g = golden("ray_dirac")
     dirac = O.ray_dirac(g["rays"], g["xvec"], g["yvec"], g["zvec"])
