@@ -54,7 +54,10 @@ class GradientExchange(object):
     then exact to ~1e-7 relative (the solvers' iterates change at that level)."""
 
     def __init__(self, mode="auto", reduce_dtype=None, dense_above=0.6):
-        assert mode in ("dense", "compact", "auto")
+        assert mode in ("dense", "compact", "auto", "sharded")
+        self.sharded = mode == "sharded"        # fused solvers: reduce-scatter + sharded update + all-gather (below)
+        if self.sharded:
+            mode = "compact"
         self.mode, self.reduce_dtype, self.dense_above = mode, reduce_dtype, float(dense_above)
         self.index = None          # int64 [n_active] flat node indices, identical on every rank
         self.fraction = 1.0
@@ -162,6 +165,29 @@ class ShardedRays(object):
         """out_full += (local rays) A^T (scale o v): fused differential weights + back-projection, no exchange."""
         return self.engine.adjoint_differential(self.origins, self.dirs, v, scale, self.Na, self.i0, self.tmax, self.Ns,
                                                 out=out_full, order=self.order)
+
+    # -- sharded model update (SURVEY 8e: "reduce-scatter by slab and keep the model update sharded") ------------------------
+    def shard_len(self, n):
+        """per-rank chunk length of a compact vector of n entries (even, so that chunk starts stay 16-byte aligned)"""
+        per = -(-n // self.world)
+        return per + (per & 1)
+
+    def reduce_scatter_compact(self, s_c_padded):
+        """sum over ranks of a compact vector padded to world * shard_len; returns THIS rank's chunk of the sum"""
+        per = s_c_padded.numel() // self.world
+        out = torch.empty(per, dtype=s_c_padded.dtype, device=s_c_padded.device)
+        rd = self.exchange.reduce_dtype
+        if rd is not None and rd != s_c_padded.dtype:
+            o2 = torch.empty(per, dtype=rd, device=s_c_padded.device)
+            dist.reduce_scatter_tensor(o2, s_c_padded.to(rd), op=dist.ReduceOp.SUM)
+            out.copy_(o2)
+        else:
+            dist.reduce_scatter_tensor(out, s_c_padded, op=dist.ReduceOp.SUM)
+        return out
+
+    def all_gather_compact(self, full_padded, chunk):
+        dist.all_gather_into_tensor(full_padded, chunk)
+        return full_padded
 
     def reduce_compact_(self, s_c):
         """In-place sum over ranks of a compact (active-set) vector."""

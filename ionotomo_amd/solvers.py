@@ -142,11 +142,15 @@ def _cgls_dense(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgto
     return x, [float(h) for h in torch.stack(hist).cpu()] if hist else []
 
 
-def _history(hist):
-    """list of device scalars (1 element or per-workgroup partials) -> list of floats, one read-back"""
+def _history(hist, reduce_over=None):
+    """list of device scalars (1 element or per-workgroup partials) -> list of floats, one read-back (and, for local
+    sums whose all-reduce was deferred, ONE stacked all-reduce over ``reduce_over``'s ranks)"""
     if not hist:
         return []
-    return [0.5 * float(v) for v in torch.stack([h.sum() for h in hist]).cpu()]
+    t = torch.stack([h.sum() for h in hist])
+    if reduce_over is not None and reduce_over.world > 1:
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
+    return [0.5 * float(v) for v in t.cpu()]
 
 
 def _fused_ok(problem, callback):
@@ -185,26 +189,55 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
     x_full.copy_(x0)
     x_c = x0.reshape(-1).index_select(0, il).contiguous()
     s_full = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
-    s_c = torch.empty_like(x_c) if problem.world > 1 else None
+    multi, sharded = problem.world > 1, problem.world > 1 and problem.exchange.sharded
+    n = idx.numel()
+    if sharded:
+        # reduce-scatter by slab, sharded update, all-gather: every rank sums and updates only its contiguous
+        # chunk of the active nodes; the collectives move the same bytes as the all-reduce, the update work is 1 / world
+        per = problem.shard_len(n)
+        lo = problem.rank * per
+        s_c = torch.zeros(per * problem.world, dtype=torch.float64, device=eng.device)
+        xg = torch.zeros_like(s_c)
+        xg[:n] = x_c
+        C_loc = torch.zeros(per, dtype=torch.float64, device=eng.device)
+        m = max(0, min(per, n - lo))
+        C_loc[:m] = C_c[lo:lo + m]
+        x_loc = xg[lo:lo + per].clone()
+    else:
+        s_c = torch.empty_like(x_c) if multi else None
     eng.bind_values(x_pad)
     hist, r, step = [], None, None
+    defer = multi and not stop                  # objective history: ONE stacked all-reduce at the end instead of one per iteration
     try:
         for k in range(n_iter + (1 if stop else 0)):
             eng.values_changed()
             tec = problem.forward_tec()
             r, S2 = eng.rays_combine(tec, problem.Na, problem.i0, -1.0, 1.0, dobs=problem.dobs, s2=Wt, out=r)   # r = d - A x
-            hist.append(problem.scalar(S2))
+            hist.append(S2.sum().reshape(1) if defer else problem.scalar(S2))
             if stop and k > 0 and (k >= n_iter or _stop_fused(hist, step, k, n_iter, pgtol)):
                 break
             problem.backproject_differential(r, L, s_full)
-            if problem.world > 1:                # sum the partial updates over ranks on the active nodes only
+            if sharded:
+                eng.compact_gather(s_full, idx, out=s_c[:n], zero=True, want_dot=False)
+                s_loc = problem.reduce_scatter_compact(s_c)
+                x_new = torch.addcmul(x_loc, C_loc, s_loc, value=relax)
+                if nonneg:
+                    x_new.clamp_(min=0)
+                if stop:
+                    step = (x_new - x_loc).abs().max().reshape(1)
+                    torch.distributed.all_reduce(step, op=torch.distributed.ReduceOp.MAX)
+                x_loc = x_new
+                problem.all_gather_compact(xg, x_loc)
+                eng.compact_scatter(x_full, idx, xg[:n])
+                continue
+            if multi:                            # sum the partial updates over ranks on the active nodes only
                 eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=False)
                 problem.reduce_compact_(s_c)
                 eng.compact_scatter(s_full, idx, s_c)
             step = eng.compact_sirt_update(x_c, C_c, s_full, idx, x_full, relax, nonneg, want_max=bool(stop))
     finally:
         eng.bind_values(None)
-    return x_full.clone(), _history(hist)
+    return x_full.clone(), _history(hist, problem if defer else None)
 
 
 def _stop_fused(hist, step_partial, k, max_iter, pgtol):
@@ -241,7 +274,18 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
     p_pad, p_full = eng.new_grid_buffer()
     eng.compact_scatter(p_full, idx, p_c)
     eng.bind_values(p_pad)
-    hist, q = [problem.scalar(rr)], None
+    n = idx.numel()
+    sharded = multi and problem.exchange.sharded
+    if sharded:                                   # see sirt: reduce-scatter, update of this rank's chunk, all-gather
+        per = problem.shard_len(n)
+        lo = problem.rank * per
+        sg = torch.zeros(per * problem.world, dtype=torch.float64, device=eng.device)
+        pg = torch.zeros_like(sg)
+        pg[:n] = p_c
+        xg = torch.zeros_like(sg)
+        xg[:n] = x_c
+        x_loc, p_loc = xg[lo:lo + per].clone(), pg[lo:lo + per].clone()
+    hist, q = [rr.sum().reshape(1) if multi else rr], None
     try:
         for k in range(n_iter):
             eng.values_changed()
@@ -249,19 +293,33 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
             qq = problem.scalar(qq)
             rr = eng.axpby_dot_(r, q, an=gamma, ad=qq, a_sign=-1.0)         # r -= alpha q
             if k + 1 < n_iter:
-                hist.append(problem.scalar(rr))
+                hist.append(rr.sum().reshape(1) if multi else rr)           # sharded rays: summed over ranks once, at the end
             problem.backproject_differential(r, Wh, s_full)
+            if sharded:
+                eng.compact_gather(s_full, idx, out=sg[:n], zero=True, want_dot=False)
+                s_loc = problem.reduce_scatter_compact(sg)
+                gnew = torch.dot(s_loc, s_loc).reshape(1)
+                torch.distributed.all_reduce(gnew, op=torch.distributed.ReduceOp.SUM)
+                x_loc.add_(p_loc * (gamma.sum() / qq.sum()))
+                p_loc = torch.add(s_loc, p_loc * (gnew.sum() / gamma.sum()))
+                problem.all_gather_compact(pg, p_loc)
+                eng.compact_scatter(p_full, idx, pg[:n])
+                gamma = gnew
+                continue
             _, gnew = eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=not multi)
             if multi:
                 problem.reduce_compact_(s_c)
                 gnew = eng.axpby_dot_(s_c, s_c, a_sign=0.0)
             eng.compact_cg_update(x_c, p_c, s_c, idx, p_full, gamma, qq, gnew, gamma)
             gamma = gnew
+        if sharded:
+            problem.all_gather_compact(xg, x_loc)
+            x_c = xg[:n]
     finally:
         eng.bind_values(None)
     x = x0.clone()
     x.view(-1).index_copy_(0, il, x_c)
-    return x, _history(hist)
+    return x, _history(hist, problem if multi else None)
 
 
 def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=0.0, max_iter=20, min_iter=5,
@@ -301,3 +359,45 @@ def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=
         if k >= min_iter and float(step.abs().max()) <= PGTOL:
             break
     return m, hist
+
+
+def steepest_descent_phase(eng, origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, clock, const, dobs, CdCt, mu0, K=1e11, i0=0,
+                           max_iter=20, min_iter=5, covariance=None, order=None, callback=None):
+    """Inversion of the reference's REAL observable -- the phase g[Na,Nt,Nd,Nf] of inversion/iterative_newton.py:86-127 --
+    for the log-model mu (ne = K exp(mu)) on one GPU, without ever materialising rays[Na,Nt,Nd,4,Ns]:
+      S = 1/2 sum (g - dobs)^2 / CdCt            (iterative_newton.py:32-38)
+      dm = [C_m] dS/dmu                          (adjoint: one gather + scatter traversal per 8 frequencies)
+      linearised exact line search eps = <J dm, dd/Cd> / <J dm, J dm/Cd>  (:542-554), J dm by a forward difference of g
+      stopping rule of the reference              (:959-962,993).
+    All arguments are device tensors except ``freqs`` (host).  Returns (mu, [S_0, S_1, ...])."""
+    mu = mu0.clone()
+    hist = []
+    W = 1.0 / CdCt
+    fd = 1e-4
+    for k in range(max_iter + 1):
+        eng.set_log_model(mu.reshape(-1), K)
+        g = eng.forward_phase(origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, clock, const, i0)
+        dd = g - dobs
+        S = 0.5 * float((dd * dd * W).sum())
+        hist.append(S)
+        if callback:
+            callback(k, mu, S)
+        if k > 0 and reference_stop(hist[-2], S, step_max, k, max_iter, min_iter):
+            break
+        if k == max_iter:
+            break
+        dm = eng.adjoint_phase(origins, dirs, (dd * W).reshape(Na, Nt * Nd, -1).contiguous(), Na, tmax, Ns, freqs, i0, order=order)
+        if covariance is not None:
+            dm = smooth_grid(eng, dm, covariance)
+        scale = float(dm.abs().max())
+        if scale == 0.0:
+            break
+        # J dm: directional derivative of g along -dm (forward difference with a step that changes mu by <= fd)
+        t = fd / scale
+        eng.set_log_model((mu - t * dm).reshape(-1), K)
+        Jdm = (eng.forward_phase(origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, clock, const, i0) - g) / t      # = -J dm
+        eps = -float((Jdm * dd * W).sum()) / max(float((Jdm * Jdm * W).sum()), 1e-300)
+        step = eps * dm
+        step_max = float(step.abs().max())
+        mu -= step
+    return mu, hist

@@ -70,7 +70,7 @@ def _worker(rank, world, port, q, exchange, engine="oracle", size=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "compact"), (3, "auto")])
+@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "compact"), (3, "auto"), (2, "sharded"), (3, "sharded")])
 def test_sharded_path_matches_single_rank(world, exchange):
     """``exchange``: the gradient all-reduce over the whole grid, or only over the nodes some ray touches."""
     ref = _run(1)
@@ -96,6 +96,6 @@ def test_sharded_path_matches_single_rank(world, exchange):
         assert np.array_equal(res[r]["xc"], res[0]["xc"])        # replicas stay bit-identical across ranks
         assert np.allclose(res[r]["adj32"], ref["adj"], rtol=0, atol=3e-7 * np.abs(ref["adj"]).max())
         assert not np.array_equal(res[r]["adj32"], ref["adj"])
-        assert res[r]["compact"] == (exchange == "compact" or (exchange == "auto" and res[r]["active"] < 0.6))
+        assert res[r]["compact"] == (exchange in ("compact", "sharded") or (exchange == "auto" and res[r]["active"] < 0.6))
         if exchange != "dense":
             assert 0.0 < res[r]["active"] < 1.0 and res[r]["active"] == res[0]["active"]

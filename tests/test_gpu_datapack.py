@@ -112,3 +112,28 @@ def test_phase_observable_on_the_device_and_its_adjoint():
         e[f] = 1e-5
         fd = (S(mu + e.reshape(mu.shape))[0] - S(mu - e.reshape(mu.shape))[0]) / 2e-5
         assert abs(fd - grad.ravel()[f]) < 1e-4 * abs(grad.ravel()[f]) + 1e-8
+
+
+def test_phase_inversion_descends():
+    """solvers.steepest_descent_phase: the reference's objective on the phase observable falls monotonically from the
+    prior towards a perturbed truth, every iterate obtained on the device (no rays array)."""
+    import torch
+    from ionotomo_amd import solvers, synthetic as syn
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="lofar", na=16, nd=6, nt=3, n=32)
+    na, nt, nd, Ns = 16, 3, 6, 33
+    eng = RayEngine(0)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    X, Y, Z = np.meshgrid(w["xvec"], w["yvec"], w["zvec"], indexing="ij")
+    mu_prior = np.log(w["ne"] / 1e11)
+    mu_true = mu_prior + 0.3 * np.exp(-(X ** 2 + Y ** 2) / 20.0 ** 2 - ((Z - 300) / 100.0) ** 2)
+    freqs = np.array([120e6, 140e6, 160e6, 180e6])
+    o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+    clock, const = torch.zeros(na, nt, dtype=torch.float64, device=eng.device), torch.zeros(na, dtype=torch.float64, device=eng.device)
+    eng.set_log_model(eng.tensor(mu_true), 1e11)
+    dobs = eng.forward_phase(o, d, na, nt, nd, w["tmax"], Ns, freqs, clock, const, 0).clone()
+    CdCt = torch.full_like(dobs, 1e-4)
+    mu, hist = solvers.steepest_descent_phase(eng, o, d, na, nt, nd, w["tmax"], Ns, freqs, clock, const, dobs, CdCt,
+                                              eng.tensor(mu_prior), K=1e11, i0=0, max_iter=12)
+    assert len(hist) >= 6 and all(b <= a * (1 + 1e-12) for a, b in zip(hist, hist[1:])) and hist[-1] < 0.2 * hist[0]
+    assert not eng.check_oob()
