@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-order", dest="order", action="store_false", help="walk rays in [Na][Nt][Nd] memory order")
+    ap.add_argument("--no-plan", dest="plan", action="store_false",
+                    help="back-project with the ray-stationary kernel (LDS tile per ray bundle) instead of the box-binned plan")
     ap.add_argument("--main-only", action="store_true", help="same as --only forward")
     ap.add_argument("--only", default=None,
                     choices=["forward", "adjoint", "cubic_forward", "cubic_adjoint", "cgls", "sirt"],
@@ -318,11 +320,15 @@ def main():
             leg = fwd
         elif args.only == "adjoint":
             leg = adjoint_leg()[0]
-            if order_t is not None:
+            if args.plan:
+                eng.plan_adjoint(o_t, d_t, TMAX, NS)
+            elif order_t is not None:
                 eng.tune_adjoint_partition(leg, R)
         elif args.only in ("cubic_forward", "cubic_adjoint"):
             ec, cf, ca, _ = cubic_legs()
             leg = cf if args.only == "cubic_forward" else ca
+            if args.plan and args.only == "cubic_adjoint":
+                ec.plan_adjoint(o_t, d_t, TMAX, NS)
         else:
             prob, x0 = solver_problem()
             fn = getattr(solvers, args.only)
@@ -375,9 +381,17 @@ def main():
                 if world > 1:
                     dist.all_reduce(grad_t)
 
-            # work partition of the back-projection balanced by measured cost: like the walk order it depends on the ray
-            # geometry only, is computed once per inversion and never changes results (engine.tune_adjoint_partition)
+            # ray-stationary back-projection (LDS tile per bundle of the walk) with its work partition balanced by measured
+            # cost, then the node-stationary one (segments binned by grid box, engine.plan_adjoint): both depend on the
+            # ray geometry only, are set up once per inversion and never change results
             extra["adjoint_partition"] = eng.tune_adjoint_partition(adj, R) if args.order else None
+            _, tkern = time_steps(adj, k2, 1, torch, dist, world)
+            extra["adjoint_ray_stationary_ms"] = tkern * 1e3
+            if args.plan:
+                t0 = time.perf_counter()
+                info = eng.plan_adjoint(o_t, d_t, TMAX, NS)
+                extra["adjoint_plan"] = {"segments": info[0], "work_units": info[1], "outside_fraction": info[2],
+                                         "build_s": time.perf_counter() - t0}
             awall, akern = time_steps(adj, k2, 1, torch, dist, world)
             iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
             extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
@@ -422,6 +436,8 @@ def main():
             copy_gbs = 2.0 * big_a.numel() * 8 / kc / 1e9
             # ---- tricubic (Lekien-Marsden derivative fields; config 2's interpolant) at the same shape
             _, kcf = time_steps(cf, k2, 1, torch, dist, 1)
+            if args.plan:
+                ec.plan_adjoint(o_t, d_t, TMAX, NS)
             _, kca = time_steps(ca, max(2, k2 // 4), 1, torch, dist, 1)
             extra["tricubic_forward_ms"] = kcf * 1e3
             extra["tricubic_forward_ray_integrals_per_s"] = R / kcf
@@ -430,7 +446,7 @@ def main():
             extra["tricubic_vs_trilinear_max_rel_dev"] = float((tc - tec_t).abs().div(tec_t.abs()).max().item())
             # ---- adjoint roofline: memory-side float atomics
             extra["adjoint_roofline"] = {"bound": "atomic", "peak": ATOMIC_PEAK_GBS, "unit": "GB/s", "kernel_ms": akern * 1e3,
-                                         "kernel": "k_adjoint_straight_tile<double, 1, 4>"}
+                                         "kernel": "k_adjoint_binned<double, false>" if args.plan else "k_adjoint_straight_tile<double, 1, 4>"}
         except Exception as exc:                                    # noqa: BLE001
             extra["error"] = "%s: %s" % (type(exc).__name__, exc)
         if world == 1:

@@ -181,6 +181,18 @@ enum { IONO_WALK_FORWARD = 0, IONO_WALK_ADJOINT = 1 };
 int iono_walk_order(iono_ctx *ctx, const double *origins, const double *directions, int64_t R, double tmax, int *order_out);
 int iono_walk_cycles(iono_ctx *ctx, int which, uint64_t *cycles_out, int capacity, int *n_chunks, int *n_units);
 int iono_walk_partition_set(iono_ctx *ctx, int which, const int64_t *starts, int n_chunks, int64_t R);
+/* Node-stationary back-projection (ionotomo_amd/csrc/iono_binned_kernels.h).  The ray geometry is fixed for a whole
+ * inversion (the reference re-derives its per-direction task split on every call, inversion/gradient.py:22-54), so the
+ * transpose can be organised around the GRID once: rays are cut into segments of <= 16 samples, the segments are binned by
+ * grid box, and every later iono_adjoint_*_straight_dev call with the SAME origins_dev / directions_dev pointers, R, tmax,
+ * Ns and interp_kind reduces each box in LDS and flushes it once (5 x fewer memory-side atomics than the ray-stationary
+ * kernel on the bench geometry).  The caller must not modify the two arrays while the plan is in use; results never depend
+ * on the plan (samples outside their box image go straight to global atomics).  Uniform (np.linspace) grids only: on any
+ * other grid no plan is built and the calls keep using the ray-stationary kernels.  A new grid clears the plan. */
+int iono_adjoint_plan_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R, double tmax,
+                          int Ns, int interp_kind);
+int iono_adjoint_plan_clear(iono_ctx *ctx);
+int iono_adjoint_plan_info(iono_ctx *ctx, int64_t *n_segments, int *n_units, double *outside_fraction);
 /* Solver vector update  y = a x + b y  on device vectors (16-byte aligned), one pass.  The coefficients are ratios
  * of DEVICE scalars, a = a_sign * a_num[0] / a_den[0], b = b_num[0] / b_den[0] (a null pointer stands for 1), so the
  * step lengths of the iteration -- eps = sum(Gdm dd/Cd) / sum(Gdm^2/Cd), inversion/iterative_newton.py:542-554; the

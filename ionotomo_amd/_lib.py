@@ -86,6 +86,9 @@ _SIGNATURES = {
     "iono_compact_sirt_update_dev": [_V, _V, _V, _V, _L, _V, _D, _I, _V],
     "iono_walk_cycles": [_I, _V, _I, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "iono_walk_partition_set": [_I, _V, _I, _L],
+    "iono_adjoint_plan_dev": [_V, _V, _L, _D, _I, _I],
+    "iono_adjoint_plan_clear": [],
+    "iono_adjoint_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
     "iono_walk_order": [_P, _P, _L, _D, ctypes.POINTER(ctypes.c_int)],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],

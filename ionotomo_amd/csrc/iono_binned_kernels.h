@@ -1,0 +1,144 @@
+// node-stationary back-projection: ray segments binned by grid box once per geometry, each box reduced in LDS and flushed once
+#ifndef IONO_BINNED_KERNELS_H
+#define IONO_BINNED_KERNELS_H
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// The ray-stationary tile kernel (iono_adjoint_kernels.h) walks bundles of neighbouring rays and flushes an LDS tile
+// per bundle and 64-sample slab: the same grid nodes are flushed by hundreds of bundles (all rays of a station share
+// its low-altitude cells; 100 timesteps of a direction nearly coincide), 12.3 M 64-B atomic requests per launch at the
+// bench shape against 0.44 M distinct 64-B segments under the fan -- the kernel sits on the memory-side atomic rate.
+// The ray geometry is fixed for a whole inversion, so the transpose can be organised the other way round, ONCE:
+//   * the grid is cut into boxes of BIN_SX x BIN_SY x BIN_SZ cells (+ a halo of BIN_H cells in x and y);
+//   * every ray is cut into segments of <= 16 consecutive samples that lie in one z-layer of boxes; a segment goes to
+//     the box around the middle of its (x, y) extent (host side, iono_adjoint_plan_dev);
+//   * segments are sorted by box; a workgroup takes a unit (a box and up to BIN_UNIT of its segments), accumulates them
+//     in an LDS image of the box (16 lanes per segment, lanes = consecutive samples = consecutive z words: conflict-free
+//     LDS atomics) and flushes the box ONCE.
+// Contributions that fall outside the box image (steep segments) go straight to global atomics, and every sample of
+// every ray is in exactly one segment by construction, so the result never depends on the quality of the binning.
+// ------------------------------------------------------------------------------------------------
+#define BIN_SX 8
+#define BIN_SY 8
+#define BIN_SZ 15
+#define BIN_H 3
+#define BIN_BX (BIN_SX + 2 * BIN_H + 1)      // nodes of the box image along x (15)
+#define BIN_BY (BIN_SY + 2 * BIN_H + 1)
+#define BIN_BZ (BIN_SZ + 1)                  // 16 z nodes
+#define BIN_BZP 17                           // padded z stride (odd: columns start on different banks)
+#define BIN_SEG 16                           // samples per segment = lanes per segment
+#define BIN_UNIT 256                         // segments per work unit
+#define BIN_TILE (BIN_BX * BIN_BY * BIN_BZP)
+
+struct BinUnit {
+    int x0, y0, z0;      // first node of the box image
+    int e_lo, e_hi;      // its segments: entries [e_lo, e_hi)
+};
+
+// ray parameters in ideal grid coordinates, computed ONCE with the kernels' own arithmetic (load_uray / load_uray_cubic)
+// so that validity and sample positions are those of the forward kernels: uray[r] = fx0, dfx, fy0, dfy, fz0, dfz, h, valid
+template <bool CUBIC>
+__global__ void k_plan_urays(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
+                             int Ns, double *__restrict__ uray) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const URay u = CUBIC ? load_uray_cubic(g, origins, dirs, r, tmax, Ns) : load_uray(g, origins, dirs, r, tmax, Ns);
+        double *o = uray + r * 8;
+        o[0] = u.fx0, o[1] = u.dfx, o[2] = u.fy0, o[3] = u.dfy, o[4] = u.fz0, o[5] = u.dfz, o[6] = u.h, o[7] = u.valid ? 1.0 : 0.0;
+    }
+}
+
+// per-ray weights of the fused modes (residual / differential), one value per ray: the binned kernel visits a ray once
+// per segment, so the reference-antenna sums are formed here, once
+template <int MODE>
+__global__ void k_ray_weights(const double *__restrict__ tec, const double *__restrict__ dobs, const double *__restrict__ cdct, int Na,
+                              int64_t NtNd, int i0, double *__restrict__ w) {
+    const int64_t R = (int64_t)Na * NtNd;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x)
+        w[r] = residual_weight<MODE>(tec, dobs, cdct, Na, NtNd, i0, r);
+}
+
+template <typename AT, bool CUBIC>
+__global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
+                                                        const BinUnit *__restrict__ units, const double *__restrict__ wray,
+                                                        int Ns, const double *__restrict__ unitw, AT *__restrict__ G, int field) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *wlds = (double *)smem;                                   // [Ns] quadrature weights
+    AT *tile = (AT *)(wlds + ((Ns + 1) & ~1));                       // [BIN_BX * BIN_BY][BIN_BZP]
+    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
+    for (int t = threadIdx.x; t < BIN_TILE; t += blockDim.x) tile[t] = (AT)0;
+    const BinUnit un = units[blockIdx.x];
+    lds_barrier();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int sub = lane & (BIN_SEG - 1), grp = wid * 4 + (lane >> 4);          // 16 segments per pass of the workgroup
+    // The segment list and the ray records are dependent gathers (entry -> ray id -> ray record): software-pipelined two
+    // deep so that a pass computes while the next pass's ray records and the one after's entries are in flight.
+    struct RayRec {
+        double2 ux, uy, uz, uh;      // (f0, df) per axis in grid coordinates; (h, valid)
+        double w;
+    };
+    // (the entry array is padded by 32 zero entries: unconditional loads; a pass beyond the unit is masked by its count)
+    auto load_entry = [&](int e) { return entries[e]; };
+    auto load_ray = [&](const uint2 en) {
+        const double2 *up = (const double2 *)(uray + (size_t)en.x * 8);
+        RayRec r;
+        r.ux = up[0], r.uy = up[1], r.uz = up[2], r.uh = up[3];
+        r.w = wray[en.x];
+        return r;
+    };
+    int e = un.e_lo + grp;
+    uint2 en0 = load_entry(e), en1 = load_entry(e + 16);
+    RayRec r0 = load_ray(en0);
+    for (; e < un.e_hi; e += 16) {
+        const uint2 en2 = load_entry(e + 32);
+        const RayRec r1 = load_ray(en1);
+        const int cnt = e < un.e_hi ? (int)(en0.y >> 16) : 0, k = (int)(en0.y & 0xffffu) + sub;
+        const double c = sub < cnt ? r0.w * r0.uh.x * wlds[min(k, Ns - 1)] : 0.0;
+        if (c != 0.0) {
+            const double kd = (double)k;
+            const double fx = fma(kd, r0.ux.y, r0.ux.x), fy = fma(kd, r0.uy.y, r0.uy.x), fz = fma(kd, r0.uz.y, r0.uz.x);
+            const double fi = fmin(__builtin_floor(__builtin_fabs(fx)), (double)(g.nx - 2)),
+                         fj = fmin(__builtin_floor(__builtin_fabs(fy)), (double)(g.ny - 2)),
+                         fk = fmin(__builtin_floor(__builtin_fabs(fz)), (double)(g.nz - 2));
+            double ax0, ax1, ay0, ay1, az0, az1;
+            axis_pair(fx - fi, field & 1, CUBIC, ax0, ax1);
+            axis_pair(fy - fj, field & 2, CUBIC, ay0, ay1);
+            axis_pair(fz - fk, field & 4, CUBIC, az0, az1);
+            const double w0 = c * ax0, w1 = c * ax1;
+            const double w00 = w0 * ay0, w01 = w0 * ay1, w10 = w1 * ay0, w11 = w1 * ay1;
+            const int i = (int)fi, j = (int)fj, kz = (int)fk;
+            const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
+            if ((a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1))) {
+                AT *t = tile + ((int)a * BIN_BY + (int)b) * BIN_BZP + (int)m;
+                atomicAdd(t, (AT)(w00 * az0));
+                atomicAdd(t + 1, (AT)(w00 * az1));
+                atomicAdd(t + BIN_BZP, (AT)(w01 * az0));
+                atomicAdd(t + BIN_BZP + 1, (AT)(w01 * az1));
+                atomicAdd(t + BIN_BY * BIN_BZP, (AT)(w10 * az0));
+                atomicAdd(t + BIN_BY * BIN_BZP + 1, (AT)(w10 * az1));
+                atomicAdd(t + (BIN_BY + 1) * BIN_BZP, (AT)(w11 * az0));
+                atomicAdd(t + (BIN_BY + 1) * BIN_BZP + 1, (AT)(w11 * az1));
+            } else {
+                global_add4<AT>(G, i, j, kz, g.ny, g.nz, w00 * az0, w01 * az0, w10 * az0, w11 * az0);
+                global_add4<AT>(G, i, j, kz + 1, g.ny, g.nz, w00 * az1, w01 * az1, w10 * az1, w11 * az1);
+            }
+        }
+        en0 = en1, en1 = en2, r0 = r1;
+    }
+    lds_barrier();
+    // ---- flush the box once: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
+    const int m = threadIdx.x & 15;
+    for (int col = threadIdx.x >> 4; col < BIN_BX * BIN_BY; col += 16) {
+        const AT v = tile[col * BIN_BZP + m];
+        if (v != (AT)0) {
+            const int a = col / BIN_BY, b = col - a * BIN_BY;
+            const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + m;
+            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz)
+                atomicAdd(G + ((size_t)gi * g.ny + gj) * g.nz + gk, v);
+        }
+    }
+}
+
+}  // namespace
+
+#endif

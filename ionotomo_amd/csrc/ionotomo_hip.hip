@@ -34,6 +34,7 @@
 #include "iono_adjoint_kernels.h"
 #include "iono_cubic_kernels.h"
 #include "iono_solver_kernels.h"
+#include "iono_binned_kernels.h"
 #include "iono_aux_kernels.h"
 
 namespace {
@@ -91,11 +92,32 @@ struct iono_ctx {
     double *d_F8 = nullptr;          // Lekien-Marsden derivative fields [node][8] of the current values (lazily built)
     bool F8_valid = false;
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
+    // node-stationary back-projection plan (iono_adjoint_plan_dev; iono_binned_kernels.h): geometry only, library-owned
+    struct AdjPlan {
+        const void *o_key = nullptr, *d_key = nullptr;     // the ray arrays it was built for (caller keeps them unchanged)
+        int64_t R = -1, n_entries = 0;
+        int Ns = 0, kind = -1, n_units = 0;
+        double tmax = 0;
+        double *d_uray = nullptr;
+        uint2 *d_entries = nullptr;
+        BinUnit *d_units = nullptr;
+        double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
+        int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
+    } plan;
+    double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
+    int64_t rayw_cap = 0;
     double *d_freqs = nullptr;       // frequencies of the phase observable on the device (cached copy of h_freqs)
     std::vector<double> h_freqs;
 };
 
 namespace {
+
+void plan_free(iono_ctx *c) {
+    if (c->plan.d_uray) (void)hipFree(c->plan.d_uray);
+    if (c->plan.d_entries) (void)hipFree(c->plan.d_entries);
+    if (c->plan.d_units) (void)hipFree(c->plan.d_units);
+    c->plan = iono_ctx::AdjPlan();
+}
 
 int fail(iono_ctx *c, int code, const std::string &msg) {
     g_last_error = msg;
@@ -393,6 +415,8 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_F8) (void)hipFree(c->d_F8);
     if (c->d_G8) (void)hipFree(c->d_G8);
     if (c->d_freqs) (void)hipFree(c->d_freqs);
+    if (c->d_rayw) (void)hipFree(c->d_rayw);
+    plan_free(c);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
     for (auto &wp : c->walk) {
@@ -470,6 +494,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     c->d_nM = nullptr;
     c->d_F8 = c->d_G8 = nullptr;
     c->d_M_ext = nullptr;
+    plan_free(c);
     c->F8_valid = false;
     c->nM_freq = -1.0;
     c->nx = nx;
@@ -838,6 +863,116 @@ int iono_walk_partition_set(iono_ctx *c, int which, const int64_t *starts, int n
 }
 
 // ---- adjoint (device pointers) ----------------------------------------------------------------
+// ---- node-stationary back-projection plan (iono_binned_kernels.h) ---------------------------------------------------------
+int iono_adjoint_plan_clear(iono_ctx *c) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    plan_free(c);
+    return IONO_OK;
+}
+
+int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, int kind) {
+    int rc = check_common(c, R, Ns, kind, 0);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    plan_free(c);
+    const bool cubic = kind == IONO_INTERP_TRICUBIC;
+    if (R == 0 || R > (int64_t)UINT32_MAX || Ns > 65535 || !(cubic ? cubic_fast_ok(c, Ns) : ideal_path_ok(c, Ns)))
+        return IONO_OK;                                  // no plan: the ray-stationary kernels serve this case
+    iono_ctx::AdjPlan &pl = c->plan;
+    HIP_TRY(c, hipMalloc((void **)&pl.d_uray, (size_t)R * 8 * sizeof(double)));
+    const GridView g = view(c);
+    if (cubic)
+        hipLaunchKernelGGL((k_plan_urays<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray);
+    else
+        hipLaunchKernelGGL((k_plan_urays<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<double> hu((size_t)R * 8);
+    HIP_TRY(c, hipMemcpyAsync(hu.data(), pl.d_uray, hu.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // segments: <= BIN_SEG consecutive samples of a ray inside one z-layer of boxes, binned by the (x, y) box around the middle
+    // of their extent.  Every sample of every valid ray lands in exactly one segment.
+    const int nbx = (c->nx - 1 + BIN_SX - 1) / BIN_SX, nby = (c->ny - 1 + BIN_SY - 1) / BIN_SY, nbz = (c->nz - 1 + BIN_SZ - 1) / BIN_SZ;
+    const int64_t nbox = (int64_t)nbx * nby * nbz;
+    auto cell = [](double f0, double df, int k, int n) {
+        const double v = std::floor(std::fabs(std::fma((double)k, df, f0)));
+        return (int)std::min(v, (double)(n - 2));
+    };
+    std::vector<uint32_t> e_ray, e_seg;
+    std::vector<int32_t> e_box;
+    const size_t guess = (size_t)R * (size_t)(Ns / BIN_SEG + nbz / 2 + 2);
+    e_ray.reserve(guess), e_seg.reserve(guess), e_box.reserve(guess);
+    int64_t outside = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        const double *u = &hu[(size_t)r * 8];
+        if (u[7] == 0.0) {
+            ++pl.n_invalid;
+            continue;
+        }
+        int k = 0;
+        while (k < Ns) {
+            const int zb = cell(u[4], u[5], k, c->nz) / BIN_SZ;
+            int ke = k + 1;
+            while (ke < Ns && ke - k < BIN_SEG && cell(u[4], u[5], ke, c->nz) / BIN_SZ == zb) ++ke;
+            const int xa = cell(u[0], u[1], k, c->nx), xb = cell(u[0], u[1], ke - 1, c->nx);
+            const int ya = cell(u[2], u[3], k, c->ny), yb = cell(u[2], u[3], ke - 1, c->ny);
+            const int bi = std::min(nbx - 1, (xa + xb + 1) / (2 * BIN_SX)), bj = std::min(nby - 1, (ya + yb + 1) / (2 * BIN_SY));
+            const int x0 = bi * BIN_SX - BIN_H, y0 = bj * BIN_SY - BIN_H;
+            if (std::min(xa, xb) < x0 || std::max(xa, xb) > x0 + BIN_BX - 2 || std::min(ya, yb) < y0 || std::max(ya, yb) > y0 + BIN_BY - 2)
+                ++outside;
+            e_ray.push_back((uint32_t)r);
+            e_seg.push_back((uint32_t)k | ((uint32_t)(ke - k) << 16));
+            e_box.push_back((int32_t)(((int64_t)bi * nby + bj) * nbz + zb));
+            k = ke;
+        }
+    }
+    const int64_t ne = (int64_t)e_ray.size();
+    if (ne == 0 || ne > (int64_t)INT32_MAX) {
+        plan_free(c);
+        return IONO_OK;
+    }
+    const int64_t n_invalid = pl.n_invalid;
+    // counting sort by box, then work units of <= BIN_UNIT segments, largest first
+    std::vector<int64_t> start((size_t)nbox + 1, 0);
+    for (int64_t e = 0; e < ne; ++e) ++start[(size_t)e_box[(size_t)e] + 1];
+    for (int64_t b = 0; b < nbox; ++b) start[(size_t)b + 1] += start[(size_t)b];
+    std::vector<uint2> entries((size_t)ne);
+    {
+        std::vector<int64_t> pos(start.begin(), start.end() - 1);
+        for (int64_t e = 0; e < ne; ++e) {
+            const int64_t q = pos[(size_t)e_box[(size_t)e]]++;
+            entries[(size_t)q] = make_uint2(e_ray[(size_t)e], e_seg[(size_t)e]);
+        }
+    }
+    std::vector<BinUnit> units;
+    for (int64_t b = 0; b < nbox; ++b) {
+        const int64_t lo = start[(size_t)b], hi = start[(size_t)b + 1];
+        if (lo == hi) continue;
+        const int zb = (int)(b % nbz), bj = (int)((b / nbz) % nby), bi = (int)(b / ((int64_t)nbz * nby));
+        for (int64_t q = lo; q < hi; q += BIN_UNIT)
+            units.push_back(BinUnit{bi * BIN_SX - BIN_H, bj * BIN_SY - BIN_H, zb * BIN_SZ, (int)q, (int)std::min(hi, q + BIN_UNIT)});
+    }
+    std::stable_sort(units.begin(), units.end(), [](const BinUnit &a, const BinUnit &b) { return a.e_hi - a.e_lo > b.e_hi - b.e_lo; });
+    entries.resize(entries.size() + 32, make_uint2(0u, 0u));          // padding: the kernel prefetches two passes ahead
+    HIP_TRY(c, hipMalloc((void **)&pl.d_entries, entries.size() * sizeof(uint2)));
+    HIP_TRY(c, hipMalloc((void **)&pl.d_units, units.size() * sizeof(BinUnit)));
+    HIP_TRY(c, hipMemcpy(pl.d_entries, entries.data(), entries.size() * sizeof(uint2), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(pl.d_units, units.data(), units.size() * sizeof(BinUnit), hipMemcpyHostToDevice));
+    pl.o_key = o, pl.d_key = d, pl.R = R, pl.Ns = Ns, pl.tmax = tmax, pl.kind = kind;
+    pl.n_entries = ne, pl.n_units = (int)units.size(), pl.n_invalid = n_invalid;
+    pl.outside_fraction = (double)outside / (double)ne;
+    return IONO_OK;
+}
+
+int iono_adjoint_plan_info(iono_ctx *c, int64_t *n_entries, int *n_units, double *outside_fraction) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (n_entries) *n_entries = c->plan.R >= 0 ? c->plan.n_entries : 0;
+    if (n_units) *n_units = c->plan.R >= 0 ? c->plan.n_units : 0;
+    if (outside_fraction) *outside_fraction = c->plan.outside_fraction;
+    return IONO_OK;
+}
+
 }  // extern "C"  (templates below need C++ linkage)
 
 // One launch of the LDS-tiled back-projection (ideal-uniform grids).  CUBIC: channel `field` of the tricubic transpose.
@@ -873,6 +1008,30 @@ template <typename AT, int MODE>
 static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *o, const double *d, const int *order,
                                   const double *w, const double *tec, const double *dobs, const double *cdct, int Na,
                                   int64_t NtNd, int i0, int64_t R, double tmax, int Ns, int kind, AT *grad) {
+    const iono_ctx::AdjPlan &pl = c->plan;
+    const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax && pl.kind == kind &&
+                         c->variant != 2 && c->variant != 7;
+    const double *wr = w;
+    if (planned && pl.n_invalid > 0) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_flags, 1, 1, c->stream));   // out-of-grid rays
+    if (planned && MODE != 0) {          // the reference-antenna sums of the fused modes, once per ray
+        if (c->rayw_cap < R) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->d_rayw) (void)hipFree(c->d_rayw);
+            c->d_rayw = nullptr, c->rayw_cap = 0;
+            HIP_TRY(c, hipMalloc((void **)&c->d_rayw, (size_t)R * sizeof(double)));
+            c->rayw_cap = R;
+        }
+        hipLaunchKernelGGL((k_ray_weights<MODE == 0 ? 1 : MODE>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, tec, dobs, cdct, Na,
+                           NtNd, i0, c->d_rayw);
+        wr = c->d_rayw;
+    }
+    const size_t bin_lds = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + sizeof(AT) * BIN_TILE;
+    if (planned && kind == IONO_INTERP_TRILINEAR) {
+        hipLaunchKernelGGL((k_adjoint_binned<AT, false>), dim3(pl.n_units), dim3(256), bin_lds, c->stream, g, pl.d_uray, pl.d_entries,
+                           pl.d_units, wr, Ns, c->d_unitw, grad, -1);
+        HIP_TRY(c, hipGetLastError());
+        return IONO_OK;
+    }
     if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
         return launch_adjoint_tile<AT, MODE, false>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, grad, -1);
     if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2) {
@@ -882,6 +1041,12 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         if (!c->d_G8) HIP_TRY(c, hipMalloc((void **)&c->d_G8, (size_t)n * LM_NF * sizeof(double)));
         HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
         for (int f = 0; f < LM_NF; ++f) {
+            if (planned) {
+                hipLaunchKernelGGL((k_adjoint_binned<double, true>), dim3(pl.n_units), dim3(256),
+                                   sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE), c->stream, g, pl.d_uray, pl.d_entries,
+                                   pl.d_units, wr, Ns, c->d_unitw, c->d_G8 + (size_t)f * n, f);
+                continue;
+            }
             const int rc = launch_adjoint_tile<double, MODE, true>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns,
                                                                    c->d_G8 + (size_t)f * n, f);
             if (rc) return rc;

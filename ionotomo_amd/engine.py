@@ -114,6 +114,23 @@ class RayEngine(object):
                       self.kind, self.rule, _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 
+    def plan_adjoint(self, origins_t, dirs_t, tmax, Ns):
+        """Bin the rays' segments by grid box ONCE (geometry only): later ``adjoint*`` calls with these same two tensors
+        reduce every box in LDS and flush it once (include/ionotomo_hip.h:iono_adjoint_plan_dev).  Returns
+        (segments, work units, fraction of segments not fully inside their box image) -- (0, 0, 0.0) when the grid is not
+        uniform and the ray-stationary kernels stay in charge.  Keep the tensors alive and unchanged."""
+        import ctypes
+        self._sync_stream()
+        self.ctx.call("iono_adjoint_plan_dev", _ptr(origins_t), _ptr(dirs_t), origins_t.shape[0], float(tmax), int(Ns), self.kind)
+        self._planned = (origins_t, dirs_t)
+        n, u, f = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_double(0)
+        self.ctx.call("iono_adjoint_plan_info", ctypes.byref(n), ctypes.byref(u), ctypes.byref(f))
+        return n.value, u.value, f.value
+
+    def clear_adjoint_plan(self):
+        self.ctx.call("iono_adjoint_plan_clear")
+        self._planned = None
+
     def adjoint_differential(self, origins_t, dirs_t, v_t, scale_t, Na, i0, tmax, Ns, out=None, accum=torch.float64,
                              order=None):
         """One launch: out += A^T (scale o v) for the differenced operator A x = G x - (G x)[i0], ray layout [Na][NtNd]

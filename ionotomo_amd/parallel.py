@@ -100,7 +100,7 @@ class ShardedRays(object):
     """This rank's slice of a [Na][P] ray bundle (+ optional data), resident on the engine's device."""
 
     def __init__(self, engine, origins, directions, tmax, Ns, dobs=None, cdct=None, i0=0, exchange="auto",
-                 reduce_dtype=None, tune=True):
+                 reduce_dtype=None, tune=True, plan=True):
         """origins/directions: [Na,P,3] (numpy or tensor, FULL problem); dobs/cdct: [Na,P].
         ``exchange`` / ``reduce_dtype``: see ``GradientExchange``; ``tune``: balance the back-projection's work
         partition by measurement (a few extra launches, once)."""
@@ -121,9 +121,14 @@ class ShardedRays(object):
         # walk order for the kernels (speed only): spatial neighbours next to each other
         self.order = engine.locality_order(self.origins, self.dirs, self.tmax) if (
             hasattr(engine, "locality_order") and self.R_local > 0) else None
-        # measured load balance of the back-projection (speed only, once per geometry; engine.tune_adjoint_partition)
+        # node-stationary back-projection plan (speed only, once per geometry; engine.plan_adjoint): when the grid is
+        # uniform every later adjoint of THESE two tensors reduces each grid box in LDS and flushes it once
+        self.plan = None
+        if plan and hasattr(engine, "plan_adjoint") and self.R_local > 0:
+            self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns)
+        # measured load balance of the ray-stationary back-projection (used when no plan could be built)
         self.partition = None
-        if tune and hasattr(engine, "tune_adjoint_partition") and self.R_local > 0:
+        if tune and not (self.plan and self.plan[0]) and hasattr(engine, "tune_adjoint_partition") and self.R_local > 0:
             ones = torch.ones(self.R_local, dtype=torch.float64, device=dev)
             scratch = torch.zeros(engine.shape, dtype=torch.float64, device=dev)
 
