@@ -10,7 +10,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libionotomo_hip.so")
+# IONOTOMO_LIB: an alternative build of the same sources (A/B builds with different -D tuning constants, the
+# -DIONO_ABLATION timing build of profiles/tools) -- never a different implementation
+LIB_PATH = os.environ.get("IONOTOMO_LIB") or os.path.join(_HERE, "libionotomo_hip.so")
 
 OK, ERR_OOB, ERR_NONFINITE, ERR_SHAPE, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 WALK_FORWARD, WALK_ADJOINT = 0, 1          # iono_walk_cycles / iono_walk_partition_set

@@ -45,10 +45,14 @@ SETS=("FETCH_SIZE" "WRITE_SIZE"
       "TA_TA_BUSY_sum TA_FLAT_READ_WAVEFRONTS_sum"
       "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM"
       "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM GRBM_GUI_ACTIVE"
-      "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum")
+      "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum"
+      "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS_ATOMIC SQ_LDS_ADDR_CONFLICT SQ_WAIT_INST_LDS")
 FIRST=${3:-1}
 if [ "$PART" = "2" ]; then
   i=0; for C in "${SETS[@]}"; do i=$((i+1)); [ $i -ge $FIRST ] && pmc forward $i "$C"; done
+fi
+if [ "$PART" = "4" ]; then      # selected sets for one leg:  run_profiles.sh <tag> 4 <leg> "<set indices>"
+  for i in $4; do pmc $3 $i "${SETS[$((i-1))]}"; done
 fi
 if [ "$PART" = "3" ]; then
   i=0; for C in "${SETS[@]}"; do i=$((i+1)); [ $i -ge $FIRST ] && pmc adjoint $i "$C"; done
