@@ -445,7 +445,8 @@ def main():
             extra["tricubic_adjoint_ms"] = kca * 1e3
             extra["tricubic_vs_trilinear_max_rel_dev"] = float((tc - tec_t).abs().div(tec_t.abs()).max().item())
             # ---- adjoint roofline: memory-side float atomics
-            extra["adjoint_roofline"] = {"bound": "atomic", "peak": ATOMIC_PEAK_GBS, "unit": "GB/s", "kernel_ms": akern * 1e3,
+            # the binned kernel is bound by LDS float-atomic throughput, the ray-stationary one by the memory-side atomic rate
+            extra["adjoint_roofline"] = {"bound": "lds_atomic" if args.plan else "memory_atomic", "kernel_ms": akern * 1e3,
                                          "kernel": "k_adjoint_binned<double, false>" if args.plan else "k_adjoint_straight_tile<double, 1, 4>"}
         except Exception as exc:                                    # noqa: BLE001
             extra["error"] = "%s: %s" % (type(exc).__name__, exc)
@@ -468,10 +469,17 @@ def main():
     rl = forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes)
     ar = extra.get("adjoint_roofline")
     ca_ = (pmc or {}).get("adjoint")
-    if ar and ca_ and ca_.get("rays") == R and "TCC_EA0_ATOMIC_sum" in ca_:
+    if ar and ca_ and ca_.get("rays") == R and "TCC_EA0_ATOMIC_sum" in ca_ and ca_.get("kernel", "").startswith(ar["kernel"]):
         ab = 64.0 * ca_["TCC_EA0_ATOMIC_sum"]                      # 64-B atomic requests leaving L2 per launch
-        ar.update({"atomic_requests_per_launch": ca_["TCC_EA0_ATOMIC_sum"], "achieved": ab / (ar["kernel_ms"] * 1e-3) / 1e9,
-                   "frac": ab / (ar["kernel_ms"] * 1e-3) / 1e9 / ATOMIC_PEAK_GBS})
+        mem = ab / (ar["kernel_ms"] * 1e-3) / 1e9
+        ar["memory_atomics"] = {"requests_per_launch": ca_["TCC_EA0_ATOMIC_sum"], "achieved_gbs": mem, "peak_gbs": ATOMIC_PEAK_GBS,
+                                "frac": mem / ATOMIC_PEAK_GBS}
+        if "SQ_LDS_IDX_ACTIVE" in ca_ and "GRBM_GUI_ACTIVE" in ca_:
+            cyc = ca_["GRBM_GUI_ACTIVE"] / 8.0
+            ar["lds"] = {"busy_frac": ca_["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc),
+                         "bank_conflict_frac": ca_.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(ca_["SQ_LDS_IDX_ACTIVE"], 1.0),
+                         "atomic_wave_instructions": ca_.get("SQ_INSTS_LDS_ATOMIC")}
+        ar["frac"] = ar["lds"]["busy_frac"] if ar["bound"] == "lds_atomic" and "lds" in ar else ar["memory_atomics"]["frac"]
     line = {
         "metric": "ray-integrals/sec through 256^3 ne grid",
         "value": value, "unit": "ray-integrals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

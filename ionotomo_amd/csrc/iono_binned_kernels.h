@@ -53,13 +53,24 @@ __global__ void k_plan_urays(GridView g, const double *__restrict__ origins, con
 }
 
 // per-ray weights of the fused modes (residual / differential), one value per ray: the binned kernel visits a ray once
-// per segment, so the reference-antenna sums are formed here, once
+// per segment, so the reference-antenna sums are formed here, once.  One wave per (time, direction) pair p, lanes =
+// antennas: the column sum over antennas is a wave reduction instead of a 62-step loop in the i0 threads.
 template <int MODE>
-__global__ void k_ray_weights(const double *__restrict__ tec, const double *__restrict__ dobs, const double *__restrict__ cdct, int Na,
-                              int64_t NtNd, int i0, double *__restrict__ w) {
-    const int64_t R = (int64_t)Na * NtNd;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x)
-        w[r] = residual_weight<MODE>(tec, dobs, cdct, Na, NtNd, i0, r);
+__global__ __launch_bounds__(256) void k_ray_weights(const double *__restrict__ tec, const double *__restrict__ dobs,
+                                                     const double *__restrict__ cdct, int Na, int64_t NtNd, int i0,
+                                                     double *__restrict__ w) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < NtNd; p += (int64_t)gridDim.x * 4) {
+        const double tref = MODE == 2 ? 0.0 : tec[(int64_t)i0 * NtNd + p];
+        double s = 0.0;
+        for (int a = lane; a < Na; a += 64) s += dd_of<MODE>(tec, dobs, cdct, tref, (int64_t)a * NtNd + p);
+        s = wave_sum_dpp(s);
+        for (int a = lane; a < Na; a += 64) {
+            const int64_t r = (int64_t)a * NtNd + p;
+            const double v = dd_of<MODE>(tec, dobs, cdct, tref, r);
+            w[r] = a == i0 ? v - s : v;
+        }
+    }
 }
 
 __device__ __forceinline__ double dpp_shr1(double v) {       // value of the previous lane of the 16-lane row (0 for its first lane)

@@ -1021,8 +1021,8 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             HIP_TRY(c, hipMalloc((void **)&c->d_rayw, (size_t)R * sizeof(double)));
             c->rayw_cap = R;
         }
-        hipLaunchKernelGGL((k_ray_weights<MODE == 0 ? 1 : MODE>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, tec, dobs, cdct, Na,
-                           NtNd, i0, c->d_rayw);
+        hipLaunchKernelGGL((k_ray_weights<MODE == 0 ? 1 : MODE>), dim3(ew_blocks(c, NtNd * 64)), dim3(256), 0, c->stream, tec, dobs,
+                           cdct, Na, NtNd, i0, c->d_rayw);
         wr = c->d_rayw;
     }
     const size_t bin_lds = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + sizeof(AT) * BIN_TILE;
