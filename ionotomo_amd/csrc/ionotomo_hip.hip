@@ -79,6 +79,7 @@ struct iono_ctx {
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     int walk_mode = 0;               // env IONOTOMO_WALK: forward walk A/B (see wave_chunk); never changes results
     bool walk_mode_set = false;
+    int fwd_plan = 0;                // env IONOTOMO_FWD_PLAN=1: the forward uses the ray plan too (node-stationary, A/B)
     int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
                                            // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
@@ -101,6 +102,10 @@ struct iono_ctx {
         double *d_uray = nullptr;
         uint2 *d_entries = nullptr;
         BinUnit *d_units = nullptr;
+        unsigned char *d_nseg = nullptr;                  // segments per ray (forward: partial sums per ray)
+        double *d_partial = nullptr;                      // [R][smax] segment partial sums of the node-stationary forward
+        int smax = 0;
+        bool fwd_ok = false;                              // every ray has <= 255 segments
         double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
         int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
     } plan;
@@ -116,6 +121,8 @@ void plan_free(iono_ctx *c) {
     if (c->plan.d_uray) (void)hipFree(c->plan.d_uray);
     if (c->plan.d_entries) (void)hipFree(c->plan.d_entries);
     if (c->plan.d_units) (void)hipFree(c->plan.d_units);
+    if (c->plan.d_nseg) (void)hipFree(c->plan.d_nseg);
+    if (c->plan.d_partial) (void)hipFree(c->plan.d_partial);
     c->plan = iono_ctx::AdjPlan();
 }
 
@@ -391,6 +398,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
     if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 4), c->walk_mode_set = true;
+    if (const char *e = getenv("IONOTOMO_FWD_PLAN")) c->fwd_plan = atoi(e);
     if (const char *e = getenv("IONOTOMO_ADJ_BUNDLE")) c->adj_mode = atoi(e) & (32 | 64 | 128);
 #ifdef IONO_ABLATION
     if (const char *e = getenv("IONOTOMO_ADJ_ABLATE")) c->adj_mode |= atoi(e) & (4 | 8);     // timing only: WRONG results
@@ -661,7 +669,16 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
     const size_t lds = lds_bytes(c);
     rc = dispatch_storage(c, [&](auto *tag) -> int {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
+        const iono_ctx::AdjPlan &pl = c->plan;
+        if (kind == IONO_INTERP_TRILINEAR && pl.fwd_ok && pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax &&
+            pl.kind == kind && c->variant != 8 && c->fwd_plan) {
+            // node-stationary forward on the ray plan: box images staged in LDS, one partial sum per segment, then per ray
+            const size_t bl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
+            hipLaunchKernelGGL((k_forward_binned<GT>), dim3(pl.n_units), block, bl, c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, Ns,
+                               c->d_unitw, pl.d_partial, pl.smax);
+            hipLaunchKernelGGL(k_forward_binned_finish, dim3(ew_blocks(c, R)), block, 0, c->stream, pl.d_uray, pl.d_nseg, pl.d_partial,
+                               pl.smax, R, tec, c->d_flags);
+        } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
             iono_ctx::WalkPart &wp = c->walk[0];
@@ -904,13 +921,16 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     const size_t guess = (size_t)R * (size_t)(Ns / BIN_SEG + nbz / 2 + 2);
     e_ray.reserve(guess), e_seg.reserve(guess), e_box.reserve(guess);
     int64_t outside = 0;
+    std::vector<unsigned char> nseg((size_t)R, 0);
+    int smax = 1;
+    bool fwd_ok = true;
     for (int64_t r = 0; r < R; ++r) {
         const double *u = &hu[(size_t)r * 8];
         if (u[7] == 0.0) {
             ++pl.n_invalid;
             continue;
         }
-        int k = 0;
+        int k = 0, j = 0;
         while (k < Ns) {
             const int zb = cell(u[4], u[5], k, c->nz) / BIN_SZ;
             int ke = k + 1;
@@ -922,10 +942,14 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
             if (std::min(xa, xb) < x0 || std::max(xa, xb) > x0 + BIN_BX - 2 || std::min(ya, yb) < y0 || std::max(ya, yb) > y0 + BIN_BY - 2)
                 ++outside;
             e_ray.push_back((uint32_t)r);
-            e_seg.push_back((uint32_t)k | ((uint32_t)(ke - k) << 16));
+            e_seg.push_back((uint32_t)k | ((uint32_t)(ke - k) << 16) | ((uint32_t)(j & 255) << 24));      // first sample, count, ordinal
             e_box.push_back((int32_t)(((int64_t)bi * nby + bj) * nbz + zb));
             k = ke;
+            ++j;
         }
+        if (j > 255) fwd_ok = false;
+        nseg[(size_t)r] = (unsigned char)std::min(j, 255);
+        smax = std::max(smax, std::min(j, 255));
     }
     const int64_t ne = (int64_t)e_ray.size();
     if (ne == 0 || ne > (int64_t)INT32_MAX) {
@@ -959,6 +983,10 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipMalloc((void **)&pl.d_units, units.size() * sizeof(BinUnit)));
     HIP_TRY(c, hipMemcpy(pl.d_entries, entries.data(), entries.size() * sizeof(uint2), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(pl.d_units, units.data(), units.size() * sizeof(BinUnit), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMalloc((void **)&pl.d_nseg, (size_t)R));
+    HIP_TRY(c, hipMemcpy(pl.d_nseg, nseg.data(), (size_t)R, hipMemcpyHostToDevice));
+    pl.smax = smax, pl.fwd_ok = fwd_ok && !cubic;
+    if (pl.fwd_ok) HIP_TRY(c, hipMalloc((void **)&pl.d_partial, (size_t)R * smax * sizeof(double)));
     pl.o_key = o, pl.d_key = d, pl.R = R, pl.Ns = Ns, pl.tmax = tmax, pl.kind = kind;
     pl.n_entries = ne, pl.n_units = (int)units.size(), pl.n_invalid = n_invalid;
     pl.outside_fraction = (double)outside / (double)ne;
