@@ -317,6 +317,22 @@ def round2_fixtures(R, w, rays, m_tci, K_ne, ne_tci):
     np.savez_compressed(os.path.join(OUT, "fermat_type_s.npz"), origins=o, directions=d, smax=smax, N=33,
                         frequency=120e6, workload="cfg1", straight=straight, shipped=shipped, meta=meta())
 
+    # ---- 13. Covariance.contract (CLEAN, ionosphere/covariance.py:284-336) as shipped: what does it do? ------------------
+    # Recorded as data: on a plain field the loop reaches border voxels whose stencil slice is empty and raises, so the
+    # function cannot be pinned by a fixture (the build replaces it by the exact inverse of the untruncated kernel).
+    C = R["ionosphere.covariance"].Covariance(dx=5.0, dy=6.0, dz=7.0)
+    phi = np.random.default_rng(0).normal(size=(12, 11, 13))
+    try:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):
+            out = C.contract(phi.copy())
+        outcome, detail = "returned", "max |out| = %r" % float(np.abs(out).max())
+    except Exception as exc:                                   # noqa: BLE001
+        outcome, detail = "raised " + type(exc).__name__, str(exc)
+    np.savez_compressed(os.path.join(OUT, "covariance_contract_behaviour.npz"), phi=phi, d=np.array([5.0, 6.0, 7.0]),
+                        outcome=outcome, detail=detail, meta=meta())
+
 
 if __name__ == "__main__":
     main()

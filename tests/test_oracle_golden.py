@@ -323,3 +323,12 @@ def test_covariance_smooth_matches_reference(golden):
         assert np.max(np.abs(k3 - g["stencil_" + tag])) < 1e-15
         out = O.smooth(g["phi_" + tag], dx, dy, dz)
         assert np.max(np.abs(out - g["out_" + tag])) < 1e-12 * np.max(np.abs(g["out_" + tag]))
+
+
+def test_reference_contract_is_unpinnable_as_shipped(golden):
+    """ionosphere/covariance.py:284-336 (CLEAN ``Covariance.contract``) RAISES on a plain 12 x 11 x 13 field in the
+    reference itself (fixture generated by running it): there is no output to pin, which is why
+    ionotomo_amd.ionosphere.covariance.Covariance.contract is the exact inverse of the untruncated kernel instead
+    (DESIGN.md section 7)."""
+    g = golden("covariance_contract_behaviour")
+    assert str(g["outcome"]).startswith("raised ValueError") and "broadcast" in str(g["detail"])
