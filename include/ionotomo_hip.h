@@ -119,6 +119,15 @@ int iono_adjoint_straight(iono_ctx *ctx, const double *origins, const double *di
 int iono_adjoint_rays(iono_ctx *ctx, const double *rays, const double *w, int64_t R, int Ns,
                       int interp_kind, int quad_rule, int scale_by_grid, double *grad_out);
 
+/* The reference's SHIPPED gradient discretisation, for comparison with it: do_gradient of
+ * inversion/gradient.py:15-20 = einsum(dirac, M, dd) with dirac = voxel chord lengths of the straight first -> last
+ * sample line (geometry/ray_dirac.py:5-34, geometry/slab_method.py:19-58).  rays[R][4][Ns], dd[R]; the grid holds M
+ * (uniform axes, as the reference assumes: it uses x[1] - x[0]).  grad_out float64[nx ny nz].  NOT the transpose of the
+ * forward model -- optimisers should use iono_adjoint_*. */
+int iono_gradient_chords(iono_ctx *ctx, const double *rays, const double *dd, int64_t R, int Ns, double *grad_out);
+int iono_gradient_chords_dev(iono_ctx *ctx, const double *rays_dev, const double *dd_dev, int64_t R, int Ns,
+                             double *grad_dev /* accumulated into */);
+
 /* ---- device-pointer (asynchronous) variants used by the inversion loop, bench.py and the
  *      multi-GPU driver.  Out-of-grid samples set a sticky device flag read by iono_check_oob. ---- */
 /* order_dev (nullable): int32 permutation of 0..R-1 giving the order in which rays are WALKED

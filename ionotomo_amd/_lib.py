@@ -67,6 +67,8 @@ _SIGNATURES = {
     "iono_forward_phase_rays": [_P, _I, _I, _I, _I, _P, _I, _P, _P, _I, _I, _P],
     "iono_adjoint_straight": [_P, _P, _P, _L, _D, _I, _I, _I, _I, _P],
     "iono_adjoint_rays": [_P, _P, _L, _I, _I, _I, _I, _P],
+    "iono_gradient_chords": [_P, _P, _L, _I, _P],
+    "iono_gradient_chords_dev": [_V, _V, _L, _I, _V],
     "iono_forward_tec_straight_dev": [_V, _V, _V, _L, _D, _I, _I, _I, _V],
     "iono_forward_tec_rays_dev": [_V, _L, _I, _I, _I, _V],
     "iono_adjoint_straight_dev": [_V, _V, _V, _V, _L, _D, _I, _I, _I, _V, _I],
@@ -336,6 +338,19 @@ class Context(object):
         kx, ky, kz, h = _smooth_args(kx, ky, kz)
         out = np.empty(self.grid_shape, dtype=np.float64)
         self.call("iono_smooth_separable", _dp(phi), _dp(out), _dp(kx), _dp(ky), _dp(kz), h)
+        return out
+
+    def gradient_chords(self, rays, dd):
+        """The reference's shipped chord-length gradient einsum(dirac, M, dd) (inversion/gradient.py:15-20) for
+        rays[..., 4, Ns] and dd[...]: NOT the transpose of the forward (include/ionotomo_hip.h)."""
+        rays = as_f64(rays)
+        Ns = rays.shape[-1]
+        R = int(np.prod(rays.shape[:-2], dtype=np.int64))
+        dd = as_f64(dd).ravel()
+        if dd.size != R:
+            raise ValueError("one weight per ray expected")
+        out = np.empty(self.grid_shape, dtype=np.float64)
+        self.call("iono_gradient_chords", _dp(rays), _dp(dd), R, int(Ns), _dp(out))
         return out
 
     def adjoint_rays(self, rays, w, rule="avg", scale_by_grid=False, kind="linear"):

@@ -541,6 +541,69 @@ __global__ __launch_bounds__(256) void k_adjoint_phase_straight(GridView g, cons
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
+// ---- the reference's SHIPPED gradient discretisation: voxel chord lengths -------------------------------
+// geometry/ray_dirac.py:5-34 + inversion/gradient.py:15-20:  grad[v] = sum_rays dd[ray] M[v] chord(ray, v), where chord is
+// the length of the straight first-sample -> last-sample line inside the voxel-centred box of node v
+// (geometry/slab_method.py:19-58, incl. its `t_enter > 0` rule and NaN -> 0), evaluated for the 27 nodes around every
+// sample and ASSIGNED (not accumulated) per ray.  Here: one wave per ray, lanes = samples; a node counts for the first
+// sample whose 3 x 3 x 3 neighbourhood contains it (cell indices are monotone along a ray, so "first" = "not in the previous
+// sample's neighbourhood") -- one atomic per (ray, node), the reference's assignment semantics without a per-ray volume.
+__device__ __forceinline__ int bisection_cell(const double *g, int n, double v) {       // geometry/tri_cubic.py:105-132
+    if (v < g[0]) return -1;
+    if (v > g[n - 1]) return n;
+    if (v == g[n - 1]) return n - 1;
+    int lo = 0, hi = n - 1;                                                           // searchsorted(side='right') - 1, clipped
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (g[mid] <= v) lo = mid; else hi = mid;
+    }
+    return min(max(lo, 0), n - 2);
+}
+__device__ __forceinline__ void slab_axis(double lo, double hi, double r0, double inv_n, double &tmin, double &tmax) {
+    double t1 = (lo - r0) * inv_n, t2 = (hi - r0) * inv_n;
+    if (t1 != t1) t1 = 0.0;
+    if (t2 != t2) t2 = 0.0;
+    tmin = fmin(t1, t2), tmax = fmax(t1, t2);
+}
+template <typename GT, typename AT>
+__global__ __launch_bounds__(256) void k_gradient_chords(GridView g, const double *__restrict__ rays, const double *__restrict__ dd,
+                                                         int64_t R, int Ns, AT *__restrict__ G) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int lane = threadIdx.x & 63;
+    const double hx = 0.5 * (ax.x[1] - ax.x[0]), hy = 0.5 * (ax.y[1] - ax.y[0]), hz = 0.5 * (ax.z[1] - ax.z[0]);
+    const GT *M = (const GT *)g.M;
+    for (RayWalk w = ray_walk(R); w.r < w.end; w.r += w.stride) {
+        const double *rx = rays + (size_t)w.r * 4 * Ns, *ry = rx + Ns, *rz = ry + Ns;
+        const double wr = dd[w.r];
+        if (wr == 0.0) continue;
+        const double ox = rx[0], oy = ry[0], oz = rz[0];
+        double nx = rx[Ns - 1] - ox, ny = ry[Ns - 1] - oy, nz = rz[Ns - 1] - oz;
+        const double nrm = sqrt(nx * nx + ny * ny + nz * nz);
+        nx /= nrm, ny /= nrm, nz /= nrm;
+        const double ix = 1.0 / nx, iy = 1.0 / ny, iz = 1.0 / nz;
+        for (int s = lane; s < Ns; s += 64) {
+            const int ci = bisection_cell(ax.x, ax.nx, rx[s]), cj = bisection_cell(ax.y, ax.ny, ry[s]), ck = bisection_cell(ax.z, ax.nz, rz[s]);
+            int pi = -100, pj = -100, pk = -100;
+            if (s > 0) pi = bisection_cell(ax.x, ax.nx, rx[s - 1]), pj = bisection_cell(ax.y, ax.ny, ry[s - 1]), pk = bisection_cell(ax.z, ax.nz, rz[s - 1]);
+            for (int xi = max(0, ci - 1); xi < min(ax.nx, ci + 2); ++xi)
+                for (int yi = max(0, cj - 1); yi < min(ax.ny, cj + 2); ++yi)
+                    for (int zi = max(0, ck - 1); zi < min(ax.nz, ck + 2); ++zi) {
+                        if (abs(xi - pi) <= 1 && abs(yi - pj) <= 1 && abs(zi - pk) <= 1) continue;       // the previous sample had it
+                        double a0, a1, b0, b1, c0, c1;
+                        slab_axis(ax.x[xi] - hx, ax.x[xi] + hx, ox, ix, a0, a1);
+                        slab_axis(ax.y[yi] - hy, ax.y[yi] + hy, oy, iy, b0, b1);
+                        slab_axis(ax.z[zi] - hz, ax.z[zi] + hz, oz, iz, c0, c1);
+                        const double t_in = fmax(fmax(a0, b0), c0), t_out = fmin(fmin(a1, b1), c1);
+                        if (t_in < t_out && t_in > 0.0) {
+                            const size_t v = ((size_t)xi * ax.ny + yi) * ax.nz + zi;
+                            atomicAdd(G + v, (AT)(wr * (double)M[v] * (t_out - t_in)));
+                        }
+                    }
+        }
+    }
+}
+
 template <typename AT, int KIND = IONO_INTERP_TRILINEAR>
 __global__ __launch_bounds__(256) void k_adjoint_rays(GridView g, const double *__restrict__ rays,
                                                       const double *__restrict__ wray, int64_t R, int Ns, int rule,

@@ -1252,6 +1252,41 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
     return IONO_OK;
 }
 
+// ---- the reference's shipped chord-length gradient (A7): do_gradient of inversion/gradient.py:15-20 -----------------------
+int iono_gradient_chords_dev(iono_ctx *c, const double *rays, const double *dd, int64_t R, int Ns, double *grad) {
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, 0);
+    if (rc) return rc;
+    if (!rays || !dd || !grad) return fail(c, IONO_ERR_ARG, "iono_gradient_chords_dev: null argument");
+    if (R == 0) return IONO_OK;
+    const GridView g = view(c);
+    dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+        hipLaunchKernelGGL((k_gradient_chords<GT, double>), dim3(ray_grid_blocks(c, R)), dim3(256), lds_bytes(c), c->stream, g, rays, dd, R,
+                           Ns, grad);
+        return IONO_OK;
+    });
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_gradient_chords(iono_ctx *c, const double *rays, const double *dd, int64_t R, int Ns, double *grad_out) {
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, 0);
+    if (rc) return rc;
+    const int64_t n = ncells(c);
+    DevBuf b(c);
+    const size_t nr = (size_t)R * 4 * Ns;
+    HIP_TRY(c, b.alloc(8 * (nr + (size_t)R + (size_t)n)));
+    double *dR = b.as<double>(), *dW = dR + nr, *dG = dW + R;
+    HIP_TRY(c, hipMemcpyAsync(dR, rays, nr * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(dW, dd, R * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(dG, 0, n * 8, c->stream));
+    rc = iono_gradient_chords_dev(c, dR, dW, R, Ns, dG);
+    if (rc) return rc;
+    HIP_TRY(c, hipMemcpyAsync(grad_out, dG, n * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return IONO_OK;
+}
+
 int iono_check_oob(iono_ctx *c, int *oob) {
     if (!c || !oob) return fail(c, IONO_ERR_ARG, "null argument");
     return read_flag(c, 0, oob);

@@ -23,13 +23,21 @@ def differential_weights(dd, i0):
 
 
 def compute_gradient(rays, g, dobs, i0, K_ne, m_tci, m_prior, CdCt, sigma_m, Nkernel, size_cell, cov_obj=None,
-                     quad="avg"):
+                     quad="avg", method="transpose"):
+    """``method="transpose"`` (default): the exact transpose of the forward model (module docstring).
+    ``method="chords"``: the reference's own discretisation, ``do_gradient`` = einsum(dirac, ne, dd) over voxel chord
+    lengths (inversion/gradient.py:15-20, geometry/ray_dirac.py), pinned to the reference's output in
+    tests/golden/ray_dirac.npz -- for comparison with the shipped code, not for optimisation.  (The reference then
+    subtracts ``gradient[i0, ...]``, i.e. indexes the GRID's first axis with an antenna index (:62); that slip is not
+    reproduced.)"""
     rays = np.asarray(rays, dtype=np.float64)
     dd = g - dobs
     dd /= (CdCt + 1e-15)                       # inversion/gradient.py:77-81
     ctx = _lib.default_context()
     ctx.set_grid(m_tci.xvec, m_tci.yvec, m_tci.zvec, None, storage=m_tci.storage)
     ctx.set_values_exp(m_tci.M, K_ne / TECU)
+    if method == "chords":
+        return ctx.gradient_chords(rays, dd)
     return ctx.adjoint_rays(rays, differential_weights(dd, i0), rule=quad, scale_by_grid=True, kind=m_tci.kind)
 
 

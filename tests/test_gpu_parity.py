@@ -362,3 +362,30 @@ def test_calc_rays_from_sky_coordinates():
     assert np.allclose(rays[:, 0, :, 2, -1], 1000.0) and np.allclose(rays[:, 0, :, :3, 0], o[:, 0, :, :])
     tec = it.do_forward_equation(rays[:, 0], tci)                   # unit field: TEC = path length
     assert np.allclose(tec, rays[:, 0, :, 3, -1], rtol=1e-12)
+
+
+def test_shipped_chord_gradient_from_the_product(ctx, golden, O):
+    """the reference's own gradient discretisation (chord lengths, inversion/gradient.py:15-20) is
+    available from the product for comparison -- pinned to the reference's ``do_gradient`` output and to the oracle's
+    restatement on a larger straight-ray case."""
+    g = golden("ray_dirac")
+    ctx.set_grid(g["xvec"], g["yvec"], g["zvec"], g["M"])
+    grad = ctx.gradient_chords(g["rays"], g["dd"])
+    assert np.max(np.abs(grad - g["grad"])) < 1e-12 * np.max(np.abs(g["grad"]))
+    rng = np.random.default_rng(0)
+    xv, yv, zv = np.linspace(-20, 20, 21), np.linspace(-15, 25, 17), np.linspace(0, 60, 25)
+    M = rng.uniform(1, 2, size=(21, 17, 25))
+    o = np.stack([rng.uniform(-8, 8, (3, 4)), rng.uniform(-8, 8, (3, 4)), np.full((3, 4), 1.0)], -1)
+    d = np.stack([rng.uniform(-0.2, 0.2, (3, 4)), rng.uniform(-0.2, 0.2, (3, 4)), np.ones((3, 4))], -1)
+    d[0, 0, :2] = 0.0                                            # a vertical ray: 0 * inf -> NaN -> 0 in the slab method
+    rays = O.straight_rays(o, d, 58.0, 30)
+    dd = rng.normal(size=(3, 4))
+    ctx.set_grid(xv, yv, zv, M)
+    ref = O.gradient_chords(rays, xv, yv, zv, M, dd)
+    got = ctx.gradient_chords(rays, dd)
+    assert np.max(np.abs(got - ref)) < 1e-12 * np.max(np.abs(ref))
+    import ionotomo_amd as it
+    m_tci = it.TriCubic(xv, yv, zv, np.log(M))
+    gch = it.compute_gradient(rays[:, None], np.zeros((3, 1, 4)), -dd[:, None, :] * 1.0, 0, 1e13, m_tci, None, np.ones((3, 1, 4)) - 1e-15,
+                              None, None, None, method="chords")
+    assert np.max(np.abs(gch - ref)) < 1e-10 * np.max(np.abs(ref))
