@@ -93,6 +93,7 @@ struct iono_ctx {
     double *d_F8 = nullptr;          // Lekien-Marsden derivative fields [node][8] of the current values (lazily built)
     bool F8_valid = false;
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
+    double *d_LMw = nullptr;         // [nodes][6] scratch of the axis-by-axis field build / fold
     // node-stationary back-projection plan (iono_adjoint_plan_dev; iono_binned_kernels.h): geometry only, library-owned
     struct AdjPlan {
         const void *o_key = nullptr, *d_key = nullptr;     // the ray arrays it was built for (caller keeps them unchanged)
@@ -422,6 +423,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->d_F8) (void)hipFree(c->d_F8);
     if (c->d_G8) (void)hipFree(c->d_G8);
+    if (c->d_LMw) (void)hipFree(c->d_LMw);
     if (c->d_freqs) (void)hipFree(c->d_freqs);
     if (c->d_rayw) (void)hipFree(c->d_rayw);
     plan_free(c);
@@ -497,6 +499,8 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     if (c->d_nM) HIP_TRY(c, hipFree(c->d_nM));
     if (c->d_F8) HIP_TRY(c, hipFree(c->d_F8));
     if (c->d_G8) HIP_TRY(c, hipFree(c->d_G8));
+    if (c->d_LMw) HIP_TRY(c, hipFree(c->d_LMw));
+    c->d_LMw = nullptr;
     c->d_axes = nullptr;
     c->d_M = nullptr;
     c->d_nM = nullptr;
@@ -639,13 +643,17 @@ static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks
 static int ensure_lm_fields(iono_ctx *c) {
     const int64_t n = ncells(c);
     if (!c->d_F8) HIP_TRY(c, hipMalloc((void **)&c->d_F8, (size_t)n * LM_NF * sizeof(double)));
+    if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
     if (!c->F8_valid) {
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_lm_fields<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c), c->d_F8, c->nx,
-                               c->ny, c->nz);
+            hipLaunchKernelGGL((k_lm_fields_z<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c),
+                               (double2 *)c->d_LMw, c->nx, c->ny, c->nz);
             return IONO_OK;
         });
+        hipLaunchKernelGGL(k_lm_fields_y, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_LMw + 2 * n, c->nx,
+                           c->ny, c->nz);
+        hipLaunchKernelGGL(k_lm_fields_x, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_LMw + 2 * n, c->d_F8, c->nx, c->ny, c->nz);
         HIP_TRY(c, hipGetLastError());
         c->F8_valid = true;
     }
@@ -1079,7 +1087,12 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                                                                    c->d_G8 + (size_t)f * n, f);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL((k_lm_fold<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_G8, grad, c->nx, c->ny, c->nz);
+        if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
+        hipLaunchKernelGGL(k_lm_fold_z, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_G8, c->d_LMw, c->nx, c->ny, c->nz);
+        hipLaunchKernelGGL(k_lm_fold_y, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_LMw, (double2 *)(c->d_LMw + 4 * n), c->nx, c->ny,
+                           c->nz);
+        hipLaunchKernelGGL((k_lm_fold_x<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double2 *)(c->d_LMw + 4 * n), grad, c->nx,
+                           c->ny, c->nz);
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }
