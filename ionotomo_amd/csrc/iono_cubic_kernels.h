@@ -64,6 +64,9 @@ __global__ __launch_bounds__(256) void k_lm_fields_y(const double2 *__restrict__
         o[1] = make_double2(z0.y, dy1);          // r = 1
     }
 }
+// z stride of F8 in nodes.  (Padding it to nz + 1 -- at 256^3 the column and plane strides, 16 KB and 4 MB, are powers of
+// two and TCP_READ_TAGCONFLICT_STALL is 15 % of the forward's cycles -- measured 8 % SLOWER: 2.07 vs 1.92 ms.)
+#define LM_NZP(nz) (nz)
 __global__ __launch_bounds__(256) void k_lm_fields_x(const double *__restrict__ Y4, double *__restrict__ F8, int nx, int ny, int nz) {
     const int64_t n = (int64_t)nx * ny * nz, sx = (int64_t)ny * nz;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(256) void k_lm_fields_x(const double *__restrict__ 
                 d0.x += cf * t0.x, d0.y += cf * t0.y, d1.x += cf * t1.x, d1.y += cf * t1.y;
             }
         }
-        double2 *o = (double2 *)(F8 + idx * LM_NF);      // index p + 2 (q + 2 r): pairs (value, Dx value) for (q, r) = 00, 10, 01, 11
+        const int64_t col = idx / nz;                    // (i, j) column; padded z stride in the output
+        double2 *o = (double2 *)(F8 + (col * LM_NZP(nz) + (idx - col * nz)) * LM_NF);      // index p + 2 (q + 2 r): (value, Dx value) for (q, r) = 00, 10, 01, 11
         o[0] = make_double2(a0.x, d0.x);
         o[1] = make_double2(a0.y, d0.y);
         o[2] = make_double2(a1.x, d1.x);
@@ -167,9 +171,10 @@ __device__ __forceinline__ double tricubic_lm(const double *__restrict__ F8, int
     const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)),
                  fk = __builtin_floor(__builtin_fabs(fz));
     const Herm hx = hermite(fx - fi), hy = hermite(fy - fj), hz = hermite(fz - fk);
-    const double lin = __builtin_fma(fi, (double)ny * (double)nz, __builtin_fma(fj, (double)nz, fk));
+    const double nzp = (double)LM_NZP(nz);
+    const double lin = __builtin_fma(fi, (double)ny * nzp, __builtin_fma(fj, nzp, fk));
     const double2 *base = (const double2 *)(F8 + (size_t)lin * LM_NF);
-    const size_t sj = (size_t)nz * (LM_NF / 2), si = (size_t)ny * sj;      // strides in double2
+    const size_t sj = (size_t)LM_NZP(nz) * (LM_NF / 2), si = (size_t)ny * sj;      // strides in double2
     double ux[2][2];                          // [a][p]: after the z and y contractions
 #pragma unroll
     for (int a = 0; a < 2; ++a) {

@@ -642,7 +642,7 @@ static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks
 // Lekien-Marsden derivative fields of the current grid values (iono_cubic_kernels.h): rebuilt after every change
 static int ensure_lm_fields(iono_ctx *c) {
     const int64_t n = ncells(c);
-    if (!c->d_F8) HIP_TRY(c, hipMalloc((void **)&c->d_F8, (size_t)n * LM_NF * sizeof(double)));
+    if (!c->d_F8) HIP_TRY(c, hipMalloc((void **)&c->d_F8, (size_t)c->nx * c->ny * LM_NZP(c->nz) * LM_NF * sizeof(double)));
     if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
     if (!c->F8_valid) {
         dispatch_storage(c, [&](auto *tag) {
