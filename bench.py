@@ -273,8 +273,8 @@ def main():
     # reused by every launch of an inversion; results are independent of it)
     order_t = eng.locality_order(o_t, d_t, TMAX) if args.order else None
 
-    def fwd():
-        eng.forward(o_t, d_t, TMAX, NS, out=tec_t)          # the forward gains nothing from the order (measured)
+    # the forward gains nothing from the walk order (measured); arguments converted once (engine.forward_launcher)
+    fwd = eng.forward_launcher(o_t, d_t, TMAX, NS, tec_t)
 
     # ---- legs that can run alone under a profiler ---------------------------------------------------------------
     def adjoint_leg():

@@ -369,6 +369,87 @@ __global__ __launch_bounds__(256, 6) void k_forward_straight_u(GridView g, const
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
+// ---- float32 storage extra: 2 x 2 (y, z) corner blocks -------------------------------------------------------------------
+// The headline kernel is bound by the NUMBER of vector-memory instructions (4 per 64 samples: a lane moves at most 16 B
+// per instruction and float64 trilinear needs four (i, j) corner columns x one 16-B z-pair).  With float32 storage the
+// four (j, k) corners of one x-plane fit ONE 16-B load if they are stored contiguously: Q4[i][j][k] = (M[i,j,k],
+// M[i,j,k+1], M[i,j+1,k], M[i,j+1,k+1]) -- 4 x the float32 memory, built by k_block_pairs whenever the values change --
+// and a sample needs TWO loads (planes i and i + 1).  A storage-mode extra (values rounded to float32 once: 1e-7 relative),
+// never the float64 headline; arithmetic stays float64.
+__global__ __launch_bounds__(256) void k_block_pairs(const float *__restrict__ M, float4 *__restrict__ Q, int64_t n, int nz) {
+    // M is the padded float32 array (one plane + one row + 2 zeros beyond n): the far corners of the last nodes read zeros
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Q[i] = make_float4(M[i], M[i + 1], M[i + nz], M[i + nz + 1]);
+}
+__device__ __forceinline__ double trilinear_q4(const float4 *__restrict__ q0p, const float4 *__restrict__ q1p, int ny, int nz, double fx,
+                                               double fy, double fz) {
+    const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
+    const double tx = fx - fi, ty = fy - fj, tz = fz - fk;
+    const double lin = __builtin_fma(fi, (double)ny * (double)nz, __builtin_fma(fj, (double)nz, fk));
+    const unsigned boff = (unsigned)lin * 16u;
+    const float4 a = *(const float4 *)((const char *)q0p + boff), b = *(const float4 *)((const char *)q1p + boff);
+    const double c00 = (double)a.x + tz * ((double)a.y - (double)a.x), c01 = (double)a.z + tz * ((double)a.w - (double)a.z);
+    const double c10 = (double)b.x + tz * ((double)b.y - (double)b.x), c11 = (double)b.z + tz * ((double)b.w - (double)b.z);
+    const double c0 = c00 + ty * (c01 - c00), c1 = c10 + ty * (c11 - c10);
+    return c0 + tx * (c1 - c0);
+}
+__global__ __launch_bounds__(256, 6) void k_forward_straight_q4(GridView g, const float4 *__restrict__ Q, const double *__restrict__ origins,
+                                                             const double *__restrict__ dirs, const int *__restrict__ order, int64_t R,
+                                                             double tmax, int Ns, int walk_mode, const double *__restrict__ unitw,
+                                                             double *__restrict__ tec, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double wlds[];
+    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int nfull = Ns >> 6, ntail0 = nfull << 6;
+    const bool tail_by_lane = (Ns - ntail0) <= 8;
+    const float4 *q0 = Q, *q1 = Q + (size_t)g.ny * g.nz;
+    const Chunk ch = wave_chunk(R, walk_mode, nullptr);
+    const double dlane = (double)lane;
+    const double *wp = wlds + lane;
+    bool oob = false;
+    for (int64_t p0 = ch.lo; p0 < ch.hi; p0 += U_MAXG * ch.stride) {
+        const int cnt = (int)min((int64_t)U_MAXG, (ch.hi - p0 + ch.stride - 1) / ch.stride);
+        URay u = {};
+        int64_t r = 0;
+        double tail = 0.0;
+        if (lane < cnt) {
+            const int64_t q = p0 + lane * ch.stride;
+            r = order ? (int64_t)order[q] : q;
+            u = load_uray(g, origins, dirs, r, tmax, Ns);
+            if (u.valid && tail_by_lane) {
+                for (int k = ntail0; k < Ns; ++k) {
+                    const double kd = (double)k;
+                    tail += wlds[k] * trilinear_q4(q0, q1, g.ny, g.nz, fma(kd, u.dfx, u.fx0), fma(kd, u.dfy, u.fy0), fma(kd, u.dfz, u.fz0));
+                }
+            }
+            if (!u.valid) oob = true;
+        }
+        double res = 0.0;
+        for (int gi = 0; gi < cnt; ++gi) {
+            const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
+            if (!ok) continue;
+            const double dfx = bcast_lane(u.dfx, gi), dfy = bcast_lane(u.dfy, gi), dfz = bcast_lane(u.dfz, gi);
+            double fx = fma(dlane, dfx, bcast_lane(u.fx0, gi));
+            double fy = fma(dlane, dfy, bcast_lane(u.fy0, gi));
+            double fz = fma(dlane, dfz, bcast_lane(u.fz0, gi));
+            const double sx64 = 64.0 * dfx, sy64 = 64.0 * dfy, sz64 = 64.0 * dfz;
+            double acc = 0.0;
+            for (int it = 0; it < nfull; ++it) {
+                acc = fma(wp[it << 6], trilinear_q4(q0, q1, g.ny, g.nz, fx, fy, fz), acc);
+                fx += sx64;
+                fy += sy64;
+                fz += sz64;
+            }
+            if (!tail_by_lane && lane + ntail0 < Ns) acc = fma(wp[ntail0], trilinear_q4(q0, q1, g.ny, g.nz, fx, fy, fz), acc);
+            const double total = wave_sum_dpp(acc);
+            if (lane == gi) res = total;
+        }
+        if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
+    }
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
 template <typename GT, int KIND>
 __global__ __launch_bounds__(256) void k_forward_rays(GridView g, const double *__restrict__ rays, int64_t R, int Ns,
                                                       int rule, double *__restrict__ tec, int *oob_flag) {

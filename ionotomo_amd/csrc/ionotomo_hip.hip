@@ -94,6 +94,8 @@ struct iono_ctx {
     bool F8_valid = false;
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
     double *d_LMw = nullptr;         // [nodes][6] scratch of the axis-by-axis field build / fold
+    float4 *d_Q4 = nullptr;          // float32 storage: 2 x 2 (y, z) corner blocks for the 2-loads-per-sample forward (lazily built)
+    bool Q4_valid = false;
     // node-stationary back-projection plan (iono_adjoint_plan_dev; iono_binned_kernels.h): geometry only, library-owned
     struct AdjPlan {
         const void *o_key = nullptr, *d_key = nullptr;     // the ray arrays it was built for (caller keeps them unchanged)
@@ -424,6 +426,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_F8) (void)hipFree(c->d_F8);
     if (c->d_G8) (void)hipFree(c->d_G8);
     if (c->d_LMw) (void)hipFree(c->d_LMw);
+    if (c->d_Q4) (void)hipFree(c->d_Q4);
     if (c->d_freqs) (void)hipFree(c->d_freqs);
     if (c->d_rayw) (void)hipFree(c->d_rayw);
     plan_free(c);
@@ -500,7 +503,9 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     if (c->d_F8) HIP_TRY(c, hipFree(c->d_F8));
     if (c->d_G8) HIP_TRY(c, hipFree(c->d_G8));
     if (c->d_LMw) HIP_TRY(c, hipFree(c->d_LMw));
+    if (c->d_Q4) HIP_TRY(c, hipFree(c->d_Q4));
     c->d_LMw = nullptr;
+    c->d_Q4 = nullptr, c->Q4_valid = false;
     c->d_axes = nullptr;
     c->d_M = nullptr;
     c->d_nM = nullptr;
@@ -538,6 +543,7 @@ static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, d
     const int64_t n = ncells(c);
     c->nM_freq = -1.0;
     c->F8_valid = false;
+    c->Q4_valid = false;
     int rc = dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
         hipLaunchKernelGGL((k_set_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, src_dev, (GT *)cur_values(c), n,
@@ -686,6 +692,22 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                                c->d_unitw, pl.d_partial, pl.smax);
             hipLaunchKernelGGL(k_forward_binned_finish, dim3(ew_blocks(c, R)), block, 0, c->stream, pl.d_uray, pl.d_nseg, pl.d_partial,
                                pl.smax, R, tec, c->d_flags);
+        } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && std::is_same<GT, float>::value && c->variant != 9 &&
+                   (uint64_t)(ncells(c) + (int64_t)c->ny * c->nz + c->nz + 2) * 16 < ((uint64_t)1 << 32)) {
+            // float32 storage extra: 2 x 2 corner blocks, two 16-B loads per sample (IONOTOMO_VARIANT=9: plain float32 kernel)
+            const int64_t n = ncells(c), padded = n + (int64_t)c->ny * c->nz + c->nz + 2;
+            if (!c->d_Q4) {
+                HIP_TRY(c, hipMalloc((void **)&c->d_Q4, (size_t)padded * sizeof(float4)));
+                HIP_TRY(c, hipMemsetAsync(c->d_Q4, 0, (size_t)padded * sizeof(float4), c->stream));
+            }
+            if (!c->Q4_valid) {
+                hipLaunchKernelGGL(k_block_pairs, dim3(ew_blocks(c, n)), block, 0, c->stream, (const float *)cur_values(c), c->d_Q4, n, c->nz);
+                c->Q4_valid = true;
+            }
+            const size_t wl = sizeof(double) * Ns;
+            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_q4, wl), R);
+            hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, order, R, tmax, Ns, c->walk_mode,
+                               c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);

@@ -190,3 +190,27 @@ def test_full_batch_tricubic_dot_product_256_cubed():
     dev = float(((tl - tec).abs() / tec.abs()).max())
     assert 1e-9 < dev < 5e-2
     assert not eng.check_oob()
+
+
+def test_solvers_with_the_tricubic_operator():
+    """CGLS / SIRT on the tricubic forward + its transpose: the fused solver passes (search direction read in place, so the
+    derivative fields are rebuilt every iteration; plan-binned channel transposes) give the iterates of the dense-vector
+    form on the same engine, and the objective falls."""
+    from ionotomo_amd import solvers
+    from problems import small_problem
+    pb = small_problem(na=6, nd=5, nt=3, n=24, Ns=33)
+    w = pb["w"]
+    eng = engine(w)
+    rng = np.random.default_rng(7)
+    prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=np.zeros((pb["na"], pb["P"])),
+                                cdct=np.full((pb["na"], pb["P"]), 1e-6), i0=pb["i0"], tune=False)
+    assert prob.plan and prob.plan[0] > 0
+    eng.set_values(eng.tensor(pb["x_true"]))
+    prob.dobs = prob.forward() + eng.tensor(rng.normal(size=pb["na"] * pb["P"]) * 1e-3)
+    x0 = eng.tensor(pb["x0"])
+    for name in ("cgls", "sirt"):
+        xf, hf = getattr(solvers, name)(prob, x0, n_iter=6)
+        xd, hd = getattr(solvers, "_%s_dense" % name)(prob, x0, n_iter=6)
+        assert np.allclose(hf, hd, rtol=1e-7) and hf[-1] < 0.5 * hf[0]
+        assert float((xf - xd).abs().max()) < 1e-7 * float(xd.abs().max())
+    assert not eng.check_oob()
