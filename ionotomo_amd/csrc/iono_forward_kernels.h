@@ -229,6 +229,29 @@ __device__ __forceinline__ Corners<GT> load_corners(const GT *__restrict__ b00, 
     const unsigned boff = (unsigned)lin * (unsigned)sizeof(GT);
     const GT *p00 = (const GT *)((const char *)b00 + boff), *p01 = (const GT *)((const char *)b01 + boff);
     const GT *p10 = (const GT *)((const char *)b10 + boff), *p11 = (const GT *)((const char *)b11 + boff);
+#ifdef IONO_FWD_ABL     // timing-only builds of profiles/tools/ablate_forward.sh (WRONG results; never in the shipped library)
+#if IONO_FWD_ABL == 1   // four loads of 8 B per lane instead of 16
+    c.c000 = c.c001 = p00[0];
+    c.c010 = c.c011 = p01[0];
+    c.c100 = c.c101 = p10[0];
+    c.c110 = c.c111 = p11[0];
+    return c;
+#elif IONO_FWD_ABL == 2   // two loads per sample
+    c.c000 = c.c010 = p00[0];
+    c.c001 = c.c011 = p00[1];
+    c.c100 = c.c110 = p11[0];
+    c.c101 = c.c111 = p11[1];
+    return c;
+#elif IONO_FWD_ABL == 3   // four loads, every wave reads the same 64 + 1 nodes of four columns: no L1 fills
+    p00 = b00 + (threadIdx.x & 63), p01 = b01 + (threadIdx.x & 63), p10 = b10 + (threadIdx.x & 63), p11 = b11 + (threadIdx.x & 63);
+    asm volatile("" : "+v"(p00), "+v"(p01), "+v"(p10), "+v"(p11) : "v"(boff));
+#elif IONO_FWD_ABL == 4   // no loads
+    c.c000 = c.c001 = c.c010 = c.c011 = c.c100 = c.c101 = c.c110 = c.c111 = (GT)lin;
+    return c;
+#elif IONO_FWD_ABL == 5   // four loads per sample, all from the lines of ONE column (a quarter of the fills, same instructions)
+    p01 = p00 + 2, p10 = p00 + 4, p11 = p00 + 6;
+#endif
+#endif
     c.c000 = p00[0];
     c.c001 = p00[1];
     c.c010 = p01[0];
@@ -301,8 +324,17 @@ __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode, const int64_t *
     return c;
 }
 
+#if defined(IONO_FWD_ABL) && IONO_FWD_ABL == 6
+#define FWD_U_WG 3
+#define FWD_U_BATCH 4
+#elif defined(IONO_FWD_ABL) && IONO_FWD_ABL == 7
+#define FWD_U_WG 4
+#define FWD_U_BATCH 2
+#else
+#define FWD_U_WG 6
+#endif
 template <typename GT>
-__global__ __launch_bounds__(256, 6) void k_forward_straight_u(GridView g, const double *__restrict__ origins,
+__global__ __launch_bounds__(256, FWD_U_WG) void k_forward_straight_u(GridView g, const double *__restrict__ origins,
                                                             const double *__restrict__ dirs, const int *__restrict__ order,
                                                             int64_t R, double tmax, int Ns, int walk_mode,
                                                             const double *__restrict__ unitw, double *__restrict__ tec,
@@ -352,7 +384,22 @@ __global__ __launch_bounds__(256, 6) void k_forward_straight_u(GridView g, const
             double acc = 0.0;
             // (a software-pipelined version of this loop -- next iteration's loads in flight during the
             //  interpolation -- measured 15 % SLOWER: +26 VGPRs cost more occupancy than the overlap won)
-            for (int it = 0; it < nfull; ++it) {
+            int it = 0;
+#ifdef FWD_U_BATCH     // timing study: the loads of FWD_U_BATCH slabs in flight before the first interpolation
+            for (; it + FWD_U_BATCH <= nfull; it += FWD_U_BATCH) {
+                Corners<GT> cc[FWD_U_BATCH];
+#pragma unroll
+                for (int b = 0; b < FWD_U_BATCH; ++b) {
+                    cc[b] = load_corners<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz);
+                    fx += sx64;
+                    fy += sy64;
+                    fz += sz64;
+                }
+#pragma unroll
+                for (int b = 0; b < FWD_U_BATCH; ++b) acc = fma(wp[(it + b) << 6], lerp_corners<GT>(cc[b]), acc);
+            }
+#endif
+            for (; it < nfull; ++it) {
                 acc = fma(wp[it << 6], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
                 fx += sx64;
                 fy += sy64;
