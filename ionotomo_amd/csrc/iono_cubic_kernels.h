@@ -66,7 +66,12 @@ __global__ __launch_bounds__(256) void k_lm_fields_y(const double2 *__restrict__
 }
 // z stride of F8 in nodes.  (Padding it to nz + 1 -- at 256^3 the column and plane strides, 16 KB and 4 MB, are powers of
 // two and TCP_READ_TAGCONFLICT_STALL is 15 % of the forward's cycles -- measured 8 % SLOWER: 2.07 vs 1.92 ms.)
-#define LM_NZP(nz) (nz)
+#ifndef LM_PAD_J
+#define LM_PAD_J 0
+#define LM_PAD_I 0
+#endif
+#define LM_NZP(nz) ((nz) + LM_PAD_J)
+#define LM_SI(ny, nz) ((int64_t)(ny) * LM_NZP(nz) + LM_PAD_I)     // x-plane stride in nodes
 __global__ __launch_bounds__(256) void k_lm_fields_x(const double *__restrict__ Y4, double *__restrict__ F8, int nx, int ny, int nz) {
     const int64_t n = (int64_t)nx * ny * nz, sx = (int64_t)ny * nz;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
@@ -85,7 +90,8 @@ __global__ __launch_bounds__(256) void k_lm_fields_x(const double *__restrict__ 
             }
         }
         const int64_t col = idx / nz;                    // (i, j) column; padded z stride in the output
-        double2 *o = (double2 *)(F8 + (col * LM_NZP(nz) + (idx - col * nz)) * LM_NF);      // index p + 2 (q + 2 r): (value, Dx value) for (q, r) = 00, 10, 01, 11
+        const int64_t jj = col - (int64_t)i * ny;
+        double2 *o = (double2 *)(F8 + (i * LM_SI(ny, nz) + jj * LM_NZP(nz) + (idx - col * nz)) * LM_NF);      // index p + 2 (q + 2 r): (value, Dx value) for (q, r) = 00, 10, 01, 11
         o[0] = make_double2(a0.x, d0.x);
         o[1] = make_double2(a0.y, d0.y);
         o[2] = make_double2(a1.x, d1.x);
@@ -172,9 +178,9 @@ __device__ __forceinline__ double tricubic_lm(const double *__restrict__ F8, int
                  fk = __builtin_floor(__builtin_fabs(fz));
     const Herm hx = hermite(fx - fi), hy = hermite(fy - fj), hz = hermite(fz - fk);
     const double nzp = (double)LM_NZP(nz);
-    const double lin = __builtin_fma(fi, (double)ny * nzp, __builtin_fma(fj, nzp, fk));
+    const double lin = __builtin_fma(fi, (double)LM_SI(ny, nz), __builtin_fma(fj, nzp, fk));
     const double2 *base = (const double2 *)(F8 + (size_t)lin * LM_NF);
-    const size_t sj = (size_t)LM_NZP(nz) * (LM_NF / 2), si = (size_t)ny * sj;      // strides in double2
+    const size_t sj = (size_t)LM_NZP(nz) * (LM_NF / 2), si = (size_t)LM_SI(ny, nz) * (LM_NF / 2);      // strides in double2
     double ux[2][2];                          // [a][p]: after the z and y contractions
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
@@ -185,6 +191,19 @@ __device__ __forceinline__ double tricubic_lm(const double *__restrict__ F8, int
             double2 n0[4], n1[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) n0[t] = col[t], n1[t] = col[4 + t];
+#ifdef IONO_LM_ABL     // timing-only builds (WRONG results): 1 = no loads, 2 = every wave reads the same lines (no fills)
+#if IONO_LM_ABL == 1
+#pragma unroll
+            for (int t = 0; t < 4; ++t) n0[t] = n1[t] = make_double2(lin, fx);
+#elif IONO_LM_ABL == 2
+            {
+                const double2 *cc = (const double2 *)F8 + (threadIdx.x & 63) * 4 + (a * 2 + b) * 512;
+                asm volatile("" : "+v"(cc) : "v"(lin));
+#pragma unroll
+                for (int t = 0; t < 4; ++t) n0[t] = cc[t], n1[t] = cc[4 + t];
+            }
+#endif
+#endif
             // z: value fields (r = 0) sit in n?[0..1], their z-slopes (r = 1) in n?[2..3]; component .x = p 0, .y = p 1
             const double v00 = hz.h0 * n0[0].x + hz.h1 * n1[0].x + hz.s0 * n0[2].x + hz.s1 * n1[2].x;     // p 0, q 0
             const double v10 = hz.h0 * n0[0].y + hz.h1 * n1[0].y + hz.s0 * n0[2].y + hz.s1 * n1[2].y;     // p 1, q 0
@@ -196,6 +215,72 @@ __device__ __forceinline__ double tricubic_lm(const double *__restrict__ F8, int
         }
     }
     return hx.h0 * ux[0][0] + hx.s0 * ux[0][1] + hx.h1 * ux[1][0] + hx.s1 * ux[1][1];
+}
+
+// The same sample evaluated by a FULL wave whose lanes are consecutive samples of one ray: the upper node (k + 1) of lane l
+// is the lower node (k) of lane l + 1 whenever the two samples sit in the same column one cell apart (80 % of the lane
+// pairs at the bench geometry), so a lane loads its lower node only (64 B) and takes the upper one from its neighbour
+// with 16 wave_shl DPP moves; the lanes without such a neighbour load theirs under an execution mask.  Each 16-B load
+// instruction of this kernel costs one L1 look-up PER LANE (the lanes are 64 B apart), which is what binds it: this halves
+// the full-wave instructions.  Same values, same arithmetic: bit-identical to tricubic_lm.  Every lane must be active.
+__device__ __forceinline__ double2 dpp_next_lane(double2 keep, double2 v) {
+    int o[4] = {__double2loint(keep.x), __double2hiint(keep.x), __double2loint(keep.y), __double2hiint(keep.y)};
+    const int q[4] = {__double2loint(v.x), __double2hiint(v.x), __double2loint(v.y), __double2hiint(v.y)};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_update_dpp(o[t], q[t], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    return make_double2(__hiloint2double(o[1], o[0]), __hiloint2double(o[3], o[2]));
+}
+struct LmCols {
+    const char *c[2][2];      // F8 + record offset of the corner columns (a, b): uniform, kept in SGPRs
+};
+__device__ __forceinline__ LmCols lm_cols(const double *F8, int ny, int nz) {
+    LmCols C;
+    for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < 2; ++b) C.c[a][b] = (const char *)(F8 + ((size_t)a * LM_SI(ny, nz) + (size_t)b * LM_NZP(nz)) * LM_NF);
+    return C;
+}
+__device__ __forceinline__ double tricubic_lm_wave(const LmCols &C, int ny, int nz, double fx, double fy, double fz) {
+    const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)),
+                 fk = __builtin_floor(__builtin_fabs(fz));
+    const Herm hx = hermite(fx - fi), hy = hermite(fy - fj), hz = hermite(fz - fk);
+    const double lin = __builtin_fma(fi, (double)LM_SI(ny, nz), __builtin_fma(fj, (double)LM_NZP(nz), fk));
+    const unsigned node = (unsigned)lin;      // (the fast tier is limited to field arrays below 4 GiB on the host)
+    const unsigned next = (unsigned)__builtin_amdgcn_update_dpp(-2, (int)node, 0x130, 0xf, 0xf, false);
+    const bool own = next != node + 1;        // no neighbour holding my upper node (lane 63 keeps -2)
+    const unsigned boff = node * (unsigned)(LM_NF * sizeof(double));
+    double res = 0.0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {             // one x-plane = two columns per batch: 8 full + 8 masked loads in flight
+        double2 n0[2][4], n1[2][4];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) n0[b][t] = ((const double2 *)(C.c[a][b] + boff))[t];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) n1[b][t] = dpp_next_lane(n0[b][t], n0[b][t]);
+        if (own) {      // (the masked loads land in the registers the DPP moves wrote)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) n1[b][t] = ((const double2 *)(C.c[a][b] + boff))[4 + t];
+        }
+        double u0 = 0.0, u1 = 0.0;            // p 0 / p 1 after the z and y contractions
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            // z: value fields (r = 0) sit in n?[0..1], their z-slopes (r = 1) in n?[2..3]; component .x = p 0, .y = p 1
+            const double v00 = hz.h0 * n0[b][0].x + hz.h1 * n1[b][0].x + hz.s0 * n0[b][2].x + hz.s1 * n1[b][2].x;     // p 0, q 0
+            const double v10 = hz.h0 * n0[b][0].y + hz.h1 * n1[b][0].y + hz.s0 * n0[b][2].y + hz.s1 * n1[b][2].y;     // p 1, q 0
+            const double v01 = hz.h0 * n0[b][1].x + hz.h1 * n1[b][1].x + hz.s0 * n0[b][3].x + hz.s1 * n1[b][3].x;     // p 0, q 1
+            const double v11 = hz.h0 * n0[b][1].y + hz.h1 * n1[b][1].y + hz.s0 * n0[b][3].y + hz.s1 * n1[b][3].y;     // p 1, q 1
+            const double wy = b ? hy.h1 : hy.h0, wys = b ? hy.s1 : hy.s0;
+            u0 += wy * v00 + wys * v01;
+            u1 += wy * v10 + wys * v11;
+        }
+        res += a ? hx.h1 * u0 + hx.s1 * u1 : hx.h0 * u0 + hx.s0 * u1;
+    }
+    return res;
 }
 
 // straight ray in ideal grid coordinates, valid when both end points lie in the tricubic domain g[2] .. g[n-3]
@@ -214,61 +299,81 @@ __device__ __forceinline__ URay load_uray_cubic(const GridView &g, const double 
 }
 
 // Same wave / chunk structure as k_forward_straight_u (iono_forward_kernels.h): one wave per ray, lanes = samples,
-// lane-parallel ray set-up for groups of 16 rays, DPP Simpson reduction, quadrature weights in LDS.
-__global__ __launch_bounds__(256, 4) void k_forward_straight_lm(GridView g, const double *__restrict__ F8,
-                                                             const double *__restrict__ origins,
-                                                             const double *__restrict__ dirs, const int *__restrict__ order,
-                                                             int64_t R, double tmax, int Ns, int walk_mode,
-                                                             const double *__restrict__ unitw, double *__restrict__ tec,
-                                                             int *oob_flag) {
+// lane-parallel ray set-up for groups of 16 rays, DPP Simpson reduction, quadrature weights in LDS.  The per-ray state of a
+// group is parked in LDS (LM_RS doubles per ray, read back as wave-uniform broadcasts): the sample loop keeps 64 VGPRs of
+// field data in flight and has none to spare for 16 rays' worth of lane-private state.
+// (2, 3 or 4 workgroups per CU measured the same to 4 %: the kernel is bound by L1 look-ups, not by latency; 2 leaves the
+//  compiler 256 VGPRs and no spills)
+#ifndef LM_WG
+#define LM_WG 2
+#endif
+#define LM_RS 10      // fx0 fy0 fz0 dfx dfy dfz h tail ray-index (as double) pad
+__global__ __launch_bounds__(256, LM_WG) void k_forward_straight_lm(GridView g, const double *__restrict__ F8,
+                                                                 const double *__restrict__ origins,
+                                                                 const double *__restrict__ dirs, const int *__restrict__ order,
+                                                                 int64_t R, double tmax, int Ns, int walk_mode,
+                                                                 const double *__restrict__ unitw, double *__restrict__ tec,
+                                                                 int *oob_flag) {
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    double *rs = wlds + ((Ns + 1) & ~1) + (threadIdx.x >> 6) * (U_MAXG * LM_RS);      // this wave's ray-state block
     const int nfull = Ns >> 6, ntail0 = nfull << 6;
     const bool tail_by_lane = (Ns - ntail0) <= 8;
     const Chunk ch = wave_chunk(R, walk_mode, nullptr);
+    const LmCols C = lm_cols(F8, g.ny, g.nz);
     const double dlane = (double)lane;
     const double *wp = wlds + lane;
     bool oob = false;
     for (int64_t q0 = ch.lo; q0 < ch.hi; q0 += U_MAXG * ch.stride) {
         const int cnt = (int)min((int64_t)U_MAXG, (ch.hi - q0 + ch.stride - 1) / ch.stride);
-        URay u = {};
-        int64_t r = 0;
-        double tail = 0.0;
+        bool valid = false;
         if (lane < cnt) {
             const int64_t q = q0 + lane * ch.stride;
-            r = order ? (int64_t)order[q] : q;
-            u = load_uray_cubic(g, origins, dirs, r, tmax, Ns);
+            const int64_t r = order ? (int64_t)order[q] : q;
+            const URay u = load_uray_cubic(g, origins, dirs, r, tmax, Ns);
+            double tail = 0.0;
             if (u.valid && tail_by_lane) {
                 for (int k = ntail0; k < Ns; ++k) {
                     const double kd = (double)k;
                     tail += wlds[k] * tricubic_lm(F8, g.ny, g.nz, fma(kd, u.dfx, u.fx0), fma(kd, u.dfy, u.fy0), fma(kd, u.dfz, u.fz0));
                 }
             }
-            if (!u.valid) oob = true;
+            valid = u.valid;
+            if (!valid) {
+                oob = true;
+                tec[r] = nan("");
+            }
+            double *w = rs + lane * LM_RS;
+            w[0] = u.fx0, w[1] = u.fy0, w[2] = u.fz0, w[3] = u.dfx, w[4] = u.dfy, w[5] = u.dfz, w[6] = u.h, w[7] = tail, w[8] = (double)r;
         }
-        double res = 0.0;
+        const unsigned long long vmask = __ballot(valid);
+        // (LDS operations of one wave execute in order: the broadcasts below see the writes above; this only stops the compiler)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         for (int gi = 0; gi < cnt; ++gi) {
-            const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
-            if (!ok) continue;
-            const double dfx = bcast_lane(u.dfx, gi), dfy = bcast_lane(u.dfy, gi), dfz = bcast_lane(u.dfz, gi);
-            double fx = fma(dlane, dfx, bcast_lane(u.fx0, gi));
-            double fy = fma(dlane, dfy, bcast_lane(u.fy0, gi));
-            double fz = fma(dlane, dfz, bcast_lane(u.fz0, gi));
+            if (!((vmask >> gi) & 1)) continue;
+            const double *p = rs + gi * LM_RS;               // wave-uniform address: one broadcast per read
+            const double dfx = p[3], dfy = p[4], dfz = p[5];
+            double fx = fma(dlane, dfx, p[0]);
+            double fy = fma(dlane, dfy, p[1]);
+            double fz = fma(dlane, dfz, p[2]);
             const double sx64 = 64.0 * dfx, sy64 = 64.0 * dfy, sz64 = 64.0 * dfz;
             double acc = 0.0;
             for (int it = 0; it < nfull; ++it) {
-                acc = fma(wp[it << 6], tricubic_lm(F8, g.ny, g.nz, fx, fy, fz), acc);
+                acc = fma(wp[it << 6], tricubic_lm_wave(C, g.ny, g.nz, fx, fy, fz), acc);
                 fx += sx64;
                 fy += sy64;
                 fz += sz64;
             }
             if (!tail_by_lane && lane + ntail0 < Ns) acc = fma(wp[ntail0], tricubic_lm(F8, g.ny, g.nz, fx, fy, fz), acc);
             const double total = wave_sum_dpp(acc);
-            if (lane == gi) res = total;
+            if (lane == 0) tec[(int64_t)p[8]] = (total + p[7]) * p[6];
         }
-        if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");        // the next group overwrites the ray-state block
+        __builtin_amdgcn_wave_barrier();
     }
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }

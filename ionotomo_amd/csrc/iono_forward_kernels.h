@@ -288,7 +288,7 @@ struct Chunk {
     int64_t lo, hi, stride;     // walk positions lo, lo+stride, ... < hi
     int64_t widx;               // index of this wave's chunk in walk order
 };
-// mode 0 (default): one contiguous chunk per wave.  mode bit 0: one contiguous chunk per WORKGROUP, its
+// mode 0 (default): one contiguous chunk per wave.  mode bit 1: XCD-interleaved (below).  mode bit 0: one contiguous chunk per WORKGROUP, its
 // 4 waves interleaved (wave w takes lo+w, lo+w+4, ...).  mode bit 2: plain block order instead of
 // XCD-major.  Both alternatives measured slower or equal on the bench workload; kept for A/B runs
 // (env IONOTOMO_WALK).
@@ -308,6 +308,16 @@ __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode, const int64_t *
         c.lo = part[c.widx];
         c.hi = part[c.widx + 1];
         c.stride = 1;
+    } else if ((mode & 2) && (gridDim.x & 7) == 0) {
+        // one contiguous eighth of the walk per XCD, ALL the waves of the XCD interleaved in it: what is in flight on an XCD
+        // at any time is one short stretch of the walk, so the lines its rays share stay in that XCD's L2
+        const int xcd = blockIdx.x & 7;
+        const int64_t nwx = (int64_t)(gridDim.x >> 3) * wpb, wi = (int64_t)(blockIdx.x >> 3) * wpb + wid;
+        const int64_t base = R / 8, rem = R % 8;
+        const int64_t lo = xcd * base + min((int64_t)xcd, rem);
+        c.hi = lo + base + (xcd < rem ? 1 : 0);
+        c.lo = lo + wi;
+        c.stride = nwx;
     } else if (mode & 1) {
         const int64_t nb = gridDim.x, base = R / nb, rem = R % nb;
         const int64_t lo = bidx * base + min(bidx, rem);

@@ -400,7 +400,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_FORCE_GENERAL")) c->force_general = atoi(e);
     if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
-    if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 4), c->walk_mode_set = true;
+    if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 2 | 4), c->walk_mode_set = true;
     if (const char *e = getenv("IONOTOMO_FWD_PLAN")) c->fwd_plan = atoi(e);
     if (const char *e = getenv("IONOTOMO_ADJ_BUNDLE")) c->adj_mode = atoi(e) & (32 | 64 | 128);
 #ifdef IONO_ABLATION
@@ -648,7 +648,11 @@ static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks
 // Lekien-Marsden derivative fields of the current grid values (iono_cubic_kernels.h): rebuilt after every change
 static int ensure_lm_fields(iono_ctx *c) {
     const int64_t n = ncells(c);
-    if (!c->d_F8) HIP_TRY(c, hipMalloc((void **)&c->d_F8, (size_t)c->nx * c->ny * LM_NZP(c->nz) * LM_NF * sizeof(double)));
+    if (!c->d_F8) {
+        const size_t fb = (size_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double);
+        HIP_TRY(c, hipMalloc((void **)&c->d_F8, fb));
+        HIP_TRY(c, hipMemsetAsync(c->d_F8, 0, fb, c->stream));      // (pad nodes: never read by a valid sample)
+    }
     if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
     if (!c->F8_valid) {
         dispatch_storage(c, [&](auto *tag) {
@@ -667,7 +671,9 @@ static int ensure_lm_fields(iono_ctx *c) {
 }
 // fast tricubic tier: ideal-uniform axes, weights in LDS, 32-bit-safe field array (IONOTOMO_VARIANT=4 forces the general tier)
 static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
-    return ideal_path_ok(c, Ns) && c->variant != 4 && c->nx >= 6 && c->ny >= 6 && c->nz >= 6;
+    // (field records of 64 B per node, addressed with 32-bit byte offsets from the column bases)
+    return ideal_path_ok(c, Ns) && c->variant != 4 && c->nx >= 6 && c->ny >= 6 && c->nz >= 6 &&
+           (uint64_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double) < ((uint64_t)1 << 32);
 }
 
 // ---- forward (device pointers) ---------------------------------------------------------------
@@ -713,7 +719,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
             iono_ctx::WalkPart &wp = c->walk[0];
             const int nw = nb * 4;                              // one chunk per wave
-            const bool use_part = wp.n == nw && wp.R == R && !(c->walk_mode & 1) && order == nullptr;
+            const bool use_part = wp.n == nw && wp.R == R && !(c->walk_mode & 3) && order == nullptr;
             const int rc2 = walk_cycles_reserve(c, wp, nw, nw);
             if (rc2) return rc2;
             hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
@@ -721,11 +727,12 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
-            const size_t wl = sizeof(double) * Ns;
-const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_lm, wl), R);
-            // default walk for this kernel: one contiguous chunk per workgroup with its 4 waves interleaved (neighbouring
-            // rays of an ordered walk then share the 64-B field records in L1): measured 1.89 vs 1.97 ms per-wave chunks
-            const int wm = c->walk_mode_set ? c->walk_mode : 1;
+            const size_t wl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + 4 * U_MAXG * LM_RS);      // weights + ray state of 4 waves
+            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_lm, wl), R);
+            // default walk for this kernel: all the waves of an XCD interleaved in that XCD's eighth of the walk (what is in
+            // flight on an XCD is then one short stretch of neighbouring rays whose field records stay in its L2):
+            // 1.49 ms against 1.60 with one contiguous chunk per wave
+            const int wm = c->walk_mode_set ? c->walk_mode : 2;
             hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, c->stream, g, c->d_F8, o, d, order, R, tmax, Ns, wm,
                                c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))      // (`order` is a speed hint: ignored here)

@@ -94,7 +94,7 @@ def test_rays_grazing_low_faces_forward_and_adjoint(OC, Ns):
     assert checked >= 8 and negatives > 0, "no accepted problem had a negative grid coordinate: the test lost its teeth"
 
 
-@pytest.mark.parametrize("env", [{"IONOTOMO_WALK": v} for v in ("1", "4", "5", "8", "32", "64", "128")] +
+@pytest.mark.parametrize("env", [{"IONOTOMO_WALK": v} for v in ("1", "2", "3", "4", "5", "8", "32", "64", "128")] +
                          [{"IONOTOMO_ADJ_BUNDLE": v} for v in ("32", "64", "128", "4", "8", "12")] +
                          [{"IONOTOMO_ADJ_ABLATE": "12"}])
 def test_ab_switches_never_change_results(env, monkeypatch, OC):
