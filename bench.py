@@ -141,7 +141,11 @@ def cpu_baseline(w, tec_gpu):
     rays = O.straight_rays(w["origins"][sub], w["directions"][sub], TMAX, NS)
     O.forward_tec_loop(rays, w["xvec"], w["yvec"], w["zvec"], ne)
     numpy_rate = rays.shape[0] / (time.perf_counter() - t1)
-    return dict(value=R / dt, unit="ray-integrals/s", cores=threads, kind="port",
+    try:
+        cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        cpu_model = "unknown"
+    return dict(value=R / dt, unit="ray-integrals/s", cores=threads, kind="port", host_cpus=os.cpu_count(), cpu_model=cpu_model,
                 sample="full per-GPU batch (%d rays x %d samples, 256^3 f64 grid) x %d repetitions, unoptimised C/OpenMP "
                        "port oracle/oracle_c.c on %d threads; numpy per-ray-loop port (1 thread, %d rays): %.3g "
                        "ray-integrals/s" % (R, NS, reps, threads, rays.shape[0], numpy_rate)), rel
@@ -420,6 +424,12 @@ def main():
                     xch32.sum_(grad_t)
                 c32wall, _ = time_steps(iteration_compact32, k2, 1, torch, dist, world)
                 extra["iteration_ms_compact_exchange_f32"] = c32wall / k2 * 1e3
+            # ---- the reference's default sampling, Ns = nz (even), with the 'avg' rule its own integrate.py spells out
+            # (secondary row; tests/golden/forward_tec_even_avg.npz pins the rule)
+            tec_even = torch.empty(R, dtype=torch.float64, device=eng.device)
+            wev, kev = time_steps(lambda: eng.forward(o_t, d_t, TMAX, NS - 1, out=tec_even), k2, 1, torch, dist, world)
+            extra["even_ns_avg_rule_ray_integrals_per_s"] = world * R * k2 / wev
+            extra["even_ns_avg_rule_vs_odd_max_rel_dev"] = float(((tec_even - tec_t).abs() / tec_t.abs()).max())
             # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
             w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32), k2, 1, torch, dist, world)
             extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
