@@ -280,6 +280,20 @@ int iono_smooth_separable(iono_ctx *ctx, const double *in, double *out, const do
 int iono_smooth_separable_dev(iono_ctx *ctx, const double *in_dev, double *out_dev, double *work_dev,
                               const double *kx, const double *ky, const double *kz, int h);
 
+/* ---- multi-GPU: the sum over ranks of the back-projected update, one process per GPU (SURVEY.md 8b `allreduce_grid`, 8e).
+ *      Replaces `da.sum(da.stack(gradient, axis=-1), axis=-1)` over the per-direction dask tasks
+ *      (inversion/gradient.py:52-54).  RCCL over xGMI, loaded lazily (dlopen "librccl.so": hosts that do the collective
+ *      themselves -- the Python layer uses torch.distributed -- never load it).  Rank 0 obtains the 128-byte id and ships
+ *      it to the other ranks over the host's own channel (dask scheduler, MPI, a file); every rank then calls
+ *      iono_comm_init (collective).  iono_comm_allreduce_dev sums `count` elements IN PLACE over all ranks, enqueued on
+ *      the ctx stream (ordered after the adjoint launch that produced them, no host synchronisation); dtype IONO_F64 or
+ *      IONO_F32.  IONO_ERR_HIP (with the RCCL message in iono_last_error) on any RCCL failure. ------------------------ */
+enum { IONO_COMM_ID_BYTES = 128 };
+int iono_comm_unique_id(iono_ctx *ctx, char id_out[IONO_COMM_ID_BYTES]);
+int iono_comm_init(iono_ctx *ctx, const char id[IONO_COMM_ID_BYTES], int rank, int nranks);
+int iono_comm_allreduce_dev(iono_ctx *ctx, void *buf_dev, int64_t count, int dtype);
+int iono_comm_destroy(iono_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ OK, ERR_OOB, ERR_NONFINITE, ERR_SHAPE, ERR_HIP, ERR_ARG = 0, -1, -2, -3, -4, -5
 WALK_FORWARD, WALK_ADJOINT = 0, 1          # iono_walk_cycles / iono_walk_partition_set
 NPART = 512                                # IONO_NPART: partial sums per dot-producing pass
 F64, F32 = 0, 1
+COMM_ID_BYTES = 128                        # IONO_COMM_ID_BYTES
 INTERP_TRILINEAR, INTERP_TRICUBIC = 0, 1
 RAY_Z, RAY_S = 0, 1                        # independent variable of a ray: Fermat(type='z' | 's')
 QUAD_SIMPSON_AVG, QUAD_SIMPSON_SCIPY, QUAD_TRAPEZOID = 0, 1, 2
@@ -98,6 +99,10 @@ _SIGNATURES = {
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],
     "iono_smooth_separable_dev": [_V, _V, _V, _P, _P, _P, _I],
+    "iono_comm_unique_id": [ctypes.c_char_p],
+    "iono_comm_init": [ctypes.c_char_p, _I, _I],
+    "iono_comm_allreduce_dev": [_V, _L, _I],
+    "iono_comm_destroy": [],
 }
 EXPORTED = sorted(list(_SIGNATURES) + ["iono_ctx_create", "iono_last_error", "iono_version", "iono_grid_values_ptr"])
 
@@ -339,6 +344,24 @@ class Context(object):
         out = np.empty(self.grid_shape, dtype=np.float64)
         self.call("iono_smooth_separable", _dp(phi), _dp(out), _dp(kx), _dp(ky), _dp(kz), h)
         return out
+
+    # ---- RCCL collective behind the C-ABI (for hosts without torch.distributed; include/ionotomo_hip.h) ----
+    def comm_unique_id(self):
+        """128 opaque bytes: rank 0 creates them and ships them to every other rank over the host's own channel."""
+        buf = ctypes.create_string_buffer(COMM_ID_BYTES)
+        self.call("iono_comm_unique_id", buf)
+        return buf.raw
+
+    def comm_init(self, comm_id, rank, nranks):
+        assert len(comm_id) == COMM_ID_BYTES
+        self.call("iono_comm_init", ctypes.create_string_buffer(bytes(comm_id), COMM_ID_BYTES), int(rank), int(nranks))
+
+    def comm_allreduce_dev(self, ptr, count, dtype=F64):
+        """In-place sum over ranks of `count` elements at device pointer `ptr`, enqueued on the ctx stream."""
+        self.call("iono_comm_allreduce_dev", ctypes.c_void_p(int(ptr)), int(count), int(dtype))
+
+    def comm_destroy(self):
+        self.call("iono_comm_destroy")
 
     def gradient_chords(self, rays, dd):
         """The reference's shipped chord-length gradient einsum(dirac, M, dd) (inversion/gradient.py:15-20) for

@@ -12,6 +12,8 @@
 //
 // Reference citations (file:line) are relative to /root/reference/src/ionotomo/.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>      // declarations only: the library is dlopen-ed by iono_comm_* (no link-time dependency)
 
 #include <algorithm>
 #include <cmath>
@@ -77,6 +79,8 @@ struct iono_ctx {
     double nM_freq = -1.0;           // frequency d_nM was built for; < 0 = stale
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
+    ncclComm_t comm = nullptr;       // iono_comm_init
+    int comm_ranks = 0;
     int walk_mode = 0;               // env IONOTOMO_WALK: forward walk A/B (see wave_chunk); never changes results
     bool walk_mode_set = false;
     int fwd_plan = 0;                // env IONOTOMO_FWD_PLAN=1: the forward uses the ray plan too (node-stationary, A/B)
@@ -437,6 +441,7 @@ int iono_ctx_destroy(iono_ctx *c) {
         if (wp.d_cyc) (void)hipFree(wp.d_cyc);
     }
     if (c->d_chunk_counter) (void)hipFree(c->d_chunk_counter);
+    (void)iono_comm_destroy(c);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
     delete c;
     return IONO_OK;
@@ -669,6 +674,13 @@ static int ensure_lm_fields(iono_ctx *c) {
     }
     return IONO_OK;
 }
+// Walk of the trilinear forward kernels when IONOTOMO_WALK does not say: one contiguous chunk of rays per wave while the array
+// they read fits the 256 MiB Infinity Cache (256^3 f64: 0.244 ms against 0.252 interleaved); beyond it, all the waves of an XCD
+// interleaved in that XCD's eighth of the rays, so that what is in flight on an XCD shares lines in ITS L2 (512^3 f64, 1 GiB:
+// 0.68 against 0.72 ms; float32 block layout at 512^3, 2 GiB: 0.53 against 0.68 ms).
+static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes) {
+    return c->walk_mode_set ? c->walk_mode : (array_bytes > ((uint64_t)256 << 20) ? 2 : 0);
+}
 // fast tricubic tier: ideal-uniform axes, weights in LDS, 32-bit-safe field array (IONOTOMO_VARIANT=4 forces the general tier)
 static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
     // (field records of 64 B per node, addressed with 32-bit byte offsets from the column bases)
@@ -712,18 +724,19 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             }
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_q4, wl), R);
-            hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, order, R, tmax, Ns, c->walk_mode,
-                               c->d_unitw, tec, c->d_flags);
+            hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, order, R, tmax, Ns,
+                               forward_walk_mode(c, (uint64_t)padded * sizeof(float4)), c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
             iono_ctx::WalkPart &wp = c->walk[0];
             const int nw = nb * 4;                              // one chunk per wave
-            const bool use_part = wp.n == nw && wp.R == R && !(c->walk_mode & 3) && order == nullptr;
+            const int wm = forward_walk_mode(c, (uint64_t)ncells(c) * sizeof(GT));
+            const bool use_part = wp.n == nw && wp.R == R && !(wm & 3) && order == nullptr;
             const int rc2 = walk_cycles_reserve(c, wp, nw, nw);
             if (rc2) return rc2;
             hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
-                               c->walk_mode, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
+                               wm, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
@@ -1623,6 +1636,100 @@ int iono_trace_fermat(iono_ctx *c, const double *o, const double *d, int64_t R, 
     if (rc) return rc;
     HIP_TRY(c, hipMemcpyAsync(rays_out, dR, nr * 8, hipMemcpyDeviceToHost, c->stream));
     return finish_host_call(c, "iono_trace_fermat");
+}
+
+// ---- multi-GPU collective (RCCL over xGMI), for hosts that do not bring their own (include/ionotomo_hip.h) -------------
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) get_id = nullptr;
+    decltype(&ncclCommInitRank) init_rank = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclCommDestroy) destroy = nullptr;
+    decltype(&ncclGetErrorString) err_str = nullptr;
+};
+Rccl *rccl(iono_ctx *c) {          // loaded on first use, kept for the life of the process
+    static Rccl r;
+    static bool tried = false;
+    if (!tried) {
+        tried = true;
+        for (const char *name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (r.lib) break;
+        }
+        if (r.lib) {
+            r.get_id = (decltype(r.get_id))dlsym(r.lib, "ncclGetUniqueId");
+            r.init_rank = (decltype(r.init_rank))dlsym(r.lib, "ncclCommInitRank");
+            r.all_reduce = (decltype(r.all_reduce))dlsym(r.lib, "ncclAllReduce");
+            r.destroy = (decltype(r.destroy))dlsym(r.lib, "ncclCommDestroy");
+            r.err_str = (decltype(r.err_str))dlsym(r.lib, "ncclGetErrorString");
+        }
+    }
+    if (!r.lib || !r.get_id || !r.init_rank || !r.all_reduce || !r.destroy || !r.err_str) {
+        fail(c, IONO_ERR_HIP, "RCCL (librccl.so) could not be loaded");
+        return nullptr;
+    }
+    return &r;
+}
+int rccl_fail(iono_ctx *c, Rccl *r, ncclResult_t e, const char *what) {
+    return fail(c, IONO_ERR_HIP, std::string(what) + ": " + r->err_str(e));
+}
+}  // namespace
+
+int iono_comm_unique_id(iono_ctx *c, char id_out[IONO_COMM_ID_BYTES]) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    static_assert(sizeof(ncclUniqueId) == IONO_COMM_ID_BYTES, "id size");
+    if (!id_out) return fail(c, IONO_ERR_ARG, "null id buffer");
+    Rccl *r = rccl(c);
+    if (!r) return IONO_ERR_HIP;
+    ncclUniqueId id;
+    const ncclResult_t e = r->get_id(&id);
+    if (e != ncclSuccess) return rccl_fail(c, r, e, "ncclGetUniqueId");
+    memcpy(id_out, id.internal, IONO_COMM_ID_BYTES);
+    return IONO_OK;
+}
+
+int iono_comm_init(iono_ctx *c, const char id_in[IONO_COMM_ID_BYTES], int rank, int nranks) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (!id_in || nranks < 1 || rank < 0 || rank >= nranks) return fail(c, IONO_ERR_ARG, "need an id and 0 <= rank < nranks");
+    if (c->comm) return fail(c, IONO_ERR_ARG, "this context already has a communicator (iono_comm_destroy first)");
+    Rccl *r = rccl(c);
+    if (!r) return IONO_ERR_HIP;
+    ncclUniqueId id;
+    memcpy(id.internal, id_in, IONO_COMM_ID_BYTES);
+    const ncclResult_t e = r->init_rank(&c->comm, nranks, id, rank);
+    if (e != ncclSuccess) {
+        c->comm = nullptr;
+        return rccl_fail(c, r, e, "ncclCommInitRank");
+    }
+    c->comm_ranks = nranks;
+    return IONO_OK;
+}
+
+int iono_comm_allreduce_dev(iono_ctx *c, void *buf, int64_t count, int dtype) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (!c->comm) return fail(c, IONO_ERR_ARG, "no communicator: call iono_comm_init on every rank first");
+    if (count < 0 || (count > 0 && !buf)) return fail(c, IONO_ERR_ARG, "bad buffer");
+    if (dtype != IONO_F64 && dtype != IONO_F32) return fail(c, IONO_ERR_ARG, "dtype must be IONO_F64 or IONO_F32");
+    if (count == 0) return IONO_OK;
+    Rccl *r = rccl(c);
+    if (!r) return IONO_ERR_HIP;
+    const ncclResult_t e = r->all_reduce(buf, buf, (size_t)count, dtype == IONO_F64 ? ncclFloat64 : ncclFloat32, ncclSum, c->comm, c->stream);
+    if (e != ncclSuccess) return rccl_fail(c, r, e, "ncclAllReduce");
+    return IONO_OK;
+}
+
+int iono_comm_destroy(iono_ctx *c) {
+    if (!c || !c->comm) return IONO_OK;
+    Rccl *r = rccl(c);
+    if (r) {
+        (void)hipSetDevice(c->device);
+        (void)hipStreamSynchronize(c->stream);
+        (void)r->destroy(c->comm);
+    }
+    c->comm = nullptr;
+    c->comm_ranks = 0;
+    return IONO_OK;
 }
 
 }  // extern "C"

@@ -326,6 +326,24 @@ class RayEngine(object):
                       float(a_sign), *[0 if t is None else _ptr(t) for t in sc[2:]])
         return y
 
+    # -- RCCL behind the C-ABI (the route for hosts without torch.distributed; parallel.py uses torch.distributed) ----
+    def comm_unique_id(self):
+        return self.ctx.comm_unique_id()
+
+    def comm_init(self, comm_id, rank, nranks):
+        self._sync_stream()
+        self.ctx.comm_init(comm_id, rank, nranks)
+
+    def comm_allreduce_(self, t):
+        """Sum the float64 / float32 device tensor ``t`` over the ranks of the communicator, in place, on the current stream."""
+        assert t.is_contiguous() and t.dtype in (torch.float64, torch.float32)
+        self._sync_stream()
+        self.ctx.comm_allreduce_dev(t.data_ptr(), t.numel(), _lib.F64 if t.dtype == torch.float64 else _lib.F32)
+        return t
+
+    def comm_destroy(self):
+        self.ctx.comm_destroy()
+
     # -- fused solver passes (csrc/iono_solver_kernels.h): dot products as per-workgroup partials, compact grid vectors ----
     def new_grid_buffer(self):
         """(padded, view): a zeroed float64 buffer the kernels can read IN PLACE as grid values (``bind_values``) and its

@@ -338,3 +338,36 @@ def test_forward_partition_never_changes_results():
     assert stats is not None and stats["tuned_ms"] <= stats["equal_count_ms"]
     assert torch.equal(eng.forward(o, d, w["tmax"], w["Ns"]), ref)
     eng.ctx.walk_partition_set(_lib.WALK_FORWARD, None, R)
+
+
+def test_cabi_collective_single_rank():
+    """iono_comm_*: RCCL behind the C-ABI (hosts without torch.distributed).  One rank is all a 1-GPU box can run: the id
+    round trip, the in-place sum on the ctx stream (identity for one rank, ordered after the kernel that produced the
+    buffer), both dtypes, and the argument errors."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload("cfg1")
+    eng = RayEngine(0)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    o, d = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+    y = torch.ones(o.shape[0], dtype=torch.float64, device="cuda")
+    g = eng.adjoint(o, d, y, w["tmax"], 65)
+    ref = g.clone()
+    with pytest.raises(Exception, match="communicator"):
+        eng.comm_allreduce_(g)
+    cid = eng.comm_unique_id()
+    assert len(cid) == 128 and any(cid)
+    eng.comm_init(cid, 0, 1)
+    with pytest.raises(Exception, match="already"):
+        eng.comm_init(cid, 0, 1)
+    eng.comm_allreduce_(g)
+    g32 = ref.to(torch.float32)
+    eng.comm_allreduce_(g32)
+    torch.cuda.synchronize()
+    assert torch.equal(g, ref) and torch.equal(g32, ref.to(torch.float32))
+    with pytest.raises(Exception):
+        eng.comm_init(cid, 3, 2)
+    eng.comm_destroy()
+    eng.comm_destroy()                                   # idempotent
+    with pytest.raises(Exception, match="communicator"):
+        eng.comm_allreduce_(g)
