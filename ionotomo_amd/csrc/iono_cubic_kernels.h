@@ -223,11 +223,13 @@ __device__ __forceinline__ double tricubic_lm(const double *__restrict__ F8, int
 // with 16 wave_shl DPP moves; the lanes without such a neighbour load theirs under an execution mask.  Each 16-B load
 // instruction of this kernel costs one L1 look-up PER LANE (the lanes are 64 B apart), which is what binds it: this halves
 // the full-wave instructions.  Same values, same arithmetic: bit-identical to tricubic_lm.  Every lane must be active.
-__device__ __forceinline__ double2 dpp_next_lane(double2 keep, double2 v) {
-    int o[4] = {__double2loint(keep.x), __double2hiint(keep.x), __double2loint(keep.y), __double2hiint(keep.y)};
+__device__ __forceinline__ double2 dpp_next_lane(double2 v) {
+    // (bound_ctrl: lane 63, which has no next lane, reads 0 -- it always loads its own upper node -- and the moves need no
+    //  initialised destination)
     const int q[4] = {__double2loint(v.x), __double2hiint(v.x), __double2loint(v.y), __double2hiint(v.y)};
+    int o[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_update_dpp(o[t], q[t], 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    for (int t = 0; t < 4; ++t) o[t] = __builtin_amdgcn_update_dpp(0, q[t], 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
     return make_double2(__hiloint2double(o[1], o[0]), __hiloint2double(o[3], o[2]));
 }
 struct LmCols {
@@ -259,7 +261,7 @@ __device__ __forceinline__ double tricubic_lm_wave(const LmCols &C, int ny, int 
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) n1[b][t] = dpp_next_lane(n0[b][t], n0[b][t]);
+            for (int t = 0; t < 4; ++t) n1[b][t] = dpp_next_lane(n0[b][t]);
         if (own) {      // (the masked loads land in the registers the DPP moves wrote)
 #pragma unroll
             for (int b = 0; b < 2; ++b)
