@@ -214,3 +214,40 @@ def test_solvers_with_the_tricubic_operator():
         assert np.allclose(hf, hd, rtol=1e-7) and hf[-1] < 0.5 * hf[0]
         assert float((xf - xd).abs().max()) < 1e-7 * float(xd.abs().max())
     assert not eng.check_oob()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_tricubic_fast_forward_random_geometry(seed, O, monkeypatch):
+    """The wave kernel shares node records between neighbouring lanes (a lane's upper node = the next lane's lower node when
+    the next sample sits one cell higher in the same column): every way that assumption can fail must fall back to the
+    lane's own loads -- rays so oblique that the column changes at every sample, more or less than one cell per sample, two
+    samples in one cell, Ns below / off a multiple of 64 (masked tail), one ray, walk orders and modes."""
+    rng = np.random.default_rng(500 + seed)
+    nx, ny, nz = (int(v) for v in rng.integers(9, 48, 3))
+    xv, yv, zv = np.linspace(-40.0, 35.0, nx), np.linspace(-28.0, 44.0, ny), np.linspace(-6.0, 110.0, nz)
+    M = rng.uniform(0.5, 2.0, size=(nx, ny, nz))
+    R = int(rng.choice([1, 5, 37, 200]))
+    Ns = int(rng.choice([3, 17, 63, 64, 65, 127, 130, 257, 300]))
+    slope = [0.02, 0.3, 1.5, 4.0][seed % 4]              # lateral cells per vertical cell: up to 4 columns per sample
+    lo, hi = np.array([xv[2], yv[2], zv[2]]), np.array([xv[-3], yv[-3], zv[-3]])       # the tricubic domain
+    z0 = rng.uniform(lo[2], lo[2] + 5.0, R)
+    z1 = hi[2] - rng.uniform(1e-6, 20.0)
+    # choose both end points inside the domain, then the direction between them
+    a = np.stack([rng.uniform(lo[0], hi[0], R), rng.uniform(lo[1], hi[1], R), z0], -1)
+    reach = slope * (z1 - z0)[:, None] * np.array([(xv[1] - xv[0]) / (zv[1] - zv[0]), (yv[1] - yv[0]) / (zv[1] - zv[0])])
+    b_xy = np.clip(a[:, :2] + rng.uniform(-1, 1, (R, 2)) * reach, lo[:2] + 1e-6, hi[:2] - 1e-6)     # (end point recomputed on the device)
+    d = np.concatenate([b_xy - a[:, :2], (z1 - z0)[:, None]], -1)
+    d *= rng.uniform(0.5, 2.0, (R, 1))                                                # not normalised on purpose
+    monkeypatch.setenv("IONOTOMO_WALK", str(seed % 4))
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0, interp="cubic")
+    eng.set_grid(xv, yv, zv)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(a), eng.tensor(d)
+    rays = O.straight_rays(a, d, z1, Ns)
+    ref = O.forward_tec(rays, xv, yv, zv, M, rule=_lib.quad_rule("avg"), kind=O.INTERP_TRICUBIC)
+    order = torch.from_numpy(rng.permutation(R).astype(np.int32)).cuda()
+    for ordr in (None, order):
+        tec = eng.forward(ot, dt, z1, Ns, order=ordr).cpu().numpy()
+        assert not eng.check_oob()
+        assert np.max(np.abs(tec - ref) / np.abs(ref)) < 1e-11, (seed, Ns, R, slope)
