@@ -146,7 +146,7 @@ __device__ __forceinline__ void axis_pair(double t, int field_bit, bool cubic, d
     }
 }
 template <typename AT, bool CUBIC>
-__device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile, AT *__restrict__ G, const int *I0, const int *J0,
+__device__ __forceinline__ void scatter_sample_tiled(const GridView &g, double *tile, AT *__restrict__ G, const int *I0, const int *J0,
                                                      int kz0, double fx, double fy, double fz, double c, int dbg = 0, int field = -1) {
     // floor(|f|): see load_corners (a validated ray may graze a low face at f = -1e-14; never cell -1)
     const double fi = fmin(__builtin_floor(__builtin_fabs(fx)), (double)(g.nx - 2)),
@@ -166,13 +166,13 @@ __device__ __forceinline__ void scatter_sample_tiled(const GridView &g, AT *tile
     const bool in0 = ((unsigned)m < (unsigned)T_TK) & (a0 < (unsigned)(T_WIN - 1)) & (b0 < (unsigned)(T_WIN - 1));
     const bool in1 = ((unsigned)(m + 1) < (unsigned)T_TK) & (a1 < (unsigned)(T_WIN - 1)) & (b1 < (unsigned)(T_WIN - 1));
     if (__all(in0 & in1)) {
-        tile_add4<AT>(tile + tile_offset((int)a0, (int)b0, m), w00 * uz, w01 * uz, w10 * uz, w11 * uz);
-        tile_add4<AT>(tile + tile_offset((int)a1, (int)b1, m + 1), w00 * tz, w01 * tz, w10 * tz, w11 * tz);
+        tile_add4<double>(tile + tile_offset((int)a0, (int)b0, m), w00 * uz, w01 * uz, w10 * uz, w11 * uz);
+        tile_add4<double>(tile + tile_offset((int)a1, (int)b1, m + 1), w00 * tz, w01 * tz, w10 * tz, w11 * tz);
         return;
     }
-    if (in0) tile_add4<AT>(tile + tile_offset((int)a0, (int)b0, m), w00 * uz, w01 * uz, w10 * uz, w11 * uz);
+    if (in0) tile_add4<double>(tile + tile_offset((int)a0, (int)b0, m), w00 * uz, w01 * uz, w10 * uz, w11 * uz);
     else if (!ADJ_ABLATE(dbg, 4)) global_add4<AT>(G, i, j, k, g.ny, g.nz, w00 * uz, w01 * uz, w10 * uz, w11 * uz);
-    if (in1) tile_add4<AT>(tile + tile_offset((int)a1, (int)b1, m + 1), w00 * tz, w01 * tz, w10 * tz, w11 * tz);
+    if (in1) tile_add4<double>(tile + tile_offset((int)a1, (int)b1, m + 1), w00 * tz, w01 * tz, w10 * tz, w11 * tz);
     else if (!ADJ_ABLATE(dbg, 4)) global_add4<AT>(G, i, j, k + 1, g.ny, g.nz, w00 * tz, w01 * tz, w10 * tz, w11 * tz);
 }
 
@@ -303,11 +303,13 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     double *ref = wlds + ((Ns + 1) & ~1);                            // [NW waves][ADJ_REF] per-wave sums and bounding boxes
     double *sub = ref + ADJ_REF * NW;                                // [3 levels][8] wave 0's nested boxes
-    AT *tile = (AT *)(sub + ADJ_SUB);                                     // [T_WIN*T_WIN][T_TKP]
+    // float64 tile whatever the accumulation type of the result (ds_add_f32 measured several times slower than ds_add_f64
+    // on gfx950: iono_binned_kernels.h); a float32 result is rounded at the flush
+    double *tile = sub + ADJ_SUB;                                         // [T_WIN*T_WIN][T_TKP]
     int *I0 = (int *)(tile + T_WIN * T_WIN * T_TKP);                 // [T_TK] window origins per z level
     int *J0 = I0 + T_TK;
     for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
-    for (int t = threadIdx.x; t < T_WIN * T_WIN * T_TKP; t += blockDim.x) tile[t] = (AT)0;
+    for (int t = threadIdx.x; t < T_WIN * T_WIN * T_TKP; t += blockDim.x) tile[t] = 0.0;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int nfull = Ns >> 6, ntail0 = nfull << 6;
     const bool tail_by_lane = (Ns - ntail0) <= 8;
@@ -474,13 +476,13 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
             lds_barrier();
             // ---- flush + re-zero: one global atomic per touched node -------------------------------------
             for (int e = threadIdx.x; e < T_WIN * T_WIN * T_TKP; e += blockDim.x) {
-                const AT v = tile[e];
-                if (v != (AT)0) {
-                    tile[e] = (AT)0;
+                const double v = tile[e];
+                if (v != 0.0) {
+                    tile[e] = 0.0;
                     const int cell = e / T_TKP, m = e - cell * T_TKP;
                     const int gi_ = I0[m] + cell / T_WIN, gj_ = J0[m] + cell % T_WIN, gk_ = kz0 + m;
                     if (m < T_TK && gi_ >= 0 && gi_ < g.nx && gj_ >= 0 && gj_ < g.ny && gk_ < g.nz && !ADJ_ABLATE(dbg, 8))
-                        atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, v);
+                        atomicAdd(G + ((size_t)gi_ * g.ny + gj_) * g.nz + gk_, (AT)v);
                 }
             }
             lds_barrier();

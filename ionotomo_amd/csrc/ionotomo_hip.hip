@@ -1060,7 +1060,7 @@ static int launch_adjoint_tile(iono_ctx *c, const GridView &g, const double *o, 
                                double tmax, int Ns, AT *grad, int field, PhaseFreqs pf = PhaseFreqs{}, int ldw = 0) {
     constexpr int NW = 4;    // waves per workgroup (8 waves sharing one tile, bundles of 128: measured 8 % slower)
     const size_t tl = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + (ADJ_REF * NW + ADJ_SUB) * sizeof(double) +
-                      sizeof(AT) * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
+                      sizeof(double) * T_WIN * T_WIN * T_TKP + 2 * T_TK * sizeof(int) + 16;
     const int per_cu = blocks_per_cu(k_adjoint_straight_tile<AT, MODE, NW, CUBIC, PHASE, GT>, 64 * NW, tl, 1);
     int nb = per_cu * c->num_cus;
     const int64_t nbund = (R + 16 * NW - 1) / (16 * NW);   // at least ~64 rays per workgroup
@@ -1103,7 +1103,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                            cdct, Na, NtNd, i0, c->d_rayw);
         wr = c->d_rayw;
     }
-    const size_t bin_lds = sizeof(double) * (((size_t)Ns + 1) & ~(size_t)1) + sizeof(AT) * BIN_TILE;
+    const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);      // float64 box image for either AT
     if (planned && kind == IONO_INTERP_TRILINEAR) {
         hipLaunchKernelGGL((k_adjoint_binned<AT, false>), dim3(pl.n_units), dim3(256), bin_lds, c->stream, g, pl.d_uray, pl.d_entries,
                            pl.d_units, wr, Ns, c->d_unitw, grad, -1);
