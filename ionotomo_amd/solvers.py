@@ -159,7 +159,30 @@ def _fused_ok(problem, callback):
             getattr(eng, "storage", "f64") in ("f64", "float64"))
 
 
-def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=None, pgtol=PGTOL):
+def _run_iterations(n, body, keep):
+    """One iteration captured into a hipGraph (through torch's stream capture: the library launches on the stream torch is
+    capturing) and replayed n - 1 times.  ``body()`` must be self-similar -- every buffer it reads or writes at a fixed
+    address -- and returns the device partial sums whose history is wanted; ``keep(k, partials)`` files them (one small
+    copy per iteration, outside the graph).  Iteration 0 runs eagerly, so every lazily created library buffer exists before
+    the capture.  Same kernels, same order.  MEASURED, and off by default because it does not pay on this stack
+    (profiles/tools/time_graph_solvers.py, 200 iterations): CGLS 63.5 against 68 us per iteration at a single-timestep
+    size (2 604 rays, 128^3) but SIRT 54.6 against 43.8 us, and 0.596 against 0.582 ms (CGLS) at the bench shape -- the
+    eager loop never waits for the host (launches are queued ahead of the GPU), so a graph has no host time to remove;
+    what bounds the small case is the ~8 us dispatch latency between dependent kernels, which graph nodes pay too."""
+    keep(0, body())
+    if n < 2:
+        return None
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        part = body()
+    for k in range(1, n):
+        g.replay()
+        keep(k, part)
+    return g              # owns the memory of every tensor created during capture: keep it until the results are copied out
+
+
+def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=None, pgtol=PGTOL, graph=False):
     """x_{k+1} = x_k + relax * C A^T L (d - A x_k),  A = differenced ray operator; L, C from row / column sums of |A|
     bounded by the un-differenced sums (keeps rho <= 1; geometry/oct_trees/Inversion.py:559,564).
     One iteration = forward launch, ONE pass over the rays (residual + objective), fused differential back-projection,
@@ -167,7 +190,11 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
     (``_sirt_dense`` is the same arithmetic with full-grid torch vectors; used when a ``callback`` wants the iterate).
     ``stop="reference"``: the reference's stopping rule (``reference_stop``; ``n_iter`` is its max_iter) on the
     objective S = 1/2 sum r^2/CdCt and the largest model change per update -- one host read-back per iteration;
-    ``stop=None`` runs exactly ``n_iter`` updates without ever synchronising with the host."""
+    ``stop=None`` runs exactly ``n_iter`` updates without ever synchronising with the host.
+    The row / column sums are those of A itself: a bound on the iteration only while its weights are non-negative (trilinear).
+    The tricubic Hermite basis has negative lobes, so with ``interp="cubic"`` SIRT carries no contraction guarantee (it can
+    diverge after a few sweeps): use ``relax`` < 1/3 (|weights| sum to < 1.44 per axis) or CGLS there.
+    ``graph=True`` (one rank, no ``stop``): iterations 1 .. n-1 replayed from one hipGraph (``_run_iterations``)."""
     if not _fused_ok(problem, callback):
         return _sirt_dense(problem, x0, n_iter, relax, nonneg, callback, stop, pgtol)
     eng = problem.engine
@@ -208,7 +235,21 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
     eng.bind_values(x_pad)
     hist, r, step = [], None, None
     defer = multi and not stop                  # objective history: ONE stacked all-reduce at the end instead of one per iteration
+    held = None
     try:
+        if graph and not multi and not stop and n_iter > 0:
+            r = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device)
+            hbuf = []
+
+            def body():
+                eng.values_changed()
+                _, S2 = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, -1.0, 1.0, dobs=problem.dobs, s2=Wt, out=r)
+                problem.backproject_differential(r, L, s_full)
+                eng.compact_sirt_update(x_c, C_c, s_full, idx, x_full, relax, nonneg, want_max=False)
+                return S2
+            held = _run_iterations(n_iter, body, lambda k, part: hbuf.append(part.clone()))
+            hist = hbuf
+            n_iter = 0
         for k in range(n_iter + (1 if stop else 0)):
             eng.values_changed()
             tec = problem.forward_tec()
@@ -237,7 +278,9 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
             step = eng.compact_sirt_update(x_c, C_c, s_full, idx, x_full, relax, nonneg, want_max=bool(stop))
     finally:
         eng.bind_values(None)
-    return x_full.clone(), _history(hist, problem if defer else None)
+    out = x_full.clone(), _history(hist, problem if defer else None)
+    del held
+    return out
 
 
 def _stop_fused(hist, step_partial, k, max_iter, pgtol):
@@ -245,14 +288,15 @@ def _stop_fused(hist, step_partial, k, max_iter, pgtol):
     return reference_stop(float(vals[0]), float(vals[1]), float(vals[2]), k, max_iter, pgtol=pgtol)
 
 
-def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL):
+def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL, graph=False):
     """CGLS on  min 1/2 || W^(1/2) (A x - d) ||^2,  W = 1/(CdCt + 1e-15).
     One iteration = forward launch (reads the search direction IN PLACE), one pass over the rays (q = W^1/2 A p and
     <q, q>), one (r -= alpha q and <r, r>), the fused differential back-projection, one gather over the active nodes
     (s and <s, s>, re-zeroing the back-projection buffer) and one update (x += alpha p, p = s + beta p, refresh of the
     grid the forward reads): 6 launches, all scalars on the device as per-workgroup partial sums.
     ``damp`` > 0 (Tikhonov term: the gradient is then non-zero off the ray fan) or a ``callback`` use the dense-vector
-    form ``_cgls_dense``.  ``stop="reference"``: the reference's stopping rule as in ``sirt``."""
+    form ``_cgls_dense``.  ``stop="reference"``: the reference's stopping rule as in ``sirt``.  ``graph=True`` (one rank): iterations
+    1 .. n-1 replayed from one hipGraph (``_run_iterations``)."""
     if damp != 0.0 or stop or not _fused_ok(problem, callback):
         return _cgls_dense(problem, x0, n_iter, damp, callback, stop, pgtol)
     eng = problem.engine
@@ -286,7 +330,25 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
         xg[:n] = x_c
         x_loc, p_loc = xg[lo:lo + per].clone(), pg[lo:lo + per].clone()
     hist, q = [rr.sum().reshape(1) if multi else rr], None
+    held = None
     try:
+        if graph and not multi and n_iter > 0:
+            q = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device)
+            gam = gamma.clone()                                   # <s, s> of the previous iteration, at a fixed address
+            hbuf = []
+
+            def body():
+                eng.values_changed()
+                _, qq = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, 1.0, 0.0, s1=Wh, out=q)
+                rr = eng.axpby_dot_(r, q, an=gam, ad=qq, a_sign=-1.0)
+                problem.backproject_differential(r, Wh, s_full)
+                _, gnew = eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=True)
+                eng.compact_cg_update(x_c, p_c, s_c, idx, p_full, gam, qq, gnew, gam)
+                gam.copy_(gnew)
+                return rr
+            held = _run_iterations(n_iter, body, lambda k, part: hbuf.append(part.clone()))
+            hist += hbuf[:n_iter - 1]                             # (the eager loop does not record the last residual either)
+            n_iter = 0
         for k in range(n_iter):
             eng.values_changed()
             q, qq = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, 1.0, 0.0, s1=Wh, out=q)      # W^1/2 A p
@@ -319,7 +381,9 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
         eng.bind_values(None)
     x = x0.clone()
     x.view(-1).index_copy_(0, il, x_c)
-    return x, _history(hist, problem if multi else None)
+    out = x, _history(hist, problem if multi else None)
+    del held
+    return out
 
 
 def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=0.0, max_iter=20, min_iter=5,

@@ -371,3 +371,35 @@ def test_cabi_collective_single_rank():
     eng.comm_destroy()                                   # idempotent
     with pytest.raises(Exception, match="communicator"):
         eng.comm_allreduce_(g)
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_graph_captured_solver_iterations_equal_the_eager_loop(interp):
+    """``graph=True``: iterations 1 .. n-1 of the fused SIRT / CGLS loops are captured into one hipGraph (the library
+    launches on the stream torch is capturing) and replayed -- the same kernels in the same order, so iterates and objective
+    history equal the eager loop's to the rounding of the back-projection's floating-point atomics (whose order differs from
+    run to run anyway); a second solve on the same engine works too."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="lofar", na=62, nd=6, nt=3, n=40)
+    eng = RayEngine(0, interp=interp)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    o, d = w["origins"].reshape(62, -1, 3), w["directions"].reshape(62, -1, 3)
+    rng = np.random.default_rng(3)
+    x_true = w["ne"] / 1e13
+    eng.set_values(eng.tensor(x_true))
+    P = o.shape[1]
+    tmax = w["tmax"] if interp == "linear" else w["zvec"][-3]
+    t = eng.forward(eng.tensor(o.reshape(-1, 3)), eng.tensor(d.reshape(-1, 3)), tmax, 41).cpu().numpy().reshape(62, P)
+    dobs = t - t[0] + rng.normal(size=t.shape) * 1e-3
+    prob = parallel.ShardedRays(eng, o, d, tmax, 41, dobs=dobs, cdct=np.full_like(dobs, 1e-6), i0=0)
+    x0 = eng.tensor(x_true * 0.8)
+    for solve in (solvers.cgls, solvers.sirt):
+        xa, ha = solve(prob, x0, n_iter=9)
+        xb, hb = solve(prob, x0, n_iter=9, graph=True)
+        xc, hc = solve(prob, x0, n_iter=9, graph=True)
+        assert len(ha) == len(hb) == len(hc) == 9
+        if solve is solvers.cgls or interp == "linear":         # (SIRT's normalisation assumes non-negative weights: no guarantee for cubic)
+            assert ha[-1] < ha[0]
+        assert np.allclose(ha, hb, rtol=1e-9, atol=1e-9 * ha[0]) and np.allclose(ha, hc, rtol=1e-9, atol=1e-9 * ha[0])
+        scale = float(xa.abs().max())
+        assert float((xa - xb).abs().max()) < 1e-9 * scale and float((xa - xc).abs().max()) < 1e-9 * scale
