@@ -9,6 +9,7 @@ import torch
 from ionotomo_amd import parallel, synthetic as syn
 
 pytestmark = pytest.mark.gpu
+SOAK = int(__import__("os").environ.get("IONO_SOAK", "1"))      # IONO_SOAK=20: twenty times the seeds (a soak run on the GPU box)
 
 
 @pytest.fixture(scope="module")
@@ -28,7 +29,7 @@ def engine(xv, yv, zv, **kw):
     return eng
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(SOAK * 8))
 def test_binned_adjoint_random_geometries(seed, OC):
     rng = np.random.default_rng(seed)
     n = [int(v) for v in rng.integers(6, 70, 3)]
@@ -118,7 +119,7 @@ def test_binned_tricubic_channels():
     assert not eng.check_oob()
 
 
-@pytest.mark.parametrize("seed", range(5))
+@pytest.mark.parametrize("seed", range(SOAK * 5))
 def test_node_stationary_forward_ab_variant(seed, OC, monkeypatch):
     """IONOTOMO_FWD_PLAN=1: the forward on the ray plan (box image staged in LDS, per-segment partial sums) -- the
     north-star LDS-staging design, kept as a measured A/B variant (profiles/r02_ab_forward_binned.json: slower than the

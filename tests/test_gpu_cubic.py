@@ -8,6 +8,7 @@ import torch
 from ionotomo_amd import _lib, parallel, synthetic as syn
 
 pytestmark = pytest.mark.gpu
+SOAK = int(__import__("os").environ.get("IONO_SOAK", "1"))      # IONO_SOAK=20: twenty times the seeds (a soak run on the GPU box)
 
 
 @pytest.fixture(scope="module")
@@ -216,7 +217,7 @@ def test_solvers_with_the_tricubic_operator():
     assert not eng.check_oob()
 
 
-@pytest.mark.parametrize("seed", range(8))
+@pytest.mark.parametrize("seed", range(SOAK * 8))
 def test_tricubic_fast_forward_random_geometry(seed, O, monkeypatch):
     """The wave kernel shares node records between neighbouring lanes (a lane's upper node = the next lane's lower node when
     the next sample sits one cell higher in the same column): every way that assumption can fail must fall back to the

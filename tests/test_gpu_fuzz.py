@@ -6,6 +6,7 @@ import pytest
 from ionotomo_amd import _lib
 
 pytestmark = pytest.mark.gpu
+SOAK = int(__import__("os").environ.get("IONO_SOAK", "1"))      # IONO_SOAK=20: twenty times the seeds (a soak run on the GPU box)
 
 
 def random_axis(rng, n, kind, lo, hi):
@@ -19,7 +20,7 @@ def random_axis(rng, n, kind, lo, hi):
     return lo + (v - v[0]) * (hi - lo) / (v[-1] - v[0])
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(SOAK * 12))
 def test_random_problem(seed):
     from oracle import oracle as O
     rng = np.random.default_rng(100 + seed)
@@ -55,7 +56,7 @@ def test_random_problem(seed):
     ctx.close()
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(SOAK * 4))
 def test_tracer_lane_mappings_agree_on_hard_geometry(seed, monkeypatch):
     """The cell-cached tracers (4 / 8 lanes per ray) against the plain lanes = rays kernels and the oracle: strongly
     tilted rays that change (i, j) column every few cells, origins exactly on grid nodes, the top reached exactly
@@ -63,8 +64,8 @@ def test_tracer_lane_mappings_agree_on_hard_geometry(seed, monkeypatch):
     from oracle import oracle as O
     rng = np.random.default_rng(500 + seed)
     kinds = [("ideal", "ideal", "ideal"), ("table", "ideal", "nonuniform"), ("nonuniform", "nonuniform", "nonuniform"),
-             ("ideal", "nonuniform", "ideal")][seed]
-    nx, ny, nz = 30 + seed, 27, 33 + 2 * seed
+             ("ideal", "nonuniform", "ideal")][seed % 4]
+    nx, ny, nz = 30 + seed % 9, 27, 33 + 2 * (seed % 7)
     xv = random_axis(rng, nx, kinds[0], -60.0, 60.0)
     yv = random_axis(rng, ny, kinds[1], -55.0, 65.0)
     zv = random_axis(rng, nz, kinds[2], 0.0, 160.0)
@@ -76,7 +77,11 @@ def test_tracer_lane_mappings_agree_on_hard_geometry(seed, monkeypatch):
     o = np.stack([rng.uniform(-12, 12, R), rng.uniform(-12, 12, R), rng.uniform(zv[2], zv[3], R)], -1)
     o[:5] = np.stack([xv[nx // 2 + np.arange(5)], yv[ny // 2 - np.arange(5)], np.full(5, zv[2])], -1)   # on nodes
     d = np.stack([rng.uniform(-0.25, 0.25, R), rng.uniform(-0.25, 0.25, R), np.ones(R)], -1)
-    tmax = zv[-3]
+    # The gradient of a TRILINEAR field jumps across cell faces, so a Runge-Kutta stage that lands on a face to within rounding
+    # is evaluated in one cell or the other depending on the last bit of z (fused vs separate multiply-add): 1e-3 km of
+    # difference in s between two correct implementations.  Seeds 0-3 have exactly representable steps (or no such hits); the
+    # soak seeds end a random distance below the top of the tricubic domain, so steps and cell widths are incommensurate.
+    tmax = zv[-3] if seed < 4 else zv[-3] - rng.uniform(0.01, 0.5)
     o[5:8, 2] = zv[0]
     Ns, sub = 41, 3
     ctxs = []
