@@ -79,10 +79,14 @@ __device__ __forceinline__ double dpp_shr1(double v) {       // value of the pre
     return __hiloint2double(hi, lo);
 }
 
-template <typename AT, bool CUBIC>
+// PNF > 0: transpose of the PHASE observable (inversion/iterative_newton.py:86-127) for PNF frequencies per pass: the ray weight
+// becomes a per-sample factor  sum_l wrf[r][l] / (2 n_p,l sqrt(1 - ne_k / n_p,l))  of the electron density ne_k interpolated at
+// the sample (gathered from the grid exactly as the forward kernel does), wray = wrf with row stride ldw.
+template <typename AT, bool CUBIC, int PNF = 0, typename GT = double>
 __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
                                                         const BinUnit *__restrict__ units, const double *__restrict__ wray,
-                                                        int Ns, const double *__restrict__ unitw, AT *__restrict__ G, int field) {
+                                                        int Ns, const double *__restrict__ unitw, AT *__restrict__ G, int field,
+                                                        PhaseFreqs pf = PhaseFreqs{}, int ldw = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     // the box image is float64 whatever the accumulation type of the result: ds_add_f32 measured FIVE times slower than
@@ -98,15 +102,21 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
     // deep so that a pass computes while the next pass's ray records and the one after's entries are in flight.
     struct RayRec {
         double2 ux, uy, uz, uh;      // (f0, df) per axis in grid coordinates; (h, valid)
-        double w;
+        double w[PNF > 0 ? PNF : 1]; // ray weight (PNF: one per frequency)
     };
+    const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
     // (the entry array is padded by 32 zero entries: unconditional loads; a pass beyond the unit is masked by its count)
     auto load_entry = [&](int e) { return entries[e]; };
     auto load_ray = [&](const uint2 en) {
         const double2 *up = (const double2 *)(uray + (size_t)en.x * 8);
         RayRec r;
         r.ux = up[0], r.uy = up[1], r.uz = up[2], r.uh = up[3];
-        r.w = wray[en.x];
+        if (PNF > 0) {
+#pragma unroll
+            for (int l = 0; l < (PNF > 0 ? PNF : 1); ++l) r.w[l] = wray[(size_t)en.x * ldw + l];
+        } else {
+            r.w[0] = wray[en.x];
+        }
         return r;
     };
     int e = un.e_lo + grp;
@@ -116,11 +126,18 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
         const uint2 en2 = load_entry(e + 32);
         const RayRec r1 = load_ray(en1);
         const int cnt = e < un.e_hi ? (int)((en0.y >> 16) & 0xffu) : 0, k = min((int)(en0.y & 0xffffu) + sub, Ns - 1);
-        const double c = sub < cnt ? r0.w * r0.uh.x * wlds[k] : 0.0;
-        const bool active = c != 0.0;
         // every lane computes (no divergence before the lane exchange below); inactive lanes carry zero weights
         const double kd = (double)k;
         const double fx = fma(kd, r0.ux.y, r0.ux.x), fy = fma(kd, r0.uy.y, r0.uy.x), fz = fma(kd, r0.uz.y, r0.uz.x);
+        double wr = r0.w[0];
+        if (PNF > 0 && sub < cnt) {  // (only real samples gather: a padding entry may belong to a ray outside the grid)
+            const double ne = trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz);
+            wr = 0.0;
+#pragma unroll
+            for (int l = 0; l < (PNF > 0 ? PNF : 1); ++l) wr += r0.w[l] * (0.5 * pf.inv_np[l]) * rsqrt(1.0 - ne * pf.inv_np[l]);
+        }
+        const double c = sub < cnt ? wr * r0.uh.x * wlds[k] : 0.0;
+        const bool active = c != 0.0;
         const double fi = fmin(__builtin_floor(__builtin_fabs(fx)), (double)(g.nx - 2)),
                      fj = fmin(__builtin_floor(__builtin_fabs(fy)), (double)(g.ny - 2)),
                      fk = fmin(__builtin_floor(__builtin_fabs(fz)), (double)(g.nz - 2));

@@ -1251,10 +1251,17 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
         const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            if (ideal)
-                hipLaunchKernelGGL((k_forward_phase_straight<GT, true>), grid, block, 0, c->stream, g, o, d, R, tmax, Ns, c->d_unitw, pf,
-                                   Nf, phi_work + f0, c->d_flags);
-            else
+            if (ideal) {
+                const size_t wl = sizeof(double) * Ns;
+#define PHASE_U(NF)                                                                                                                 \
+    hipLaunchKernelGGL((k_forward_phase_u<GT, NF>), dim3(chunk_grid_blocks(resident_blocks(c, k_forward_phase_u<GT, NF>, wl), R)), block, \
+                       wl, c->stream, g, o, d, R, tmax, Ns, c->d_unitw, pf, Nf, phi_work + f0, c->d_flags)
+                if (pf.nf == 1) PHASE_U(1);
+                else if (pf.nf == 2) PHASE_U(2);
+                else if (pf.nf <= 4) PHASE_U(4);
+                else PHASE_U(8);
+#undef PHASE_U
+            } else
                 hipLaunchKernelGGL((k_forward_phase_straight<GT, false>), grid, block, lds_bytes(c), c->stream, g, o, d, R, tmax, Ns,
                                    c->d_unitw, pf, Nf, phi_work + f0, c->d_flags);
             return IONO_OK;
@@ -1281,10 +1288,26 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
     const GridView g = view(c);
     hipLaunchKernelGGL(k_phase_weights, dim3(ew_blocks(c, R * Nf)), dim3(256), 0, c->stream, y, c->d_freqs, Na, NtNd, Nf, i0, wrf_work);
     const bool tiled = ideal_path_ok(c, Ns) && c->variant != 2;
+    const iono_ctx::AdjPlan &pl = c->plan;
+    const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax &&
+                         pl.kind == IONO_INTERP_TRILINEAR && c->variant != 2 && c->variant != 7;
+    if (planned && pl.n_invalid > 0) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_flags, 1, 1, c->stream));   // out-of-grid rays
     for (int f0 = 0; f0 < Nf; f0 += 8) {
         const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
         rc = dispatch_storage(c, [&](auto *tag) -> int {
             using GT = std::remove_pointer_t<decltype(tag)>;
+            if (planned) {      // node-stationary: box images in LDS, ne gathered per sample (iono_binned_kernels.h)
+                const size_t bl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
+#define PHASE_BIN(NF)                                                                                                              \
+    hipLaunchKernelGGL((k_adjoint_binned<double, false, NF, GT>), dim3(pl.n_units), dim3(256), bl, c->stream, g, pl.d_uray,         \
+                       pl.d_entries, pl.d_units, wrf_work + f0, Ns, c->d_unitw, grad, -1, pf, Nf)
+                if (pf.nf == 1) PHASE_BIN(1);
+                else if (pf.nf == 2) PHASE_BIN(2);
+                else if (pf.nf <= 4) PHASE_BIN(4);
+                else PHASE_BIN(8);
+#undef PHASE_BIN
+                return IONO_OK;
+            }
             if (tiled)
                 return launch_adjoint_tile<double, 0, false, true, GT>(c, g, o, d, order, wrf_work + f0, nullptr, nullptr, nullptr, Na,
                                                                        NtNd, i0, R, tmax, Ns, grad, -1, pf, Nf);

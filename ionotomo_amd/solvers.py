@@ -438,6 +438,8 @@ def steepest_descent_phase(eng, origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, cloc
     hist = []
     W = 1.0 / CdCt
     fd = 1e-4
+    if hasattr(eng, "plan_adjoint"):           # node-stationary transpose for every iteration (geometry only, speed only)
+        eng.plan_adjoint(origins, dirs, tmax, Ns)
     for k in range(max_iter + 1):
         eng.set_log_model(mu.reshape(-1), K)
         g = eng.forward_phase(origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, clock, const, i0)

@@ -96,6 +96,20 @@ def test_phase_observable_on_the_device_and_its_adjoint():
                 assert np.max(np.abs(gg - gref)) < 1e-10 * np.max(np.abs(gref))
             gne = eng.adjoint_phase(ot, dt, yt, na, w["tmax"], Ns, freqs, 2, wrt_log_model=False).cpu().numpy()
             assert np.max(np.abs(gne * np.exp(mu) * 1e11 - gref)) < 1e-10 * np.max(np.abs(gref))
+            # the node-stationary (box-binned) transpose once the geometry is planned: 1, 2, 4 and 8 frequencies per pass
+            if eng.plan_adjoint(ot, dt, w["tmax"], Ns)[0] > 0:
+                gp = eng.adjoint_phase(ot, dt, yt, na, w["tmax"], Ns, freqs, 2).cpu().numpy()
+                assert np.max(np.abs(gp - gref)) < 1e-10 * np.max(np.abs(gref))
+                for nf in sorted({1, 2, min(5, freqs.size)}):
+                    fs, ys = freqs[:nf], np.ascontiguousarray(y[..., :nf])
+                    gr = O.gradient_phase(mu, xv, w["yvec"], w["zvec"], rays, fs, ys, K=1e11, i0=2)
+                    gq = eng.adjoint_phase(ot, dt, eng.tensor(ys.reshape(na, nt * nd, nf)), na, w["tmax"], Ns, fs, 2).cpu().numpy()
+                    assert np.max(np.abs(gq - gr)) < 1e-10 * np.max(np.abs(gr)), nf
+                    gf = eng.forward_phase(ot, dt, na, nt, nd, w["tmax"], Ns, fs, eng.tensor(clock), eng.tensor(const), 2).cpu().numpy()
+                    assert np.max(np.abs(gf - ref[..., :nf])) < 1e-11 * np.max(np.abs(ref))
+                eng.clear_adjoint_plan()
+            else:
+                assert xv is xv_nu
     # finite difference of S = 1/2 sum (g - dobs)^2 / CdCt through the device path
     dobs, CdCt = ref + rng.normal(size=ref.shape) * 0.1, rng.uniform(0.5, 2.0, size=ref.shape) * 0.01
     ct, kt = eng.tensor(clock), eng.tensor(const)
