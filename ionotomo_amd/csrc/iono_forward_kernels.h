@@ -250,6 +250,26 @@ __device__ __forceinline__ Corners<GT> load_corners(const GT *__restrict__ b00, 
     return c;
 #elif IONO_FWD_ABL == 5   // four loads per sample, all from the lines of ONE column (a quarter of the fills, same instructions)
     p01 = p00 + 2, p10 = p00 + 4, p11 = p00 + 6;
+#elif IONO_FWD_ABL == 9   // exact results: agent-scope loads (sc1: served by L2, never allocated in the L1)
+    if constexpr (sizeof(GT) == 8) {
+        typedef GT vec2 __attribute__((ext_vector_type(2)));
+        vec2 a, b, e, f;
+        asm volatile("global_load_dwordx4 %0, %4, %5 sc1\n\tglobal_load_dwordx4 %1, %4, %6 sc1\n\t"
+                     "global_load_dwordx4 %2, %4, %7 sc1\n\tglobal_load_dwordx4 %3, %4, %8 sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&v"(e), "=&v"(f)
+                     : "v"(boff), "s"(b00), "s"(b01), "s"(b10), "s"(b11)
+                     : "memory");
+        c.c000 = a.x, c.c001 = a.y, c.c010 = b.x, c.c011 = b.y, c.c100 = e.x, c.c101 = e.y, c.c110 = f.x, c.c111 = f.y;
+        return c;
+    }
+#elif IONO_FWD_ABL == 8   // exact results: non-temporal loads -- no L1 allocation (and streaming in L2)
+    {
+        typedef GT vec2 __attribute__((ext_vector_type(2)));
+        const vec2 a = __builtin_nontemporal_load((const vec2 *)p00), b = __builtin_nontemporal_load((const vec2 *)p01);
+        const vec2 e = __builtin_nontemporal_load((const vec2 *)p10), f = __builtin_nontemporal_load((const vec2 *)p11);
+        c.c000 = a.x, c.c001 = a.y, c.c010 = b.x, c.c011 = b.y, c.c100 = e.x, c.c101 = e.y, c.c110 = f.x, c.c111 = f.y;
+        return c;
+    }
 #endif
 #endif
     c.c000 = p00[0];

@@ -33,7 +33,8 @@ print(json.dumps({"ms_median": float(np.median(ts)), "ms_min": float(min(ts))}))
 NAMES = {0: "shipped kernel", 1: "4 loads of 8 B per lane", 2: "2 loads of 16 B", 3: "4 loads, same 4 line runs for every wave (no fills)",
          4: "no loads (VALU + LDS weights only)", 5: "4 loads from the line run of ONE column (1/4 of the fills)",
          6: "shipped loads, slab loop unrolled x 4 at 3 workgroups per CU (16 loads in flight per wave)",
-         7: "shipped loads, slab loop unrolled x 2 at 4 workgroups per CU (8 loads in flight per wave)"}
+         7: "shipped loads, slab loop unrolled x 2 at 4 workgroups per CU (8 loads in flight per wave)",
+         8: "exact: non-temporal loads (nt)", 9: "exact: agent-scope loads (sc1, bypassing the L1)"}
 out = {}
 runs = [(v, 0) for v in (0, 1, 2, 3, 4, 5, 6, 7)] + [(0, b) for b in (2, 3, 4, 5)] + [(3, b) for b in (2, 4)] + [(5, b) for b in (2, 4)]
 if len(sys.argv) > 1:
@@ -47,7 +48,7 @@ for v, bpc in runs:
     r = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
     key = "abl%d%s" % (v, "_wg%d" % bpc if bpc else "")
     try:
-        out[key] = dict(json.loads(r.stdout.strip().splitlines()[-1]), what=NAMES[v], workgroups_per_cu=bpc or "resident (6)")
+        out[key] = dict(json.loads(r.stdout.strip().splitlines()[-1]), what=NAMES.get(v, "variant %d" % v), workgroups_per_cu=bpc or "resident (6)")
     except Exception:
         out[key] = {"error": r.stderr[-400:]}
     print(key, out[key], flush=True)
