@@ -277,8 +277,10 @@ def main():
     # reused by every launch of an inversion; results are independent of it)
     order_t = eng.locality_order(o_t, d_t, TMAX) if args.order else None
 
-    # the forward gains nothing from the walk order (measured); arguments converted once (engine.forward_launcher)
-    fwd = eng.forward_launcher(o_t, d_t, TMAX, NS, tec_t)
+    # the forward kernels walk the rays in the "coherent" order (nearly identical rays -- one line of sight a few seconds apart
+    # -- on neighbouring waves at the same time: RayEngine.coherent_order; geometry only, once); arguments converted once
+    forder_t = eng.coherent_order(o_t, d_t) if args.order else None
+    fwd = eng.forward_launcher(o_t, d_t, TMAX, NS, tec_t, order=forder_t)
 
     # ---- legs that can run alone under a profiler ---------------------------------------------------------------
     def adjoint_leg():
@@ -302,7 +304,7 @@ def main():
         yc = torch.randn(R, dtype=torch.float64, device=ec.device)
 
         def cf():
-            ec.forward(o_t, d_t, TMAX, NS, out=tc, order=order_t)
+            ec.forward(o_t, d_t, TMAX, NS, out=tc, order=forder_t)
 
         def ca():
             gc.zero_()
@@ -427,11 +429,11 @@ def main():
             # ---- the reference's default sampling, Ns = nz (even), with the 'avg' rule its own integrate.py spells out
             # (secondary row; tests/golden/forward_tec_even_avg.npz pins the rule)
             tec_even = torch.empty(R, dtype=torch.float64, device=eng.device)
-            wev, kev = time_steps(lambda: eng.forward(o_t, d_t, TMAX, NS - 1, out=tec_even), k2, 1, torch, dist, world)
+            wev, kev = time_steps(lambda: eng.forward(o_t, d_t, TMAX, NS - 1, out=tec_even, order=forder_t), k2, 1, torch, dist, world)
             extra["even_ns_avg_rule_ray_integrals_per_s"] = world * R * k2 / wev
             extra["even_ns_avg_rule_vs_odd_max_rel_dev"] = float(((tec_even - tec_t).abs() / tec_t.abs()).max())
             # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
-            w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32), k2, 1, torch, dist, world)
+            w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, world)
             extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
             extra["f32_grid_vl1d_frac"] = R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9 / VL1D_PEAK_GBS
             extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())

@@ -84,6 +84,26 @@ class RayEngine(object):
                       self.kind, self.rule, _ptr(out))
         return out
 
+    @staticmethod
+    def coherent_order(origins_t, dirs_t, bits=16):
+        """Permutation for the FORWARD kernels: rays grouped by origin (antenna), and inside a group sorted along a 2-D
+        Morton curve of their direction, so that neighbours in the walk are NEARLY IDENTICAL rays (the same line of sight a
+        few seconds apart).  Given an order, the forward kernel interleaves all the waves of an XCD in it, so those rays
+        run on neighbouring waves at the same time and share the lines they read in the L1 (0.212 instead of 0.224 ms at the
+        bench shape; a 4-D Morton order of foot and end points -- ``locality_order``, made for the back-projection --
+        measured slower than no order here).  Host-side plumbing, results do not depend on it."""
+        o, d = origins_t, dirs_t
+        _, ant = torch.unique(o, dim=0, return_inverse=True)
+        s = d[:, :2] / d[:, 2:3]
+        lo = s.min(dim=0).values
+        span = (s.max(dim=0).values - lo).clamp_min(1e-300)
+        q = ((s - lo) / span * ((1 << bits) - 1)).to(torch.int64).clamp_(0, (1 << bits) - 1)
+        code = ant.to(torch.int64) << (2 * bits)
+        for b in range(bits):
+            code |= ((q[:, 0] >> b) & 1) << (2 * b)
+            code |= ((q[:, 1] >> b) & 1) << (2 * b + 1)
+        return torch.argsort(code, stable=True).to(torch.int32).contiguous()
+
     def forward_launcher(self, origins_t, dirs_t, tmax, Ns, out, order=None):
         """A zero-argument callable that enqueues ``forward`` with every argument converted once (an inversion calls the same
         launch thousands of times: the per-call Python work -- stream look-up, pointer conversions -- is ~5 us of a

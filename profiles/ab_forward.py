@@ -35,7 +35,7 @@ order1 = engines[0][1].locality_order(o_t, d_t, bench.TMAX)
 # ORDER=2: (antenna, direction, time) -- consecutive rays are the same line of sight 8 s apart
 idx = torch.arange(R, device="cuda").reshape(bench.NA, bench.NT, bench.ND)
 order2 = idx.permute(0, 2, 1).reshape(-1).to(torch.int32).contiguous()
-orders = {0: None, 1: order1, 2: order2}
+orders = {0: None, 1: order1, 2: order2, 3: RayEngine.coherent_order(o_t, d_t)}     # 3: generic (antenna, direction-Morton)
 out = torch.empty(R, dtype=torch.float64, device="cuda")
 times = {s: [] for s, _, _ in engines}
 ref = None
