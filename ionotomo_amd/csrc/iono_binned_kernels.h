@@ -52,6 +52,96 @@ __global__ void k_plan_urays(GridView g, const double *__restrict__ origins, con
     }
 }
 
+// The plan itself, on the device (one thread per ray; a host loop over R x Ns samples took 0.26 s at the bench shape, eight
+// times a 50-iteration inversion).  Segments: <= BIN_SEG consecutive samples of a ray inside one z-layer of boxes, filed under
+// the (x, y) box around the middle of their extent; every sample of every valid ray lands in exactly one segment.
+//   pass 1 (EMIT = false): nseg[r] (-1: the ray leaves the grid) and the number of segments per box;
+//   pass 2 (EMIT = true, after an exclusive scan of the box counts on the host): entries[box_start + slot] = (ray, first
+//           sample | count << 16 | ordinal << 24), slot from an atomic counter of the box (order inside a box is immaterial:
+//           every segment of a unit goes to the same LDS image).
+// Cells use the kernels' own expression floor(|fma(k, df, f0)|), so a segment never disagrees with the samples it holds.
+__device__ __forceinline__ int plan_cell(double f0, double df, int k, int n) {
+    return (int)fmin(__builtin_floor(__builtin_fabs(__builtin_fma((double)k, df, f0))), (double)(n - 2));
+}
+// Wave-aggregated counter update: the 64 rays of a wave are neighbours and file their k-th segments under a handful of boxes,
+// so one lane per distinct box adds the number of lanes that share it (per-segment atomics on a few hot addresses made the two
+// passes 8.6 + 9.5 ms; aggregated: see profiles/tools/time_plan.py).  Must be called by the whole wave; returns this lane's slot
+// (old counter value + rank among the lanes with the same key) when WANT_SLOT.
+template <bool WANT_SLOT>
+__device__ __forceinline__ int wave_counter_add(int *__restrict__ ctr, int key, bool active) {
+    const int lane = threadIdx.x & 63;
+    int slot = 0;
+    unsigned long long todo = __ballot(active);
+    while (todo) {                                           // wave-uniform
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k0 = __builtin_amdgcn_readlane(key, leader);
+        const bool mine = active && key == k0;
+        const unsigned long long same = __ballot(mine);
+        int base = 0;
+        if (lane == leader) {
+            if (WANT_SLOT) base = atomicAdd(ctr + k0, __popcll(same));
+            else atomicAdd(ctr + k0, __popcll(same));
+        }
+        if (WANT_SLOT) {
+            base = __builtin_amdgcn_readlane(base, leader);
+            if (mine) slot = base + __popcll(same & ((1ull << lane) - 1ull));
+        }
+        todo &= ~same;
+    }
+    return slot;
+}
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_plan_segments(const double *__restrict__ uray, int64_t R, int Ns, int nx, int ny, int nz,
+                                                       int nbx, int nby, int nbz, int *__restrict__ nseg,
+                                                       int *__restrict__ box_count, const int *__restrict__ box_start,
+                                                       int *__restrict__ box_fill, uint2 *__restrict__ entries,
+                                                       unsigned long long *__restrict__ outside) {
+    // whole waves walk the ray range together (the counter update is a wave operation): the loop bound is rounded up to a
+    // multiple of the grid's thread count and lanes beyond R idle
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t r0 = (int64_t)blockIdx.x * blockDim.x; r0 < R; r0 += nthreads) {
+        const int64_t r = r0 + threadIdx.x;
+        bool valid = r < R;
+        double fx0 = 0, dfx = 0, fy0 = 0, dfy = 0, fz0 = 0, dfz = 0;
+        if (valid) {
+            const double *u = uray + r * 8;
+            valid = u[7] != 0.0;
+            fx0 = u[0], dfx = u[1], fy0 = u[2], dfy = u[3], fz0 = u[4], dfz = u[5];
+            if (!valid && !EMIT) nseg[r] = -1;
+        }
+        int k = valid ? 0 : Ns, j = 0, out = 0;
+        while (__any(k < Ns)) {
+            const bool active = k < Ns;
+            int box = 0, ke = k;
+            if (active) {
+                const int zb = plan_cell(fz0, dfz, k, nz) / BIN_SZ;
+                ke = k + 1;
+                while (ke < Ns && ke - k < BIN_SEG && plan_cell(fz0, dfz, ke, nz) / BIN_SZ == zb) ++ke;
+                const int xa = plan_cell(fx0, dfx, k, nx), xb = plan_cell(fx0, dfx, ke - 1, nx);
+                const int ya = plan_cell(fy0, dfy, k, ny), yb = plan_cell(fy0, dfy, ke - 1, ny);
+                const int bi = min(nbx - 1, (xa + xb + 1) / (2 * BIN_SX)), bj = min(nby - 1, (ya + yb + 1) / (2 * BIN_SY));
+                box = (bi * nby + bj) * nbz + zb;
+                if (!EMIT) {
+                    const int x0 = bi * BIN_SX - BIN_H, y0 = bj * BIN_SY - BIN_H;
+                    out += (min(xa, xb) < x0) | (max(xa, xb) > x0 + BIN_BX - 2) | (min(ya, yb) < y0) | (max(ya, yb) > y0 + BIN_BY - 2);
+                }
+            }
+            if (EMIT) {
+                const int slot = wave_counter_add<true>(box_fill, box, active);
+                if (active)
+                    entries[box_start[box] + slot] = make_uint2((unsigned)r, (unsigned)k | ((unsigned)(ke - k) << 16) | ((unsigned)(j & 255) << 24));
+            } else {
+                wave_counter_add<false>(box_count, box, active);
+            }
+            if (active) k = ke, ++j;
+        }
+        if (!EMIT && valid) {
+            nseg[r] = j;
+            if (out) atomicAdd(outside, (unsigned long long)out);
+        }
+    }
+}
+
 // per-ray weights of the fused modes (residual / differential), one value per ray: the binned kernel visits a ray once
 // per segment, so the reference-antenna sums are formed here, once.  One wave per (time, direction) pair p, lanes =
 // antennas: the column sum over antennas is a wave reduction instead of a 62-step loop in the i0 threads.

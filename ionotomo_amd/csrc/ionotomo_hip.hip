@@ -115,6 +115,7 @@ struct iono_ctx {
         bool fwd_ok = false;                              // every ray has <= 255 segments
         double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
         int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
+        size_t cap_uray = 0, cap_entries = 0, cap_units = 0, cap_nseg = 0, cap_partial = 0;      // bytes (grow-only: a new geometry reuses them)
     } plan;
     double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
     int64_t rayw_cap = 0;
@@ -131,6 +132,24 @@ void plan_free(iono_ctx *c) {
     if (c->plan.d_nseg) (void)hipFree(c->plan.d_nseg);
     if (c->plan.d_partial) (void)hipFree(c->plan.d_partial);
     c->plan = iono_ctx::AdjPlan();
+}
+// forget the plan but keep its buffers: the next geometry (a new timestep's directions) reuses them -- hipMalloc / hipFree
+// pairs were half of the 19 ms a re-plan cost
+void plan_reset(iono_ctx *c) {
+    iono_ctx::AdjPlan &p = c->plan, fresh;
+    fresh.d_uray = p.d_uray, fresh.d_entries = p.d_entries, fresh.d_units = p.d_units, fresh.d_nseg = p.d_nseg, fresh.d_partial = p.d_partial;
+    fresh.cap_uray = p.cap_uray, fresh.cap_entries = p.cap_entries, fresh.cap_units = p.cap_units, fresh.cap_nseg = p.cap_nseg;
+    fresh.cap_partial = p.cap_partial;
+    p = fresh;
+}
+template <typename T>
+hipError_t plan_reserve(T *&ptr, size_t &cap, size_t bytes) {
+    if (bytes <= cap && ptr) return hipSuccess;
+    if (ptr) (void)hipFree(ptr);
+    ptr = nullptr, cap = 0;
+    const hipError_t e = hipMalloc((void **)&ptr, bytes + bytes / 8 + 256);
+    if (e == hipSuccess) cap = bytes + bytes / 8 + 256;
+    return e;
 }
 
 int fail(iono_ctx *c, int code, const std::string &msg) {
@@ -945,82 +964,69 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     int rc = check_common(c, R, Ns, kind, 0);
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    plan_free(c);
+    plan_reset(c);
     const bool cubic = kind == IONO_INTERP_TRICUBIC;
     if (R == 0 || R > (int64_t)UINT32_MAX || Ns > 65535 || !(cubic ? cubic_fast_ok(c, Ns) : ideal_path_ok(c, Ns)))
         return IONO_OK;                                  // no plan: the ray-stationary kernels serve this case
     iono_ctx::AdjPlan &pl = c->plan;
-    HIP_TRY(c, hipMalloc((void **)&pl.d_uray, (size_t)R * 8 * sizeof(double)));
+    HIP_TRY(c, plan_reserve(pl.d_uray, pl.cap_uray, (size_t)R * 8 * sizeof(double)));
     const GridView g = view(c);
     if (cubic)
         hipLaunchKernelGGL((k_plan_urays<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray);
     else
         hipLaunchKernelGGL((k_plan_urays<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray);
     HIP_TRY(c, hipGetLastError());
-    std::vector<double> hu((size_t)R * 8);
-    HIP_TRY(c, hipMemcpyAsync(hu.data(), pl.d_uray, hu.size() * sizeof(double), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // segments: <= BIN_SEG consecutive samples of a ray inside one z-layer of boxes, binned by the (x, y) box around the middle
-    // of their extent.  Every sample of every valid ray lands in exactly one segment.
     const int nbx = (c->nx - 1 + BIN_SX - 1) / BIN_SX, nby = (c->ny - 1 + BIN_SY - 1) / BIN_SY, nbz = (c->nz - 1 + BIN_SZ - 1) / BIN_SZ;
     const int64_t nbox = (int64_t)nbx * nby * nbz;
-    auto cell = [](double f0, double df, int k, int n) {
-        const double v = std::floor(std::fabs(std::fma((double)k, df, f0)));
-        return (int)std::min(v, (double)(n - 2));
-    };
-    std::vector<uint32_t> e_ray, e_seg;
-    std::vector<int32_t> e_box;
-    const size_t guess = (size_t)R * (size_t)(Ns / BIN_SEG + nbz / 2 + 2);
-    e_ray.reserve(guess), e_seg.reserve(guess), e_box.reserve(guess);
-    int64_t outside = 0;
+    if (nbox > (int64_t)INT32_MAX / 4) {
+        plan_reset(c);
+        return IONO_OK;
+    }
+    // pass 1 on the device: segments per ray and per box (iono_binned_kernels.h:k_plan_segments)
+    DevBuf scratch(c);
+    const size_t off_cnt = ((size_t)R * sizeof(int) + 15) & ~(size_t)15, off_start = off_cnt + (size_t)nbox * sizeof(int),
+                 off_fill = off_start + (size_t)nbox * sizeof(int), off_out = (off_fill + (size_t)nbox * sizeof(int) + 7) & ~(size_t)7;
+    HIP_TRY(c, scratch.alloc(off_out + 16));
+    char *sb = scratch.as<char>();
+    int *d_nseg32 = (int *)sb, *d_cnt = (int *)(sb + off_cnt), *d_start = (int *)(sb + off_start), *d_fill = (int *)(sb + off_fill);
+    unsigned long long *d_out = (unsigned long long *)(sb + off_out);
+    HIP_TRY(c, hipMemsetAsync(sb + off_cnt, 0, off_out + 16 - off_cnt, c->stream));
+    hipLaunchKernelGGL((k_plan_segments<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz, nbx,
+                       nby, nbz, d_nseg32, d_cnt, (const int *)nullptr, (int *)nullptr, (uint2 *)nullptr, d_out);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<int> h_nseg((size_t)R), h_cnt((size_t)nbox);
+    unsigned long long outside = 0;
+    HIP_TRY(c, hipMemcpyAsync(h_nseg.data(), d_nseg32, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)nbox * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&outside, d_out, sizeof(outside), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     std::vector<unsigned char> nseg((size_t)R, 0);
     int smax = 1;
     bool fwd_ok = true;
     for (int64_t r = 0; r < R; ++r) {
-        const double *u = &hu[(size_t)r * 8];
-        if (u[7] == 0.0) {
+        const int j = h_nseg[(size_t)r];
+        if (j < 0) {
             ++pl.n_invalid;
             continue;
-        }
-        int k = 0, j = 0;
-        while (k < Ns) {
-            const int zb = cell(u[4], u[5], k, c->nz) / BIN_SZ;
-            int ke = k + 1;
-            while (ke < Ns && ke - k < BIN_SEG && cell(u[4], u[5], ke, c->nz) / BIN_SZ == zb) ++ke;
-            const int xa = cell(u[0], u[1], k, c->nx), xb = cell(u[0], u[1], ke - 1, c->nx);
-            const int ya = cell(u[2], u[3], k, c->ny), yb = cell(u[2], u[3], ke - 1, c->ny);
-            const int bi = std::min(nbx - 1, (xa + xb + 1) / (2 * BIN_SX)), bj = std::min(nby - 1, (ya + yb + 1) / (2 * BIN_SY));
-            const int x0 = bi * BIN_SX - BIN_H, y0 = bj * BIN_SY - BIN_H;
-            if (std::min(xa, xb) < x0 || std::max(xa, xb) > x0 + BIN_BX - 2 || std::min(ya, yb) < y0 || std::max(ya, yb) > y0 + BIN_BY - 2)
-                ++outside;
-            e_ray.push_back((uint32_t)r);
-            e_seg.push_back((uint32_t)k | ((uint32_t)(ke - k) << 16) | ((uint32_t)(j & 255) << 24));      // first sample, count, ordinal
-            e_box.push_back((int32_t)(((int64_t)bi * nby + bj) * nbz + zb));
-            k = ke;
-            ++j;
         }
         if (j > 255) fwd_ok = false;
         nseg[(size_t)r] = (unsigned char)std::min(j, 255);
         smax = std::max(smax, std::min(j, 255));
     }
-    const int64_t ne = (int64_t)e_ray.size();
+    // exclusive scan of the box counts; work units of <= BIN_UNIT segments, largest first
+    std::vector<int> start((size_t)nbox + 1, 0);
+    int64_t ne = 0;
+    for (int64_t b = 0; b < nbox; ++b) {
+        start[(size_t)b] = (int)ne;
+        ne += h_cnt[(size_t)b];
+        if (ne > (int64_t)INT32_MAX) break;
+    }
     if (ne == 0 || ne > (int64_t)INT32_MAX) {
-        plan_free(c);
+        plan_reset(c);
         return IONO_OK;
     }
+    start[(size_t)nbox] = (int)ne;
     const int64_t n_invalid = pl.n_invalid;
-    // counting sort by box, then work units of <= BIN_UNIT segments, largest first
-    std::vector<int64_t> start((size_t)nbox + 1, 0);
-    for (int64_t e = 0; e < ne; ++e) ++start[(size_t)e_box[(size_t)e] + 1];
-    for (int64_t b = 0; b < nbox; ++b) start[(size_t)b + 1] += start[(size_t)b];
-    std::vector<uint2> entries((size_t)ne);
-    {
-        std::vector<int64_t> pos(start.begin(), start.end() - 1);
-        for (int64_t e = 0; e < ne; ++e) {
-            const int64_t q = pos[(size_t)e_box[(size_t)e]]++;
-            entries[(size_t)q] = make_uint2(e_ray[(size_t)e], e_seg[(size_t)e]);
-        }
-    }
     std::vector<BinUnit> units;
     for (int64_t b = 0; b < nbox; ++b) {
         const int64_t lo = start[(size_t)b], hi = start[(size_t)b + 1];
@@ -1030,15 +1036,21 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
             units.push_back(BinUnit{bi * BIN_SX - BIN_H, bj * BIN_SY - BIN_H, zb * BIN_SZ, (int)q, (int)std::min(hi, q + BIN_UNIT)});
     }
     std::stable_sort(units.begin(), units.end(), [](const BinUnit &a, const BinUnit &b) { return a.e_hi - a.e_lo > b.e_hi - b.e_lo; });
-    entries.resize(entries.size() + 32, make_uint2(0u, 0u));          // padding: the kernel prefetches two passes ahead
-    HIP_TRY(c, hipMalloc((void **)&pl.d_entries, entries.size() * sizeof(uint2)));
-    HIP_TRY(c, hipMalloc((void **)&pl.d_units, units.size() * sizeof(BinUnit)));
-    HIP_TRY(c, hipMemcpy(pl.d_entries, entries.data(), entries.size() * sizeof(uint2), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMemcpy(pl.d_units, units.data(), units.size() * sizeof(BinUnit), hipMemcpyHostToDevice));
-    HIP_TRY(c, hipMalloc((void **)&pl.d_nseg, (size_t)R));
+    // pass 2 on the device: the segments into their boxes (+ 32 zero entries: the kernel prefetches two passes ahead)
+    HIP_TRY(c, plan_reserve(pl.d_entries, pl.cap_entries, ((size_t)ne + 32) * sizeof(uint2)));
+    HIP_TRY(c, hipMemsetAsync(pl.d_entries + ne, 0, 32 * sizeof(uint2), c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_start, start.data(), (size_t)nbox * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL((k_plan_segments<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz, nbx,
+                       nby, nbz, (int *)nullptr, (int *)nullptr, (const int *)d_start, d_fill, pl.d_entries, (unsigned long long *)nullptr);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, plan_reserve(pl.d_units, pl.cap_units, units.size() * sizeof(BinUnit)));
+    HIP_TRY(c, hipMemcpyAsync(pl.d_units, units.data(), units.size() * sizeof(BinUnit), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));          // (start / units are host vectors; scratch goes back to the pool)
+    HIP_TRY(c, plan_reserve(pl.d_nseg, pl.cap_nseg, (size_t)R));
     HIP_TRY(c, hipMemcpy(pl.d_nseg, nseg.data(), (size_t)R, hipMemcpyHostToDevice));
     pl.smax = smax, pl.fwd_ok = fwd_ok && !cubic;
-    if (pl.fwd_ok) HIP_TRY(c, hipMalloc((void **)&pl.d_partial, (size_t)R * smax * sizeof(double)));
+    if (pl.fwd_ok && c->fwd_plan) HIP_TRY(c, plan_reserve(pl.d_partial, pl.cap_partial, (size_t)R * smax * sizeof(double)));
+    else pl.fwd_ok = false;      // (the node-stationary FORWARD is an opt-in A/B: no 40 MB of partial sums otherwise)
     pl.o_key = o, pl.d_key = d, pl.R = R, pl.Ns = Ns, pl.tmax = tmax, pl.kind = kind;
     pl.n_entries = ne, pl.n_units = (int)units.size(), pl.n_invalid = n_invalid;
     pl.outside_fraction = (double)outside / (double)ne;
