@@ -459,7 +459,7 @@ def main():
             # ---- adjoint roofline: memory-side float atomics
             # the binned kernel is bound by LDS float-atomic throughput, the ray-stationary one by the memory-side atomic rate
             extra["adjoint_roofline"] = {"bound": "lds_atomic" if args.plan else "memory_atomic", "kernel_ms": akern * 1e3,
-                                         "kernel": "k_adjoint_binned<double, false>" if args.plan else "k_adjoint_straight_tile<double, 1, 4>"}
+                                         "kernel": "k_adjoint_binned<double, false, 0, double>" if args.plan else "k_adjoint_straight_tile<double, 1, 4>"}
         except Exception as exc:                                    # noqa: BLE001
             extra["error"] = "%s: %s" % (type(exc).__name__, exc)
         if world == 1:
