@@ -141,6 +141,13 @@ def cpu_baseline(w, tec_gpu):
     rays = O.straight_rays(w["origins"][sub], w["directions"][sub], TMAX, NS)
     O.forward_tec_loop(rays, w["xvec"], w["yvec"], w["zvec"], ne)
     numpy_rate = rays.shape[0] / (time.perf_counter() - t1)
+    # ... and the vectorised form of the phase observable (iterative_newton.py:86-127: one gather over all samples, Nf = 2)
+    o6, d6 = (w[k].reshape(NA, NT, ND, 3)[:, :1].reshape(-1, 3) for k in ("origins", "directions"))     # one timestep
+    rays6 = O.straight_rays(o6, d6, TMAX, NS).reshape(NA, 1, ND, 4, NS)
+    t2 = time.perf_counter()
+    O.forward_phase(w["m"] + np.log(w["K_ne"] / 1e11), np.zeros((NA, 1)), np.zeros(NA), w["xvec"], w["yvec"], w["zvec"], rays6,
+                    np.array([120e6, 150e6]), K=1e11, i0=0)
+    phase_rate = rays6.shape[0] * rays6.shape[2] / (time.perf_counter() - t2)
     try:
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
@@ -148,7 +155,8 @@ def cpu_baseline(w, tec_gpu):
     return dict(value=R / dt, unit="ray-integrals/s", cores=threads, kind="port", host_cpus=os.cpu_count(), cpu_model=cpu_model,
                 sample="full per-GPU batch (%d rays x %d samples, 256^3 f64 grid) x %d repetitions, unoptimised C/OpenMP "
                        "port oracle/oracle_c.c on %d threads; numpy per-ray-loop port (1 thread, %d rays): %.3g "
-                       "ray-integrals/s" % (R, NS, reps, threads, rays.shape[0], numpy_rate)), rel
+                       "ray-integrals/s; numpy vectorised phase port (1 process, %d rays x 2 frequencies): %.3g ray-integrals/s"
+                       % (R, NS, reps, threads, rays.shape[0], numpy_rate, rays6.shape[0] * rays6.shape[2], phase_rate)), rel
 
 
 def load_pmc(sha):
