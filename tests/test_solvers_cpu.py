@@ -116,3 +116,25 @@ def test_sirt_is_a_contraction_in_its_own_norms():
     errs, res = np.array(errs), np.array(res)
     assert np.all(np.diff(errs) <= 1e-12 * errs[0]) and errs[-1] < errs[0]
     assert np.all(np.diff(res) <= 1e-12 * res[0]) and res[-1] < 0.05 * res[0]
+
+
+def test_walk_orders_are_permutations_on_cpu():
+    """RayEngine.coherent_order / locality_order are host-side torch plumbing (no kernel involved): permutations of the rays,
+    the coherent one grouping by antenna with neighbouring directions adjacent."""
+    import torch
+    from ionotomo_amd.engine import RayEngine
+    from ionotomo_amd import synthetic as syn
+    w = syn.make_workload(antennas="lofar", na=20, nd=6, nt=7, n=16)
+    o = torch.from_numpy(w["origins"].reshape(-1, 3).copy())
+    d = torch.from_numpy(w["directions"].reshape(-1, 3).copy())
+    R = o.shape[0]
+    for order in (RayEngine.coherent_order(o, d), RayEngine.locality_order(o, d, w["tmax"])):
+        assert order.dtype == torch.int32 and torch.equal(torch.sort(order.long()).values, torch.arange(R))
+    co = RayEngine.coherent_order(o, d).long()
+    same_antenna = (o[co][1:] == o[co][:-1]).all(dim=1)
+    assert int((~same_antenna).sum()) == 20 - 1                      # one boundary between consecutive antenna groups
+    # inside a group neighbours point almost the same way: far closer than two random rays of the group
+    dn = d / d.norm(dim=1, keepdim=True)
+    step = (dn[co][1:] - dn[co][:-1]).norm(dim=1)[same_antenna].median()
+    rand = (dn[co][torch.randperm(R)][1:] - dn[co][:-1]).norm(dim=1).median()
+    assert float(step) < 0.25 * float(rand)
