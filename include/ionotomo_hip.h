@@ -131,9 +131,11 @@ int iono_gradient_chords_dev(iono_ctx *ctx, const double *rays_dev, const double
 /* ---- device-pointer (asynchronous) variants used by the inversion loop, bench.py and the
  *      multi-GPU driver.  Out-of-grid samples set a sticky device flag read by iono_check_oob. ---- */
 /* order_dev (nullable): int32 permutation of 0..R-1 giving the order in which rays are WALKED
- * (results still land in tec_dev[ray]); sort rays so that neighbours in the walk are neighbours in
- * space and the grid lines they share stay in L1/L2.  Speed only; kernels for non-uniform grids
- * and the tricubic ignore it. */
+ * (results still land in tec_dev[ray]).  Given an order, the ideal-uniform forward kernels (trilinear,
+ * float32 blocks, tricubic) interleave all the waves of an XCD in it, so neighbours in the order run
+ * at the same time on neighbouring waves: make them NEARLY IDENTICAL rays (one antenna, one line of
+ * sight a few seconds apart -- RayEngine.coherent_order) and the lines they read meet in the L1.
+ * Speed only; the kernels for non-uniform grids ignore it. */
 int iono_forward_tec_straight_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev,
                                   const int *order_dev, int64_t R, double tmax, int Ns, int interp_kind,
                                   int quad_rule, double *tec_dev);
