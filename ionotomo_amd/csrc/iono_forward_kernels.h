@@ -591,6 +591,16 @@ __global__ __launch_bounds__(256) void k_forward_phase_rays(GridView g, const do
 // The same observable with the samples generated in-kernel on straight z-parametrised rays (rays[R,4,Ns] never
 // exists): phi[r][l] = h_r sum_k w_k (1 - sqrt(1 - ne_k / n_p,l)).  IDEAL: ideal-uniform grid coordinates (one fma per
 // axis, unclamped corner loads); otherwise axis tables in LDS and the exact searchsorted cell rule.
+// 1 - sqrt(1 - x) for the phase observable, x = ne / n_p.  A float64 square root is ~35 instruction slots
+// (quarter-rate seed + two Newton steps) and the observable needs one per sample and FREQUENCY; for x <= 0.01 -- any
+// ionosphere above 30 MHz -- six terms of the binomial series are exact to 3e-14 relative (the next term is 0.032 x^6 of the
+// first), which is tighter than 1 - sqrt(1 - x) itself evaluates in float64 (cancellation: 1e-16 / x).  Larger x (checked per
+// wave) takes the square root.  (The transpose's 1 / sqrt(1 - x) keeps the root: that kernel is bound by its LDS atomics.)
+__device__ __forceinline__ double phase_one_minus_sqrt(double x, bool small) {
+    if (small)
+        return x * fma(x, fma(x, fma(x, fma(x, fma(x, 21.0 / 1024.0, 7.0 / 256.0), 5.0 / 128.0), 1.0 / 16.0), 1.0 / 8.0), 0.5);
+    return 1.0 - sqrt(1.0 - x);
+}
 struct PhaseFreqs {
     double inv_np[8];      // 1 / (1.2404e-2 nu^2)  (iterative_newton.py:112)
     int nf;
@@ -670,6 +680,9 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
     const Chunk ch = wave_chunk(R, 0, nullptr);
     const double dlane = (double)lane;
     const double *wp = wlds + lane;
+    double inv_np_max = 0.0;                                  // the lowest frequency of the pass has the largest ne / n_p
+#pragma unroll
+    for (int l = 0; l < NF; ++l) inv_np_max = fmax(inv_np_max, pf.inv_np[l]);
     bool oob = false;
     for (int64_t q0 = ch.lo; q0 < ch.hi; q0 += U_MAXG) {
         const int cnt = (int)min((int64_t)U_MAXG, ch.hi - q0);
@@ -685,7 +698,7 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
                     const double ne = trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fma(kd, u.dfx, u.fx0), fma(kd, u.dfy, u.fy0),
                                                       fma(kd, u.dfz, u.fz0));
 #pragma unroll
-                    for (int l = 0; l < NF; ++l) tail[l] = fma(wlds[k], 1.0 - sqrt(1.0 - ne * pf.inv_np[l]), tail[l]);
+                    for (int l = 0; l < NF; ++l) tail[l] = fma(wlds[k], phase_one_minus_sqrt(ne * pf.inv_np[l], false), tail[l]);
                 }
             }
             if (!u.valid) {
@@ -707,8 +720,10 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
             for (int l = 0; l < NF; ++l) acc[l] = 0.0;
             for (int it = 0; it < nfull; ++it) {
                 const double ne = trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), c = wp[it << 6];
+                // wave-uniform (a NaN takes the square-root path); one or two frequencies per pass: the plain root measured faster
+                const bool small = NF >= 4 && !__any(!(ne * inv_np_max <= 0.01));
 #pragma unroll
-                for (int l = 0; l < NF; ++l) acc[l] = fma(c, 1.0 - sqrt(1.0 - ne * pf.inv_np[l]), acc[l]);
+                for (int l = 0; l < NF; ++l) acc[l] = fma(c, phase_one_minus_sqrt(ne * pf.inv_np[l], small), acc[l]);
                 fx += sx64;
                 fy += sy64;
                 fz += sz64;
@@ -716,7 +731,7 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
             if (!tail_by_lane && lane + ntail0 < Ns) {
                 const double ne = trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), c = wp[ntail0];
 #pragma unroll
-                for (int l = 0; l < NF; ++l) acc[l] = fma(c, 1.0 - sqrt(1.0 - ne * pf.inv_np[l]), acc[l]);
+                for (int l = 0; l < NF; ++l) acc[l] = fma(c, phase_one_minus_sqrt(ne * pf.inv_np[l], false), acc[l]);
             }
             const double hh = bcast_lane(u.h, gi);
 #pragma unroll

@@ -1271,8 +1271,7 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
     hipLaunchKernelGGL((k_forward_phase_u<GT, NF>), dim3(chunk_grid_blocks(resident_blocks(c, k_forward_phase_u<GT, NF>, wl), R)), block, \
                        wl, c->stream, g, o, d, R, tmax, Ns, c->d_unitw, pf, Nf, phi_work + f0, c->d_flags)
                 if (pf.nf == 1) PHASE_U(1);
-                else if (pf.nf == 2) PHASE_U(2);
-                else if (pf.nf <= 4) PHASE_U(4);
+                else if (pf.nf <= 4) PHASE_U(4);          // (two frequencies: the 4-slot series kernel beats two plain roots)
                 else PHASE_U(8);
 #undef PHASE_U
             } else
