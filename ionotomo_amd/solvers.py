@@ -396,31 +396,31 @@ def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=
     eng = problem.engine
     m = m0.clone()
     hist = []
+    Wt = 1.0 / (problem.cdct + 1e-15)
     for k in range(max_iter):
         eng.set_log_model(m.reshape(-1), K_scale)
         tec = problem.forward_tec()
         t2 = tec.view(problem.Na, problem.P_local)
         resid = (t2 - t2[problem.i0:problem.i0 + 1]).reshape(-1) - problem.dobs
-        S = objective(problem, resid)
+        rw = resid * Wt
+        S = 0.5 * problem.dot_rays(resid, rw)                        # host read-back 1 of 2: the stopping rule needs it
         hist.append(S)
         if callback:
             callback(k, m, S)
         if k >= min_iter and len(hist) > 1 and (hist[-2] - S) <= FACTR * EPS * max(abs(hist[-2]), abs(S), 1.0):
             break
-        ne = K_scale * torch.exp(m)
-        dm = problem.gradient_from_tec(tec) * ne                  # d S / d m  (exp at nodes => node-wise product)
+        ne = torch.exp(m).mul_(K_scale)
+        dm = problem.gradient_from_tec(tec).mul_(ne)                 # d S / d m  (exp at nodes => node-wise product)
         if covariance is not None:
             dm = smooth_grid(eng, dm, covariance)
         if m_prior is not None and prior_weight > 0:
             dm = dm + prior_weight * (m - m_prior)
-        # linearised exact line search along -dm: d(A ne)/d eps = -A (ne * dm)
-        _set_x(problem, ne * dm)
+        # linearised exact line search along -dm: d(A ne)/d eps = -A (ne * dm); the step length stays on the device
+        _set_x(problem, ne.mul_(dm))
         Gdm = problem.forward()
-        Wt = 1.0 / (problem.cdct + 1e-15)
-        eps = problem.dot_rays(Gdm, resid * Wt) / max(problem.dot_rays(Gdm, Gdm * Wt), 1e-300)
-        step = eps * dm
-        m -= step
-        if k >= min_iter and float(step.abs().max()) <= PGTOL:
+        eps = problem.dot_rays_t(Gdm, rw) / problem.dot_rays_t(Gdm, Gdm * Wt).clamp_min(1e-300)
+        m.addcmul_(dm, eps, value=-1.0)                              # m -= eps dm
+        if k >= min_iter and float(eps.abs() * torch.linalg.vector_norm(dm, ord=float("inf"))) <= PGTOL:   # read-back 2
             break
     return m, hist
 
