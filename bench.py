@@ -287,7 +287,9 @@ def main():
 
     # the forward kernels walk the rays in the "coherent" order (nearly identical rays -- one line of sight a few seconds apart
     # -- on neighbouring waves at the same time: RayEngine.coherent_order; geometry only, once); arguments converted once
-    forder_t = eng.coherent_order(o_t, d_t) if args.order else None
+    forder_t = None
+    if args.order:
+        forder_t = order_t if os.environ.get("IONO_BENCH_FWD_ORDER", "coherent") == "locality" else eng.coherent_order(o_t, d_t)
     fwd = eng.forward_launcher(o_t, d_t, TMAX, NS, tec_t, order=forder_t)
 
     # ---- legs that can run alone under a profiler ---------------------------------------------------------------

@@ -204,6 +204,18 @@ int iono_adjoint_plan_dev(iono_ctx *ctx, const double *origins_dev, const double
                           int Ns, int interp_kind);
 int iono_adjoint_plan_clear(iono_ctx *ctx);
 int iono_adjoint_plan_info(iono_ctx *ctx, int64_t *n_segments, int *n_units, double *outside_fraction);
+/* Bundle-stationary forward (ionotomo_amd/csrc/iono_forward_kernels.h: k_forward_bundle).  The same observation as for the
+ * back-projection plan: the rays of forward_equation (inversion/forward_equation.py:13-33) are fixed for a whole inversion,
+ * so they can be organised once: sorted along a 4-D Morton curve of foot and end point, cut into bundles of <= 64 nearly
+ * coincident rays, and every later iono_forward_tec_straight_dev call with the SAME origins_dev / directions_dev pointers,
+ * R, tmax and Ns (trilinear, float64 storage, np.linspace axes) gives a workgroup one bundle: the voxel neighbourhood the
+ * bundle needs for 8 consecutive samples is copied to LDS once (LDS-DMA) and every ray interpolates from there.  The
+ * caller must not modify the two arrays while the plan is in use.  TEC never depends on the plan: a chunk whose
+ * neighbourhood does not fit the LDS image takes direct loads with bit-identical arithmetic, and a ray's partial sums are
+ * added in a fixed order.  No plan is built (and the other forward kernels serve the call) on other grids / storage. */
+int iono_forward_plan_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R, double tmax, int Ns);
+int iono_forward_plan_clear(iono_ctx *ctx);
+int iono_forward_plan_info(iono_ctx *ctx, int64_t *n_bundles, int *n_chunks, double *fit_fraction);
 /* Solver vector update  y = a x + b y  on device vectors (16-byte aligned), one pass.  The coefficients are ratios
  * of DEVICE scalars, a = a_sign * a_num[0] / a_den[0], b = b_num[0] / b_den[0] (a null pointer stands for 1), so the
  * step lengths of the iteration -- eps = sum(Gdm dd/Cd) / sum(Gdm^2/Cd), inversion/iterative_newton.py:542-554; the

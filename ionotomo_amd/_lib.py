@@ -94,6 +94,9 @@ _SIGNATURES = {
     "iono_adjoint_plan_dev": [_V, _V, _L, _D, _I, _I],
     "iono_adjoint_plan_clear": [],
     "iono_adjoint_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
+    "iono_forward_plan_dev": [_V, _V, _L, _D, _I],
+    "iono_forward_plan_clear": [],
+    "iono_forward_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
     "iono_walk_order": [_P, _P, _L, _D, ctypes.POINTER(ctypes.c_int)],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],

@@ -446,6 +446,251 @@ __global__ __launch_bounds__(256, FWD_U_WG) void k_forward_straight_u(GridView g
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
+// ---- lanes = rays: 64 NEIGHBOURING rays of a walk order per wave, all at the same sample index ---------------------------------
+// k_forward_straight_u (lanes = samples) re-fetches the whole algorithmic volume from L2 every launch: a wave-load covers 64
+// samples of ONE ray (~20 lines, each used once), so nothing a wave reads is ever read again by it.  Given a walk order whose
+// neighbours are nearly the same ray (RayEngine.locality_order: 4-D Morton code of foot and end point), the transposed mapping
+// -- lane l of a wave = ray order[64 w + l], every lane at the same sample k, k = 0 .. Ns-1 in sequence -- makes the 64 lanes
+// of a wave-load read a handful of lines (the bundle is a few columns wide), and the line a lane used at sample k serves its
+// samples k+1 .. (z advances < 1 cell per sample, 16 nodes per line).  The Simpson weight is wave-uniform (a scalar load),
+// each lane owns its whole sum (no DPP reduction, no broadcasts, no tail case), and the per-sample arithmetic is unchanged.
+// Positions are re-based every T_REBASE samples (f = fma(k0, df, f0), then one add per sample) so that rounding does not
+// accumulate over the ray.  One wave-task = 64 rays; tasks are numbered XCD-major (blocks b, b + 8, ... share an XCD), so an
+// XCD's L2 sees one contiguous eighth of the walk.
+#define T_REBASE 32
+#ifndef T_UNROLL
+#define T_UNROLL 4
+#endif
+#ifndef T_WAVES
+#define T_WAVES 4
+#endif
+template <typename GT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T_WAVES, T_WAVES))) void k_forward_straight_t(GridView g, const double *__restrict__ origins,
+                                                            const double *__restrict__ dirs, const int *__restrict__ order,
+                                                            int64_t R, double tmax, int Ns, const double *__restrict__ unitw,
+                                                            double *__restrict__ tec, int *oob_flag) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    int64_t bidx = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bidx = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const int64_t q = (bidx * wpb + wid) * 64 + lane;
+    if (q - lane >= R) return;                                  // (wave-uniform)
+    const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
+    URay u = {};
+    int64_t r = 0;
+    if (q < R) {
+        r = order ? (int64_t)order[q] : q;
+        u = load_uray(g, origins, dirs, r, tmax, Ns);
+    }
+    const bool oob = q < R && !u.valid;
+    // lanes without a valid ray walk cell (0, 0, 0) in place: same instruction stream, in-bounds loads, result discarded
+    const double fx0 = u.valid ? u.fx0 : 0.0, fy0 = u.valid ? u.fy0 : 0.0, fz0 = u.valid ? u.fz0 : 0.0;
+    const double dfx = u.valid ? u.dfx : 0.0, dfy = u.valid ? u.dfy : 0.0, dfz = u.valid ? u.dfz : 0.0;
+    double acc = 0.0;
+    for (int k0 = 0; k0 < Ns; k0 += T_REBASE) {
+        const double kd = (double)k0;
+        double fx = fma(kd, dfx, fx0), fy = fma(kd, dfy, fy0), fz = fma(kd, dfz, fz0);
+        const int ke = min(k0 + T_REBASE, Ns);
+        int k = k0;
+        for (; k + T_UNROLL <= ke; k += T_UNROLL) {
+            Corners<GT> cc[T_UNROLL];
+#pragma unroll
+            for (int b = 0; b < T_UNROLL; ++b) {
+                cc[b] = load_corners<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz);
+                fx += dfx;
+                fy += dfy;
+                fz += dfz;
+            }
+#pragma unroll
+            for (int b = 0; b < T_UNROLL; ++b) acc = fma(unitw[k + b], lerp_corners<GT>(cc[b]), acc);
+        }
+        for (; k < ke; ++k) {
+            acc = fma(unitw[k], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
+            fx += dfx;
+            fy += dfy;
+            fz += dfz;
+        }
+    }
+    if (q < R) tec[r] = u.valid ? acc * u.h : nan("");
+    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- bundle-stationary forward: the voxel neighbourhood of <= 64 neighbouring rays staged in LDS ---------------------------------
+// Counters of the two mappings above (profiles/r03_ab_forward_lanes_rays.json): the vector L1 charges a 16-B wave-load one tag
+// look-up per (4-lane group, line) -- 27 per wave-load with lanes = samples (column changes, 128-B boundaries), 33 with lanes =
+// rays -- and keeps nothing between the steps of a wave (the live lines of 16-24 waves against 256 lines of L1), so either
+// mapping moves the full algorithmic volume L2 -> L1.  What the rays of a compact bundle read in B_KC consecutive samples is a
+// window of a few dozen columns x ten levels.  Here a WORKGROUP owns a bundle (lane = ray, a forward plan cuts the walk order
+// into bundles whose windows fit: iono_forward_plan_dev) and its four waves own one quarter of the samples each; per chunk of
+// B_KC samples a wave copies the window into ITS OWN LDS region with LDS-DMA (global_load_lds_dwordx4: 16-B pieces, lane-linear
+// image, column = 5 pieces = 10 levels; no register staging, no workgroup barrier inside the loop -- the waves are
+// independent until the final sum) and every lane interpolates its B_KC samples from LDS (4 x ds_read2_b64 per sample).  The
+// windows (origin, extent, "fits") are wave-uniform, computed once per geometry by k_bundle_windows and read with scalar loads.
+// Arithmetic per ray is position-for-position that of the direct loads (absolute grid coordinates, re-based every B_KC
+// samples; the window origin only enters the integer LDS address), so a chunk whose window does not fit takes the direct
+// loads with bit-identical results, the four quarter sums are added in a fixed order, and TEC does not depend on how the
+// rays were bundled: exactness never depends on the plan.
+#define B_KC 8                                   // samples per chunk
+#define B_PPC 5                                  // 16-B pieces per staged column: 10 levels >= 7 dfz + 2 (+ 1 to start on an even level)
+#define B_LEV (2 * B_PPC)
+#define B_CAPCOLS 120                            // columns per wave image
+#define B_WAVE_LDS (B_CAPCOLS * B_PPC * 16)      // 9 600 B per wave, 4 waves per workgroup
+#define B_SPLIT 4                                // z-parts of a ray = waves of a workgroup
+template <bool MAX>
+__device__ __forceinline__ int wave_minmax_i32(int v) {
+#define IONO_MM_STEP(CTRL, ROWS)                                                       \
+    {                                                                                  \
+        const int o_ = __builtin_amdgcn_update_dpp(v, v, CTRL, ROWS, 0xf, false);     \
+        v = MAX ? max(v, o_) : min(v, o_);                                             \
+    }
+    IONO_MM_STEP(0x111, 0xf)     // row_shr:1
+    IONO_MM_STEP(0x112, 0xf)     // row_shr:2
+    IONO_MM_STEP(0x114, 0xf)     // row_shr:4
+    IONO_MM_STEP(0x118, 0xf)     // row_shr:8  -> lane 15 of each row
+    IONO_MM_STEP(0x142, 0xa)     // row_bcast:15 into rows 1, 3
+    IONO_MM_STEP(0x143, 0xc)     // row_bcast:31 into rows 2, 3 -> lane 63
+#undef IONO_MM_STEP
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+struct BundleRays {          // the rays of a bundle, one per lane; lanes without a valid ray walk along the first valid one
+    double fx0, fy0, fz0, dfx, dfy, dfz, h;
+    int64_t r;
+    bool mine, valid, any;
+};
+__device__ __forceinline__ BundleRays load_bundle(const GridView &g, const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                  const int *__restrict__ order, const int *__restrict__ bstart, int b, double tmax, int Ns) {
+    const int lane = threadIdx.x & 63;
+    const int q0 = bstart[b], cnt = bstart[b + 1] - q0;
+    BundleRays B;
+    URay u = {};
+    B.r = 0;
+    B.mine = lane < cnt;
+    if (B.mine) {
+        B.r = order[q0 + lane];
+        u = load_uray(g, origins, dirs, B.r, tmax, Ns);
+    }
+    B.valid = u.valid;
+    const unsigned long long vmask = __ballot(u.valid);
+    B.any = vmask != 0;
+    const int src = B.any ? __builtin_ctzll(vmask) : 0;
+    B.fx0 = u.valid ? u.fx0 : bcast_lane(u.fx0, src), B.fy0 = u.valid ? u.fy0 : bcast_lane(u.fy0, src);
+    B.fz0 = u.valid ? u.fz0 : bcast_lane(u.fz0, src);
+    B.dfx = u.valid ? u.dfx : bcast_lane(u.dfx, src), B.dfy = u.valid ? u.dfy : bcast_lane(u.dfy, src);
+    B.dfz = u.valid ? u.dfz : bcast_lane(u.dfz, src);
+    B.h = u.h;
+    return B;
+}
+
+// window of chunk c of bundle b: {imin, jmin, kz0 (even), wx | wy << 8 | fits << 16}; one wave per bundle
+__global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                       const int *__restrict__ order, const int *__restrict__ bstart, int nb, double tmax,
+                                                       int Ns, int nchunks, uint4 *__restrict__ win) {
+    const int b = blockIdx.x;
+    if (b >= nb) return;
+    const BundleRays B = load_bundle(g, origins, dirs, order, bstart, b, tmax, Ns);
+    const double eps = 1e-9;       // the samples of a chunk are reached by accumulation from its first one: margin of the window
+    for (int c = 0; c < nchunks; ++c) {
+        uint4 w = make_uint4(0, 0, 0, 0);
+        if (B.any) {
+            const int k0 = c * B_KC, ke = min(k0 + B_KC, Ns);
+            const double kd0 = (double)k0, kd1 = (double)(ke - 1);
+            const double fx = fma(kd0, B.dfx, B.fx0), fy = fma(kd0, B.dfy, B.fy0), fz = fma(kd0, B.dfz, B.fz0);
+            const double fxe = fma(kd1, B.dfx, B.fx0), fye = fma(kd1, B.dfy, B.fy0), fze = fma(kd1, B.dfz, B.fz0);
+            const int imin = wave_minmax_i32<false>((int)fmax(fmin(fx, fxe) - eps, 0.0)), imax = wave_minmax_i32<true>((int)(fmax(fx, fxe) + eps));
+            const int jmin = wave_minmax_i32<false>((int)fmax(fmin(fy, fye) - eps, 0.0)), jmax = wave_minmax_i32<true>((int)(fmax(fy, fye) + eps));
+            const int kmin = wave_minmax_i32<false>((int)fmax(fmin(fz, fze) - eps, 0.0)), kmax = wave_minmax_i32<true>((int)(fmax(fz, fze) + eps));
+            const int kz0 = kmin & ~1;
+            const int wx = imax - imin + 2, wy = jmax - jmin + 2, nlev = kmax + 2 - kz0;
+            const bool fits = (g.nz & 1) == 0 && wx * wy <= B_CAPCOLS && wx < 256 && wy < 256 && nlev <= B_LEV;
+            w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0, (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u));
+        }
+        if ((threadIdx.x & 63) == 0) win[(size_t)b * nchunks + c] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_forward_bundle(
+    GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, const int *__restrict__ order,
+    const int *__restrict__ bstart, const uint4 *__restrict__ win, int nb, int nchunks, double tmax, int Ns,
+    const double *__restrict__ unitw, double *__restrict__ tec, int *oob_flag, unsigned max_boff) {
+    extern __shared__ __attribute__((aligned(16))) char blds[];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);     // XCD-major: neighbouring bundles share an L2
+    if (b >= nb) return;
+    const double *M = (const double *)g.M;
+    const double *b00 = M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
+    const BundleRays B = load_bundle(g, origins, dirs, order, bstart, b, tmax, Ns);
+    if (wid == 0 && __any(B.mine && !B.valid) && lane == 0) atomicOr(oob_flag, 1);
+    if (!B.any) {
+        if (wid == 0 && B.mine) tec[B.r] = nan("");
+        return;
+    }
+    char *img = blds + wid * B_WAVE_LDS;
+    double *part = (double *)(blds + B_SPLIT * B_WAVE_LDS);
+    const uint4 *wb = win + (size_t)b * nchunks;
+    const int c0 = nchunks * wid / B_SPLIT, c1 = nchunks * (wid + 1) / B_SPLIT;
+    double acc = 0.0;
+    for (int c = c0; c < c1; ++c) {
+        const int k0 = c * B_KC, ke = min(k0 + B_KC, Ns);
+        const double kd0 = (double)k0;
+        double fx = fma(kd0, B.dfx, B.fx0), fy = fma(kd0, B.dfy, B.fy0), fz = fma(kd0, B.dfz, B.fz0);
+        const uint4 w = wb[c];
+        const int imin = __builtin_amdgcn_readfirstlane((int)w.x), jmin = __builtin_amdgcn_readfirstlane((int)w.y),
+                  kz0 = __builtin_amdgcn_readfirstlane((int)w.z), wxy = __builtin_amdgcn_readfirstlane((int)w.w);
+        const int wx = wxy & 255, wy = (wxy >> 8) & 255;
+        if (wxy >> 16) {
+            // ---- stage the window: piece p = column (p / 5) x levels kz0 + 2 (p % 5), + 1; the image is lane-linear in p ----
+            const int npieces = wx * wy * B_PPC;
+            const float inv_wy = 1.0f / (float)wy;
+            const unsigned colbase = ((unsigned)imin * (unsigned)g.ny + (unsigned)jmin) * (unsigned)g.nz + (unsigned)kz0;
+            for (int p0 = 0; p0 < npieces; p0 += 64) {
+                const int p = p0 + lane;
+                if (p < npieces) {
+                    const int col = (int)(((unsigned)p * 52429u) >> 18);            // p / 5 (exact for p < 2^16)
+                    const int pc = p - col * B_PPC;
+                    const int di = (int)(((float)col + 0.5f) * inv_wy);
+                    const int dj = col - di * wy;
+                    const unsigned eoff = colbase + ((unsigned)di * (unsigned)g.ny + (unsigned)dj) * (unsigned)g.nz + 2u * (unsigned)pc;
+                    const unsigned boff = min(eoff * 8u, max_boff);                 // (beyond the padded allocation: weight-0 corners only)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)M + boff),
+                                                     (__attribute__((address_space(3))) void *)(img + p0 * 16), 16, 0, 0);
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // ---- B_KC samples per lane from the image; the window origin only shifts the (integer) node offset ------------
+            const double cw = (double)(wy * B_LEV), cj = (double)B_LEV;
+            const double nbase = -(((double)imin * (double)wy + (double)jmin) * (double)B_LEV + (double)kz0);
+            const unsigned row2 = (unsigned)wy * (B_LEV * 8);
+#pragma unroll 2
+            for (int k = k0; k < ke; ++k) {
+                const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)),
+                             fk = __builtin_floor(__builtin_fabs(fz));
+                const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk + nbase)) * 8u;
+                const double *p = (const double *)(img + a), *p2 = (const double *)(img + a + row2);
+                Corners<double> cc;
+                cc.c000 = p[0], cc.c001 = p[1], cc.c010 = p[B_LEV], cc.c011 = p[B_LEV + 1];
+                cc.c100 = p2[0], cc.c101 = p2[1], cc.c110 = p2[B_LEV], cc.c111 = p2[B_LEV + 1];
+                cc.tx = fx - fi, cc.ty = fy - fj, cc.tz = fz - fk;
+                acc = fma(unitw[k], lerp_corners<double>(cc), acc);
+                fx += B.dfx;
+                fy += B.dfy;
+                fz += B.dfz;
+            }
+        } else {
+            for (int k = k0; k < ke; ++k) {
+                acc = fma(unitw[k], trilinear_u<double>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
+                fx += B.dfx;
+                fy += B.dfy;
+                fz += B.dfz;
+            }
+        }
+    }
+    // ---- the four z-parts of a ray, added in a fixed order ------------------------------------------------------------------
+    part[wid * 64 + lane] = acc;
+    __syncthreads();
+    if (wid == 0 && B.mine) tec[B.r] = B.valid ? (((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane]) * B.h : nan("");
+}
+
 // ---- float32 storage extra: 2 x 2 (y, z) corner blocks -------------------------------------------------------------------
 // The headline kernel is bound by the NUMBER of vector-memory instructions (4 per 64 samples: a lane moves at most 16 B
 // per instruction and float64 trilinear needs four (i, j) corner columns x one 16-B z-pair).  With float32 storage the

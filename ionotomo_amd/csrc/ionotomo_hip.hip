@@ -117,6 +117,17 @@ struct iono_ctx {
         int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
         size_t cap_uray = 0, cap_entries = 0, cap_units = 0, cap_nseg = 0, cap_partial = 0;      // bytes (grow-only: a new geometry reuses them)
     } plan;
+    // bundle plan of the forward (iono_forward_plan_dev; k_forward_bundle): geometry only, library-owned
+    struct FwdPlan {
+        const void *o_key = nullptr, *d_key = nullptr;
+        int64_t R = -1;
+        int Ns = 0, nb = 0, nchunks = 0;
+        double tmax = 0;
+        int *d_order = nullptr, *d_bstart = nullptr;
+        uint4 *d_win = nullptr;
+        size_t cap_order = 0, cap_bstart = 0, cap_win = 0;
+        double fit_fraction = 0;         // chunks whose window fits the LDS image
+    } fplan;
     double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
     int64_t rayw_cap = 0;
     double *d_freqs = nullptr;       // frequencies of the phase observable on the device (cached copy of h_freqs)
@@ -150,6 +161,13 @@ hipError_t plan_reserve(T *&ptr, size_t &cap, size_t bytes) {
     const hipError_t e = hipMalloc((void **)&ptr, bytes + bytes / 8 + 256);
     if (e == hipSuccess) cap = bytes + bytes / 8 + 256;
     return e;
+}
+
+void fplan_free(iono_ctx *c) {
+    if (c->fplan.d_order) (void)hipFree(c->fplan.d_order);
+    if (c->fplan.d_bstart) (void)hipFree(c->fplan.d_bstart);
+    if (c->fplan.d_win) (void)hipFree(c->fplan.d_win);
+    c->fplan = iono_ctx::FwdPlan();
 }
 
 int fail(iono_ctx *c, int code, const std::string &msg) {
@@ -453,6 +471,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_freqs) (void)hipFree(c->d_freqs);
     if (c->d_rayw) (void)hipFree(c->d_rayw);
     plan_free(c);
+    fplan_free(c);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
     for (auto &wp : c->walk) {
@@ -536,6 +555,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     c->d_F8 = c->d_G8 = nullptr;
     c->d_M_ext = nullptr;
     plan_free(c);
+    fplan_free(c);
     c->F8_valid = false;
     c->nM_freq = -1.0;
     c->nx = nx;
@@ -702,11 +722,132 @@ static int ensure_lm_fields(iono_ctx *c) {
 static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes, const int *order) {
     return c->walk_mode_set ? c->walk_mode : (order || array_bytes > ((uint64_t)256 << 20) ? 2 : 0);
 }
+// Forward mapping on ideal-uniform grids without a bundle plan: lanes = samples of one ray (k_forward_straight_u).
+// IONOTOMO_VARIANT=11 selects lanes = 64 neighbouring rays of the walk order (k_forward_straight_t), 10 forces lanes = samples
+// even on a planned geometry: A/B runs; results agree to rounding.
+static bool lanes_are_rays(const iono_ctx *c, int64_t R, const int *order) {
+    (void)R, (void)order;
+    return c->variant == 11;          // measured slower than lanes = samples at every order (profiles/r03_ab_forward_lanes_rays.json)
+}
 // fast tricubic tier: ideal-uniform axes, weights in LDS, 32-bit-safe field array (IONOTOMO_VARIANT=4 forces the general tier)
 static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
     // (field records of 64 B per node, addressed with 32-bit byte offsets from the column bases)
     return ideal_path_ok(c, Ns) && c->variant != 4 && c->nx >= 6 && c->ny >= 6 && c->nz >= 6 &&
            (uint64_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double) < ((uint64_t)1 << 32);
+}
+
+// ---- bundle plan of the forward (k_forward_bundle) ---------------------------------------------------------------------------
+// Geometry only, once per inversion: (1) the rays sorted along a 4-D Morton curve of foot and end point in grid cells (neighbours
+// in the walk nearly coincide all the way up); (2) the walk cut greedily into bundles of <= 64 rays whose window -- the columns
+// the bundle touches in any B_KC consecutive samples, bounded through the extents at the two ends (positions are linear in the
+// sample index, so the extent of a bundle is convex in it) + the drift of its steepest ray -- fits the LDS image of one wave;
+// (3) the exact window of every (bundle, chunk), by the device (k_bundle_windows).  Host part: O(R log R) on R x 48 B copied
+// back once.  No plan (non-uniform axes, float32 storage, odd nz): the other forward kernels serve the launch.
+int iono_forward_plan_clear(iono_ctx *c) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    fplan_free(c);
+    return IONO_OK;
+}
+
+int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns) {
+    int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, 0);
+    if (rc) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    iono_ctx::FwdPlan &fp = c->fplan;
+    fp.R = -1, fp.nb = 0, fp.o_key = fp.d_key = nullptr;
+    if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || c->storage != IONO_F64 || (c->nz & 1) || !o || !d) return IONO_OK;
+    std::vector<double> ho((size_t)R * 3), hd((size_t)R * 3);
+    HIP_TRY(c, hipMemcpy(ho.data(), o, (size_t)R * 24, hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(hd.data(), d, (size_t)R * 24, hipMemcpyDeviceToHost));
+    struct HRay { float fx0, fy0, fxe, fye, fz0, adx, ady, dz; };
+    std::vector<HRay> hr((size_t)R);
+    std::vector<std::pair<uint64_t, int>> key((size_t)R);
+    const double q = 4.0 / 3.0;
+    for (int64_t r = 0; r < R; ++r) {
+        const double ox = ho[3 * r], oy = ho[3 * r + 1], oz = ho[3 * r + 2], dx = hd[3 * r], dy = hd[3 * r + 1], dz = hd[3 * r + 2];
+        const double nrm = std::sqrt(dx * dx + dy * dy + dz * dz), pz = dz / nrm, sx = dx / nrm / pz, sy = dy / nrm / pz;
+        const double L = tmax - oz, Lstep = L / (double)(Ns - 1), xe = ox + sx * L, ye = oy + sy * L, ze = oz + L;
+        const bool valid = (ox >= c->g0[0]) & (ox <= c->glast[0]) & (xe >= c->g0[0]) & (xe <= c->glast[0]) & (oy >= c->g0[1]) & (oy <= c->glast[1]) &
+                           (ye >= c->g0[1]) & (ye <= c->glast[1]) & (oz >= c->g0[2]) & (oz <= c->glast[2]) & (ze >= c->g0[2]) & (ze <= c->glast[2]);
+        HRay &h = hr[(size_t)r];
+        h.fx0 = (float)((ox - c->g0[0]) * c->inv_h[0]), h.fy0 = (float)((oy - c->g0[1]) * c->inv_h[1]);
+        h.fxe = (float)((xe - c->g0[0]) * c->inv_h[0]), h.fye = (float)((ye - c->g0[1]) * c->inv_h[1]);
+        h.fz0 = (float)((oz - c->g0[2]) * c->inv_h[2]);
+        h.adx = (float)std::fabs(sx * Lstep * c->inv_h[0]), h.ady = (float)std::fabs(sy * Lstep * c->inv_h[1]), h.dz = (float)std::fabs(Lstep * c->inv_h[2]);
+        uint64_t code = ~(uint64_t)0;               // rays that leave the grid: at the end of the walk, in bundles of their own
+        if (valid) {
+            code = 0;
+            const float v[4] = {h.fx0, h.fy0, h.fxe, h.fye};
+            for (int dim = 0; dim < 4; ++dim) {
+                double t = v[dim] * q;
+                if (!(t > 0)) t = 0;
+                if (t > 32767.0) t = 32767.0;
+                const uint64_t u = (uint64_t)t;
+                for (int b = 0; b < 15; ++b) code |= ((u >> b) & 1ull) << (4 * b + dim);
+            }
+        }
+        key[(size_t)r] = {code, (int)r};
+    }
+    std::sort(key.begin(), key.end());
+    std::vector<int> order((size_t)R), bstart;
+    bstart.reserve((size_t)R / 32 + 2);
+    const float inf = 3.0e38f;
+    float x0lo = inf, x0hi = -inf, y0lo = inf, y0hi = -inf, xelo = inf, xehi = -inf, yelo = inf, yehi = -inf, zlo = inf, zhi = -inf, ax = 0, ay = 0, az = 0;
+    int cnt = 0;
+    bool cur_valid = true;
+    auto reset = [&]() { x0lo = y0lo = xelo = yelo = zlo = inf, x0hi = y0hi = xehi = yehi = zhi = -inf, ax = ay = az = 0, cnt = 0; };
+    for (int64_t i = 0; i < R; ++i) {
+        const int r = key[(size_t)i].second;
+        order[(size_t)i] = r;
+        const bool valid = key[(size_t)i].first != ~(uint64_t)0;
+        const HRay &h = hr[(size_t)r];
+        // the bundle with this ray added
+        const float nx0lo = std::min(x0lo, h.fx0), nx0hi = std::max(x0hi, h.fx0), ny0lo = std::min(y0lo, h.fy0), ny0hi = std::max(y0hi, h.fy0);
+        const float nxelo = std::min(xelo, h.fxe), nxehi = std::max(xehi, h.fxe), nyelo = std::min(yelo, h.fye), nyehi = std::max(yehi, h.fye);
+        const float nzlo = std::min(zlo, h.fz0), nzhi = std::max(zhi, h.fz0), nax = std::max(ax, h.adx), nay = std::max(ay, h.ady), naz = std::max(az, h.dz);
+        const int wxb = (int)std::floor(std::max(nx0hi - nx0lo, nxehi - nxelo) + nax * (B_KC - 1) + 1e-3f) + 3;
+        const int wyb = (int)std::floor(std::max(ny0hi - ny0lo, nyehi - nyelo) + nay * (B_KC - 1) + 1e-3f) + 3;
+        const int nlb = (int)std::floor((nzhi - nzlo) + naz * (B_KC - 1) + 1e-3f) + 4;
+        const bool ok = cnt < 64 && valid == cur_valid && (!valid || (wxb * wyb <= B_CAPCOLS && nlb <= B_LEV));
+        if (cnt == 0 || !ok) {            // (a single ray whose own window does not fit still gets a bundle: its chunks take the direct loads)
+            bstart.push_back((int)i);
+            reset();
+            cur_valid = valid;
+            x0lo = x0hi = h.fx0, y0lo = y0hi = h.fy0, xelo = xehi = h.fxe, yelo = yehi = h.fye, zlo = zhi = h.fz0, ax = h.adx, ay = h.ady, az = h.dz;
+            cnt = 1;
+        } else {
+            x0lo = nx0lo, x0hi = nx0hi, y0lo = ny0lo, y0hi = ny0hi, xelo = nxelo, xehi = nxehi, yelo = nyelo, yehi = nyehi;
+            zlo = nzlo, zhi = nzhi, ax = nax, ay = nay, az = naz;
+            ++cnt;
+        }
+    }
+    bstart.push_back((int)R);
+    const int nb = (int)bstart.size() - 1, nchunks = (Ns + B_KC - 1) / B_KC;
+    HIP_TRY(c, plan_reserve(fp.d_order, fp.cap_order, (size_t)R * sizeof(int)));
+    HIP_TRY(c, plan_reserve(fp.d_bstart, fp.cap_bstart, bstart.size() * sizeof(int)));
+    HIP_TRY(c, plan_reserve(fp.d_win, fp.cap_win, (size_t)nb * nchunks * sizeof(uint4)));
+    HIP_TRY(c, hipMemcpy(fp.d_order, order.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpy(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_bundle_windows, dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart, nb, tmax, Ns, nchunks, fp.d_win);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<uint4> hw((size_t)nb * nchunks);
+    HIP_TRY(c, hipMemcpyAsync(hw.data(), fp.d_win, hw.size() * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    size_t fits = 0;
+    for (const uint4 &w : hw) fits += (w.w >> 16) & 1u;
+    fp.fit_fraction = hw.empty() ? 0.0 : (double)fits / (double)hw.size();
+    fp.o_key = o, fp.d_key = d, fp.R = R, fp.Ns = Ns, fp.tmax = tmax, fp.nb = nb, fp.nchunks = nchunks;
+    return IONO_OK;
+}
+
+int iono_forward_plan_info(iono_ctx *c, int64_t *n_bundles, int *n_chunks, double *fit_fraction) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    if (n_bundles) *n_bundles = c->fplan.R >= 0 ? c->fplan.nb : 0;
+    if (n_chunks) *n_chunks = c->fplan.R >= 0 ? c->fplan.nchunks : 0;
+    if (fit_fraction) *fit_fraction = c->fplan.R >= 0 ? c->fplan.fit_fraction : 0.0;
+    return IONO_OK;
 }
 
 // ---- forward (device pointers) ---------------------------------------------------------------
@@ -747,6 +888,20 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_q4, wl), R);
             hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, order, R, tmax, Ns,
                                forward_walk_mode(c, (uint64_t)padded * sizeof(float4), order), c->d_unitw, tec, c->d_flags);
+        } else if (kind == IONO_INTERP_TRILINEAR && std::is_same<GT, double>::value && c->fplan.R == R && c->fplan.o_key == o &&
+                   c->fplan.d_key == d && c->fplan.Ns == Ns && c->fplan.tmax == tmax && ideal_path_ok(c) && c->variant != 10 && c->variant != 11) {
+            // bundle-stationary: one workgroup per planned bundle of <= 64 rays, windows staged in LDS (iono_forward_plan_dev)
+            const iono_ctx::FwdPlan &fp = c->fplan;
+            const uint64_t padded = (uint64_t)ncells(c) + (uint64_t)c->ny * c->nz + c->nz + 2;
+            hipLaunchKernelGGL(k_forward_bundle, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double),
+                               c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec, c->d_flags,
+                               (unsigned)((padded - 2) * 8));
+        } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c) && lanes_are_rays(c, R, order)) {
+            // lanes = 64 neighbouring rays of the walk order; one wave-task per 64 rays (A/B: IONOTOMO_VARIANT=11)
+            const int64_t tasks = (R + 63) / 64;
+            const int64_t nb = ((tasks + 3) / 4 + 7) / 8 * 8;
+            hipLaunchKernelGGL((k_forward_straight_t<GT>), dim3((unsigned)nb), block, 0, c->stream, g, o, d, order, R, tmax, Ns, c->d_unitw,
+                               tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);

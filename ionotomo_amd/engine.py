@@ -162,6 +162,23 @@ class RayEngine(object):
         self.ctx.call("iono_adjoint_plan_info", ctypes.byref(n), ctypes.byref(u), ctypes.byref(f))
         return n.value, u.value, f.value
 
+    def plan_forward(self, origins_t, dirs_t, tmax, Ns):
+        """Bundle the rays ONCE (geometry only): later ``forward`` calls with these same two tensors give every workgroup a
+        bundle of <= 64 nearly coincident rays whose voxel neighbourhood is staged in LDS
+        (include/ionotomo_hip.h:iono_forward_plan_dev).  Returns (bundles, chunks per ray, fraction of chunks served from LDS)
+        -- (0, 0, 0.0) when no plan applies (non-uniform grid, float32 storage).  Keep the tensors alive and unchanged."""
+        import ctypes
+        self._sync_stream()
+        self.ctx.call("iono_forward_plan_dev", _ptr(origins_t), _ptr(dirs_t), origins_t.shape[0], float(tmax), int(Ns))
+        self._fplanned = (origins_t, dirs_t)
+        n, k, f = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_double(0)
+        self.ctx.call("iono_forward_plan_info", ctypes.byref(n), ctypes.byref(k), ctypes.byref(f))
+        return n.value, k.value, f.value
+
+    def clear_forward_plan(self):
+        self.ctx.call("iono_forward_plan_clear")
+        self._fplanned = None
+
     def clear_adjoint_plan(self):
         self.ctx.call("iono_adjoint_plan_clear")
         self._planned = None

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of forward-kernel variants in ONE process (guide rule 24).
-    python profiles/ab_forward.py "VARIANT=0" "VARIANT=1" "VARIANT=0,BLOCKS_PER_CU=4" ...
+    python profiles/ab_forward.py "VARIANT=0" "VARIANT=1" "VARIANT=0,BLOCKS_PER_CU=4" "PLAN=1" ...
+ORDER=0..3: walk order handed to the kernel (none / locality / antenna-direction-time / coherent); PLAN=1: bundle plan.
 Each spec sets IONOTOMO_<KEY> env vars before creating its own context/engine."""
 import os
 import sys
@@ -24,13 +25,21 @@ for spec in specs:
             del os.environ[k]
     storage = kv.pop("STORAGE", "f64")
     use_order = int(kv.pop("ORDER", "0"))
+    use_plan = int(kv.pop("PLAN", "0"))
     for k, v in kv.items():
         os.environ["IONOTOMO_" + k] = v
     e = RayEngine(0, storage=storage)
     e.set_grid(w["xvec"], w["yvec"], w["zvec"])
     e.set_log_model(e.tensor(w["m"]), w["K_ne"] / 1e13)
-    engines.append((spec, e, use_order))
+    engines.append((spec, e, use_order, use_plan))
 o_t, d_t = engines[0][1].tensor(w["origins"]), engines[0][1].tensor(w["directions"])
+for spec, e, _, use_plan in engines:
+    if use_plan:
+        import time
+        t0 = time.perf_counter()
+        info = e.plan_forward(o_t, d_t, bench.TMAX, bench.NS)
+        print("%s: forward plan %s built in %.1f ms" % (spec, info, (time.perf_counter() - t0) * 1e3), flush=True)
+engines = [x[:3] for x in engines]
 order1 = engines[0][1].locality_order(o_t, d_t, bench.TMAX)
 # ORDER=2: (antenna, direction, time) -- consecutive rays are the same line of sight 8 s apart
 idx = torch.arange(R, device="cuda").reshape(bench.NA, bench.NT, bench.ND)
