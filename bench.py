@@ -242,6 +242,8 @@ def main():
     ap.add_argument("--no-order", dest="order", action="store_false", help="walk rays in [Na][Nt][Nd] memory order")
     ap.add_argument("--no-plan", dest="plan", action="store_false",
                     help="back-project with the ray-stationary kernel (LDS tile per ray bundle) instead of the box-binned plan")
+    ap.add_argument("--no-fwd-plan", dest="fwd_plan", action="store_false",
+                    help="forward without the bundle plan (lanes = samples kernel k_forward_straight_u on the coherent walk order)")
     ap.add_argument("--main-only", action="store_true", help="same as --only forward")
     ap.add_argument("--only", default=None,
                     choices=["forward", "adjoint", "cubic_forward", "cubic_adjoint", "cgls", "sirt"],
@@ -291,6 +293,12 @@ def main():
     if args.order:
         forder_t = order_t if os.environ.get("IONO_BENCH_FWD_ORDER", "coherent") == "locality" else eng.coherent_order(o_t, d_t)
     fwd = eng.forward_launcher(o_t, d_t, TMAX, NS, tec_t, order=forder_t)
+    # bundle plan of the forward (geometry only, once per inversion like the walk orders: engine.plan_forward)
+    fwd_plan_info = None
+    if args.fwd_plan:
+        t0 = time.perf_counter()
+        info = eng.plan_forward(o_t, d_t, TMAX, NS)
+        fwd_plan_info = {"bundles": info[0], "chunks_per_ray": info[1], "lds_chunk_fraction": info[2], "build_s": time.perf_counter() - t0}
 
     # ---- legs that can run alone under a profiler ---------------------------------------------------------------
     def adjoint_leg():

@@ -535,6 +535,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T_WAVES, T_
 #define B_CAPCOLS 120                            // columns per wave image
 #define B_WAVE_LDS (B_CAPCOLS * B_PPC * 16)      // 9 600 B per wave, 4 waves per workgroup
 #define B_SPLIT 4                                // z-parts of a ray = waves of a workgroup
+#ifndef B_UNROLL
+#define B_UNROLL 2
+#endif
+#ifndef B_WPE
+#define B_WPE 4, 5
+#endif
+#define B_MAXWY (64 / B_PPC)                     // one wave-load stages one row of the window (wy columns x B_PPC pieces <= 64 lanes)
 template <bool MAX>
 __device__ __forceinline__ int wave_minmax_i32(int v) {
 #define IONO_MM_STEP(CTRL, ROWS)                                                       \
@@ -601,19 +608,19 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
             const int kmin = wave_minmax_i32<false>((int)fmax(fmin(fz, fze) - eps, 0.0)), kmax = wave_minmax_i32<true>((int)(fmax(fz, fze) + eps));
             const int kz0 = kmin & ~1;
             const int wx = imax - imin + 2, wy = jmax - jmin + 2, nlev = kmax + 2 - kz0;
-            const bool fits = (g.nz & 1) == 0 && wx * wy <= B_CAPCOLS && wx < 256 && wy < 256 && nlev <= B_LEV;
+            const bool fits = (g.nz & 1) == 0 && wx * wy <= B_CAPCOLS && wx < 256 && wy <= B_MAXWY && nlev <= B_LEV;
             w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0, (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u));
         }
         if ((threadIdx.x & 63) == 0) win[(size_t)b * nchunks + c] = w;
     }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_forward_bundle(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) void k_forward_bundle(
     GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, const int *__restrict__ order,
     const int *__restrict__ bstart, const uint4 *__restrict__ win, int nb, int nchunks, double tmax, int Ns,
-    const double *__restrict__ unitw, double *__restrict__ tec, int *oob_flag, unsigned max_boff) {
+    const double *__restrict__ unitw, double *__restrict__ tec, int *oob_flag) {
     extern __shared__ __attribute__((aligned(16))) char blds[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform: scalar loop control)
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);     // XCD-major: neighbouring bundles share an L2
     if (b >= nb) return;
@@ -626,7 +633,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         return;
     }
     char *img = blds + wid * B_WAVE_LDS;
+    char *blds0 = blds - (unsigned)(size_t)blds;                // LDS address 0: `a` below is a complete LDS byte address
     double *part = (double *)(blds + B_SPLIT * B_WAVE_LDS);
+    const int lane_dj = (int)(((unsigned)lane * 52429u) >> 18);                 // lane / 5
+    const unsigned lane_off = ((unsigned)lane_dj * (unsigned)g.nz + 2u * (unsigned)(lane - B_PPC * lane_dj)) * 8u;
     const uint4 *wb = win + (size_t)b * nchunks;
     const int c0 = nchunks * wid / B_SPLIT, c1 = nchunks * (wid + 1) / B_SPLIT;
     double acc = 0.0;
@@ -639,34 +649,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                   kz0 = __builtin_amdgcn_readfirstlane((int)w.z), wxy = __builtin_amdgcn_readfirstlane((int)w.w);
         const int wx = wxy & 255, wy = (wxy >> 8) & 255;
         if (wxy >> 16) {
-            // ---- stage the window: piece p = column (p / 5) x levels kz0 + 2 (p % 5), + 1; the image is lane-linear in p ----
-            const int npieces = wx * wy * B_PPC;
-            const float inv_wy = 1.0f / (float)wy;
-            const unsigned colbase = ((unsigned)imin * (unsigned)g.ny + (unsigned)jmin) * (unsigned)g.nz + (unsigned)kz0;
-            for (int p0 = 0; p0 < npieces; p0 += 64) {
-                const int p = p0 + lane;
-                if (p < npieces) {
-                    const int col = (int)(((unsigned)p * 52429u) >> 18);            // p / 5 (exact for p < 2^16)
-                    const int pc = p - col * B_PPC;
-                    const int di = (int)(((float)col + 0.5f) * inv_wy);
-                    const int dj = col - di * wy;
-                    const unsigned eoff = colbase + ((unsigned)di * (unsigned)g.ny + (unsigned)dj) * (unsigned)g.nz + 2u * (unsigned)pc;
-                    const unsigned boff = min(eoff * 8u, max_boff);                 // (beyond the padded allocation: weight-0 corners only)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)((const char *)M + boff),
-                                                     (__attribute__((address_space(3))) void *)(img + p0 * 16), 16, 0, 0);
+            // ---- stage the window row by row: lane = (column dj = lane / 5, piece pc = lane % 5 = levels kz0 + 2 pc, + 1) of row di;
+            //      the image is lane-linear: row di at byte di * wy * 80, column dj at + 80 dj.  Source = a wave-uniform row base
+            //      + a per-lane offset that never changes: no vector arithmetic per load.
+            if (lane_dj < wy) {
+                const char *rowp = (const char *)M + ((size_t)((size_t)imin * g.ny + jmin) * g.nz + kz0) * 8;
+                const unsigned rstride = (unsigned)wy * (B_PPC * 16);
+                for (int di = 0; di < wx; ++di) {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + lane_off),
+                                                     (__attribute__((address_space(3))) void *)(img + di * rstride), 16, 0, 0);
+                    rowp += (size_t)g.ny * g.nz * 8;
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // ---- B_KC samples per lane from the image; the window origin only shifts the (integer) node offset ------------
             const double cw = (double)(wy * B_LEV), cj = (double)B_LEV;
-            const double nbase = -(((double)imin * (double)wy + (double)jmin) * (double)B_LEV + (double)kz0);
+            // (node offset of the window origin: subtracted from the LDS byte address with 32-bit wrap-around)
+            const unsigned ibase = (unsigned)(size_t)img - (((unsigned)imin * (unsigned)wy + (unsigned)jmin) * B_LEV + (unsigned)kz0) * 8u;
             const unsigned row2 = (unsigned)wy * (B_LEV * 8);
-#pragma unroll 2
+#pragma unroll B_UNROLL
             for (int k = k0; k < ke; ++k) {
                 const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)),
                              fk = __builtin_floor(__builtin_fabs(fz));
-                const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk + nbase)) * 8u;
-                const double *p = (const double *)(img + a), *p2 = (const double *)(img + a + row2);
+                const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * 8u + ibase;
+                const double *p = (const double *)(blds0 + a), *p2 = (const double *)(blds0 + a + row2);
                 Corners<double> cc;
                 cc.c000 = p[0], cc.c001 = p[1], cc.c010 = p[B_LEV], cc.c011 = p[B_LEV + 1];
                 cc.c100 = p2[0], cc.c101 = p2[1], cc.c110 = p2[B_LEV], cc.c111 = p2[B_LEV + 1];

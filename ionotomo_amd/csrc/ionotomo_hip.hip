@@ -228,12 +228,15 @@ hipError_t DevBuf::alloc(size_t bytes) {
     return hipSuccess;
 }
 
+// elements of a values array as the kernels address it: the grid + one plane + one row + 2 (unclamped far-corner reads of a
+// sample on a top face, weight 0: trilinear_u) + 16 (the LDS windows of k_forward_bundle are staged ten levels at a time)
+int64_t padded_count(const iono_ctx *c) { return (int64_t)c->nx * c->ny * c->nz + (int64_t)c->ny * c->nz + c->nz + 2 + 16; }
 size_t lds_bytes(const iono_ctx *c) { return sizeof(double) * (size_t)(c->nx + c->ny + c->nz); }
 int64_t ncells(const iono_ctx *c) { return (int64_t)c->nx * c->ny * c->nz; }
 // fast kernels: all three axes uniform (cell guess off by at most one), 32-bit element offsets
 bool fast_path_ok(const iono_ctx *c) {
     // 32-bit BYTE offsets (SGPR base + VGPR offset addressing), padded far-corner reads included
-    const uint64_t bytes = ((uint64_t)ncells(c) + (uint64_t)c->ny * c->nz + c->nz + 2) * (c->storage == IONO_F64 ? 8 : 4);
+    const uint64_t bytes = (uint64_t)padded_count(c) * (c->storage == IONO_F64 ? 8 : 4);
     return c->uniform[0] && c->uniform[1] && c->uniform[2] && bytes < ((uint64_t)1 << 32) && c->force_general != 1;
 }
 bool ideal_path_ok(const iono_ctx *c) { return fast_path_ok(c) && c->ideal && c->force_general == 0; }
@@ -576,7 +579,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     HIP_TRY(c, hipMemcpy(c->d_axes, cat.data(), cat.size() * sizeof(double), hipMemcpyHostToDevice));
     const size_t esz = storage == IONO_F64 ? 8 : 4;
     // + one plane + one row + 2 zero elements: see trilinear_u (unclamped far-corner reads, weight 0)
-    const size_t padded = (size_t)ncells(c) + (size_t)ny * nz + nz + 2;
+    const size_t padded = (size_t)padded_count(c);
     HIP_TRY(c, hipMalloc(&c->d_M, padded * esz));
     HIP_TRY(c, hipMemset(c->d_M, 0, padded * esz));
     if (M) return iono_grid_set_values(c, M);
@@ -810,7 +813,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         const int wxb = (int)std::floor(std::max(nx0hi - nx0lo, nxehi - nxelo) + nax * (B_KC - 1) + 1e-3f) + 3;
         const int wyb = (int)std::floor(std::max(ny0hi - ny0lo, nyehi - nyelo) + nay * (B_KC - 1) + 1e-3f) + 3;
         const int nlb = (int)std::floor((nzhi - nzlo) + naz * (B_KC - 1) + 1e-3f) + 4;
-        const bool ok = cnt < 64 && valid == cur_valid && (!valid || (wxb * wyb <= B_CAPCOLS && nlb <= B_LEV));
+        const bool ok = cnt < 64 && valid == cur_valid && (!valid || (wxb * wyb <= B_CAPCOLS && wyb <= B_MAXWY && nlb <= B_LEV));
         if (cnt == 0 || !ok) {            // (a single ray whose own window does not fit still gets a bundle: its chunks take the direct loads)
             bstart.push_back((int)i);
             reset();
@@ -873,9 +876,9 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             hipLaunchKernelGGL(k_forward_binned_finish, dim3(ew_blocks(c, R)), block, 0, c->stream, pl.d_uray, pl.d_nseg, pl.d_partial,
                                pl.smax, R, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && std::is_same<GT, float>::value && c->variant != 9 &&
-                   (uint64_t)(ncells(c) + (int64_t)c->ny * c->nz + c->nz + 2) * 16 < ((uint64_t)1 << 32)) {
+                   (uint64_t)padded_count(c) * 16 < ((uint64_t)1 << 32)) {
             // float32 storage extra: 2 x 2 corner blocks, two 16-B loads per sample (IONOTOMO_VARIANT=9: plain float32 kernel)
-            const int64_t n = ncells(c), padded = n + (int64_t)c->ny * c->nz + c->nz + 2;
+            const int64_t n = ncells(c), padded = padded_count(c);
             if (!c->d_Q4) {
                 HIP_TRY(c, hipMalloc((void **)&c->d_Q4, (size_t)padded * sizeof(float4)));
                 HIP_TRY(c, hipMemsetAsync(c->d_Q4, 0, (size_t)padded * sizeof(float4), c->stream));
@@ -892,10 +895,8 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                    c->fplan.d_key == d && c->fplan.Ns == Ns && c->fplan.tmax == tmax && ideal_path_ok(c) && c->variant != 10 && c->variant != 11) {
             // bundle-stationary: one workgroup per planned bundle of <= 64 rays, windows staged in LDS (iono_forward_plan_dev)
             const iono_ctx::FwdPlan &fp = c->fplan;
-            const uint64_t padded = (uint64_t)ncells(c) + (uint64_t)c->ny * c->nz + c->nz + 2;
             hipLaunchKernelGGL(k_forward_bundle, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double),
-                               c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec, c->d_flags,
-                               (unsigned)((padded - 2) * 8));
+                               c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c) && lanes_are_rays(c, R, order)) {
             // lanes = 64 neighbouring rays of the walk order; one wave-task per 64 rays (A/B: IONOTOMO_VARIANT=11)
             const int64_t tasks = (R + 63) / 64;
@@ -987,7 +988,7 @@ int iono_grid_padded_size(iono_ctx *c, int64_t *count) {
     int rc = need_grid(c);
     if (rc) return rc;
     if (!count) return fail(c, IONO_ERR_ARG, "null count");
-    *count = ncells(c) + (int64_t)c->ny * c->nz + c->nz + 2;
+    *count = padded_count(c);
     return IONO_OK;
 }
 
