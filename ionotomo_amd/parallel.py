@@ -129,6 +129,11 @@ class ShardedRays(object):
         self.plan = None
         if plan and hasattr(engine, "plan_adjoint") and self.R_local > 0:
             self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns)
+        # bundle plan of the forward (speed only, once per geometry; engine.plan_forward): every later forward of THESE two
+        # tensors gives a workgroup <= 64 nearly coincident rays and stages their voxel neighbourhood in LDS
+        self.forward_plan = None
+        if plan and hasattr(engine, "plan_forward") and self.R_local > 0:
+            self.forward_plan = engine.plan_forward(self.origins, self.dirs, self.tmax, self.Ns)
         # measured load balance of the ray-stationary back-projection (used when no plan could be built)
         self.partition = None
         if tune and not (self.plan and self.plan[0]) and hasattr(engine, "tune_adjoint_partition") and self.R_local > 0:

@@ -1,0 +1,195 @@
+"""Bundle-stationary forward -- iono_forward_plan_dev / k_forward_bundle (the voxel neighbourhood of <= 64 nearly coincident rays
+staged in LDS) -- against the C oracle and the direct-load kernels: random geometries incl. steep rays whose windows do not
+fit the LDS image, odd nz (no LDS path at all), rays that leave the grid, every quadrature rule, sample counts below one chunk,
+rays on the grid faces, the bench shape, and the two properties the design promises: TEC does not depend on how the rays were
+bundled (bit for bit), and a stale plan is never used.  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from ionotomo_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+SOAK = int(__import__("os").environ.get("IONO_SOAK", "1"))
+
+
+@pytest.fixture(scope="module")
+def OC():
+    from oracle import oracle_c
+    return oracle_c
+
+
+def engine(xv, yv, zv, **kw):
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0, **kw)
+    eng.set_grid(xv, yv, zv)
+    return eng
+
+
+def random_rays(rng, xv, yv, zv, R, steep, cluster):
+    """R rays from the z = zlo plane; ``cluster``: feet and slopes drawn around a few centres (compact bundles) or uniformly."""
+    zlo, zhi = zv[0] + rng.uniform(0, 0.3) * (zv[-1] - zv[0]), zv[-1] - rng.uniform(0, 0.2) * (zv[-1] - zv[0])
+    if cluster:
+        nc = int(rng.integers(1, 6))
+        cx, cy = rng.uniform(xv[0], xv[-1], nc), rng.uniform(yv[0], yv[-1], nc)
+        sx, sy = rng.normal(size=nc) * steep, rng.normal(size=nc) * steep
+        pick = rng.integers(0, nc, R)
+        hx, hy = xv[1] - xv[0], yv[1] - yv[0]
+        o = np.stack([cx[pick] + rng.normal(size=R) * 2 * hx, cy[pick] + rng.normal(size=R) * 2 * hy, np.full(R, zlo)], 1)
+        d = np.stack([sx[pick] + rng.normal(size=R) * 0.01, sy[pick] + rng.normal(size=R) * 0.01, np.ones(R)], 1)
+    else:
+        o = np.stack([rng.uniform(xv[0], xv[-1], R), rng.uniform(yv[0], yv[-1], R), np.full(R, zlo)], 1)
+        d = np.stack([rng.normal(size=R) * steep, rng.normal(size=R) * steep, np.ones(R)], 1)
+    o[:, 2] += rng.uniform(0, 0.4, R) * (zv[1] - zv[0])                    # antennas at slightly different heights
+    end = o + d * ((zhi - o[:, 2]) / d[:, 2])[:, None]
+    inside = ((o[:, 0] >= xv[0]) & (o[:, 0] <= xv[-1]) & (o[:, 1] >= yv[0]) & (o[:, 1] <= yv[-1]) &
+              (end[:, 0] >= xv[0]) & (end[:, 0] <= xv[-1]) & (end[:, 1] >= yv[0]) & (end[:, 1] <= yv[-1]))
+    return o, d, zhi, inside
+
+
+@pytest.mark.parametrize("seed", range(SOAK * 12))
+def test_bundle_forward_random_geometries(seed, OC):
+    rng = np.random.default_rng(1000 + seed)
+    n = [int(v) for v in rng.integers(6, 70, 3)]
+    if seed % 4 != 3:
+        n[2] += n[2] & 1                                                  # even nz: the LDS path; every fourth case keeps any nz
+    xv, yv, zv = (np.linspace(0.0, float(rng.uniform(20, 200)), m) for m in n)
+    R = int(rng.integers(1, 1500))
+    Ns = int(rng.choice([2, 3, 7, 8, 9, 16, 17, 33, 64, 65, 100, 257]))
+    steep = float(rng.choice([0.02, 0.3, 1.5]))
+    o, d, zhi, inside = random_rays(rng, xv, yv, zv, R, steep, cluster=bool(seed % 2))
+    quad = ["avg", "scipy", "trapz"][seed % 3]
+    eng = engine(xv, yv, zv, quad=quad)
+    M = rng.uniform(1, 2, size=n)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    direct = eng.forward(ot, dt, zhi, Ns).cpu().numpy()                    # no plan: lanes = samples
+    assert eng.check_oob() == (not inside.all())
+    nb, nchunks, fit = eng.plan_forward(ot, dt, zhi, Ns)
+    if n[2] % 2 == 0:
+        assert nb >= (R + 63) // 64 and nchunks == (Ns + 7) // 8 and 0.0 <= fit <= 1.0
+    else:
+        assert nb == 0                                                     # odd nz: columns do not start on 16-B boundaries
+    tec = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    assert eng.check_oob() == (not inside.all())                           # rays leaving the grid: NaN + flag
+    assert np.all(np.isnan(tec[~inside])) and np.all(np.isfinite(tec[inside]))
+    if inside.any():
+        assert np.max(np.abs(tec[inside] - direct[inside])) <= 2e-13 * np.max(np.abs(direct[inside])), (n, R, Ns, steep, fit)
+        if quad == "avg" or (quad == "scipy" and Ns % 2 == 1):
+            ref = OC.forward_tec_straight(xv, yv, zv, M, o[inside], d[inside], zhi, Ns)
+            assert np.max(np.abs(tec[inside] - ref)) <= 1e-12 * np.max(np.abs(ref)), (n, R, Ns, steep, fit)
+    eng.clear_forward_plan()
+    again = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    eng.check_oob()
+    assert np.array_equal(again, direct, equal_nan=True)
+
+
+def test_tec_does_not_depend_on_the_bundling():
+    """The same rays inside different batches (hence different bundles, windows and LDS / direct-load decisions) give the same
+    bits: per-ray arithmetic is position-for-position that of the direct loads and the four z-parts add in a fixed order."""
+    w = syn.make_workload("cfg2")
+    eng = engine(w["xvec"], w["yvec"], w["zvec"])
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    rng = np.random.default_rng(5)
+    # many rays per antenna: jitter the directions so that bundles fill
+    o = np.repeat(o, 6, axis=0)
+    d = np.repeat(d, 6, axis=0) + rng.normal(size=(o.shape[0], 3)) * np.array([5e-4, 5e-4, 0.0])
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    nb, _, fit = eng.plan_forward(ot, dt, w["tmax"], w["Ns"])
+    assert nb > 0 and fit > 0.5
+    full = eng.forward(ot, dt, w["tmax"], w["Ns"]).cpu().numpy()
+    for k in range(3):
+        sel = np.sort(rng.choice(o.shape[0], size=o.shape[0] // (2 + k), replace=False))
+        os_, ds_ = eng.tensor(o[sel]), eng.tensor(d[sel])
+        nb2, _, _ = eng.plan_forward(os_, ds_, w["tmax"], w["Ns"])
+        assert nb2 > 0
+        part = eng.forward(os_, ds_, w["tmax"], w["Ns"]).cpu().numpy()
+        assert np.array_equal(part, full[sel])
+    assert not eng.check_oob()
+
+
+def test_stale_or_foreign_plan_is_never_used(OC):
+    w = syn.make_workload("cfg1")
+    eng = engine(w["xvec"], w["yvec"], w["zvec"])
+    M = w["ne"] / 1e13
+    eng.set_values(eng.tensor(M))
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    ref = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], M, o, d, w["tmax"], w["Ns"])
+    assert eng.plan_forward(ot, dt, w["tmax"], w["Ns"])[0] > 0
+    # other tensors / other Ns / other tmax: the plan does not apply, the launch is served by the direct kernels
+    o2, d2 = eng.tensor(o[::-1].copy()), eng.tensor(d[::-1].copy())
+    t2 = eng.forward(o2, d2, w["tmax"], w["Ns"]).cpu().numpy()
+    assert np.max(np.abs(t2 - ref[::-1])) < 1e-12 * np.max(np.abs(ref))
+    t3 = eng.forward(ot, dt, w["tmax"], w["Ns"] + 2).cpu().numpy()
+    ref3 = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], M, o, d, w["tmax"], w["Ns"] + 2)
+    assert np.max(np.abs(t3 - ref3)) < 1e-12 * np.max(np.abs(ref3))
+    # the planned launch itself
+    t1 = eng.forward(ot, dt, w["tmax"], w["Ns"]).cpu().numpy()
+    assert np.max(np.abs(t1 - ref)) < 1e-12 * np.max(np.abs(ref))
+    # new values on the same axes keep the plan (geometry only) ...
+    import ctypes
+    nbun = ctypes.c_int64(-1)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    eng.set_values(eng.tensor(2.0 * M))
+    eng.ctx.call("iono_forward_plan_info", ctypes.byref(nbun), None, None)
+    assert nbun.value > 0
+    t4 = eng.forward(ot, dt, w["tmax"], w["Ns"]).cpu().numpy()
+    assert np.max(np.abs(t4 - 2.0 * ref)) < 1e-12 * np.max(np.abs(ref))
+    # ... new axes clear it
+    xs = w["xvec"] - 0.37 * (w["xvec"][1] - w["xvec"][0])
+    eng.set_grid(xs, w["yvec"], w["zvec"])
+    eng.set_values(eng.tensor(M))
+    eng.ctx.call("iono_forward_plan_info", ctypes.byref(nbun), None, None)
+    assert nbun.value == 0
+    t5 = eng.forward(ot, dt, w["tmax"], w["Ns"]).cpu().numpy()
+    ref5 = OC.forward_tec_straight(xs, w["yvec"], w["zvec"], M, o, d, w["tmax"], w["Ns"])
+    assert np.max(np.abs(t5 - ref5)) < 1e-12 * np.max(np.abs(ref5))
+    assert not eng.check_oob()
+
+
+def test_rays_on_the_grid_faces_and_the_last_bundle(OC):
+    """Vertical rays exactly on the low / high x and y faces, feet on the bottom face, ends on the top face: windows that touch
+    the padded plane / row beyond the grid (weight-0 corners), and a ray count that leaves a one-ray last bundle."""
+    n = (12, 10, 16)
+    xv, yv, zv = np.linspace(-3.0, 8.0, n[0]), np.linspace(0.0, 9.0, n[1]), np.linspace(0.0, 30.0, n[2])
+    rng = np.random.default_rng(3)
+    M = rng.uniform(1, 2, size=n)
+    feet = [(xv[0], yv[0]), (xv[-1], yv[-1]), (xv[0], yv[-1]), (xv[-1], yv[0]), (xv[3], yv[-1]), (xv[-1], yv[4]), (xv[5], yv[5])]
+    o = np.array([[x, y, zv[0]] for x, y in feet] * 19 + [[xv[2], yv[2], zv[0]]])             # 134 rays
+    d = np.tile([0.0, 0.0, 1.0], (o.shape[0], 1))
+    for Ns in (16, 17, 31):
+        eng = engine(xv, yv, zv)
+        eng.set_values(eng.tensor(M))
+        ot, dt = eng.tensor(o), eng.tensor(d)
+        assert eng.plan_forward(ot, dt, zv[-1], Ns)[0] >= 3
+        tec = eng.forward(ot, dt, zv[-1], Ns).cpu().numpy()
+        assert not eng.check_oob()
+        ref = OC.forward_tec_straight(xv, yv, zv, M, o, d, zv[-1], Ns)
+        assert np.max(np.abs(tec - ref)) < 1e-12 * np.max(np.abs(ref))
+
+
+def test_bundle_forward_bench_shape(OC):
+    import bench
+    w = bench.build_workload(0)
+    eng = engine(w["xvec"], w["yvec"], w["zvec"])
+    ne = np.exp(w["m"]) * (w["K_ne"] / 1e13)
+    eng.set_values(eng.tensor(ne))
+    ot, dt = eng.tensor(w["origins"]), eng.tensor(w["directions"])
+    direct = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
+    nb, nchunks, fit = eng.plan_forward(ot, dt, bench.TMAX, bench.NS)
+    R = w["origins"].shape[0]
+    assert R / 64 <= nb <= R / 40 and nchunks == 33 and fit > 0.99
+    tec = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
+    assert not eng.check_oob()
+    assert np.max(np.abs(tec - direct) / np.abs(direct)) < 1e-13
+    sel = np.random.default_rng(0).choice(R, 3000, replace=False)
+    ref = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], ne, w["origins"][sel], w["directions"][sel], bench.TMAX, bench.NS)
+    assert np.max(np.abs(tec[sel] - ref) / np.abs(ref)) < 1e-12
+    # bound to a caller-owned values buffer (what the solvers do): same kernel, same numbers
+    padded, view = eng.new_grid_buffer()
+    view.copy_(eng.tensor(ne))
+    eng.bind_values(padded)
+    tec2 = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
+    assert np.array_equal(tec2, tec)
