@@ -58,6 +58,61 @@ __global__ __launch_bounds__(256) void k_read(const char *__restrict__ base, siz
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;      // never true for the zero-filled buffer + keeps the loads
 }
 
+// LDS read rates, one instruction form per kernel (inline asm: the compiler picks its own mix otherwise).  KIND 0: ds_read2_b64 on
+// 8-B-aligned (not 16-B-aligned) pairs; 1: ds_read_b64; 2: ds_read_b128 on 16-B-aligned addresses; 3: ds_read_b128 on addresses
+// that are only 8-B aligned (what a (level, level + 1) pair of float64 nodes is).  Lanes read consecutive 16-B (8-B) words.
+typedef double dbl2 __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(256) void k_lds(int iters, unsigned *__restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) double buf[4096 + 64];
+    for (int i = threadIdx.x; i < 4096 + 64; i += 256) buf[i] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    unsigned pos = wid * 512;
+    const unsigned base = (unsigned)(size_t)buf;
+    double acc = 0.0;
+    for (int it = 0; it < iters; ++it) {
+        dbl2 v[8];
+        double w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned a16 = base + (((pos + 2 * lane) & 4094) << 3), a8 = base + (((pos + lane) & 4095) << 3);
+            if (KIND == 0) asm volatile("ds_read2_b64 %0, %1 offset0:1 offset1:2" : "=v"(v[u]) : "v"(a16));
+            else if (KIND == 1) asm volatile("ds_read_b64 %0, %1" : "=v"(w[u]) : "v"(a8));
+            else if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(a16));
+            else asm volatile("ds_read_b128 %0, %1 offset:8" : "=v"(v[u]) : "v"(a16));
+            pos += 130;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (KIND == 1) {
+                asm volatile("" : "+v"(w[u]));
+                acc += w[u];
+            } else {
+                asm volatile("" : "+v"(v[u]));
+                acc += v[u].x + v[u].y;
+            }
+        }
+    }
+    if (acc == 1.2345) sink[0] = 1;
+}
+template <int KIND>
+double run_lds(int blocks, int iters, unsigned *sink, hipStream_t s) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    hipLaunchKernelGGL((k_lds<KIND>), dim3(blocks), dim3(256), 0, s, iters, sink);
+    CK(hipEventRecord(a, s));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_lds<KIND>), dim3(blocks), dim3(256), 0, s, iters, sink);
+    CK(hipEventRecord(b, s));
+    CK(hipEventSynchronize(b));
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return ms / reps * 1e-3;
+}
+
 template <int SHAPE>
 double run(const char *buf, size_t window, int wg_private, int blocks, int iters, unsigned *sink, hipStream_t s) {
     hipEvent_t a, b;
@@ -105,6 +160,14 @@ int main() {
                "\"l20_lane_gbs\": %.1f}",
                c.name, wl * 1024 / t0 / 1e9, t0 / (wl / cus) * 1e9, t1 / (wl / cus) * 1e9, t2 / (wl / cus) * 1e9, t3 / (wl / cus) * 1e9,
                wl * 1024 / t3 / 1e9);
+    }
+    {
+        const int iters = 2048;
+        const double lanes = (double)blocks * 256 * iters * 8;
+        const double t0 = run_lds<0>(blocks, iters, sink, s), t1 = run_lds<1>(blocks, iters, sink, s), t2 = run_lds<2>(blocks, iters, sink, s),
+                     t3 = run_lds<3>(blocks, iters, sink, s);
+        printf(", \"lds\": {\"read2_b64_gbs\": %.1f, \"read_b64_gbs\": %.1f, \"read_b128_gbs\": %.1f, \"read_b128_8B_aligned_gbs\": %.1f}",
+               lanes * 16 / t0 / 1e9, lanes * 8 / t1 / 1e9, lanes * 16 / t2 / 1e9, lanes * 16 / t3 / 1e9);
     }
     printf("}\n");
     return 0;

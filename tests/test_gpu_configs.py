@@ -163,6 +163,11 @@ def test_config4_620k_rays_256_cubed(cfg4, OC, monkeypatch):
     dtec = t2 - t2[0:1]
     yfull = y.reshape(na, P)
     full = parallel.ShardedRays(eng, o4, d4, tmax, Ns, i0=0, tune=False)
+    # (the sharded problems plan their forward -- bundles of nearly coincident rays, engine.plan_forward -- and a planned ray's
+    #  bits do not depend on the bundling; the unplanned launch above runs another kernel and agrees to rounding)
+    dfull = full.forward().cpu().numpy().reshape(na, P)
+    assert np.max(np.abs(dfull - dtec)) < 1e-13 * np.max(np.abs(t2))
+    dtec = dfull
     gfull = full.adjoint(full.slice(yfull)).cpu().numpy()
     gsum = np.zeros_like(gfull)
     for r in range(8):
