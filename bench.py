@@ -10,11 +10,15 @@ trilinear interpolation, Simpson quadrature, float64) over this rank's batch of 
 62 LOFAR-HBA stations x 42 directions x 100 timesteps = 260,400 rays, Ns = 257 samples each,
 through a 256^3 electron-density grid resident in HBM.  Weak scaling: every rank owns its own
 (time, direction) block of rays and a replica of the grid; the forward needs no collective.
-Rank 0 prints ONE JSON line.  `roofline` prices the kernel against the roof that binds it (the
-per-CU vector-L1 / texture-address path: the 128 MiB grid is cache-resident, so HBM is not the
-limiter) and reports the HBM-side, L2-side and compulsory figures next to it (DESIGN.md section 4
-gives the formulas).  Extra keys report the adjoint, a forward + adjoint + all-reduce iteration,
-CGLS / SIRT iterations, the tricubic path, float32 storage and the single-timestep launch.
+Rank 0 prints ONE JSON line on stdout (the headline part of it also goes to stderr as soon as it
+is measured, before any leg that contains a collective).  `roofline` prices the kernel against the
+on-chip path its bytes flow through (LDS reads: the 128 MiB grid is cache-resident, so HBM is not
+the limiter), with the denominators measured on this box by profiles/tools/cache_peaks, and reports
+the HBM-side, L2-side, vector-L1 and compulsory figures next to it (DESIGN.md section 4 gives the
+formulas).  Extra keys: the adjoint, a forward + adjoint + all-reduce iteration, CGLS / SIRT
+iterations, the tricubic path, float32 storage, the single-timestep launch, and `cfg4`: BASELINE
+config 4 (62 x 100 x 100 = 620,000 rays split over the N ranks: STRONG scaling) with the
+per-iteration exchange measured by itself.
 
     python bench.py --only forward|adjoint|cubic_forward|cubic_adjoint|cgls|sirt --steps K
 runs ONE leg alone (clean rocprofv3 --stats / --pmc averages) and prints a short JSON line.
@@ -23,6 +27,7 @@ import argparse
 import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -33,14 +38,17 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 NA, ND, NT, NGRID, NS, TMAX = 62, 42, 100, 256, 257, 1000.0
-# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 achievable); L2 ~34.5 TB/s aggregate; vector L1 /
-# texture-address path 64 B/clk/CU x 256 CUs x 2.4 GHz; memory-side float atomics ~1.3 TB/s of added bytes
+# /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 achievable); L2 ~34.5 TB/s aggregate; LDS 256 B/clk/CU for
+# ds_read_b64 / b128; vector L1 64 B/clk/CU (not in the guide: measured by profiles/tools/cache_peaks, 37.9 TB/s = 61.7 B/clk/CU);
+# memory-side float atomics ~1.3 TB/s of added bytes.  Every on-chip denominator is ALSO measured on the box in the same run.
 HBM_PEAK_GBS = 8000.0
 L2_PEAK_GBS = 34500.0
-VL1D_PEAK_GBS = 64 * 256 * 2.4
+VL1D_NOMINAL_GBS = 64 * 256 * 2.4
+LDS_B64_NOMINAL_GBS = 256 * 256 * 2.4
 ATOMIC_PEAK_GBS = 1300.0
 MAX_RANKS_FOR_DOMAIN = 8
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_counters.json")
+PEAKS_TOOL = os.path.join(ROOT, "profiles", "tools", "cache_peaks")
 
 
 def algorithmic_bytes_per_ray(ns, grid_elem_bytes, corners=8):
@@ -90,22 +98,35 @@ def build_workload(rank):
                 origins=origins.reshape(-1, 3), directions=directions.reshape(-1, 3))
 
 
+def build_cfg4(w):
+    """BASELINE config 4: 62 antennas x 100 directions x 100 timesteps = 620,000 rays (the FULL problem, identical on every
+    rank: ShardedRays takes this rank's (time, direction) block) on a 256^3 grid of their own bounding box.  The node values
+    are the headline workload's (a synthetic ionosphere either way; parity at this size: tests/test_gpu_configs.py)."""
+    from ionotomo_amd import synthetic as syn
+    ants = syn.lofar_enu_km()
+    dirs = syn.rotate_about_pole(syn.facet_directions(100, 4.0, 1), 100)
+    origins, directions = syn.ray_bundle(ants, dirs)                                   # [Na,Nt,Nd,3]
+    xv, yv, zv = syn.domain_for(origins.reshape(-1, 3), directions.reshape(-1, 3), NGRID, TMAX)
+    return dict(xvec=xv, yvec=yv, zvec=zv, m=w["m"], K_ne=w["K_ne"], origins=origins.reshape(NA, -1, 3),
+                directions=directions.reshape(NA, -1, 3))
+
+
 def time_steps(fn, steps, warmup, torch, dist, world):
-    """W warmups, then EXACTLY K steps bracketed by barrier + synchronize; per-step HIP-event
-    times on the launch stream (torch's current stream == the ctx stream).  Returns
-    (wall seconds MAX over ranks, mean kernel seconds per step on this rank)."""
+    """W warmups, then EXACTLY K steps bracketed by barrier + synchronize; one pair of HIP events on the launch stream
+    (torch's current stream == the ctx stream) around the K launches: device time per step with nothing between the
+    launches but the launches themselves.  Returns (wall seconds MAX over ranks, mean device seconds per step on this rank)."""
     for _ in range(warmup):
         fn()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for a, b in evs:
-        a.record()
+    a.record()
+    for _ in range(steps):
         fn()
-        b.record()
+    b.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -115,7 +136,7 @@ def time_steps(fn, steps, warmup, torch, dist, world):
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)        # MAX over ranks
         wall = float(t.item())
-    kern = float(np.mean([a.elapsed_time(b) for a, b in evs])) * 1e-3
+    kern = a.elapsed_time(b) * 1e-3 / steps
     return wall, kern
 
 
@@ -170,6 +191,19 @@ def load_pmc(sha):
     return p, p.get("source", "")
 
 
+def measured_peaks():
+    """On-chip denominators measured on THIS box, in this run (a child process, after the timed region): vector-L1 / L2 /
+    Infinity-Cache / HBM rates of 16-B wave-loads by access shape, LDS rates by read form (profiles/tools/cache_peaks.hip,
+    compiled by __graft_entry__.build)."""
+    if not os.path.exists(PEAKS_TOOL):
+        return None
+    try:
+        out = subprocess.run([PEAKS_TOOL], capture_output=True, timeout=120, text=True).stdout
+        return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    except Exception as exc:                                    # noqa: BLE001
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def fabric_bytes(c):
     """L2 fabric-side read bytes from the request-size counters (exact), else FETCH_SIZE (KiB; counts 64 B per
     request whatever its size -- MI355X_MICROARCH.md, HBM section) as a lower bound."""
@@ -182,26 +216,50 @@ def fabric_bytes(c):
     return None, None
 
 
-def forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes):
+def forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes, peaks, planned):
+    """Where the algorithmic bytes (Ns x 8 corners x 8 B + 56 per ray, no credit for reuse) flow, and how busy that
+    path is.  Planned (bundle-stationary, k_forward_bundle): every corner value a lane uses is read from LDS (eight ds_read_b64
+    per sample), so the LDS read path carries the algorithmic volume; the vector L1 / L2 only carry the window copies
+    (counters).  Unplanned (k_forward_straight_u): every corner value crosses the vector L1."""
     bytes_ray = algorithmic_bytes_per_ray(NS, 8)
     achieved = R * bytes_ray / kern / 1e9
     compulsory = (grid_bytes + R * 56) / kern / 1e9
-    rl = {"bound": "vl1d", "achieved": achieved, "peak": VL1D_PEAK_GBS, "unit": "GB/s", "frac": achieved / VL1D_PEAK_GBS,
-          "traffic": None, "kernel": "k_forward_straight_u<double>", "kernel_ms": kern * 1e3,
+    pk = peaks if isinstance(peaks, dict) and "lds" in peaks else {}
+    lds_meas = pk.get("lds", {}).get("read_b64_gbs")
+    vl1d_meas = pk.get("vl1d", {}).get("dense_gbs")
+    l2_meas = pk.get("l2", {}).get("dense_gbs")
+    if planned:
+        bound, kernel, nominal, meas = "lds", "k_forward_bundle", LDS_B64_NOMINAL_GBS, lds_meas
+        note = ("Bundle-stationary forward: the voxel neighbourhood of <= 64 nearly coincident rays is copied to LDS once per 8 "
+                "samples (LDS-DMA) and every corner value a lane asks for is an LDS read (eight ds_read_b64 per sample), so the "
+                "ALGORITHMIC bytes (Ns x 8 corners x 8 B + 56 per ray, no credit for reuse) are the load of the LDS read path and "
+                "`frac` is its utilisation against the ds_read_b64 rate MEASURED on this box (`peak_nominal`: 256 B/clk/CU).  The "
+                "counters next to it say how busy each unit was (`units`): float64 vector-instruction issue first, the LDS "
+                "second.  The 128 MiB grid is L2 / Infinity-Cache resident: the HBM side carries far less "
+                "(`hbm.counter_gbs`: L2 fabric-side requests, Infinity-Cache hits included; `hbm.compulsory_gbs`: grid + ray I/O "
+                "once per launch), which is why the algorithmic rate exceeds the HBM peak (`hbm.algorithmic_over_peak`) -- HBM is "
+                "not the roof of this kernel.")
+    else:
+        bound, kernel, nominal, meas = "vl1d", "k_forward_straight_u<double>", VL1D_NOMINAL_GBS, vl1d_meas
+        note = ("lanes = samples kernel: every corner value a lane asks for crosses the per-CU vector L1 / texture-address path, so "
+                "the algorithmic bytes are that path's load; `peak` is its dense 16-B wave-load rate measured on this box.")
+    peak = meas if meas else nominal
+    rl = {"bound": bound, "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+          "peak_nominal": nominal, "peak_measured": meas, "frac_of_nominal": achieved / nominal,
+          "traffic": None, "kernel": kernel, "kernel_ms": kern * 1e3,
           "algorithmic_bytes_per_ray": bytes_ray, "algorithmic_gbs": achieved,
           "hbm": {"peak": HBM_PEAK_GBS, "algorithmic_over_peak": achieved / HBM_PEAK_GBS, "compulsory_gbs": compulsory,
                   "compulsory_frac": compulsory / HBM_PEAK_GBS, "copy_gbs_measured": copy_gbs,
+                  "dense_read_gbs_measured": pk.get("hbm", {}).get("dense_gbs"),
                   "counter_gbs": None, "counter_frac": None},
-          "l2": {"peak": L2_PEAK_GBS, "request_gbs": None, "frac": None},
-          "pmc": pmc_note,
-          "note": "Every corner value a lane asks for crosses the per-CU vector L1 / texture-address path (64 B/clk/CU), so "
-                  "the ALGORITHMIC bytes (Ns x 8 corners x 8 B + 56 per ray, no credit for reuse) are that path's load and "
-                  "`frac` is its utilisation.  The 128 MiB grid is L2 / Infinity-Cache resident: the HBM side carries far "
-                  "less (`hbm.counter_gbs`: L2 fabric-side requests, Infinity-Cache hits included; `hbm.compulsory_gbs`: "
-                  "grid + ray I/O once per launch), which is why the algorithmic rate exceeds the HBM peak "
-                  "(`hbm.algorithmic_over_peak`) -- HBM is not the roof of this kernel."}
+          "l2": {"peak": L2_PEAK_GBS, "peak_measured": l2_meas, "request_gbs": None, "frac": None},
+          "vl1d": {"peak_nominal": VL1D_NOMINAL_GBS, "peak_measured": vl1d_meas,
+                   "ns_per_16B_wave_load_per_cu": {k: pk.get("vl1d", {}).get(k)
+                                                   for k in ("dense_ns_per_wave_load_per_cu", "same_ns", "l4_ns", "l20_ns")}},
+          "lds": {"peak_nominal_b64": LDS_B64_NOMINAL_GBS, "measured": pk.get("lds")},
+          "pmc": pmc_note, "note": note}
     c = (pmc or {}).get("forward")
-    if c and c.get("rays") == R and c.get("Ns") == NS:
+    if c and c.get("rays") == R and c.get("Ns") == NS and c.get("kernel", "").startswith(kernel.split("<")[0]):
         fb, how = fabric_bytes(c)
         if fb is not None:
             fb += 1024.0 * c.get("WRITE_SIZE", 0.0)
@@ -212,25 +270,104 @@ def forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes):
             rl["hbm"]["traffic_over_compulsory"] = fb / (grid_bytes + R * 56)
         if "TCP_TCC_READ_REQ_sum" in c:
             req = 128.0 * c["TCP_TCC_READ_REQ_sum"] / kern / 1e9          # L1 -> L2 read requests are 128-B lines
-            rl["l2"]["request_gbs"], rl["l2"]["frac"] = req, req / L2_PEAK_GBS
+            rl["l2"]["request_gbs"], rl["l2"]["frac"] = req, req / (l2_meas or L2_PEAK_GBS)
+            rl["l2"]["request_bytes_per_launch"] = 128.0 * c["TCP_TCC_READ_REQ_sum"]
         if "TCP_TOTAL_CACHE_ACCESSES_sum" in c and "TCP_TCC_READ_REQ_sum" in c:
-            rl["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
-        if "GRBM_GUI_ACTIVE" in c and "TA_TA_BUSY_sum" in c:
+            rl["vl1d"]["tag_lookups_per_launch"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            rl["vl1d"]["hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+        if "GRBM_GUI_ACTIVE" in c:
             cyc = c["GRBM_GUI_ACTIVE"] / 8.0                      # per-XCD active cycles of the launch (profiled run)
-            rl["vl1d"] = {"ta_busy_frac": c["TA_TA_BUSY_sum"] / (256.0 * cyc),
-                          "ta_addr_stalled_by_tc_frac": c.get("TA_ADDR_STALLED_BY_TC_CYCLES_sum", 0.0) / (256.0 * cyc),
-                          "tcp_tag_lookups_per_clk_per_cu": c.get("TCP_TOTAL_CACHE_ACCESSES_sum", 0.0) / (256.0 * cyc),
-                          "profiled_clock_ghz": cyc / (kern * 1e9)}
-        if "SQ_INSTS_VMEM_RD" in c:
-            # wave-level load instructions per launch and the cycles the 256 CUs had per instruction
-            rl["vmem"] = {"wave_loads_per_launch": c["SQ_INSTS_VMEM_RD"],
-                          "cu_cycles_per_wave_load_at_2p4GHz": kern * 2.4e9 * 256 / c["SQ_INSTS_VMEM_RD"]}
-            for k in ("TA_TA_BUSY_sum", "TA_ADDR_STALLED_BY_TC_CYCLES_sum", "TA_DATA_STALLED_BY_TC_CYCLES_sum",
-                      "TCP_PENDING_STALL_CYCLES_sum", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_ANY",
-                      "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"):
+            units = {"profiled_clock_ghz": cyc / (kern * 1e9)}
+            if "SQ_ACTIVE_INST_VALU" in c:                       # quad-cycles summed over the chip; 1 024 SIMDs
+                units["valu_busy_frac"] = 4.0 * c["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc)
+            if "SQ_LDS_IDX_ACTIVE" in c:
+                units["lds_busy_frac"] = c["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc)
+                units["lds_bank_conflict_frac"] = c.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c["SQ_LDS_IDX_ACTIVE"], 1.0)
+            if "TA_TA_BUSY_sum" in c:
+                units["ta_busy_frac"] = c["TA_TA_BUSY_sum"] / (256.0 * cyc)
+            for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_SALU", "SQ_WAVES"):
                 if k in c:
-                    rl["vmem"][k] = c[k]
+                    units[k] = c[k]
+            rl["units"] = units
     return rl
+
+
+def exchange_legs(eng, fwd, adj, grad_t, o_t, d_t, order_t, R, k2, torch, dist, world, backend):
+    """The per-iteration exchange of the back-projected update over the N ranks, by itself and inside an iteration, with
+    what proves which library carried it: backend, world size, RCCL version, bytes and milliseconds per all-reduce."""
+    from ionotomo_amd.parallel import GradientExchange
+    out = {"backend": dist.get_backend(), "requested_backend": backend, "world_size": dist.get_world_size()}
+    try:
+        out["nccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:                                               # noqa: BLE001
+        out["nccl_version"] = None
+    ones = torch.ones(R, dtype=torch.float64, device=eng.device)
+    xch = GradientExchange("compact").plan(eng.adjoint(o_t, d_t, ones, TMAX, NS, order=order_t))
+    xch32 = GradientExchange("compact", reduce_dtype=torch.float32)
+    xch32.index, xch32.fraction = xch.index, xch.fraction
+    dense = GradientExchange("dense")
+    out["exchange_active_node_fraction"] = xch.fraction
+    n_active = int(xch.index.numel()) if xch.index is not None else grad_t.numel()
+    for name, x, nbytes in (("dense_f64", dense, grad_t.numel() * 8), ("compact_f64", xch, n_active * 8),
+                            ("compact_f32", xch32, n_active * 4)):
+        wall, _ = time_steps(lambda x=x: x.sum_(grad_t), k2, 2, torch, dist, world)
+        out["allreduce_" + name] = {"bytes": nbytes, "ms": wall / k2 * 1e3,
+                                    "bus_gbs": 2.0 * (world - 1) / world * nbytes / (wall / k2) / 1e9}
+
+        def iteration(x=x):
+            fwd()
+            adj()
+            x.sum_(grad_t)
+        wall, _ = time_steps(iteration, k2, 1, torch, dist, world)
+        out["iteration_ms_" + name] = wall / k2 * 1e3
+    return out
+
+
+def cfg4_leg(w, local, k2, torch, dist, world):
+    """BASELINE config 4 as written: 62 x 100 x 100 = 620,000 rays, 256^3 grid, rays sharded over the N ranks by (time,
+    direction) block (ShardedRays / pair_block), the adjoint update summed over ranks every iteration.  Total work is fixed:
+    STRONG scaling."""
+    from ionotomo_amd import parallel, solvers
+    from ionotomo_amd.engine import RayEngine
+    c4 = build_cfg4(w)
+    e4 = RayEngine(local, storage="f64")
+    e4.set_grid(c4["xvec"], c4["yvec"], c4["zvec"])
+    x0 = torch.exp(e4.tensor(c4["m"])).mul_(c4["K_ne"] / 1e13).reshape(e4.shape)
+    e4.set_values(x0.reshape(-1))
+    P = c4["origins"].shape[1]
+    prob = parallel.ShardedRays(e4, c4["origins"], c4["directions"], TMAX, NS, dobs=np.zeros((NA, P)), cdct=np.full((NA, P), 1e-6),
+                                i0=0, tune=False)
+    Rtot = NA * P
+    out = {"rays_total": Rtot, "rays_this_rank": prob.R_local, "scaling": "strong", "exchange": prob.exchange.mode,
+           "forward_plan": prob.forward_plan, "adjoint_plan": prob.plan}
+    wall, kern = time_steps(prob.forward_tec, k2, 2, torch, dist, world)
+    assert not e4.check_oob(), "config-4 rays left the grid"
+    out["forward_ray_integrals_per_s"] = Rtot * k2 / wall
+    out["forward_ms"] = wall / k2 * 1e3
+    e4.set_values((x0 * 1.1).reshape(-1))
+    prob.dobs = prob.forward().clone()
+    e4.set_values(x0.reshape(-1))
+    tec = prob.forward_tec()
+    k3 = max(3, k2 // 2)
+
+    def iteration():
+        prob.forward_tec()
+        prob.gradient_from_tec(tec)
+    wall, _ = time_steps(iteration, k3, 1, torch, dist, world)
+    out["iteration_ms_fwd_adj_exchange"] = wall / k3 * 1e3
+    for name in ("cgls", "sirt"):
+        fn = getattr(solvers, name)
+        fn(prob, x0, n_iter=2)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        fn(prob, x0, n_iter=10)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        out["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 10 * 1e3
+    return out
 
 
 def main():
@@ -244,6 +381,7 @@ def main():
                     help="back-project with the ray-stationary kernel (LDS tile per ray bundle) instead of the box-binned plan")
     ap.add_argument("--no-fwd-plan", dest="fwd_plan", action="store_false",
                     help="forward without the bundle plan (lanes = samples kernel k_forward_straight_u on the coherent walk order)")
+    ap.add_argument("--no-cfg4", dest="cfg4", action="store_false", help="skip the config-4 (620,000 rays, strong scaling) leg")
     ap.add_argument("--main-only", action="store_true", help="same as --only forward")
     ap.add_argument("--only", default=None,
                     choices=["forward", "adjoint", "cubic_forward", "cubic_adjoint", "cgls", "sirt"],
@@ -286,19 +424,17 @@ def main():
     # walk order: rays whose paths nearly coincide run back to back (geometry only, computed once,
     # reused by every launch of an inversion; results are independent of it)
     order_t = eng.locality_order(o_t, d_t, TMAX) if args.order else None
-
-    # the forward kernels walk the rays in the "coherent" order (nearly identical rays -- one line of sight a few seconds apart
-    # -- on neighbouring waves at the same time: RayEngine.coherent_order; geometry only, once); arguments converted once
-    forder_t = None
-    if args.order:
-        forder_t = order_t if os.environ.get("IONO_BENCH_FWD_ORDER", "coherent") == "locality" else eng.coherent_order(o_t, d_t)
+    # the unplanned forward kernels walk the rays in the "coherent" order (RayEngine.coherent_order; geometry only, once)
+    forder_t = eng.coherent_order(o_t, d_t) if args.order else None
     fwd = eng.forward_launcher(o_t, d_t, TMAX, NS, tec_t, order=forder_t)
     # bundle plan of the forward (geometry only, once per inversion like the walk orders: engine.plan_forward)
     fwd_plan_info = None
     if args.fwd_plan:
         t0 = time.perf_counter()
         info = eng.plan_forward(o_t, d_t, TMAX, NS)
-        fwd_plan_info = {"bundles": info[0], "chunks_per_ray": info[1], "lds_chunk_fraction": info[2], "build_s": time.perf_counter() - t0}
+        fwd_plan_info = {"bundles": info[0], "chunks_per_ray": info[1], "lds_chunk_fraction": info[2],
+                         "build_s": time.perf_counter() - t0}
+    planned = bool(fwd_plan_info and fwd_plan_info["bundles"])
 
     # ---- legs that can run alone under a profiler ---------------------------------------------------------------
     def adjoint_leg():
@@ -363,7 +499,7 @@ def main():
         if rank == 0:
             per = 10 if args.only in ("cgls", "sirt") else 1
             print(json.dumps({"only": args.only, "n_gpus": world, "steps": k, "ms_per_launch_or_iteration": kern * 1e3 / per,
-                              "rays": R, "csrc_sha": csrc_sha()}))
+                              "rays": R, "forward_plan": fwd_plan_info, "csrc_sha": csrc_sha()}))
         if world > 1:
             dist.destroy_process_group()
         return
@@ -372,12 +508,37 @@ def main():
     assert not eng.check_oob(), "rays left the grid"
     value = world * R * args.steps / wall
     tec_gpu = tec_t.cpu().numpy()
+    sha = csrc_sha()
+    line = {
+        "metric": "ray-integrals/sec through 256^3 ne grid",
+        "value": value, "unit": "ray-integrals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "62 ant (LOFAR-HBA) x 42 dir x 100 times per GPU = %d straight rays, Ns=%d, 256^3 f64 ne "
+                               "grid, trilinear + Simpson, forward TEC" % (R, NS),
+                   "rays_per_gpu": R, "samples_per_ray": NS, "grid": [NGRID] * 3, "interp": "trilinear",
+                   "quadrature": "simpson", "sharding": "rays by (time,direction) block, grid replicated",
+                   "forward_kernel": "k_forward_bundle (bundle plan)" if planned else "k_forward_straight_u (no plan)"},
+        "csrc_sha": sha,
+    }
+    if rank == 0:
+        # the headline is on record before any leg that contains a collective (the ONE stdout line comes at the end)
+        print("bench.py headline (repeated in the final stdout line): " + json.dumps(line), file=sys.stderr, flush=True)
 
     # everything below is reported next to the headline number.  Nothing in it may be able to lose the headline line or
     # hang a multi-rank run: every rank allocates what the legs need FIRST, the ranks agree that all of them succeeded,
-    # and only then enter code with collectives (which is the same on every rank).
-    extra = {}
-    ok = 1
+    # and only then enter code with collectives (the same on every rank); after every leg with a collective the ranks
+    # agree again before the next one starts.
+    extra = {"forward_plan": fwd_plan_info}
+
+    def agree(ok):
+        if world == 1:
+            return bool(ok)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=eng.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    ok = True
     try:
         adj, grad_t, dobs_t, cdct_t = adjoint_leg()
         eng32 = RayEngine(local, storage="f32")
@@ -388,72 +549,43 @@ def main():
         big_b = torch.empty_like(big_a)
         ec, cf, ca, tc = cubic_legs()
     except Exception as exc:                                    # noqa: BLE001
-        ok = 0
+        ok = False
         extra["error"] = "%s: %s" % (type(exc).__name__, exc)
-    if world > 1:
-        flag = torch.tensor([ok], dtype=torch.int32, device=eng.device)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        ok = int(flag.item())
+    ok = agree(ok)
     copy_gbs = None
+    k2 = max(3, min(25, args.steps // 4))
     if ok:
+        # ---- legs WITHOUT collectives (a failure here costs this rank's extras only) ------------------------------------
         try:
-            k2 = max(3, min(25, args.steps // 4))
-
-            def iteration():
-                fwd()
-                adj()
-                if world > 1:
-                    dist.all_reduce(grad_t)
-
             # ray-stationary back-projection (LDS tile per bundle of the walk) with its work partition balanced by measured
             # cost, then the node-stationary one (segments binned by grid box, engine.plan_adjoint): both depend on the
             # ray geometry only, are set up once per inversion and never change results
             extra["adjoint_partition"] = eng.tune_adjoint_partition(adj, R) if args.order else None
-            _, tkern = time_steps(adj, k2, 1, torch, dist, world)
+            _, tkern = time_steps(adj, k2, 1, torch, dist, 1)
             extra["adjoint_ray_stationary_ms"] = tkern * 1e3
             if args.plan:
                 t0 = time.perf_counter()
                 info = eng.plan_adjoint(o_t, d_t, TMAX, NS)
                 extra["adjoint_plan"] = {"segments": info[0], "work_units": info[1], "outside_fraction": info[2],
                                          "build_s": time.perf_counter() - t0}
-            awall, akern = time_steps(adj, k2, 1, torch, dist, world)
-            iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
-            extra["adjoint_ray_integrals_per_s"] = world * R * k2 / awall
+            _, akern = time_steps(adj, k2, 1, torch, dist, 1)
             extra["adjoint_ms"] = akern * 1e3
-            extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
-            if world > 1:
-                # the same iteration with the update exchanged only over the nodes some rank's rays reach
-                # (ionotomo_amd/parallel.py:GradientExchange; the plan is built once per geometry)
-                from ionotomo_amd.parallel import GradientExchange
-                ones = torch.ones(R, dtype=torch.float64, device=eng.device)
-                xch = GradientExchange("compact").plan(eng.adjoint(o_t, d_t, ones, TMAX, NS, order=order_t))
-
-                def iteration_compact():
-                    fwd()
-                    adj()
-                    xch.sum_(grad_t)
-                cwall, _ = time_steps(iteration_compact, k2, 1, torch, dist, world)
-                extra["iteration_ms_compact_exchange"] = cwall / k2 * 1e3
-                extra["exchange_active_node_fraction"] = xch.fraction
-                xch32 = GradientExchange("compact", reduce_dtype=torch.float32)
-                xch32.index, xch32.fraction = xch.index, xch.fraction
-
-                def iteration_compact32():
-                    fwd()
-                    adj()
-                    xch32.sum_(grad_t)
-                c32wall, _ = time_steps(iteration_compact32, k2, 1, torch, dist, world)
-                extra["iteration_ms_compact_exchange_f32"] = c32wall / k2 * 1e3
+            extra["adjoint_ray_integrals_per_s_per_gpu"] = R / akern
+            # ---- the lanes = samples forward on the coherent walk order (what the planned kernel replaced)
+            if planned:
+                eng.clear_forward_plan()
+                _, ku = time_steps(fwd, k2, 1, torch, dist, 1)
+                extra["forward_unplanned_ms"] = ku * 1e3
+                eng.plan_forward(o_t, d_t, TMAX, NS)
             # ---- the reference's default sampling, Ns = nz (even), with the 'avg' rule its own integrate.py spells out
             # (secondary row; tests/golden/forward_tec_even_avg.npz pins the rule)
             tec_even = torch.empty(R, dtype=torch.float64, device=eng.device)
-            wev, kev = time_steps(lambda: eng.forward(o_t, d_t, TMAX, NS - 1, out=tec_even, order=forder_t), k2, 1, torch, dist, world)
-            extra["even_ns_avg_rule_ray_integrals_per_s"] = world * R * k2 / wev
+            _, kev = time_steps(lambda: eng.forward(o_t, d_t, TMAX, NS - 1, out=tec_even, order=forder_t), k2, 1, torch, dist, 1)
+            extra["even_ns_avg_rule_ray_integrals_per_s_per_gpu"] = R / kev
             extra["even_ns_avg_rule_vs_odd_max_rel_dev"] = float(((tec_even - tec_t).abs() / tec_t.abs()).max())
             # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
-            w32, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, world)
-            extra["f32_grid_ray_integrals_per_s"] = world * R * k2 / w32
-            extra["f32_grid_vl1d_frac"] = R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9 / VL1D_PEAK_GBS
+            _, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, 1)
+            extra["f32_grid_ray_integrals_per_s_per_gpu"] = R / k32
             extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
             sel = torch.arange(R, device=eng.device).reshape(NA, NT, ND)[:, 0, :].reshape(-1)
             o1, d1 = o_t[sel].contiguous(), d_t[sel].contiguous()
@@ -464,24 +596,21 @@ def main():
             # ---- measured device-to-device copy (1 GiB read + 1 GiB written): the achievable HBM rate on this box
             _, kc = time_steps(lambda: big_b.copy_(big_a), 10, 2, torch, dist, 1)
             copy_gbs = 2.0 * big_a.numel() * 8 / kc / 1e9
+            del big_a, big_b
             # ---- tricubic (Lekien-Marsden derivative fields; config 2's interpolant) at the same shape
             _, kcf = time_steps(cf, k2, 1, torch, dist, 1)
             if args.plan:
                 ec.plan_adjoint(o_t, d_t, TMAX, NS)
             _, kca = time_steps(ca, max(2, k2 // 4), 1, torch, dist, 1)
             extra["tricubic_forward_ms"] = kcf * 1e3
-            extra["tricubic_forward_ray_integrals_per_s"] = R / kcf
-            extra["tricubic_forward_vl1d_frac"] = R * algorithmic_bytes_per_ray(NS, 8, 64) / kcf / 1e9 / VL1D_PEAK_GBS
+            extra["tricubic_forward_ray_integrals_per_s_per_gpu"] = R / kcf
             extra["tricubic_adjoint_ms"] = kca * 1e3
             extra["tricubic_vs_trilinear_max_rel_dev"] = float((tc - tec_t).abs().div(tec_t.abs()).max().item())
-            # ---- adjoint roofline: memory-side float atomics
             # the binned kernel is bound by LDS float-atomic throughput, the ray-stationary one by the memory-side atomic rate
             extra["adjoint_roofline"] = {"bound": "lds_atomic" if args.plan else "memory_atomic", "kernel_ms": akern * 1e3,
-                                         "kernel": "k_adjoint_binned<double, false, 0, double>" if args.plan else "k_adjoint_straight_tile<double, 1, 4>"}
-        except Exception as exc:                                    # noqa: BLE001
-            extra["error"] = "%s: %s" % (type(exc).__name__, exc)
-        if world == 1:
-            try:                                               # single-rank only: the solvers at the bench shape
+                                         "kernel": "k_adjoint_binned<double, false, 0, double>" if args.plan
+                                         else "k_adjoint_straight_tile<double, 1, 4>"}
+            if world == 1:                                  # single-rank only: the solvers at the bench shape
                 prob, x0 = solver_problem()
                 for name in ("cgls", "sirt"):
                     fn = getattr(solvers, name)
@@ -491,12 +620,40 @@ def main():
                     fn(prob, x0, n_iter=30)
                     torch.cuda.synchronize()
                     extra["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 30 * 1e3
+                del prob
+                if planned:                                 # (the solver problem planned its own tensors: back to the bench's)
+                    eng.plan_forward(o_t, d_t, TMAX, NS)
+                if args.plan:
+                    eng.plan_adjoint(o_t, d_t, TMAX, NS)
+        except Exception as exc:                                    # noqa: BLE001
+            extra["error"] = "%s: %s" % (type(exc).__name__, exc)
+        # ---- legs WITH collectives: all ranks or none ---------------------------------------------------------------------
+        if agree("error" not in extra):
+            try:
+                def iteration():
+                    fwd()
+                    adj()
+                    if world > 1:
+                        dist.all_reduce(grad_t)
+                iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
+                extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
             except Exception as exc:                                    # noqa: BLE001
-                extra["solver_error"] = "%s: %s" % (type(exc).__name__, exc)
+                extra["error"] = "%s: %s" % (type(exc).__name__, exc)
+        if world > 1 and agree("error" not in extra):
+            try:
+                extra["distributed"] = exchange_legs(eng, fwd, adj, grad_t, o_t, d_t, order_t, R, k2, torch, dist, world, backend)
+            except Exception as exc:                                    # noqa: BLE001
+                extra["error"] = "%s: %s" % (type(exc).__name__, exc)
+        # ---- config 4: 620,000 rays split over the ranks (strong scaling), forward / iteration / CGLS / SIRT -------------------
+        if args.cfg4 and agree("error" not in extra):
+            try:
+                extra["cfg4"] = cfg4_leg(w, local, k2, torch, dist, world)
+            except Exception as exc:                                    # noqa: BLE001
+                extra["cfg4"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
-    sha = csrc_sha()
     pmc, pmc_note = load_pmc(sha)
-    rl = forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes)
+    peaks = measured_peaks() if (rank == 0 and world == 1) else None
+    rl = forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes, peaks, planned)
     ar = extra.get("adjoint_roofline")
     ca_ = (pmc or {}).get("adjoint")
     if ar and ca_ and ca_.get("rays") == R and "TCC_EA0_ATOMIC_sum" in ca_ and ca_.get("kernel", "").startswith(ar["kernel"]):
@@ -510,19 +667,8 @@ def main():
                          "bank_conflict_frac": ca_.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(ca_["SQ_LDS_IDX_ACTIVE"], 1.0),
                          "atomic_wave_instructions": ca_.get("SQ_INSTS_LDS_ATOMIC")}
         ar["frac"] = ar["lds"]["busy_frac"] if ar["bound"] == "lds_atomic" and "lds" in ar else ar["memory_atomics"]["frac"]
-    line = {
-        "metric": "ray-integrals/sec through 256^3 ne grid",
-        "value": value, "unit": "ray-integrals/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "62 ant (LOFAR-HBA) x 42 dir x 100 times per GPU = %d straight rays, Ns=%d, 256^3 f64 ne "
-                               "grid, trilinear + Simpson, forward TEC" % (R, NS),
-                   "rays_per_gpu": R, "samples_per_ray": NS, "grid": [NGRID] * 3, "interp": "trilinear",
-                   "quadrature": "simpson", "sharding": "rays by (time,direction) block, grid replicated"},
-        "roofline": rl,
-        "csrc_sha": sha,
-        "extra": extra,
-    }
+    line["roofline"] = rl
+    line["extra"] = extra
     if rank == 0 and world == 1 and not args.no_cpu:
         cb, relerr = cpu_baseline(w, tec_gpu)
         line["cpu_baseline"] = cb

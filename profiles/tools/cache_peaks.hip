@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_lds(int iters, unsigned *__restrict__ s
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const unsigned a16 = base + (((pos + 2 * lane) & 4094) << 3), a8 = base + (((pos + lane) & 4095) << 3);
-            if (KIND == 0) asm volatile("ds_read2_b64 %0, %1 offset0:1 offset1:2" : "=v"(v[u]) : "v"(a16));
+            if (KIND == 0) asm volatile("ds_read2_b64 %0, %1 offset0:1 offset1:2" : "=v"(v[u]) : "v"(a8));        // (lanes 8 B apart: no bank conflict)
             else if (KIND == 1) asm volatile("ds_read_b64 %0, %1" : "=v"(w[u]) : "v"(a8));
             else if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(a16));
             else asm volatile("ds_read_b128 %0, %1 offset:8" : "=v"(v[u]) : "v"(a16));
