@@ -7,14 +7,22 @@ inversion box (inversion/initial_model.py:13-36).  The rotation itself is plain 
     ha = LST - RA_phase,   R = [east, north, up] evaluated at (longitude - ha, latitude = Dec_phase)
     p_pointing = R (p_itrs - p_centre)                                  (pointing_frame.py:149-186)
 
-so the frame's w axis points at the phase centre, u is "east" there and v "north".  What astropy adds
-on top is the Earth-orientation chain (precession, nutation, polar motion, UT1-UTC) inside
-``sidereal_time`` and inside the ICRS -> ITRS step for the directions.  Here both use the IAU-1982 GMST
-polynomial and a pure rotation about the pole -- good to ~1e-4 rad in absolute pointing, while facet
-offsets RELATIVE to the phase centre (what the ray fan depends on) are unaffected at that level.
-PARITY UNPINNED against the reference (astropy is not installed in the build image); the axis
-conventions the reference's own tests pin (tests/test_frames.py:40-164, cases a-d) are restated in
-tests/test_frames_conventions.py.  Host-side numpy, runs once per timestep: not on the hot path.
+so the frame's w axis points at the direction whose OF-DATE right ascension / declination equal the phase centre's ICRS
+numbers (the reference subtracts an ICRS right ascension from a mean sidereal time of date: pointing_frame.py:151-152 --
+reproduced as is), u is "east" there and v "north".  What astropy adds on top is the Earth-orientation chain inside the
+ICRS -> ITRS step for the facet directions (geometry/calc_rays.py:122-139).  Here that chain is
+
+    r_itrs = R3(GAST) N(t) P(t) r_icrs
+
+with the IAU-1976 precession matrix P (Lieske angles), the IAU-1980 nutation N truncated to its four largest terms
+(0.05 arc-seconds), GAST = GMST82 + dpsi cos(eps) and UT1 = UTC, no polar motion, no frame bias.  Pinned to the published
+IAU SOFA check values (t_sofa_c.c: iauGmst82, iauPmat76, iauNut80, iauObl80, iauGd2gc, iauGc2gd) in
+tests/test_frames_conventions.py.  Residual against a full IAU-2006/2000A chain with IERS data: UT1-UTC (<= 0.9 s = 13.5
+arc-seconds of Earth rotation, not knowable offline), polar motion (<= 0.3"), IAU-1976 vs 2006 precession (0.08" by 2026),
+truncated nutation (0.05"), frame bias (0.02"): <= 14" = 7e-5 rad in absolute direction, common to every facet; a ray at 5
+degrees from the zenith changes its slant factor by tan(z) x 7e-5 = 6e-6.  PARITY otherwise UNPINNED against the reference
+(astropy is not installed in the build image); the axis conventions the reference's own tests pin (tests/test_frames.py:40-164,
+cases a-d) are restated in tests/test_frames_conventions.py.  Host-side numpy, runs once per timestep: not on the hot path.
 """
 import numpy as np
 
@@ -46,6 +54,71 @@ def gmst_rad(unix_utc):
     return np.deg2rad(gmst_deg % 360.0)
 
 
+ARCSEC = np.pi / 180.0 / 3600.0
+
+
+def _r1(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[1.0, 0.0, 0.0], [0.0, c, s], [0.0, -s, c]])
+
+
+def _r2(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, 0.0, -s], [0.0, 1.0, 0.0], [s, 0.0, c]])
+
+
+def _r3(a):
+    c, s = np.cos(a), np.sin(a)
+    return np.array([[c, s, 0.0], [-s, c, 0.0], [0.0, 0.0, 1.0]])
+
+
+def julian_date(unix_utc):
+    return float(unix_utc) / 86400.0 + 2440587.5
+
+
+def precession_matrix(jd):
+    """Mean equator and equinox of J2000.0 -> of date: IAU 1976 (Lieske et al. 1977 angles; = iauPmat76)."""
+    t = (jd - 2451545.0) / 36525.0
+    zeta = (2306.2181 * t + 0.30188 * t ** 2 + 0.017998 * t ** 3) * ARCSEC
+    z = (2306.2181 * t + 1.09468 * t ** 2 + 0.018203 * t ** 3) * ARCSEC
+    theta = (2004.3109 * t - 0.42665 * t ** 2 - 0.041833 * t ** 3) * ARCSEC
+    return _r3(-z) @ _r2(theta) @ _r3(-zeta)
+
+
+def mean_obliquity(jd):
+    """IAU 1980 mean obliquity of the ecliptic [rad] (= iauObl80)."""
+    t = (jd - 2451545.0) / 36525.0
+    return (84381.448 - 46.8150 * t - 0.00059 * t ** 2 + 0.001813 * t ** 3) * ARCSEC
+
+
+def nutation(jd):
+    """(dpsi, deps) [rad]: the four largest terms of the IAU 1980 series (0.05 arc-seconds against iauNut80)."""
+    t = (jd - 2451545.0) / 36525.0
+    om = np.deg2rad(125.04452 - 1934.136261 * t)
+    ls = np.deg2rad(280.4665 + 36000.7698 * t)
+    lm = np.deg2rad(218.3165 + 481267.8813 * t)
+    dpsi = (-17.20 * np.sin(om) - 1.32 * np.sin(2 * ls) - 0.23 * np.sin(2 * lm) + 0.21 * np.sin(2 * om)) * ARCSEC
+    deps = (9.20 * np.cos(om) + 0.57 * np.cos(2 * ls) + 0.10 * np.cos(2 * lm) - 0.09 * np.cos(2 * om)) * ARCSEC
+    return dpsi, deps
+
+
+def icrs_to_itrs_matrix(unix_utc):
+    """Celestial (ICRS ~ mean J2000) -> terrestrial rotation at a UTC instant: R3(GAST) N P (module docstring for what is left out)."""
+    jd = julian_date(unix_utc)
+    eps = mean_obliquity(jd)
+    dpsi, deps = nutation(jd)
+    N = _r1(-(eps + deps)) @ _r3(-dpsi) @ _r1(eps)
+    gast = float(gmst_rad(unix_utc)) + dpsi * np.cos(eps)
+    return _r3(gast) @ N @ precession_matrix(jd)
+
+
+def icrs_direction_in_itrs(ra, dec, unix_utc):
+    """Unit vectors in ITRS of ICRS (ra, dec) [rad] at a UTC instant (what astropy's ICRS -> ITRS does to a direction)."""
+    ra, dec = np.asarray(ra, dtype=np.float64), np.asarray(dec, dtype=np.float64)
+    r = np.stack([np.cos(dec) * np.cos(ra), np.cos(dec) * np.sin(ra), np.sin(dec)], axis=-1)
+    return r @ icrs_to_itrs_matrix(unix_utc).T
+
+
 def pointing_rotation(lon, lst, ra, dec):
     """R = [east, north, up] at (lon - (lst - ra), dec): rows are the Pointing axes u, v, w in ITRS
     (astro/frames/pointing_frame.py:149-165)."""
@@ -58,7 +131,8 @@ def itrs_to_pointing_km(xyz_m, centre_m, R):
 
 
 def icrs_to_itrs_direction(ra, dec, gmst):
-    """Unit vectors in ITRS for equatorial (ra, dec) [rad] at Greenwich sidereal angle ``gmst``."""
+    """Unit vectors in ITRS for OF-DATE equatorial (ra, dec) [rad] at Greenwich sidereal angle ``gmst`` (a pure rotation about the
+    pole; ICRS directions go through ``icrs_direction_in_itrs``)."""
     ra, dec = np.asarray(ra, dtype=np.float64), np.asarray(dec, dtype=np.float64)
     lon = ra - gmst
     return np.stack([np.cos(dec) * np.cos(lon), np.cos(dec) * np.sin(lon), np.sin(dec)], axis=-1)
@@ -81,7 +155,7 @@ def model_frame_bundle_from_sky(antennas_itrs_m, patches_radec, times_unix, cent
         g = gmst_rad(t)
         R = pointing_rotation(lon, g + lon, phase_radec[0], phase_radec[1])
         origins[:, j, :, :] = itrs_to_pointing_km(ants, centre_itrs_m, R)[:, None, :]
-        directions[:, j, :, :] = (icrs_to_itrs_direction(pat[:, 0], pat[:, 1], g) @ R.T)[None, :, :]
+        directions[:, j, :, :] = (icrs_direction_in_itrs(pat[:, 0], pat[:, 1], t) @ R.T)[None, :, :]
     return origins, directions
 
 

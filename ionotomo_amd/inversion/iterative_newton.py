@@ -4,9 +4,11 @@
 NOTE on parity: the reference's ``forward_equation`` here passes 4-D coordinate arrays to
 ``TriCubic.interp``, whose ``np.reshape(rgi(np.array([x,y,z]).T), np.shape(x))``
 (geometry/tri_cubic.py:70) returns the values in transposed order for ndim > 1 -- every sample
-lands on the wrong ray.  This build implements the evidently intended semantics (sample k of ray
-(a,t,d) stays with that ray).  tests/test_oracle_golden.py pins every other term of the formula
-against the reference's actual output by emulating that permutation in the oracle.
+lands on the wrong ray.  This build implements the evidently intended semantics by default (sample k
+of ray (a,t,d) stays with that ray); ``forward_equation(..., compat="reference")`` reproduces the
+reference's ACTUAL output bit-for-formula (the same permutation applied to the sample coordinates,
+path lengths untouched) and is pinned to the golden vector directly on the GPU
+(tests/test_gpu_parity.py::test_phase_forward_reference_compat_matches_the_golden_directly).
 """
 import numpy as np
 
@@ -16,10 +18,25 @@ TECU = 1e13
 speedoflight = 299792458.
 
 
-def forward_equation(model, tci, rays, freqs, K=1e11, i0=0, quad="avg"):
+def forward_equation(model, tci, rays, freqs, K=1e11, i0=0, quad="avg", compat=None):
     """g[Na,Nt,Nd,Nf] = const_i + 2 pi nu clock_ij - (2 pi nu / c) [int (1-n) ds - ref]
-    (inversion/iterative_newton.py:86-127).  Like the reference it leaves ``tci.M = K exp(mu)``."""
+    (inversion/iterative_newton.py:86-127).  Like the reference it leaves ``tci.M = K exp(mu)``.
+
+    ``compat="reference"``: the output of the reference AS SHIPPED -- its ``TriCubic.interp`` hands the 4-D coordinate arrays
+    to scipy transposed and reshapes the values back without transposing (geometry/tri_cubic.py:70, called from
+    iterative_newton.py:108), so the electron density integrated along ray (a, t, d) at sample k is the one found at the
+    sample whose flat index in [N, Nd, Nt, Na] order equals the flat index of (a, t, d, k) in [Na, Nt, Nd, N] order, while the
+    path lengths ``s`` stay in place.  Same kernels, coordinates permuted on the host."""
     rays = np.asarray(rays, dtype=np.float64)
+    if compat == "reference":
+        if rays.ndim != 5:
+            raise ValueError("compat='reference' needs rays[Na,Nt,Nd,4,N]")
+        rays = rays.copy()
+        shp = rays[..., 0, :].shape
+        for c in range(3):
+            rays[..., c, :] = np.reshape(rays[..., c, :].transpose(3, 2, 1, 0), shp)
+    elif compat is not None:
+        raise ValueError("compat must be None or 'reference'")
     mu, clock, const = model
     ne = np.exp(mu)
     ne *= K

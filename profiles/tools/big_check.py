@@ -41,6 +41,15 @@ tec = torch.empty(R, dtype=torch.float64, device="cuda")
 order = e.coherent_order(o, d)
 out["forward_ms"] = timeit(lambda: e.forward(o, d, w["tmax"], Ns, out=tec, order=order))
 assert not e.check_oob()
+# bundle-stationary forward on its geometry plan (round 3)
+t0 = time.perf_counter()
+out["forward_plan"] = e.plan_forward(o, d, w["tmax"], Ns)
+out["forward_plan_build_ms"] = (time.perf_counter() - t0) * 1e3
+tecp = torch.empty_like(tec)
+out["forward_planned_ms"] = timeit(lambda: e.forward(o, d, w["tmax"], Ns, out=tecp))
+out["planned_vs_unplanned_max_rel"] = float(((tecp - tec).abs() / tec.abs()).max())
+out["forward_planned_algorithmic_gbs"] = R * (Ns * 64 + 56) / out["forward_planned_ms"] / 1e6
+e.clear_forward_plan()
 sel = rng.choice(R, 400, replace=False)
 ref = OC.forward_tec_straight(xv, yv, zv, M.cpu().numpy(), w["origins"].reshape(-1, 3)[sel], w["directions"].reshape(-1, 3)[sel], w["tmax"], Ns)
 out["forward_vs_c_oracle_max_rel"] = float(np.max(np.abs(tec.cpu().numpy()[sel] - ref) / np.abs(ref)))

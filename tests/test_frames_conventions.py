@@ -57,10 +57,43 @@ def test_geodesy_gmst_and_bundle_shapes():
     pat = np.stack([phase[0] + np.array([0.0, 0.01, -0.02]), phase[1] + np.array([0.0, 0.015, 0.01])], -1)
     o, d = frames.model_frame_bundle_from_sky(ra_.get_antenna_locs(), pat, [t0, t0 + 8.0], ra_.get_center(), phase)
     assert o.shape == d.shape == (62, 2, 3, 3)
-    assert np.allclose(d[0, 0, 0], [0, 0, 1], atol=1e-12)           # the phase centre itself
+    # the phase centre's ICRS numbers define the frame as OF-DATE coordinates (the reference's own formula), so the ICRS source
+    # itself sits off the w axis by the precession + nutation since J2000 (0.3 degrees in 2023)
+    assert 3e-3 < np.arccos(d[0, 0, 0, 2]) < 8e-3
     assert np.allclose(np.linalg.norm(d, axis=-1), 1.0)
     assert np.abs(o[:, 0, 0, :]).max() < 80.0                       # stations within ~80 km of the centre
     # 8 s of Earth rotation moves the antennas in the frame by ~ 8 s * 7.29e-5 rad/s * 60 km
     assert 0 < np.abs(o[:, 1] - o[:, 0]).max() < 0.1
     xv, yv, zv = frames.determine_inversion_domain(5.0, o[:, 0, 0, :], d[0, 0], 1000.0, padding=20)
     assert zv[0] < o[:, 0, 0, 2].min() - 90 and zv[-1] > 1000 + 90 and abs((xv[1] - xv[0]) - 5.0) < 0.2
+
+
+def test_earth_orientation_against_published_sofa_check_values():
+    """IAU SOFA's own test values (t_sofa_c.c): iauGmst82, iauPmat76, iauNut80, iauObl80, iauGd2gc, iauGc2gd (WGS84)."""
+    unix = lambda mjd: (mjd - 40587.0) * 86400.0
+    assert abs(float(frames.gmst_rad(unix(53736.0))) - 1.754174981860675096) < 1e-9
+    P = frames.precession_matrix(2400000.5 + 50123.9999)
+    ref = np.array([[0.9999995504328350733, 0.8696632209480960785e-3, 0.3779153474959888345e-3],
+                    [-0.8696632209485112192e-3, 0.9999996218428560614, -0.1643284776111886407e-6],
+                    [-0.3779153474950335077e-3, -0.1643306746147366896e-6, 0.9999999285899790119]])
+    assert np.max(np.abs(P - ref)) < 1e-14
+    dpsi, deps = frames.nutation(2400000.5 + 53736.0)
+    assert abs(dpsi - (-0.9643658353226563966e-5)) < 2.5e-7 and abs(deps - 0.4060051006879713322e-4) < 2.5e-7     # 0.05 arc-seconds
+    assert abs(frames.mean_obliquity(2400000.5 + 54388.0) - 0.4090751347643816218) < 1e-14
+    lon, lat, h = frames.geodetic_from_itrs([2e6, 3e6, 5.244e6])
+    assert abs(lon - 0.9827937232473290680) < 1e-14 and abs(lat - 0.97160184819075459) < 1e-13 and abs(h - 331.4172461426059892) < 1e-7
+    # ... and the inverse (iauGd2gc) through the ENU rotation's normal: a point h above the ellipsoid along "up"
+    e, p, hh = 3.1, -0.5, 2500.0
+    a, f = frames.WGS84_A, frames.WGS84_F
+    e2 = f * (2 - f)
+    N = a / np.sqrt(1 - e2 * np.sin(p) ** 2)
+    foot = np.array([N * np.cos(p) * np.cos(e), N * np.cos(p) * np.sin(e), N * (1 - e2) * np.sin(p)])
+    xyz = foot + hh * enu_rotation(e, p)[2]
+    assert np.max(np.abs(xyz - [-5599000.5577049947, 233011.67223479203, -3040909.4706983363])) < 1e-7
+    # the celestial -> terrestrial matrix is a rotation, and without precession / nutation it is the pure spin of icrs_to_itrs_direction
+    M = frames.icrs_to_itrs_matrix(unix(53736.0))
+    assert np.allclose(M @ M.T, np.eye(3), atol=1e-14) and abs(np.linalg.det(M) - 1) < 1e-14
+    t0 = unix(51544.5)                       # J2000.0: precession is the identity, nutation a few arc-seconds
+    d_full = frames.icrs_direction_in_itrs(1.0, 0.5, t0)
+    d_spin = frames.icrs_to_itrs_direction(1.0, 0.5, frames.gmst_rad(t0))
+    assert np.arccos(np.clip(d_full @ d_spin, -1, 1)) < 1e-4

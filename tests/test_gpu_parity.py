@@ -212,6 +212,24 @@ def test_phase_forward_matches_oracle(ctx, golden, O):
     assert abs(itn.neg_log_like(g["g"], g["dobs"], g["CdCt"]) - float(g["S"])) < 1e-12 * float(g["S"])
 
 
+def test_phase_forward_reference_compat_matches_the_golden_directly(ctx, golden):
+    """The PRODUCT against the reference's actual output (tests/golden/phase_forward.npz: iterative_newton.forward_equation run
+    in the build container, transposed-reshape slip of tri_cubic.py:70 included) -- no oracle in between."""
+    import ionotomo_amd as it
+    from ionotomo_amd.inversion import iterative_newton as itn
+    g, c = golden("phase_forward"), golden("cast_ray")
+    w = syn.make_workload("cfg1")
+    mu = np.log(w["ne"] / 1e11)
+    tci = it.TriCubic(w["xvec"], w["yvec"], w["zvec"], w["ne"])
+    out = itn.forward_equation((mu, g["clock"], g["const"]), tci, c["rays65"], g["freqs"], K=float(g["K"]), i0=int(g["i0"]),
+                               compat="reference")
+    assert np.max(np.abs(out - g["g"])) < 1e-12 * np.max(np.abs(g["g"]))
+    S = itn.neg_log_like(out, g["dobs"], g["CdCt"])
+    assert abs(S - float(g["S"])) < 1e-10 * abs(float(g["S"]))
+    with pytest.raises(ValueError):
+        itn.forward_equation((mu, g["clock"], g["const"]), tci, c["rays65"], g["freqs"], compat="scipy")
+
+
 # --------------------------------------------------------------------------- adjoint
 def test_adjoint_matches_oracle_and_dot_product(ctx, O):
     w = syn.make_workload("cfg1")
