@@ -204,6 +204,17 @@ int iono_adjoint_plan_dev(iono_ctx *ctx, const double *origins_dev, const double
                           int Ns, int interp_kind);
 int iono_adjoint_plan_clear(iono_ctx *ctx);
 int iono_adjoint_plan_info(iono_ctx *ctx, int64_t *n_segments, int *n_units, double *outside_fraction);
+/* Device memory for hosts that keep operands resident between calls but have no torch (the reference-signature facade:
+ * a line search calls forward_equation(rays, K_ne, m_tci, i0) again and again with the SAME rays,
+ * inversion/line_search.py:56,71,83).  iono_dev_download is also the end of a chain of *_dev launches: it waits for the
+ * ctx stream and returns IONO_ERR_OOB if a sample left the grid.  iono_scale_by_grid_dev: grad *= grid values
+ * (d/dm = ne d/dne for the log-model, what scale_by_grid does in the host entry points). */
+int iono_dev_alloc(iono_ctx *ctx, size_t bytes, void **out_dev);
+int iono_dev_free(iono_ctx *ctx, void *p_dev);
+int iono_dev_upload(iono_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int iono_dev_zero(iono_ctx *ctx, void *p_dev, size_t bytes);
+int iono_dev_download(iono_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int iono_scale_by_grid_dev(iono_ctx *ctx, double *grad_dev);
 /* Bundle-stationary forward (ionotomo_amd/csrc/iono_forward_kernels.h: k_forward_bundle).  The same observation as for the
  * back-projection plan: the rays of forward_equation (inversion/forward_equation.py:13-33) are fixed for a whole inversion,
  * so they can be organised once: sorted along a 4-D Morton curve of foot and end point, cut into bundles of <= 64 nearly

@@ -94,6 +94,12 @@ _SIGNATURES = {
     "iono_adjoint_plan_dev": [_V, _V, _L, _D, _I, _I],
     "iono_adjoint_plan_clear": [],
     "iono_adjoint_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
+    "iono_dev_alloc": [ctypes.c_size_t, ctypes.POINTER(_V)],
+    "iono_dev_free": [_V],
+    "iono_dev_upload": [_V, _V, ctypes.c_size_t],
+    "iono_dev_zero": [_V, ctypes.c_size_t],
+    "iono_dev_download": [_V, _V, ctypes.c_size_t],
+    "iono_scale_by_grid_dev": [_V],
     "iono_forward_plan_dev": [_V, _V, _L, _D, _I],
     "iono_forward_plan_clear": [],
     "iono_forward_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
@@ -170,11 +176,90 @@ class Context(object):
         self.grid_shape = None
         self.storage = None
         self._axes = (None, None, None)
+        self._axes_ids, self._axes_objs = None, (None, None, None)
+        self._dev_arrays = []          # facade cache: [(weakref to a host array, shape, device pointer, bytes)], most recent first
+        self._values_key = None        # facade cache: what the device grid values were computed from
+        self._scratch = {}
 
     def close(self):
         if getattr(self, "_h", None) is not None and self.pid == os.getpid():
+            for _, _, ptr, _ in getattr(self, "_dev_arrays", []):
+                self._lib.iono_dev_free(self._h, ptr)
+            for ptr, _ in getattr(self, "_scratch", {}).values():
+                self._lib.iono_dev_free(self._h, ptr)
+            self._dev_arrays, self._scratch = [], {}
             self._lib.iono_ctx_destroy(self._h)
         self._h = None
+
+    # -- facade cache (the reference API hands over host arrays; a line search hands over the SAME ones again and again) ----
+    def dev_alloc(self, nbytes):
+        p = _V()
+        self.call("iono_dev_alloc", int(nbytes), ctypes.byref(p))
+        return _V(p.value)
+
+    def resident(self, a, keep=3, max_bytes=4 << 30):
+        """Device pointer of a copy of the float64 host array ``a``, uploaded once per OBJECT: the key is the array's identity
+        (a weak reference) and shape -- a caller that overwrites the array in place must pass a new object (or call
+        ``forget``).  The ``keep`` most recently used arrays stay resident."""
+        import weakref
+        for i, (ref, shape, ptr, nb) in enumerate(self._dev_arrays):
+            if ref() is a and shape == a.shape:
+                if i:
+                    self._dev_arrays.insert(0, self._dev_arrays.pop(i))
+                return ptr
+        if not (isinstance(a, np.ndarray) and a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]) or a.nbytes > max_bytes:
+            return None
+        ptr = self.dev_alloc(a.nbytes)
+        self.call("iono_dev_upload", ptr, _V(a.ctypes.data), a.nbytes)
+        self._dev_arrays.insert(0, (weakref.ref(a), a.shape, ptr, a.nbytes))
+        live = []
+        for j, ent in enumerate(self._dev_arrays):
+            if j < keep and ent[0]() is not None:
+                live.append(ent)
+            else:
+                self.call("iono_dev_free", ent[2])
+        self._dev_arrays = live
+        return ptr
+
+    def forget(self, a=None):
+        """Drop the resident copy of ``a`` (all of them with no argument) and the record of what the grid values came from."""
+        keep = []
+        for ent in self._dev_arrays:
+            if a is None or ent[0]() is a or ent[0]() is None:
+                self.call("iono_dev_free", ent[2])
+            else:
+                keep.append(ent)
+        self._dev_arrays = keep
+        self._values_key = None
+
+    def scratch(self, name, nbytes):
+        """A named grow-only device buffer (outputs of the resident facade path)."""
+        ptr, cap = self._scratch.get(name, (None, 0))
+        if cap < nbytes:
+            if ptr is not None:
+                self.call("iono_dev_free", ptr)
+            ptr, cap = self.dev_alloc(nbytes + nbytes // 4 + 64), nbytes + nbytes // 4 + 64
+            self._scratch[name] = (ptr, cap)
+        return ptr
+
+    @staticmethod
+    def _fingerprint(M):
+        """Cheap content check of a grid-sized array (identity alone would miss ``m_tci.M += step``): three contiguous runs of
+        64 values (start, middle, end) + 128 evenly spaced ones, ~3 us.  An in-place change confined to nodes between the probes
+        is NOT seen -- assign a new array (``m_tci.M = ...``, which is what the reference's solvers do) or call
+        ``Context.forget()``."""
+        f = M.reshape(-1)
+        n = f.size
+        mid = n >> 1
+        return (float(f[:64].sum()), float(f[mid:mid + 64].sum()), float(f[-64:].sum()), float(f[::max(1, n // 128)].sum()), n)
+
+    def set_values_exp_cached(self, M, scale):
+        """grid values <- scale * exp(M) unless they already are (same object, same fingerprint, same scale)."""
+        M = as_f64(M)
+        key = (id(M), M.ctypes.data, M.shape, float(scale), self._fingerprint(M), self.grid_shape, self.storage)
+        if key != self._values_key:
+            self.set_values_exp(M, scale)
+            self._values_key = key
 
     def __del__(self):
         try:
@@ -200,6 +285,8 @@ class Context(object):
 
     # -- grid ------------------------------------------------------------------------------------
     def set_grid(self, xvec, yvec, zvec, M=None, storage="f64"):
+        if M is None and self._axes_ids == (id(xvec), id(yvec), id(zvec), storage) and self._axes_objs[0] is xvec:
+            return                        # the very arrays of the last call (a TriCubic's own axes): nothing to compare
         xv, yv, zv = as_f64(xvec).ravel(), as_f64(yvec).ravel(), as_f64(zvec).ravel()
         Mp = None
         if M is not None:
@@ -209,10 +296,13 @@ class Context(object):
             Mp = _dp(M)
         same = (self.grid_shape == (xv.size, yv.size, zv.size) and self.storage == storage_code(storage)
                 and all(np.array_equal(a, b) for a, b in zip(self._axes, (xv, yv, zv))))
+        self._axes_ids, self._axes_objs = (id(xvec), id(yvec), id(zvec), storage), (xvec, yvec, zvec)
         if same:                      # same axes: keep the device allocation, refresh the values only
             if Mp is not None:
+                self._values_key = None
                 self.call("iono_grid_set_values", Mp)
             return
+        self._values_key = None
         self.call("iono_grid_set", _dp(xv), xv.size, _dp(yv), yv.size, _dp(zv), zv.size, Mp, storage_code(storage))
         self.grid_shape = (xv.size, yv.size, zv.size)
         self.storage = storage_code(storage)
@@ -221,11 +311,13 @@ class Context(object):
     def set_values(self, M):
         M = as_f64(M)
         self._need(M.size)
+        self._values_key = None
         self.call("iono_grid_set_values", _dp(M))
 
     def set_values_exp(self, m, scale):
         m = as_f64(m)
         self._need(m.size)
+        self._values_key = None
         self.call("iono_grid_set_exp", _dp(m), float(scale))
 
     def get_values(self):

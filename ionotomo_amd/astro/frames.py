@@ -119,6 +119,13 @@ def icrs_direction_in_itrs(ra, dec, unix_utc):
     return r @ icrs_to_itrs_matrix(unix_utc).T
 
 
+def itrs_direction_to_icrs(v_itrs, unix_utc):
+    """(ra, dec) [N,2] in ICRS of ITRS direction vectors [N,3] at a UTC instant: the inverse of ``icrs_direction_in_itrs``."""
+    v = np.atleast_2d(np.asarray(v_itrs, dtype=np.float64)) @ icrs_to_itrs_matrix(unix_utc)      # rows: M^T v
+    v = v / np.linalg.norm(v, axis=1)[:, None]
+    return np.stack([np.arctan2(v[:, 1], v[:, 0]) % (2 * np.pi), np.arcsin(np.clip(v[:, 2], -1, 1))], axis=-1)
+
+
 def pointing_rotation(lon, lst, ra, dec):
     """R = [east, north, up] at (lon - (lst - ra), dec): rows are the Pointing axes u, v, w in ITRS
     (astro/frames/pointing_frame.py:149-165)."""

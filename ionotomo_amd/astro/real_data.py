@@ -24,7 +24,7 @@ import time as _time
 import numpy as np
 
 from .radio_array import RadioArray, generate_example_radio_array
-from .frames import geodetic_from_itrs, gmst_rad, pointing_rotation
+from .frames import geodetic_from_itrs, gmst_rad, itrs_direction_to_icrs, pointing_rotation
 
 # slot name -> which of the (antenna, time, direction, frequency) axes it carries
 _SLOT_AXES = {"phase": (0, 1, 2, 3), "variance": (0, 1, 2, 3), "prop": (0, 1, 2, 3), "clock": (0, 1), "const": (0,)}
@@ -319,8 +319,7 @@ def sky_from_pointing_dirs(dirs_uvw, centre_itrs_m, phase_radec, unix_time):
     g = gmst_rad(unix_time)
     R = pointing_rotation(lon, g + lon, phase_radec[0], phase_radec[1])
     v = np.asarray(dirs_uvw, dtype=np.float64) @ R                 # rows of R are u, v, w in ITRS
-    ra = (np.arctan2(v[:, 1], v[:, 0]) + g) % (2 * np.pi)
-    return np.stack([ra, np.arcsin(np.clip(v[:, 2] / np.linalg.norm(v, axis=1), -1, 1))], axis=-1)
+    return itrs_direction_to_icrs(v, unix_time)
 
 
 def generate_example_datapack(Nant=10, Ntime=1, Ndir=10, Nfreqs=4, fov=4., alt=90., az=0., time=None, radio_array=None,
@@ -349,8 +348,7 @@ def generate_example_datapack(Nant=10, Ntime=1, Ndir=10, Nfreqs=4, fov=4., alt=9
     enu = np.array([np.cos(a) * np.sin(z), np.cos(a) * np.cos(z), np.sin(a)])
     from ..synthetic import enu_rotation
     v = enu @ enu_rotation(lon, lat)
-    g = gmst_rad(t0)
-    phase_centre = np.array([(np.arctan2(v[1], v[0]) + g) % (2 * np.pi), np.arcsin(np.clip(v[2], -1, 1))])
+    phase_centre = itrs_direction_to_icrs(v, t0)[0]
     phi = np.deg2rad(rng.uniform(-fov / 2., fov / 2., Ndir))
     theta = np.deg2rad(rng.uniform(0., 360., Ndir))
     uvw = np.stack([np.cos(theta) * np.sin(phi), np.sin(theta) * np.sin(phi), np.cos(phi)], -1)

@@ -128,6 +128,8 @@ struct iono_ctx {
         size_t cap_order = 0, cap_bstart = 0, cap_win = 0;
         double fit_fraction = 0;         // chunks whose window fits the LDS image
     } fplan;
+    char *h_pinned = nullptr;        // pinned staging of small downloads (iono_dev_download): result + flags in one round trip
+    size_t pinned_cap = 0;
     double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
     int64_t rayw_cap = 0;
     double *d_freqs = nullptr;       // frequencies of the phase observable on the device (cached copy of h_freqs)
@@ -475,6 +477,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_rayw) (void)hipFree(c->d_rayw);
     plan_free(c);
     fplan_free(c);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
     for (auto &wp : c->walk) {
@@ -1633,6 +1636,76 @@ static int adjoint_host_finish(iono_ctx *c, double *dG, int scale_by_grid, doubl
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(grad_out, dG, n * 8, hipMemcpyDeviceToHost, c->stream));
     return finish_host_call(c, what);
+}
+
+// ---- device memory for hosts that keep operands resident between calls without torch (the reference-signature facade) ---------
+int iono_dev_alloc(iono_ctx *c, size_t bytes, void **out) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (!out) return fail(c, IONO_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    HIP_TRY(c, hipMalloc(out, bytes ? bytes : 8));
+    return IONO_OK;
+}
+int iono_dev_free(iono_ctx *c, void *p) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (!p) return IONO_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(p));
+    return IONO_OK;
+}
+int iono_dev_upload(iono_ctx *c, void *dst_dev, const void *src_host, size_t bytes) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (bytes && (!dst_dev || !src_host)) return fail(c, IONO_ERR_ARG, "iono_dev_upload: null pointer");
+    HIP_TRY(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return IONO_OK;
+}
+int iono_dev_zero(iono_ctx *c, void *p_dev, size_t bytes) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (bytes && !p_dev) return fail(c, IONO_ERR_ARG, "iono_dev_zero: null pointer");
+    HIP_TRY(c, hipMemsetAsync(p_dev, 0, bytes, c->stream));
+    return IONO_OK;
+}
+// also the end of a chain of _dev launches: waits for the ctx stream and turns an out-of-grid flag into IONO_ERR_OOB
+int iono_dev_download(iono_ctx *c, void *dst_host, const void *src_dev, size_t bytes) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (bytes && (!dst_host || !src_dev)) return fail(c, IONO_ERR_ARG, "iono_dev_download: null pointer");
+    if (bytes <= ((size_t)1 << 20)) {
+        // small results (a [Na,Nt,Nd] dTEC is 20 kB): payload and flags through pinned memory, ONE wait on the stream
+        if (c->pinned_cap < bytes + 16) {
+            if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+            c->h_pinned = nullptr, c->pinned_cap = 0;
+            HIP_TRY(c, hipHostMalloc((void **)&c->h_pinned, ((size_t)1 << 20) + 16, hipHostMallocDefault));
+            c->pinned_cap = ((size_t)1 << 20) + 16;
+        }
+        int *hf = (int *)(c->h_pinned + ((bytes + 15) & ~(size_t)15));
+        HIP_TRY(c, hipMemcpyAsync(c->h_pinned, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(hf, c->d_flags, 2 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(dst_host, c->h_pinned, bytes);
+        if (hf[0]) {
+            hf[0] = 0;
+            HIP_TRY(c, hipMemcpy(c->d_flags, hf, 2 * sizeof(int), hipMemcpyHostToDevice));
+            return fail(c, IONO_ERR_OOB, "iono_dev_download: One of the requested xi is out of bounds");
+        }
+        return IONO_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, c->stream));
+    return finish_host_call(c, "iono_dev_download");
+}
+// grad *= grid values: d/dm = ne d/dne for the log-model (what the host entry points' scale_by_grid does)
+int iono_scale_by_grid_dev(iono_ctx *c, double *grad_dev) {
+    int rc = need_grid(c);
+    if (rc) return rc;
+    if (!grad_dev) return fail(c, IONO_ERR_ARG, "iono_scale_by_grid_dev: null pointer");
+    const int64_t n = ncells(c);
+    dispatch_storage(c, [&](auto *tag) {
+        using GT = std::remove_pointer_t<decltype(tag)>;
+        hipLaunchKernelGGL((k_scale_by_grid<double, GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, grad_dev, (const GT *)cur_values(c), n);
+        return IONO_OK;
+    });
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
 }
 
 int iono_walk_order(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int *order_out) {

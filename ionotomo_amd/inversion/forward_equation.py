@@ -31,16 +31,31 @@ def do_forward_equation(rays, ne_tci, quad="avg"):
 
 
 def forward_equation(rays, K_ne, m_tci, i0, quad="avg"):
-    """dtec[Na,Nt,Nd] using reference antenna ``i0`` (forward_equation.py:36-51)."""
+    """dtec[Na,Nt,Nd] using reference antenna ``i0`` (forward_equation.py:36-51).
+
+    A line search calls this again and again with the SAME ``rays`` array and a new model each time
+    (inversion/line_search.py:56,71,83): the rays stay resident on the device (keyed on the array OBJECT and its shape:
+    ``Context.resident``), the node values are recomputed only when the model changed (``Context.set_values_exp_cached``),
+    and only the [Na,Nt,Nd] result crosses PCIe -- a repeated call costs three small launches and one 20 kB copy."""
+    rays_in = rays
     rays = np.asarray(rays, dtype=np.float64)
     Na, Nt, Nd, _, Ns = rays.shape
     ctx = _lib.default_context()
     ctx.set_grid(m_tci.xvec, m_tci.yvec, m_tci.zvec, None, storage=m_tci.storage)
-    ctx.set_values_exp(m_tci.M, K_ne / TECU)
-    tec = ctx.forward_tec_rays(rays, kind=m_tci.kind, rule=quad)
-    tec = np.ascontiguousarray(tec.reshape(Na, Nt * Nd))
-    ctx.call("iono_subtract_reference", _lib._dp(tec), Na, Nt * Nd, int(i0))
-    return tec.reshape(Na, Nt, Nd)
+    ctx.set_values_exp_cached(m_tci.M, K_ne / TECU)
+    rays_dev = ctx.resident(rays) if rays is rays_in else None        # (a converted copy has no identity to key on)
+    if rays_dev is None:
+        tec = ctx.forward_tec_rays(rays, kind=m_tci.kind, rule=quad)
+        tec = np.ascontiguousarray(tec.reshape(Na, Nt * Nd))
+        ctx.call("iono_subtract_reference", _lib._dp(tec), Na, Nt * Nd, int(i0))
+        return tec.reshape(Na, Nt, Nd)
+    R = Na * Nt * Nd
+    tec_dev = ctx.scratch("tec", R * 8)
+    ctx.call("iono_forward_tec_rays_dev", rays_dev, R, int(Ns), _lib.interp_kind(m_tci.kind), _lib.quad_rule(quad), tec_dev)
+    ctx.call("iono_subtract_reference_dev", tec_dev, Na, Nt * Nd, int(i0))
+    tec = np.empty((Na, Nt, Nd), dtype=np.float64)
+    ctx.call("iono_dev_download", _lib._V(tec.ctypes.data), tec_dev, R * 8)
+    return tec
 
 
 def forward_equation_dask(rays, K_ne, m_tci, i0, quad="avg"):

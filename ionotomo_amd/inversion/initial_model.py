@@ -6,7 +6,7 @@ pyiri2016 Fortran package), and optionally multiplies by a log-normal Matern-5/2
 """
 import numpy as np
 
-from ..astro.frames import (determine_inversion_domain, geodetic_from_itrs, gmst_rad, icrs_to_itrs_direction,
+from ..astro.frames import (determine_inversion_domain, geodetic_from_itrs, gmst_rad, icrs_direction_in_itrs,
                             itrs_to_pointing_km, pointing_rotation)
 from ..geometry.tri_cubic import TriCubic
 from ..ionosphere.iri import a_priori_model_
@@ -37,7 +37,7 @@ def create_initial_model(datapack, ant_idx=-1, time_idx=-1, dir_idx=-1, zmax=100
     patches, _ = datapack.get_directions(dir_idx=dir_idx)
     centre, phase, fixtime, R = model_frame_of(datapack, time_idx)
     ants_km = itrs_to_pointing_km(antennas, centre, R)
-    dirs = icrs_to_itrs_direction(patches[:, 0], patches[:, 1], gmst_rad(fixtime)) @ R.T
+    dirs = icrs_direction_in_itrs(patches[:, 0], patches[:, 1], fixtime) @ R.T
     xvec, yvec, zvec = determine_inversion_domain(spacing, ants_km, dirs, zmax, padding=padding)
     X, Y, Z = np.meshgrid(xvec, yvec, zvec, indexing='ij')
     itrs = np.stack([X.ravel(), Y.ravel(), Z.ravel()], -1) * 1000.0 @ R + centre

@@ -85,13 +85,30 @@ w2 = syn.make_workload("cfg2")
 rays_h = it.calc_rays(w2["origins"][:, 0, 0, :], w2["directions"][0], [0.0], None, None, None,
                       it.TriCubic(w2["xvec"], w2["yvec"], w2["zvec"], w2["ne"]), 120e6, True, w2["tmax"], w2["Ns"])
 m_tci = it.TriCubic(w2["xvec"], w2["yvec"], w2["zvec"], w2["m"])
-it.forward_equation(rays_h, w2["K_ne"], m_tci, 0)
-t0 = time.perf_counter()
-for _ in range(5):
+from ionotomo_amd import _lib as _il  # noqa: E402
+ts = []
+for _ in range(5):                       # every call from a cold cache: grid + 10.7 MB of rays over PCIe
+    _il.default_context().forget()
+    t0 = time.perf_counter()
     it.forward_equation(rays_h, w2["K_ne"], m_tci, 0)
-dt = (time.perf_counter() - t0) / 5
+    ts.append(time.perf_counter() - t0)
+dt = float(np.median(ts))
 out["cfg2_facade_forward_equation_ms_pcie_inclusive"] = dt * 1e3
 out["cfg2_facade_ray_integrals_per_s_pcie_inclusive"] = rays_h.shape[0] * rays_h.shape[2] / dt
+it.forward_equation(rays_h, w2["K_ne"], m_tci, 0)
+ts = []
+for _ in range(50):                      # the same rays and model again (a line search's repeated evaluations): resident operands
+    t0 = time.perf_counter()
+    it.forward_equation(rays_h, w2["K_ne"], m_tci, 0)
+    ts.append(time.perf_counter() - t0)
+out["cfg2_facade_forward_equation_us_resident_second_call"] = float(np.median(ts)) * 1e6
+ts = []
+for k in range(20):                      # a new model every call (m + alpha dm), the same rays
+    m2 = it.TriCubic(w2["xvec"], w2["yvec"], w2["zvec"], w2["m"] + 1e-3 * k)
+    t0 = time.perf_counter()
+    it.forward_equation(rays_h, w2["K_ne"], m2, 0)
+    ts.append(time.perf_counter() - t0)
+out["cfg2_facade_forward_equation_us_resident_rays_new_model"] = float(np.median(ts)) * 1e6
 
 # ---------------------------------------------------------------- cfg5 (one GPU's share)
 wb = bench.build_workload(0)
