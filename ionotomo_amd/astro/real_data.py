@@ -14,8 +14,9 @@ Index conventions are the reference's (:145-260): ``-1`` selects a whole axis, i
 sorted order, and a getter returns the outer-product block of the selected indices.
 
 Storage: ``save``/``load`` use ``.npz`` natively; a filename ending in ``.hdf5``/``.h5`` uses the
-reference's ``datapack/*`` HDF5 layout (:43-117) and needs h5py (not installed in the build image, so
-that branch is untested here).  PARITY UNPINNED: the reference class cannot be instantiated without
+reference's ``datapack/*`` HDF5 layout (:43-117) through the pure-numpy reader / writer of utils/hdf5_lite.py, pinned by a file
+the reference's own ``DataPack.save`` wrote with real h5py (tests/golden/datapack_reference_h5py.hdf5).  Otherwise
+PARITY UNPINNED: the reference class cannot be instantiated without
 astropy; the behaviour its own test pins (tests/test_astro.py:15-35) is restated in
 tests/test_datapack.py.
 """
@@ -275,41 +276,40 @@ class DataPack(object):
         self.ref_ant = ref or None
 
     def _save_hdf5(self, filename):
-        import h5py
-        dt = h5py.special_dtype(vlen=str)
-        with h5py.File(filename, "w") as f:
-            f.create_dataset("datapack/antennas/labels", data=np.array(self.antenna_labels, dtype=object), dtype=dt)
-            f["datapack/antennas"].attrs["frequency"] = self.radio_array.frequency
-            f.create_dataset("datapack/antennas/locs", data=self.antennas)
-            f.create_dataset("datapack/directions/patchnames", data=np.array(self.patch_names, dtype=object), dtype=dt)
-            f.create_dataset("datapack/directions/ra", data=np.rad2deg(self.directions[:, 0]))
-            f.create_dataset("datapack/directions/dec", data=np.rad2deg(self.directions[:, 1]))
-            f.create_dataset("datapack/times/timestamps", data=np.array(self.timestamps, dtype=object), dtype=dt)
-            f.create_dataset("datapack/times/gps", data=self.times - _UNIX_MINUS_GPS)
-            f.create_dataset("datapack/freqs", data=self.freqs)
-            for name in ("phase", "variance", "clock", "const"):
-                if getattr(self, name, None) is not None:
-                    f.create_dataset("datapack/" + name, data=getattr(self, name))
-            f["datapack/phase"].attrs["ref_ant"] = str(self.ref_ant)
+        """The reference's ``datapack/*`` layout (astro/real_data.py:43-79): same dataset names, dtypes (float64, variable-length
+        UTF-8 strings) and attributes, written by utils/hdf5_lite.py (h5py / h5dump read it: tests/test_hdf5_lite.py)."""
+        from ..utils import hdf5_lite
+        dp = {"antennas": {"labels": np.array(self.antenna_labels, dtype=object), "locs": np.asarray(self.antennas, dtype=np.float64),
+                           "@attrs": {"frequency": float(self.radio_array.frequency)}},
+              "directions": {"patchnames": np.array(self.patch_names, dtype=object), "ra": np.rad2deg(self.directions[:, 0]),
+                             "dec": np.rad2deg(self.directions[:, 1])},
+              "times": {"timestamps": np.array(self.timestamps, dtype=object), "gps": np.asarray(self.times) - _UNIX_MINUS_GPS},
+              "freqs": np.asarray(self.freqs, dtype=np.float64)}
+        for name in ("phase", "variance", "clock", "const"):
+            if getattr(self, name, None) is not None:
+                dp[name] = np.asarray(getattr(self, name), dtype=np.float64)
+        if "phase" in dp:
+            dp["phase@attrs"] = {"ref_ant": str(self.ref_ant)}
+        hdf5_lite.write(filename, {"datapack": dp})
 
     def _load_hdf5(self, filename):
-        import h5py
-        with h5py.File(filename, "r") as f:
-            d = dict(antenna_labels=f["datapack/antennas/labels"][:].astype(str),
-                     antennas=f["datapack/antennas/locs"][:, :],
-                     patch_names=f["datapack/directions/patchnames"][:].astype(str),
-                     directions=np.deg2rad(np.stack([f["datapack/directions/ra"][:], f["datapack/directions/dec"][:]], -1)),
-                     timestamps=f["datapack/times/timestamps"][:].astype(str),
-                     times=f["datapack/times/gps"][:] + _UNIX_MINUS_GPS, freqs=f["datapack/freqs"][:])
-            na, nt, nd, nf = len(d["antennas"]), len(d["times"]), len(d["directions"]), len(d["freqs"])
-            shapes = {"phase": (na, nt, nd, nf), "variance": (na, nt, nd, nf), "clock": (na, nt), "const": (na,)}
-            for name, shp in shapes.items():
-                d[name] = f["datapack/" + name][...] if "datapack/" + name in f else np.zeros(shp)
-            ref = f["datapack/phase"].attrs.get("ref_ant", None) if "datapack/phase" in f else None
-            d["radio_array"] = RadioArray(antenna_pos=d["antennas"], frequency=f["datapack/antennas"].attrs["frequency"])
+        """A datapack written by the reference (h5py) or by ``_save_hdf5`` (astro/real_data.py:81-117)."""
+        from ..utils import hdf5_lite
+        f = hdf5_lite.read(filename)["datapack"]
+        d = dict(antenna_labels=np.asarray(f["antennas"]["labels"]).astype(str), antennas=f["antennas"]["locs"],
+                 patch_names=np.asarray(f["directions"]["patchnames"]).astype(str),
+                 directions=np.deg2rad(np.stack([f["directions"]["ra"], f["directions"]["dec"]], -1)),
+                 timestamps=np.asarray(f["times"]["timestamps"]).astype(str), times=f["times"]["gps"] + _UNIX_MINUS_GPS,
+                 freqs=f["freqs"])
+        na, nt, nd, nf = len(d["antennas"]), len(d["times"]), len(d["directions"]), len(d["freqs"])
+        shapes = {"phase": (na, nt, nd, nf), "variance": (na, nt, nd, nf), "clock": (na, nt), "const": (na,)}
+        for name, shp in shapes.items():
+            d[name] = f[name] if name in f else np.zeros(shp)
+        ref = f.get("phase@attrs", {}).get("ref_ant", None)
+        d["radio_array"] = RadioArray(antenna_pos=d["antennas"], frequency=f["antennas"]["@attrs"]["frequency"])
         self.add_data_dict(**d)
         if ref is not None and str(ref) != "None":
-            self.set_reference_antenna(str(np.array(ref).astype(str).item(0)))
+            self.set_reference_antenna(str(ref))
 
 
 def sky_from_pointing_dirs(dirs_uvw, centre_itrs_m, phase_radec, unix_time):

@@ -134,29 +134,33 @@ class TriCubic(object):
         X, Y, Z = np.meshgrid(self.xvec, self.yvec, self.zvec, indexing='ij')
         return X.flatten(order='C'), Y.flatten(order='C'), Z.flatten(order='C')
 
-    # -- storage: HDF5 "TCI/{xvec,yvec,zvec,M}" (geometry/tri_cubic.py:81-99) or .npz with the same four names ----
+    # -- storage: HDF5 "TCI/{xvec,yvec,zvec,M}" (geometry/tri_cubic.py:81-99; + the frame attributes inversion/solution.py:26-47
+    #    adds to "TCI") through the pure-numpy reader / writer of utils/hdf5_lite.py, or .npz with the same four names ----------
     def load(self, filename, **kwargs):
+        self.frame_attrs = {}
         if str(filename).endswith(".npz"):
             with np.load(filename, allow_pickle=False) as z:
                 xvec, yvec, zvec, M = z["xvec"], z["yvec"], z["zvec"], z["M"]
         else:
-            import h5py                                  # not installed in the build image: branch untested there
-            with h5py.File(filename, 'r') as f:
-                xvec, yvec, zvec, M = f["TCI/xvec"][:], f["TCI/yvec"][:], f["TCI/zvec"][:], f["TCI/M"][:, :, :]
+            from ..utils import hdf5_lite
+            t = hdf5_lite.read(filename)["TCI"]
+            xvec, yvec, zvec, M = t["xvec"], t["yvec"], t["zvec"], t["M"]
+            self.frame_attrs = dict(t.get("@attrs", {}))          # obstime, fixtime [gps s], location [km], phase [deg] when present
         self.xvec, self.yvec, self.zvec = xvec, yvec, zvec
         self.M = M
 
-    def save(self, filename):
+    def save(self, filename, frame_attrs=None):
         arrays = {k: np.asarray(v, dtype=np.double) for k, v in
                   (("xvec", self.xvec), ("yvec", self.yvec), ("zvec", self.zvec), ("M", self.M))}
         if str(filename).endswith(".npz"):
             with open(filename, "wb") as f:
                 np.savez(f, **arrays)
             return
-        import h5py
-        with h5py.File(filename, 'w') as f:
-            for k, v in arrays.items():
-                f.create_dataset("TCI/" + k, data=v)
+        from ..utils import hdf5_lite
+        attrs = frame_attrs if frame_attrs is not None else getattr(self, "frame_attrs", None)
+        if attrs:
+            arrays["@attrs"] = dict(attrs)
+        hdf5_lite.write(filename, {"TCI": arrays})
 
 
 def bisection(array, value):

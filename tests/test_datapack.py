@@ -120,23 +120,3 @@ def test_full_objective_prior_terms():
     assert abs(s_full - want) < 1e-10 * abs(want)
 
 
-def test_hdf5_round_trip_of_tci_and_datapack(tmp_path):
-    """The reference's on-disk layouts -- ``TCI/{xvec,yvec,zvec,M}`` (geometry/tri_cubic.py:81-99) and ``datapack/*``
-    (astro/real_data.py:43-117) -- written and read back through h5py.  Skipped where h5py is not installed (this
-    build image has no HDF5 library; the ``.npz`` containers with the same dataset names are tested above)."""
-    h5py = pytest.importorskip("h5py")
-    from ionotomo_amd import TriCubic
-    rng = np.random.default_rng(0)
-    tci = TriCubic(np.linspace(0, 1, 5), np.linspace(-1, 1, 6), np.linspace(0, 10, 7), rng.normal(size=(5, 6, 7)))
-    f = str(tmp_path / "tci.hdf5")
-    tci.save(f)
-    with h5py.File(f, "r") as h:
-        assert set(h["TCI"].keys()) == {"xvec", "yvec", "zvec", "M"} and h["TCI/M"].shape == (5, 6, 7)
-    back = TriCubic(np.zeros(2), np.zeros(2), np.zeros(2), np.zeros((2, 2, 2)))
-    back.load(f)
-    assert np.array_equal(back.M, tci.M) and np.array_equal(back.zvec, tci.zvec)
-    dp = generate_example_datapack(Nant=4, Ntime=3, Ndir=2, time=1.5e9, seed=1)
-    g = str(tmp_path / "dp.hdf5")
-    dp.save(g)
-    dp2 = DataPack(filename=g)
-    assert np.allclose(dp2.phase, dp.phase) and np.allclose(dp2.antennas, dp.antennas) and list(dp2.antenna_labels) == list(dp.antenna_labels)

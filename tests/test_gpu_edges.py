@@ -228,3 +228,13 @@ def test_even_N_both_rules_against_their_fixtures(golden):
         t_rays = ctx.forward_tec_rays(c["rays64"], rule=rule)
         t_str = ctx.forward_tec_straight(w["origins"], w["directions"], w["tmax"], 64, rule=rule).reshape(8, 1, 8)
         assert rel(t_rays, gg["tec64"]) < 1e-12 and rel(t_str, gg["tec64"]) < 1e-12
+    # the default rule against the UNMODIFIED reference on the scipy it was written for (scipy 1.7.1 ``simps``; round 3:
+    # oracle/make_golden_conda.py) -- even N = 64 and 32, odd N = 65, through the facade and both kernels
+    g_un = golden("forward_tec_even_simps_unmodified")
+    for N in (64, 32, 65):
+        rays = g_un["rays%d" % N]
+        d = it.forward_equation(rays, K_ne, m_tci, i0)
+        assert np.max(np.abs(d - g_un["dtec%d" % N])) < 1e-12 * scale, N
+        assert rel(ctx.forward_tec_rays(rays, rule="avg"), g_un["tec%d" % N]) < 1e-12, N
+        t_str = ctx.forward_tec_straight(w["origins"], w["directions"], w["tmax"], N, rule="avg").reshape(8, 1, 8)
+        assert rel(t_str, g_un["tec%d" % N]) < 1e-9, N            # (in-kernel rays vs the reference's LSODA rays: 1e-9 km)

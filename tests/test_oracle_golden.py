@@ -80,6 +80,31 @@ def test_forward_equation_even_N_reference_era_avg_rule(golden):
     assert rel(other, g["tec64"]) > 1e-8
 
 
+def test_forward_equation_even_N_unmodified_reference_on_its_own_scipy(golden):
+    """The direct pin of quad='avg': inversion/forward_equation.py run UNMODIFIED under scipy 1.7.1, whose ``simps`` is the
+    function the reference was written against (oracle/make_golden_conda.py, the image's second interpreter) -- no alias, no
+    re-bound name.  Even N = 64 and 32 (the reference default N = nz is even), odd N = 65 for completeness; the rays are the
+    reference's own cast_ray output under that interpreter."""
+    g = golden("forward_tec_even_simps_unmodified")
+    assert "1.7" in str(g["meta"])
+    w = syn.make_workload("cfg1")
+    K_ne, i0 = float(g["K_ne"]), int(g["i0"])
+    ne = O.ne_from_log_model(w["m"], K_ne)
+    for N in (64, 32, 65):
+        rays = g["rays%d" % N]
+        assert rel(rays, O.straight_rays(w["origins"], w["directions"], w["tmax"], N)) < 1e-9          # (LSODA tolerance of cast_ray)
+        tec = O.forward_tec(rays, w["xvec"], w["yvec"], w["zvec"], ne, O.QUAD_SIMPSON_AVG)
+        assert rel(tec, g["tec%d" % N]) < 1e-13, N
+        dtec = O.forward_equation(rays, K_ne, w["xvec"], w["yvec"], w["zvec"], w["m"], i0, O.QUAD_SIMPSON_AVG)
+        assert np.max(np.abs(dtec - g["dtec%d" % N])) < 1e-13 * np.max(np.abs(g["tec%d" % N])), N
+    other = O.forward_tec(g["rays64"], w["xvec"], w["yvec"], w["zvec"], ne, O.QUAD_SIMPSON_SCIPY)
+    assert rel(other, g["tec64"]) > 1e-8                                       # today's scipy rule is a different number
+    # round 2's fixture (the even='avg' composition bound into the reference module) was the same rule: the two pins agree
+    g2, c = golden("forward_tec_even_avg"), golden("cast_ray")
+    t2 = O.forward_tec(c["rays64"], w["xvec"], w["yvec"], w["zvec"], ne, O.QUAD_SIMPSON_AVG)
+    assert rel(t2, g2["tec64"]) < 1e-13 and rel(g2["tec64"], g["tec64"]) < 1e-9
+
+
 def test_simpson_avg_rule_is_exact_for_quadratics_and_matches_definition():
     rng = np.random.default_rng(0)
     s = np.sort(rng.uniform(0, 3, size=(5, 10)), axis=-1)
