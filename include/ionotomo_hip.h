@@ -295,6 +295,21 @@ int iono_compact_sirt_update_dev(iono_ctx *ctx, double *x_dev, const double *C_d
 int iono_trace_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R,
                           double tmax, int Ns, double frequency, int bend, int interp_kind, int substeps,
                           int independent, double *rays_dev);
+/* Curved-ray TEC and its transpose WITHOUT the rays: the reference's curved path is cast_ray -> Fermat.integrate_ray ->
+ * forward_equation on the returned samples (geometry/calc_rays.py:61-96, inversion/fermat.py:58-72,150-174,
+ * inversion/forward_equation.py:27-28); rays[R][4][Ns] is 5.1 GB at config 4's ray count.  These two entry points run the same
+ * RK4 stepper as iono_trace_fermat_dev (identical samples) and accumulate the non-uniform Simpson rule on the fly
+ * (k_fermat_tec, iono_fermat_kernels.h):
+ *   tec[r]  = ne_scale * sum_k c_k(s) ne(x_k)                     (== iono_trace_fermat_dev + iono_forward_tec_rays_dev)
+ *   grad   += ne_scale * sum_r w[r] sum_k c_k(s) W(x_k)           (== ... + iono_adjoint_rays_dev; the path is held fixed)
+ * The grid must hold ne [m^-3] (the refractive index is derived from it at `frequency`); interp_kind_n interpolates n
+ * for the ray equation, interp_kind_ne the integrand.  float64 storage only. */
+int iono_forward_tec_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R, double tmax,
+                                int Ns, double frequency, int bend, int interp_kind_n, int substeps, int independent,
+                                int interp_kind_ne, int quad_rule, double ne_scale, double *tec_dev);
+int iono_adjoint_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, const double *w_dev, int64_t R,
+                            double tmax, int Ns, double frequency, int bend, int interp_kind_n, int substeps, int independent,
+                            int interp_kind_ne, int quad_rule, double ne_scale, double *grad_dev);
 int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
 
 /* ---- model-covariance smoothing C_m: Covariance.smooth =

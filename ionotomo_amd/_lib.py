@@ -105,6 +105,8 @@ _SIGNATURES = {
     "iono_forward_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
     "iono_walk_order": [_P, _P, _L, _D, ctypes.POINTER(ctypes.c_int)],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _V],
+    "iono_forward_tec_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],
+    "iono_adjoint_fermat_dev": [_V, _V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],
     "iono_smooth_separable_dev": [_V, _V, _V, _P, _P, _P, _I],

@@ -1,0 +1,134 @@
+// fused curved-ray kernels: the Fermat ray ODE and the line integral (or its transpose) in ONE traversal, rays[R,4,Ns] never exists
+#ifndef IONO_FERMAT_KERNELS_H
+#define IONO_FERMAT_KERNELS_H
+
+namespace {
+
+// The reference's curved path is cast_ray -> Fermat.integrate_ray -> forward_equation on the returned samples
+// (geometry/calc_rays.py:61-96, inversion/fermat.py:58-72,150-174, inversion/forward_equation.py:27-28): the samples of every ray are
+// stored (x, y, z, s: 4 Ns doubles per ray = 5.1 GB at config 4's ray count) and then integrated with Simpson's rule on the
+// NON-UNIFORM abscissae s.  Here the RK4 stepper of k_trace_fermat (same right-hand side, same order of operations: the samples
+// are bit-identical to the traced ones) feeds a streaming form of that quadrature, so a ray is traced and integrated -- or traced
+// and back-projected -- in registers.
+//
+// Streaming quadrature.  Every rule the explicit-sample kernels know (quad_weight, iono_device_common.h: composite Simpson for odd
+// N; for even N the reference-era even='avg' rule or scipy >= 1.11's end correction; trapezoid) is a sum of contributions of
+// intervals (k-1, k) and of triples (k-2, k-1, k), so the weight of sample k-2 is final once sample k has been seen: a window of
+// three abscissae / weights, one finished weight per step, the last two flushed at the end.
+struct StreamQuad {
+    double s0, s1, w0, w1;       // abscissae and weights-so-far of samples k-2 and k-1
+    int N, rule;
+    __device__ __forceinline__ void init(int N_, int rule_, double s_first) {
+        N = N_, rule = rule_, s0 = 0.0, w0 = 0.0, s1 = s_first, w1 = 0.0;
+    }
+    // sample k >= 1 at abscissa s2: returns the FINAL weight of sample k-2 (meaningful for k >= 2) and shifts the window
+    __device__ __forceinline__ double feed(int k, double s2) {
+        double w2 = 0.0;
+        const double h1 = s2 - s1;
+        if (rule == IONO_QUAD_TRAPEZOID || N == 2) {
+            w1 += 0.5 * h1, w2 += 0.5 * h1;
+        } else {
+            const bool even = !(N & 1), avg = even && rule == IONO_QUAD_SIMPSON_AVG;
+            if (avg && (k == 1 || k == N - 1)) w1 += 0.25 * h1, w2 += 0.25 * h1;      // the two trapezoid ends, halved by the average
+            if (k >= 2) {
+                const double h0 = s1 - s0, hs = h0 + h1;
+                // Simpson pairs: odd N and the scipy rule pair (0,1,2), (2,3,4), ...; 'avg' also pairs (1,2,3), (3,4,5), ..., each at 1/2
+                const double f = (k & 1) ? (avg && k >= 3 ? 0.5 : 0.0) : (avg ? 0.5 : 1.0);
+                if (f != 0.0) {
+                    const double c = f * hs / 6.0;
+                    w0 += c * (2.0 - h1 / h0), w1 += c * (hs * hs / (h0 * h1)), w2 += c * (2.0 - h0 / h1);
+                }
+                if (even && !avg && k == N - 1) {                                       // scipy >= 1.11: last interval from the last three points
+                    w2 += (2.0 * h1 * h1 + 3.0 * h0 * h1) / (6.0 * hs), w1 += (h1 * h1 + 3.0 * h0 * h1) / (6.0 * h0);
+                    w0 -= h1 * h1 * h1 / (6.0 * h0 * hs);
+                }
+            }
+        }
+        const double out = w0;
+        s0 = s1, s1 = s2, w0 = w1, w1 = w2;
+        return out;
+    }
+};
+
+// KN: interpolant of the refractive index (the tracer's right-hand side); kne (run-time): interpolant of the integrand.
+// ADJ = false: tec[r] = ne_scale * sum_k c_k ne(x_k);  ADJ = true: G += ne_scale * w[r] * c_k * (interpolation weights at x_k).
+// Lanes = rays; samples that leave the grid are skipped and flagged, as in k_forward_rays / k_adjoint_rays.
+template <int KN, bool BEND, bool ADJ>
+__global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__restrict__ nM, const double *__restrict__ origins,
+                                                   const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps, int rule,
+                                                   int stype, int kne, double ne_scale, const double *__restrict__ wray,
+                                                   double *__restrict__ tec, double *__restrict__ G, int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const Axes ax = stage_axes(g, lds);
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double wr = ADJ ? wray[r] * ne_scale : 0.0;
+    if (ADJ && wr == 0.0) return;
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm, u.py = dy / nrm, u.pz = dz / nrm;
+    u.x = origins[3 * r], u.y = origins[3 * r + 1], u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
+    const double ztop = ax.z[ax.nz - 1] + 1e-9 * fabs(tmax);
+    bool oob = false;
+    // value of the integrand (forward) or "inside" marker (adjoint) of the samples in the window
+    auto inside = [&](const FState &p) {
+        return !(kne == IONO_INTERP_TRILINEAR ? sample_outside<IONO_INTERP_TRILINEAR>(ax, p.x, p.y, p.z)
+                                               : sample_outside<IONO_INTERP_TRICUBIC>(ax, p.x, p.y, p.z));
+    };
+    auto value = [&](const FState &p) {
+        return kne == IONO_INTERP_TRILINEAR ? sample_at<double, IONO_INTERP_TRILINEAR>(g, ax, p.x, p.y, p.z)
+                                            : sample_at<double, IONO_INTERP_TRICUBIC>(g, ax, p.x, p.y, p.z);
+    };
+    auto scatter = [&](const FState &p, double wgt) {
+        if (kne == IONO_INTERP_TRILINEAR) scatter_trilinear<double>(g, ax, G, p.x, p.y, p.z, wgt);
+        else scatter_tricubic<double>(g, ax, G, p.x, p.y, p.z, wgt);
+    };
+    StreamQuad q;
+    q.init(Ns, rule, 0.0);
+    FState p0 = u, p1 = u;                 // positions of samples k-2, k-1 (adjoint)
+    double y0 = 0.0, y1 = 0.0;             // integrand at samples k-2, k-1 (forward)
+    bool in0 = false, in1 = inside(u);
+    if (!in1) oob = true;
+    if (!ADJ && in1) y1 = value(u);
+    double acc = 0.0;
+    for (int k = 1; k < Ns; ++k) {
+        for (int sub = 0; sub < substeps; ++sub) {
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs<KN, BEND>(g, nM, axpy(u, ca, kprev), stype);
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= outside(ax.x, ax.nx, u.x) || outside(ax.y, ax.ny, u.y) || !(u.z >= ax.z[0] && u.z <= ztop);
+        const bool in2 = inside(u);
+        if (!in2) oob = true;
+        const double y2 = (!ADJ && in2) ? value(u) : 0.0;
+        const double wk = q.feed(k, u.s);                       // final weight of sample k-2
+        if (k >= 2 && in0) {
+            if (ADJ) scatter(p0, wr * wk);
+            else acc = fma(wk, y0, acc);
+        }
+        p0 = p1, p1 = u, y0 = y1, y1 = y2, in0 = in1, in1 = in2;
+    }
+    // the last two samples (the window after the final shift: k-2 = Ns-2, k-1 = Ns-1)
+    if (Ns >= 2 && in0) {
+        if (ADJ) scatter(p0, wr * q.w0);
+        else acc = fma(q.w0, y0, acc);
+    }
+    if (in1) {
+        if (ADJ) scatter(p1, wr * q.w1);
+        else acc = fma(q.w1, y1, acc);
+    }
+    if (!ADJ) tec[r] = acc * ne_scale;
+    if (oob) atomicOr(oob_flag, 1);
+}
+
+}  // namespace
+
+#endif

@@ -38,6 +38,7 @@
 #include "iono_solver_kernels.h"
 #include "iono_binned_kernels.h"
 #include "iono_aux_kernels.h"
+#include "iono_fermat_kernels.h"
 
 namespace {
 thread_local std::string g_last_error;
@@ -1884,6 +1885,54 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
 #undef LAUNCH_F
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
+}
+
+// ---- fused curved-ray forward / transpose (iono_fermat_kernels.h): trace and integrate in one traversal ---------------------------
+static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const double *dD, const double *dW, int64_t R, double tmax, int Ns,
+                             double frequency, int bend, int kind_n, int substeps, int independent, int kind_ne, int rule, double ne_scale,
+                             double *tec, double *grad) {
+    int rc = check_common(c, R, Ns, kind_n, rule);
+    if (rc) return rc;
+    rc = check_common(c, R, Ns, kind_ne, rule);
+    if (rc) return rc;
+    if (independent != IONO_RAY_Z && independent != IONO_RAY_S) return fail(c, IONO_ERR_ARG, "bad independent variable");
+    if (substeps < 1 || !(frequency > 0)) return fail(c, IONO_ERR_ARG, "need substeps >= 1 and frequency > 0");
+    if (c->storage != IONO_F64) return fail(c, IONO_ERR_ARG, "the fused curved-ray kernels need float64 grid storage");
+    if (!dO || !dD || (adjoint ? (!dW || !grad) : !tec)) return fail(c, IONO_ERR_ARG, "null pointer");
+    if (R == 0) return IONO_OK;
+    const int64_t n = ncells(c);
+    if (!c->d_nM) HIP_TRY(c, hipMalloc((void **)&c->d_nM, (size_t)n * 8));
+    if (c->nM_freq != frequency) {       // n = sqrt(1 - 8.98^2 ne / nu^2) at the nodes, rebuilt when ne or nu changed
+        hipLaunchKernelGGL((k_ne_to_n<double>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double *)cur_values(c), c->d_nM, n, frequency);
+        c->nM_freq = frequency;
+    }
+    const GridView g = view(c);
+    const dim3 grid((unsigned)((R + 63) / 64)), block(64);
+    const size_t lds = lds_bytes(c);
+#define LAUNCH_FT(K, B, A)                                                                                                              \
+    hipLaunchKernelGGL((k_fermat_tec<K, B, A>), grid, block, lds, c->stream, g, c->d_nM, dO, dD, R, tmax, Ns, substeps, rule, independent,   \
+                       kind_ne, ne_scale, dW, tec, grad, c->d_flags)
+    if (kind_n == IONO_INTERP_TRILINEAR) {
+        if (adjoint) { if (bend) LAUNCH_FT(IONO_INTERP_TRILINEAR, true, true); else LAUNCH_FT(IONO_INTERP_TRILINEAR, false, true); }
+        else { if (bend) LAUNCH_FT(IONO_INTERP_TRILINEAR, true, false); else LAUNCH_FT(IONO_INTERP_TRILINEAR, false, false); }
+    } else {
+        if (adjoint) { if (bend) LAUNCH_FT(IONO_INTERP_TRICUBIC, true, true); else LAUNCH_FT(IONO_INTERP_TRICUBIC, false, true); }
+        else { if (bend) LAUNCH_FT(IONO_INTERP_TRICUBIC, true, false); else LAUNCH_FT(IONO_INTERP_TRICUBIC, false, false); }
+    }
+#undef LAUNCH_FT
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
+int iono_forward_tec_fermat_dev(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, double frequency, int bend,
+                                int kind_n, int substeps, int independent, int kind_ne, int rule, double ne_scale, double *tec) {
+    return fermat_tec_launch(c, false, o, d, nullptr, R, tmax, Ns, frequency, bend, kind_n, substeps, independent, kind_ne, rule, ne_scale, tec,
+                             nullptr);
+}
+
+int iono_adjoint_fermat_dev(iono_ctx *c, const double *o, const double *d, const double *w, int64_t R, double tmax, int Ns, double frequency,
+                            int bend, int kind_n, int substeps, int independent, int kind_ne, int rule, double ne_scale, double *grad) {
+    return fermat_tec_launch(c, true, o, d, w, R, tmax, Ns, frequency, bend, kind_n, substeps, independent, kind_ne, rule, ne_scale, nullptr, grad);
 }
 
 int iono_trace_fermat(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, double frequency, int bend,

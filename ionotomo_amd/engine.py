@@ -253,6 +253,32 @@ class RayEngine(object):
                       int(bool(bend)), _lib.interp_kind(kind), int(substeps), _lib.ray_type(type), _ptr(out))
         return out
 
+    def forward_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=True, kind="linear", substeps=4, type="z", ne_kind=None,
+                       ne_scale=1.0, out=None):
+        """tec[R] along the Fermat rays WITHOUT materialising them: RK4 stepper + streaming non-uniform Simpson in one kernel
+        (== ``forward_rays(trace_fermat(...))`` to rounding; include/ionotomo_hip.h:iono_forward_tec_fermat_dev).  The grid must
+        hold ne [m^-3]; ``kind`` interpolates the refractive index, ``ne_kind`` (default: the engine's) the integrand."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        if out is None:
+            out = torch.empty(R, dtype=torch.float64, device=self.device)
+        nk = self.kind if ne_kind is None else _lib.interp_kind(ne_kind)
+        self.ctx.call("iono_forward_tec_fermat_dev", _ptr(origins_t), _ptr(dirs_t), R, float(tmax), int(Ns), float(frequency),
+                      int(bool(bend)), _lib.interp_kind(kind), int(substeps), _lib.ray_type(type), nk, self.rule, float(ne_scale), _ptr(out))
+        return out
+
+    def adjoint_fermat(self, origins_t, dirs_t, w_t, tmax, Ns, frequency, bend=True, kind="linear", substeps=4, type="z",
+                       ne_kind=None, ne_scale=1.0, out=None):
+        """out[nx,ny,nz] += transpose of ``forward_fermat`` applied to w (the ray paths held fixed): re-trace and scatter."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        if out is None:
+            out = torch.zeros(self.shape, dtype=torch.float64, device=self.device)
+        nk = self.kind if ne_kind is None else _lib.interp_kind(ne_kind)
+        self.ctx.call("iono_adjoint_fermat_dev", _ptr(origins_t), _ptr(dirs_t), _ptr(w_t), R, float(tmax), int(Ns), float(frequency),
+                      int(bool(bend)), _lib.interp_kind(kind), int(substeps), _lib.ray_type(type), nk, self.rule, float(ne_scale), _ptr(out))
+        return out
+
     def forward_rays(self, rays_t, out=None, kind=None):
         """tec[R] along explicit samples rays[R,4,Ns] (device), non-uniform Simpson in-kernel."""
         self._sync_stream()

@@ -79,6 +79,30 @@ for kind in ("linear", "cubic"):
 assert not eng.check_oob()
 del big
 
+# ---------------------------------------------------------------- fused curved-ray forward / transpose (round 3: no rays[R,4,Ns])
+w3 = syn.make_workload("cfg2", margin_cells=16)
+e3 = RayEngine(0)
+e3.set_grid(w3["xvec"], w3["yvec"], w3["zvec"])
+e3.set_values(e3.tensor(w3["ne"]))
+o3, d3 = e3.tensor(w3["origins"].reshape(-1, 3)), e3.tensor(w3["directions"].reshape(-1, 3))
+for kind in ("linear", "cubic"):
+    out["cfg3_fused_forward_%s_ms" % kind] = timeit(lambda: e3.forward_fermat(o3, d3, w3["tmax"], w3["Ns"], 120e6, bend=True, kind=kind, substeps=4), 10, 2)
+y3 = torch.randn(o3.shape[0], dtype=torch.float64, device="cuda")
+g3 = torch.zeros(e3.shape, dtype=torch.float64, device="cuda")
+out["cfg3_fused_adjoint_linear_ms"] = timeit(lambda: e3.adjoint_fermat(o3, d3, y3, w3["tmax"], w3["Ns"], 120e6, bend=True, kind="linear", substeps=4, out=g3), 5, 1)
+w4 = syn.make_workload("cfg4", margin_cells=16)
+e4 = RayEngine(0)
+e4.set_grid(w4["xvec"], w4["yvec"], w4["zvec"])
+e4.set_values(e4.tensor(w4["ne"]))
+o4, d4 = e4.tensor(w4["origins"].reshape(-1, 3)), e4.tensor(w4["directions"].reshape(-1, 3))
+t4 = torch.empty(o4.shape[0], dtype=torch.float64, device="cuda")
+out["fused_620k_bending_rays_256_forward_ms"] = timeit(lambda: e4.forward_fermat(o4, d4, w4["tmax"], w4["Ns"], 150e6, bend=True, kind="linear", substeps=2, out=t4), 3, 1)
+out["fused_620k_bending_rays_per_s"] = o4.shape[0] / out["fused_620k_bending_rays_256_forward_ms"] * 1e3
+y4 = torch.randn(o4.shape[0], dtype=torch.float64, device="cuda")
+g4 = torch.zeros(e4.shape, dtype=torch.float64, device="cuda")
+out["fused_620k_bending_rays_256_adjoint_ms"] = timeit(lambda: e4.adjoint_fermat(o4, d4, y4, w4["tmax"], w4["Ns"], 150e6, bend=True, kind="linear", substeps=2, out=g4), 2, 1)
+del e4, o4, d4, t4, y4, g4, w4
+
 # ---------------------------------------------------------------- PCIe-inclusive facade call (host numpy in/out)
 import ionotomo_amd as it  # noqa: E402
 w2 = syn.make_workload("cfg2")

@@ -1,0 +1,125 @@
+"""Fused curved-ray kernels -- iono_forward_tec_fermat_dev / iono_adjoint_fermat_dev (k_fermat_tec: RK4 stepper + streaming
+non-uniform Simpson, rays[R,4,Ns] never materialised) -- against the two-step path they replace (trace_fermat -> forward_rays /
+adjoint of explicit rays), the oracle's RK4 + quadrature, every quadrature rule and sample-count parity, both independent
+variables, both interpolants, config 3 at its stated size, and 620,000 bending rays through 256^3 in one launch (config 4's ray
+count: the explicit rays would be 5.1 GB).  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from ionotomo_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import oracle
+    return oracle
+
+
+def make_engine(w, **kw):
+    from ionotomo_amd.engine import RayEngine
+    eng = RayEngine(0, **kw)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    return eng
+
+
+@pytest.mark.parametrize("quad", ["avg", "scipy", "trapz"])
+@pytest.mark.parametrize("Ns", [2, 3, 4, 9, 16, 33])
+def test_streaming_quadrature_equals_the_explicit_sample_kernels(quad, Ns):
+    """Every rule and parity of N: fused == trace + explicit-sample integral (same samples bit for bit, weights to rounding)."""
+    w = syn.make_workload(antennas="example", na=5, nd=4, nt=2, n=20, margin_cells=8)
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    for kind, typ in (("linear", "z"), ("cubic", "z"), ("linear", "s")):
+        eng = make_engine(w, quad=quad, interp=kind)
+        eng.set_values(eng.tensor(w["ne"]))
+        ot, dt = eng.tensor(o), eng.tensor(d)
+        tmax = w["tmax"] if typ == "z" else 0.8 * w["tmax"]
+        rays = eng.trace_fermat(ot, dt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ)
+        two_step = eng.forward_rays(rays).cpu().numpy()
+        fused = eng.forward_fermat(ot, dt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ).cpu().numpy()
+        assert not eng.check_oob()
+        assert np.max(np.abs(fused - two_step)) <= 1e-12 * np.max(np.abs(two_step)), (kind, typ)
+        # transpose: re-trace + scatter == scatter along the stored rays, and <G x, y> = <x, G^T y>
+        y = np.random.default_rng(Ns).normal(size=len(o))
+        yt = eng.tensor(y)
+        g_f = eng.adjoint_fermat(ot, dt, yt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ)
+        lhs, rhs = float((eng.tensor(fused) * yt).sum()), float((g_f * eng.tensor(w["ne"])).sum())
+        assert abs(lhs - rhs) <= 1e-11 * np.linalg.norm(fused) * np.linalg.norm(y), (kind, typ)
+        assert not eng.check_oob()
+
+
+def test_fused_adjoint_equals_the_explicit_ray_adjoint():
+    from ionotomo_amd import _lib
+    w = syn.make_workload(antennas="example", na=6, nd=5, nt=1, n=24, margin_cells=8)
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    rng = np.random.default_rng(1)
+    y = rng.normal(size=len(o))
+    for kind in ("linear", "cubic"):
+        eng = make_engine(w, interp=kind)
+        eng.set_values(eng.tensor(w["ne"]))
+        ot, dt, yt = eng.tensor(o), eng.tensor(d), eng.tensor(y)
+        rays = eng.trace_fermat(ot, dt, w["tmax"], 21, 60e6, bend=True, kind=kind, substeps=2)
+        ref = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
+        eng.ctx.call("iono_adjoint_rays_dev", _lib._V(rays.data_ptr()), _lib._V(yt.data_ptr()), len(o), 21, eng.kind, eng.rule,
+                     _lib._V(ref.data_ptr()), _lib.F64)
+        got = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, bend=True, kind=kind, substeps=2, ne_scale=1.0)
+        assert float((got - ref).abs().max()) <= 1e-11 * float(ref.abs().max()), kind
+        # ne_scale scales both directions
+        got2 = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, bend=True, kind=kind, substeps=2, ne_scale=1e-13)
+        assert float((got2 * 1e13 - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
+        assert not eng.check_oob()
+
+
+@pytest.mark.parametrize("kind", ["linear", "cubic"])
+def test_config3_fused_equals_trace_then_integrate_and_the_oracle(kind, O):
+    w = syn.make_workload("cfg2", margin_cells=16)
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"]))
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    Ns, freq = w["Ns"], 120e6
+    rays_t = eng.trace_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=4)
+    for tk, ok in (("linear", O.INTERP_TRILINEAR), ("cubic", O.INTERP_TRICUBIC)):
+        two_step = eng.forward_rays(rays_t, kind=tk).cpu().numpy()
+        fused = eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=4, ne_kind=tk).cpu().numpy()
+        assert np.max(np.abs(fused - two_step) / np.abs(two_step)) < 1e-12
+        idx = np.sort(np.random.default_rng(0).choice(len(o), 104, replace=False))
+        nM = O.ne_to_n(w["ne"], freq)
+        field = (O.n_field_trilinear if kind == "linear" else O.n_field_tricubic)(w["xvec"], w["yvec"], w["zvec"], nM)
+        ref_rays = O.fermat_trace(o[idx], d[idx], w["tmax"], Ns, field, bend=True, substeps=4)
+        tref = O.forward_tec(ref_rays, w["xvec"], w["yvec"], w["zvec"], w["ne"], kind=ok)
+        assert np.max(np.abs(fused[idx] - tref) / np.abs(tref)) < 1e-10
+    assert not eng.check_oob()
+
+
+def test_620k_bending_rays_through_256_cubed_in_one_launch():
+    """Config 4's ray count with the bending tracer: one launch, no 5.1 GB ray buffer; sampled against trace + integrate, the
+    transpose by the dot-product test on a subset (plain hardware atomics: the full batch is timed in profiles/)."""
+    w = syn.make_workload("cfg4", margin_cells=16)
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"]))
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    R, Ns, freq = len(o), w["Ns"], 150e6
+    assert R == 620000
+    free0 = torch.cuda.mem_get_info()[0]
+    tec = eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind="linear", substeps=2, ne_scale=1e-13)
+    torch.cuda.synchronize()
+    assert free0 - torch.cuda.mem_get_info()[0] < (1 << 30)                     # nothing like R x 4 x Ns x 8 B = 5.1 GB was allocated
+    assert not eng.check_oob()
+    tec = tec.cpu().numpy()
+    assert np.all(np.isfinite(tec)) and np.all(tec > 0)
+    idx = np.sort(np.random.default_rng(2).choice(R, 4096, replace=False))
+    oi, di = eng.tensor(o[idx]), eng.tensor(d[idx])
+    rays = eng.trace_fermat(oi, di, w["tmax"], Ns, freq, bend=True, kind="linear", substeps=2)
+    two = eng.forward_rays(rays).cpu().numpy() * 1e-13
+    assert np.max(np.abs(tec[idx] - two) / two) < 1e-12
+    straight = eng.forward(oi, di, w["tmax"], Ns).cpu().numpy() * 1e-13
+    assert np.max(np.abs(two - straight) / straight) > 1e-6                       # the rays really bend
+    y = eng.tensor(np.random.default_rng(3).normal(size=len(idx)))
+    g = eng.adjoint_fermat(oi, di, y, w["tmax"], Ns, freq, bend=True, kind="linear", substeps=2, ne_scale=1e-13)
+    lhs, rhs = float((eng.tensor(tec[idx]) * y).sum()), float((g * eng.tensor(w["ne"])).sum())
+    assert abs(lhs - rhs) < 1e-10 * np.linalg.norm(tec[idx]) * float(y.norm())
+    assert not eng.check_oob()
