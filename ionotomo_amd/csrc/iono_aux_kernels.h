@@ -223,15 +223,21 @@ __device__ __forceinline__ FState fermat_rates(double n, double nx, double ny, d
 __device__ __forceinline__ double fermat_step(double tmax, double z0, int Ns, int substeps, int stype) {
     return (stype ? tmax : tmax - z0) / (double)((Ns - 1) * substeps);
 }
+// (out of line: inlined into the lanes = rays kernels -- four RK4 stages, in k_fermat_tec beside the integrand's own evaluation --
+//  the 216-tap value-and-gradient evaluation pushed them to 512 VGPRs + 1 kB of scratch per lane)
+__device__ __attribute__((noinline)) void tricubic_n_and_gradient(const GridView &g, const double *nM, double x, double y, double z,
+                                                                  double &n, double &nx, double &ny, double &nz) {
+    GridView gn = g;
+    gn.M = nM;
+    tricubic_eval<double, true>(gn, g.axes, g.axes + g.nx, g.axes + g.nx + g.ny, x, y, z, n, nx, ny, nz);
+}
 template <int KIND, bool BEND>
 __device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u, int stype) {
     double n, nx, ny, nz;
     if (KIND == IONO_INTERP_TRILINEAR) {
         trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
     } else {
-        GridView gn = g;
-        gn.M = nM;
-        tricubic_eval<double, true>(gn, g.axes, g.axes + g.nx, g.axes + g.nx + g.ny, u.x, u.y, u.z, n, nx, ny, nz);
+        tricubic_n_and_gradient(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
     }
     if (!BEND) nx = ny = nz = 0.0;
     if (stype) return fermat_rates(n, nx, ny, nz, u, 1);
