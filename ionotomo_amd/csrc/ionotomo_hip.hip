@@ -896,7 +896,11 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, order, R, tmax, Ns,
                                forward_walk_mode(c, (uint64_t)padded * sizeof(float4), order), c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && std::is_same<GT, double>::value && c->fplan.R == R && c->fplan.o_key == o &&
-                   c->fplan.d_key == d && c->fplan.Ns == Ns && c->fplan.tmax == tmax && ideal_path_ok(c) && c->variant != 10 && c->variant != 11) {
+                   c->fplan.d_key == d && c->fplan.Ns == Ns && c->fplan.tmax == tmax && ideal_path_ok(c) && c->variant != 10 && c->variant != 11 &&
+                   ((c->fplan.nb >= 2 * c->num_cus && c->fplan.fit_fraction >= 0.5 && R >= (int64_t)16 * c->fplan.nb) || c->variant == 12)) {
+            // (a workgroup per bundle: below two bundles per CU -- a single timestep is 214 -- the lanes = samples kernel, one wave
+            //  per ray, fills the chip better: 7.5 against 11 us at config 2; likewise when the plan is poor: windows that mostly do
+            //  not fit the LDS image, or bundles of a few rays.  IONOTOMO_VARIANT=12 forces the bundle kernel)
             // bundle-stationary: one workgroup per planned bundle of <= 64 rays, windows staged in LDS (iono_forward_plan_dev)
             const iono_ctx::FwdPlan &fp = c->fplan;
             hipLaunchKernelGGL(k_forward_bundle, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double),

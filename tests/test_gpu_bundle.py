@@ -19,9 +19,21 @@ def OC():
     return oracle_c
 
 
-def engine(xv, yv, zv, **kw):
+def engine(xv, yv, zv, force_bundle=True, **kw):
+    """``force_bundle``: IONOTOMO_VARIANT=12 while the context is created -- a planned launch then runs k_forward_bundle whatever
+    the number of bundles (by default the library keeps the lanes = samples kernel below two bundles per CU, where it is faster)."""
+    import os
     from ionotomo_amd.engine import RayEngine
-    eng = RayEngine(0, **kw)
+    old = os.environ.get("IONOTOMO_VARIANT")
+    if force_bundle:
+        os.environ["IONOTOMO_VARIANT"] = "12"
+    try:
+        eng = RayEngine(0, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("IONOTOMO_VARIANT", None)
+        else:
+            os.environ["IONOTOMO_VARIANT"] = old
     eng.set_grid(xv, yv, zv)
     return eng
 
@@ -82,6 +94,17 @@ def test_bundle_forward_random_geometries(seed, OC):
     again = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
     eng.check_oob()
     assert np.array_equal(again, direct, equal_nan=True)
+    # without the override a small or poor plan (fewer than two bundles per CU, windows that mostly do not fit, bundles of a few
+    # rays) is kept but not used: the lanes = samples kernel's bits
+    eng2 = engine(xv, yv, zv, force_bundle=False, quad=quad)
+    eng2.set_values(eng2.tensor(M))
+    nb2, _, fit2 = eng2.plan_forward(ot, dt, zhi, Ns)
+    small = eng2.forward(ot, dt, zhi, Ns).cpu().numpy()
+    eng2.check_oob()
+    if nb2 < 512 or fit2 < 0.5 or R < 16 * nb2:
+        assert np.array_equal(small, direct, equal_nan=True)
+    elif inside.any():
+        assert np.max(np.abs(small[inside] - direct[inside])) <= 2e-13 * np.max(np.abs(direct[inside]))
 
 
 def test_tec_does_not_depend_on_the_bundling():
@@ -173,7 +196,7 @@ def test_rays_on_the_grid_faces_and_the_last_bundle(OC):
 def test_bundle_forward_bench_shape(OC):
     import bench
     w = bench.build_workload(0)
-    eng = engine(w["xvec"], w["yvec"], w["zvec"])
+    eng = engine(w["xvec"], w["yvec"], w["zvec"], force_bundle=False)            # the default dispatch: 4 838 bundles >= 2 per CU
     ne = np.exp(w["m"]) * (w["K_ne"] / 1e13)
     eng.set_values(eng.tensor(ne))
     ot, dt = eng.tensor(w["origins"]), eng.tensor(w["directions"])
