@@ -617,6 +617,42 @@ __device__ __forceinline__ BundleRays load_bundle(const GridView &g, const doubl
     return B;
 }
 
+// ---- plan, device part 1: per ray a 4-D Morton key of foot and end point (3/4-cell quanta) and a 32-byte summary for the cut ----
+struct BundleSummary {          // grid coordinates of foot and end, |drift| per sample, first level; adx < 0: the ray leaves the grid
+    float fx0, fy0, fxe, fye, fz0, adx, ady, dz;
+};
+__global__ __launch_bounds__(256) void k_bundle_keys(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R,
+                                                     double tmax, int Ns, unsigned long long *__restrict__ keys, int *__restrict__ idx,
+                                                     BundleSummary *__restrict__ rec) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const URay u = load_uray(g, origins, dirs, r, tmax, Ns);
+        BundleSummary h;
+        const double n1 = (double)(Ns - 1);
+        h.fx0 = (float)u.fx0, h.fy0 = (float)u.fy0, h.fxe = (float)fma(n1, u.dfx, u.fx0), h.fye = (float)fma(n1, u.dfy, u.fy0);
+        h.fz0 = (float)u.fz0, h.adx = (float)fabs(u.dfx), h.ady = (float)fabs(u.dfy), h.dz = (float)fabs(u.dfz);
+        unsigned long long code = ~0ull;               // rays that leave the grid: at the end of the walk, in bundles of their own
+        if (u.valid) {
+            code = 0;
+            const float v[4] = {h.fx0, h.fy0, h.fxe, h.fye};
+#pragma unroll
+            for (int dim = 0; dim < 4; ++dim) {
+                float t = v[dim] * (4.0f / 3.0f);
+                t = t > 0.0f ? (t < 32767.0f ? t : 32767.0f) : 0.0f;
+                const unsigned long long q = (unsigned long long)t;
+#pragma unroll
+                for (int b = 0; b < 15; ++b) code |= ((q >> b) & 1ull) << (4 * b + dim);
+            }
+        } else {
+            h.adx = -1.0f;
+        }
+        keys[r] = code, idx[r] = (int)r, rec[r] = h;
+    }
+}
+__global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__restrict__ rec, const int *__restrict__ order, int64_t R,
+                                                       BundleSummary *__restrict__ sorted) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) sorted[i] = rec[order[i]];
+}
+
 // window of chunk c of bundle b: {imin, jmin, kz0 (even), wx | wy << 8 | fits << 16}; one wave per bundle
 __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs,
                                                        const int *__restrict__ order, const int *__restrict__ bstart, int nb, double tmax,

@@ -25,6 +25,8 @@
 #include <type_traits>
 #include <vector>
 
+#include <rocprim/device/device_radix_sort.hpp>      // device sort of the bundle plan's Morton keys
+
 #include "../../include/ionotomo_hip.h"
 
 #define IONO_VERSION 200
@@ -748,8 +750,9 @@ static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
 // in the walk nearly coincide all the way up); (2) the walk cut greedily into bundles of <= 64 rays whose window -- the columns
 // the bundle touches in any B_KC consecutive samples, bounded through the extents at the two ends (positions are linear in the
 // sample index, so the extent of a bundle is convex in it) + the drift of its steepest ray -- fits the LDS image of one wave;
-// (3) the exact window of every (bundle, chunk), by the device (k_bundle_windows).  Host part: O(R log R) on R x 48 B copied
-// back once.  No plan (non-uniform axes, float32 storage, odd nz): the other forward kernels serve the launch.
+// (3) the exact window of every (bundle, chunk), by the device (k_bundle_windows).  Keys, sort (rocPRIM radix sort) and windows run
+// on the device; the host only cuts the sorted walk (one sequential pass over R 32-byte ray summaries).  No plan (non-uniform
+// axes, float32 storage, odd nz): the other forward kernels serve the launch.
 int iono_forward_plan_clear(iono_ctx *c) {
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
     (void)hipSetDevice(c->device);
@@ -765,40 +768,29 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     iono_ctx::FwdPlan &fp = c->fplan;
     fp.R = -1, fp.nb = 0, fp.o_key = fp.d_key = nullptr;
     if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || c->storage != IONO_F64 || (c->nz & 1) || !o || !d) return IONO_OK;
-    std::vector<double> ho((size_t)R * 3), hd((size_t)R * 3);
-    HIP_TRY(c, hipMemcpy(ho.data(), o, (size_t)R * 24, hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(hd.data(), d, (size_t)R * 24, hipMemcpyDeviceToHost));
-    struct HRay { float fx0, fy0, fxe, fye, fz0, adx, ady, dz; };
-    std::vector<HRay> hr((size_t)R);
-    std::vector<std::pair<uint64_t, int>> key((size_t)R);
-    const double q = 4.0 / 3.0;
-    for (int64_t r = 0; r < R; ++r) {
-        const double ox = ho[3 * r], oy = ho[3 * r + 1], oz = ho[3 * r + 2], dx = hd[3 * r], dy = hd[3 * r + 1], dz = hd[3 * r + 2];
-        const double nrm = std::sqrt(dx * dx + dy * dy + dz * dz), pz = dz / nrm, sx = dx / nrm / pz, sy = dy / nrm / pz;
-        const double L = tmax - oz, Lstep = L / (double)(Ns - 1), xe = ox + sx * L, ye = oy + sy * L, ze = oz + L;
-        const bool valid = (ox >= c->g0[0]) & (ox <= c->glast[0]) & (xe >= c->g0[0]) & (xe <= c->glast[0]) & (oy >= c->g0[1]) & (oy <= c->glast[1]) &
-                           (ye >= c->g0[1]) & (ye <= c->glast[1]) & (oz >= c->g0[2]) & (oz <= c->glast[2]) & (ze >= c->g0[2]) & (ze <= c->glast[2]);
-        HRay &h = hr[(size_t)r];
-        h.fx0 = (float)((ox - c->g0[0]) * c->inv_h[0]), h.fy0 = (float)((oy - c->g0[1]) * c->inv_h[1]);
-        h.fxe = (float)((xe - c->g0[0]) * c->inv_h[0]), h.fye = (float)((ye - c->g0[1]) * c->inv_h[1]);
-        h.fz0 = (float)((oz - c->g0[2]) * c->inv_h[2]);
-        h.adx = (float)std::fabs(sx * Lstep * c->inv_h[0]), h.ady = (float)std::fabs(sy * Lstep * c->inv_h[1]), h.dz = (float)std::fabs(Lstep * c->inv_h[2]);
-        uint64_t code = ~(uint64_t)0;               // rays that leave the grid: at the end of the walk, in bundles of their own
-        if (valid) {
-            code = 0;
-            const float v[4] = {h.fx0, h.fy0, h.fxe, h.fye};
-            for (int dim = 0; dim < 4; ++dim) {
-                double t = v[dim] * q;
-                if (!(t > 0)) t = 0;
-                if (t > 32767.0) t = 32767.0;
-                const uint64_t u = (uint64_t)t;
-                for (int b = 0; b < 15; ++b) code |= ((u >> b) & 1ull) << (4 * b + dim);
-            }
-        }
-        key[(size_t)r] = {code, (int)r};
-    }
-    std::sort(key.begin(), key.end());
-    std::vector<int> order((size_t)R), bstart;
+    // keys and ray summaries on the device, device radix sort; only the sorted 32-byte summaries travel to the host for the cut
+    DevBuf scratch(c);
+    const size_t off_k0 = 0, off_k1 = off_k0 + (size_t)R * 8, off_i0 = off_k1 + (size_t)R * 8, off_i1 = off_i0 + (size_t)R * 4,
+                 off_r0 = (off_i1 + (size_t)R * 4 + 31) & ~(size_t)31, off_r1 = off_r0 + (size_t)R * sizeof(BundleSummary),
+                 off_tmp = off_r1 + (size_t)R * sizeof(BundleSummary);
+    size_t tmp_bytes = 0;
+    HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr,
+                                         (int *)nullptr, (size_t)R, 0, 64, c->stream));
+    HIP_TRY(c, scratch.alloc(off_tmp + tmp_bytes + 256));
+    char *sb = scratch.as<char>();
+    unsigned long long *k0 = (unsigned long long *)(sb + off_k0), *k1 = (unsigned long long *)(sb + off_k1);
+    int *i0 = (int *)(sb + off_i0), *i1 = (int *)(sb + off_i1);
+    BundleSummary *r0 = (BundleSummary *)(sb + off_r0), *r1 = (BundleSummary *)(sb + off_r1);
+    hipLaunchKernelGGL(k_bundle_keys, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, view(c), o, d, R, tmax, Ns, k0, i0, r0);
+    HIP_TRY(c, rocprim::radix_sort_pairs(sb + off_tmp, tmp_bytes, k0, k1, i0, i1, (size_t)R, 0, 64, c->stream));
+    hipLaunchKernelGGL(k_bundle_gather, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, r0, i1, R, r1);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<BundleSummary> hr((size_t)R);
+    HIP_TRY(c, hipMemcpyAsync(hr.data(), r1, (size_t)R * sizeof(BundleSummary), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, plan_reserve(fp.d_order, fp.cap_order, (size_t)R * sizeof(int)));
+    HIP_TRY(c, hipMemcpyAsync(fp.d_order, i1, (size_t)R * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<int> bstart;
     bstart.reserve((size_t)R / 32 + 2);
     const float inf = 3.0e38f;
     float x0lo = inf, x0hi = -inf, y0lo = inf, y0hi = -inf, xelo = inf, xehi = -inf, yelo = inf, yehi = -inf, zlo = inf, zhi = -inf, ax = 0, ay = 0, az = 0;
@@ -806,10 +798,8 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     bool cur_valid = true;
     auto reset = [&]() { x0lo = y0lo = xelo = yelo = zlo = inf, x0hi = y0hi = xehi = yehi = zhi = -inf, ax = ay = az = 0, cnt = 0; };
     for (int64_t i = 0; i < R; ++i) {
-        const int r = key[(size_t)i].second;
-        order[(size_t)i] = r;
-        const bool valid = key[(size_t)i].first != ~(uint64_t)0;
-        const HRay &h = hr[(size_t)r];
+        const BundleSummary &h = hr[(size_t)i];                  // (walk order)
+        const bool valid = h.adx >= 0.0f;
         // the bundle with this ray added
         const float nx0lo = std::min(x0lo, h.fx0), nx0hi = std::max(x0hi, h.fx0), ny0lo = std::min(y0lo, h.fy0), ny0hi = std::max(y0hi, h.fy0);
         const float nxelo = std::min(xelo, h.fxe), nxehi = std::max(xehi, h.fxe), nyelo = std::min(yelo, h.fye), nyehi = std::max(yehi, h.fye);
@@ -832,10 +822,8 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     }
     bstart.push_back((int)R);
     const int nb = (int)bstart.size() - 1, nchunks = (Ns + B_KC - 1) / B_KC;
-    HIP_TRY(c, plan_reserve(fp.d_order, fp.cap_order, (size_t)R * sizeof(int)));
     HIP_TRY(c, plan_reserve(fp.d_bstart, fp.cap_bstart, bstart.size() * sizeof(int)));
     HIP_TRY(c, plan_reserve(fp.d_win, fp.cap_win, (size_t)nb * nchunks * sizeof(uint4)));
-    HIP_TRY(c, hipMemcpy(fp.d_order, order.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(c, hipMemcpy(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_bundle_windows, dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart, nb, tmax, Ns, nchunks, fp.d_win);
     HIP_TRY(c, hipGetLastError());
