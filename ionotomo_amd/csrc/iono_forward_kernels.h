@@ -514,6 +514,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T_WAVES, T_
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
+// 1 - sqrt(1 - x) for the phase observable, x = ne / n_p.  A float64 square root is ~35 instruction slots
+// (quarter-rate seed + two Newton steps) and the observable needs one per sample and FREQUENCY; for x <= 0.01 -- any
+// ionosphere above 30 MHz -- six terms of the binomial series are exact to 3e-14 relative (the next term is 0.032 x^6 of the
+// first), which is tighter than 1 - sqrt(1 - x) itself evaluates in float64 (cancellation: 1e-16 / x).  Larger x (checked per
+// wave) takes the square root.  (The transpose's 1 / sqrt(1 - x) keeps the root: that kernel is bound by its LDS atomics.)
+__device__ __forceinline__ double phase_one_minus_sqrt(double x, bool small) {
+    if (small)
+        return x * fma(x, fma(x, fma(x, fma(x, fma(x, 21.0 / 1024.0, 7.0 / 256.0), 5.0 / 128.0), 1.0 / 16.0), 1.0 / 8.0), 0.5);
+    return 1.0 - sqrt(1.0 - x);
+}
+struct PhaseFreqs {
+    double inv_np[8];      // 1 / (1.2404e-2 nu^2)  (iterative_newton.py:112)
+    int nf;
+};
+
 // ---- bundle-stationary forward: the voxel neighbourhood of <= 64 neighbouring rays staged in LDS ---------------------------------
 // Counters of the two mappings above (profiles/r03_ab_forward_lanes_rays.json): the vector L1 charges a 16-B wave-load one tag
 // look-up per (4-lane group, line) -- 27 per wave-load with lanes = samples (column changes, 128-B boundaries), 33 with lanes =
@@ -680,10 +695,14 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
     }
 }
 
+// NF = 0: TEC (tec[r]).  NF > 0: the phase observable's per-frequency integrals of 1 - sqrt(1 - ne / n_p) for NF frequencies per
+// pass (out[r * ldf + l]; inversion/iterative_newton.py:108-119), same traversal, NF accumulators per lane.
+template <int NF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) void k_forward_bundle(
     GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, const int *__restrict__ order,
     const int *__restrict__ bstart, const uint4 *__restrict__ win, int nb, int nchunks, double tmax, int Ns,
-    const double *__restrict__ unitw, double *__restrict__ tec, int *oob_flag) {
+    const double *__restrict__ unitw, double *__restrict__ tec, int *oob_flag, PhaseFreqs pf, int ldf) {
+    constexpr int NA = NF > 0 ? NF : 1;
     extern __shared__ __attribute__((aligned(16))) char blds[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform: scalar loop control)
     int b = blockIdx.x;
@@ -694,17 +713,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
     const BundleRays B = load_bundle(g, origins, dirs, order, bstart, b, tmax, Ns);
     if (wid == 0 && __any(B.mine && !B.valid) && lane == 0) atomicOr(oob_flag, 1);
     if (!B.any) {
-        if (wid == 0 && B.mine) tec[B.r] = nan("");
+        if (wid == 0 && B.mine) {
+            if (NF == 0) tec[B.r] = nan("");
+            else
+                for (int l = 0; l < pf.nf; ++l) tec[(size_t)B.r * ldf + l] = nan("");
+        }
         return;
     }
     char *img = blds + wid * B_WAVE_LDS;
-    char *blds0 = blds - (unsigned)(size_t)blds;                // LDS address 0: `a` below is a complete LDS byte address
     double *part = (double *)(blds + B_SPLIT * B_WAVE_LDS);
     const int lane_dj = (int)(((unsigned)lane * 52429u) >> 18);                 // lane / 5
     const unsigned lane_off = ((unsigned)lane_dj * (unsigned)g.nz + 2u * (unsigned)(lane - B_PPC * lane_dj)) * 8u;
     const uint4 *wb = win + (size_t)b * nchunks;
     const int c0 = nchunks * wid / B_SPLIT, c1 = nchunks * (wid + 1) / B_SPLIT;
-    double acc = 0.0;
+    double inv_np_max = 0.0;                                  // the lowest frequency of the pass has the largest ne / n_p
+#pragma unroll
+    for (int l = 0; l < NA; ++l) inv_np_max = NF > 0 ? fmax(inv_np_max, pf.inv_np[l]) : 0.0;
+    double acc[NA];
+#pragma unroll
+    for (int l = 0; l < NA; ++l) acc[l] = 0.0;
+    // one sample: quadrature weight x integrand(interpolated ne)
+    auto add = [&](double wk, double ne) {
+        if (NF == 0) {
+            acc[0] = fma(wk, ne, acc[0]);
+        } else {
+            // (series instead of the square root while ne / n_p <= 0.01 on the whole wave: phase_one_minus_sqrt)
+            const bool small = NF >= 4 && !__any(!(ne * inv_np_max <= 0.01));
+#pragma unroll
+            for (int l = 0; l < NA; ++l) acc[l] = fma(wk, phase_one_minus_sqrt(ne * pf.inv_np[l], small), acc[l]);
+        }
+    };
     for (int c = c0; c < c1; ++c) {
         const int k0 = c * B_KC, ke = min(k0 + B_KC, Ns);
         const double kd0 = (double)k0;
@@ -732,8 +770,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
             // (node offset of the window origin: subtracted from the LDS byte address with 32-bit wrap-around)
             const unsigned ibase = (unsigned)(size_t)img - (((unsigned)imin * (unsigned)wy + (unsigned)jmin) * B_LEV + (unsigned)kz0) * 8u;
             const unsigned row2 = (unsigned)wy * (B_LEV * 8);
-#ifndef B_COMPILER_READS     // eight ds_read_b64 per sample (2 LDS cycles each) instead of the four ds_read2_b64 (8 each) the compiler forms:
-                             // 0.133 -> 0.111 ms.  B_UNROLL samples' reads in flight; the asm loads are waited for by hand.
+            // eight ds_read_b64 per sample (2 LDS cycles each) instead of the four ds_read2_b64 (8 each) the compiler forms from
+            // plain loads: 0.133 -> 0.111 ms.  B_UNROLL samples' reads in flight; the asm loads are waited for by hand.
             int k = k0;
             for (; k + B_UNROLL <= ke; k += B_UNROLL) {
                 Corners<double> cc[B_UNROLL];
@@ -749,7 +787,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
                 for (int u = 0; u < B_UNROLL; ++u) {
                     lds_wait(8 * (B_UNROLL - 1 - u));
                     lds_pin8(cc[u]);
-                    acc = fma(unitw[k + u], lerp_corners<double>(cc[u]), acc);
+                    add(unitw[k + u], lerp_corners<double>(cc[u]));
                 }
             }
             for (; k < ke; ++k) {
@@ -759,28 +797,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
                 lds_read8(ca, a0, a0 + row2);
                 lds_wait(0);
                 lds_pin8(ca);
-                acc = fma(unitw[k], lerp_corners<double>(ca), acc);
+                add(unitw[k], lerp_corners<double>(ca));
             }
-#else
-#pragma unroll B_UNROLL
-            for (int k = k0; k < ke; ++k) {
-                const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)),
-                             fk = __builtin_floor(__builtin_fabs(fz));
-                const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * 8u + ibase;
-                const double *p = (const double *)(blds0 + a), *p2 = (const double *)(blds0 + a + row2);
-                Corners<double> cc;
-                cc.c000 = p[0], cc.c001 = p[1], cc.c010 = p[B_LEV], cc.c011 = p[B_LEV + 1];
-                cc.c100 = p2[0], cc.c101 = p2[1], cc.c110 = p2[B_LEV], cc.c111 = p2[B_LEV + 1];
-                cc.tx = fx - fi, cc.ty = fy - fj, cc.tz = fz - fk;
-                acc = fma(unitw[k], lerp_corners<double>(cc), acc);
-                fx += B.dfx;
-                fy += B.dfy;
-                fz += B.dfz;
-            }
-#endif
         } else {
             for (int k = k0; k < ke; ++k) {
-                acc = fma(unitw[k], trilinear_u<double>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
+                add(unitw[k], trilinear_u<double>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz));
                 fx += B.dfx;
                 fy += B.dfy;
                 fz += B.dfz;
@@ -788,9 +809,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
         }
     }
     // ---- the four z-parts of a ray, added in a fixed order ------------------------------------------------------------------
-    part[wid * 64 + lane] = acc;
+#pragma unroll
+    for (int l = 0; l < NA; ++l) part[(l * B_SPLIT + wid) * 64 + lane] = acc[l];
     __syncthreads();
-    if (wid == 0 && B.mine) tec[B.r] = B.valid ? (((part[lane] + part[64 + lane]) + part[128 + lane]) + part[192 + lane]) * B.h : nan("");
+    if (wid == 0 && B.mine) {
+#pragma unroll
+        for (int l = 0; l < NA; ++l) {
+            const double *pl = part + l * B_SPLIT * 64 + lane;
+            const double tot = ((pl[0] + pl[64]) + pl[128]) + pl[192];
+            if (NF == 0) tec[B.r] = B.valid ? tot * B.h : nan("");
+            else if (l < pf.nf) tec[(size_t)B.r * ldf + l] = B.valid ? tot * B.h : nan("");
+        }
+    }
 }
 
 // ---- float32 storage extra: 2 x 2 (y, z) corner blocks -------------------------------------------------------------------
@@ -938,20 +968,6 @@ __global__ __launch_bounds__(256) void k_forward_phase_rays(GridView g, const do
 // The same observable with the samples generated in-kernel on straight z-parametrised rays (rays[R,4,Ns] never
 // exists): phi[r][l] = h_r sum_k w_k (1 - sqrt(1 - ne_k / n_p,l)).  IDEAL: ideal-uniform grid coordinates (one fma per
 // axis, unclamped corner loads); otherwise axis tables in LDS and the exact searchsorted cell rule.
-// 1 - sqrt(1 - x) for the phase observable, x = ne / n_p.  A float64 square root is ~35 instruction slots
-// (quarter-rate seed + two Newton steps) and the observable needs one per sample and FREQUENCY; for x <= 0.01 -- any
-// ionosphere above 30 MHz -- six terms of the binomial series are exact to 3e-14 relative (the next term is 0.032 x^6 of the
-// first), which is tighter than 1 - sqrt(1 - x) itself evaluates in float64 (cancellation: 1e-16 / x).  Larger x (checked per
-// wave) takes the square root.  (The transpose's 1 / sqrt(1 - x) keeps the root: that kernel is bound by its LDS atomics.)
-__device__ __forceinline__ double phase_one_minus_sqrt(double x, bool small) {
-    if (small)
-        return x * fma(x, fma(x, fma(x, fma(x, fma(x, 21.0 / 1024.0, 7.0 / 256.0), 5.0 / 128.0), 1.0 / 16.0), 1.0 / 8.0), 0.5);
-    return 1.0 - sqrt(1.0 - x);
-}
-struct PhaseFreqs {
-    double inv_np[8];      // 1 / (1.2404e-2 nu^2)  (iterative_newton.py:112)
-    int nf;
-};
 template <typename GT, bool IDEAL>
 __global__ __launch_bounds__(256) void k_forward_phase_straight(GridView g, const double *__restrict__ origins,
                                                                 const double *__restrict__ dirs, int64_t R, double tmax, int Ns,

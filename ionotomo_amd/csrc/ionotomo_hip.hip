@@ -734,6 +734,13 @@ static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes, const int 
 // Forward mapping on ideal-uniform grids without a bundle plan: lanes = samples of one ray (k_forward_straight_u).
 // IONOTOMO_VARIANT=11 selects lanes = 64 neighbouring rays of the walk order (k_forward_straight_t), 10 forces lanes = samples
 // even on a planned geometry: A/B runs; results agree to rounding.
+// the bundle plan serves this launch: same ray arrays, R, tmax, Ns, and it fills the chip / is good (see the forward dispatch)
+static bool fplan_serves(const iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns) {
+    const iono_ctx::FwdPlan &fp = c->fplan;
+    return c->storage == IONO_F64 && fp.R == R && fp.o_key == o && fp.d_key == d && fp.Ns == Ns && fp.tmax == tmax && ideal_path_ok(c) &&
+           c->variant != 10 && c->variant != 11 &&
+           ((fp.nb >= 2 * c->num_cus && fp.fit_fraction >= 0.5 && R >= (int64_t)16 * fp.nb) || c->variant == 12);
+}
 static bool lanes_are_rays(const iono_ctx *c, int64_t R, const int *order) {
     (void)R, (void)order;
     return c->variant == 11;          // measured slower than lanes = samples at every order (profiles/r03_ab_forward_lanes_rays.json)
@@ -883,16 +890,15 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_q4, wl), R);
             hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, order, R, tmax, Ns,
                                forward_walk_mode(c, (uint64_t)padded * sizeof(float4), order), c->d_unitw, tec, c->d_flags);
-        } else if (kind == IONO_INTERP_TRILINEAR && std::is_same<GT, double>::value && c->fplan.R == R && c->fplan.o_key == o &&
-                   c->fplan.d_key == d && c->fplan.Ns == Ns && c->fplan.tmax == tmax && ideal_path_ok(c) && c->variant != 10 && c->variant != 11 &&
-                   ((c->fplan.nb >= 2 * c->num_cus && c->fplan.fit_fraction >= 0.5 && R >= (int64_t)16 * c->fplan.nb) || c->variant == 12)) {
+        } else if (kind == IONO_INTERP_TRILINEAR && std::is_same<GT, double>::value && fplan_serves(c, o, d, R, tmax, Ns)) {
             // (a workgroup per bundle: below two bundles per CU -- a single timestep is 214 -- the lanes = samples kernel, one wave
             //  per ray, fills the chip better: 7.5 against 11 us at config 2; likewise when the plan is poor: windows that mostly do
             //  not fit the LDS image, or bundles of a few rays.  IONOTOMO_VARIANT=12 forces the bundle kernel)
             // bundle-stationary: one workgroup per planned bundle of <= 64 rays, windows staged in LDS (iono_forward_plan_dev)
             const iono_ctx::FwdPlan &fp = c->fplan;
-            hipLaunchKernelGGL(k_forward_bundle, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double),
-                               c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec, c->d_flags);
+            hipLaunchKernelGGL((k_forward_bundle<0>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double),
+                               c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec, c->d_flags,
+                               PhaseFreqs{}, 0);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c) && lanes_are_rays(c, R, order)) {
             // lanes = 64 neighbouring rays of the walk order; one wave-task per 64 rays (A/B: IONOTOMO_VARIANT=11)
             const int64_t tasks = (R + 63) / 64;
@@ -1415,6 +1421,18 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
     const bool ideal = ideal_path_ok(c, Ns);
     for (int f0 = 0; f0 < Nf; f0 += 8) {
         const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
+        if (fplan_serves(c, o, d, R, tmax, Ns)) {      // bundle-stationary (k_forward_bundle<NF>: windows in LDS), as the TEC forward
+            const iono_ctx::FwdPlan &fp = c->fplan;
+#define PHASE_B(NF)                                                                                                                        \
+    hipLaunchKernelGGL((k_forward_bundle<NF>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block,                                               \
+                       B_SPLIT * B_WAVE_LDS + NF * B_SPLIT * 64 * sizeof(double), c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, \
+                       fp.nchunks, tmax, Ns, c->d_unitw, phi_work + f0, c->d_flags, pf, Nf)
+            if (pf.nf == 1) PHASE_B(1);
+            else if (pf.nf <= 4) PHASE_B(4);
+            else PHASE_B(8);
+#undef PHASE_B
+            continue;
+        }
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
             if (ideal) {

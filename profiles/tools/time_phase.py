@@ -39,6 +39,12 @@ for planned in (False, True):
     g = torch.empty(bench.NA, bench.NT, bench.ND, nf, dtype=torch.float64, device="cuda")
     if not planned:
         out["forward_phase_nf%d_ms" % nf] = timeit(lambda: e.forward_phase(o, d, bench.NA, bench.NT, bench.ND, bench.TMAX, bench.NS, freqs, clock, const, 0, out=g))
+        g0 = g.clone()
+        e.plan_forward(o, d, bench.TMAX, bench.NS)            # bundle plan (round 3): the same observable from LDS windows
+        out["forward_phase_bundle_nf%d_ms" % nf] = timeit(lambda: e.forward_phase(o, d, bench.NA, bench.NT, bench.ND, bench.TMAX, bench.NS, freqs, clock, const, 0, out=g))
+        out["forward_phase_bundle_vs_direct_nf%d_max_abs" % nf] = float((g - g0).abs().max())
+        out["forward_phase_nf%d_max_abs_value" % nf] = float(g0.abs().max())
+        e.clear_forward_plan()
     y = torch.randn(bench.NA, bench.NT * bench.ND, nf, dtype=torch.float64, device="cuda")
     grad = torch.zeros(e.shape, dtype=torch.float64, device="cuda")
 

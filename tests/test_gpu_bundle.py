@@ -216,3 +216,35 @@ def test_bundle_forward_bench_shape(OC):
     eng.bind_values(padded)
     tec2 = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
     assert np.array_equal(tec2, tec)
+
+
+def test_phase_observable_on_the_bundle_plan(OC):
+    """iterative_newton.forward_equation's observable (per-frequency integrals of 1 - sqrt(1 - ne / n_p)) through k_forward_bundle<NF>:
+    equal to the direct-load kernels for 1, 3 and 8 frequencies, rays that leave the grid give NaN + flag."""
+    import bench
+    w = bench.build_workload(0)
+    na, nt, nd = bench.NA, 12, bench.ND
+    sel = np.arange(bench.NA * bench.NT * bench.ND).reshape(bench.NA, bench.NT, bench.ND)[:, :nt].reshape(-1)
+    o, d = w["origins"][sel].copy(), w["directions"][sel].copy()
+    eng = engine(w["xvec"], w["yvec"], w["zvec"])
+    eng.set_log_model(eng.tensor(w["m"]), w["K_ne"])                    # ne [m^-3]
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    rng = np.random.default_rng(0)
+    clock = eng.tensor(rng.normal(size=(na, nt)) * 1e-9)
+    const = eng.tensor(rng.normal(size=na))
+    for nf in (1, 3, 8):
+        freqs = np.linspace(110e6, 170e6, nf)
+        eng.clear_forward_plan()
+        direct = eng.forward_phase(ot, dt, na, nt, nd, bench.TMAX, bench.NS, freqs, clock, const, 2).cpu().numpy()
+        nb, _, fit = eng.plan_forward(ot, dt, bench.TMAX, bench.NS)
+        assert nb > 0 and fit > 0.9
+        planned = eng.forward_phase(ot, dt, na, nt, nd, bench.TMAX, bench.NS, freqs, clock, const, 2).cpu().numpy()
+        assert planned.shape == (na, nt, nd, nf) and np.all(np.isfinite(planned))
+        assert np.max(np.abs(planned - direct)) < 1e-11 * np.max(np.abs(direct)), nf
+    assert not eng.check_oob()
+    bad = d.copy()
+    bad[7, :2] = [3.0, 3.0]                                              # one ray out through the side
+    bt = eng.tensor(bad)
+    eng.plan_forward(ot, bt, bench.TMAX, bench.NS)
+    g = eng.forward_phase(ot, bt, na, nt, nd, bench.TMAX, bench.NS, np.array([150e6]), clock, const, 2).cpu().numpy().reshape(-1)
+    assert eng.check_oob() and np.isnan(g[7]) and np.isfinite(g[8])
