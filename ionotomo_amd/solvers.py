@@ -440,6 +440,8 @@ def steepest_descent_phase(eng, origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, cloc
     fd = 1e-4
     if hasattr(eng, "plan_adjoint"):           # node-stationary transpose for every iteration (geometry only, speed only)
         eng.plan_adjoint(origins, dirs, tmax, Ns)
+    if hasattr(eng, "plan_forward"):           # ... and the bundle plan of the forward (windows in LDS): same two tensors
+        eng.plan_forward(origins, dirs, tmax, Ns)
     for k in range(max_iter + 1):
         eng.set_log_model(mu.reshape(-1), K)
         g = eng.forward_phase(origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, clock, const, i0)
