@@ -1918,7 +1918,8 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
     }
     const GridView g = view(c);
     const dim3 grid((unsigned)((R + 63) / 64)), block(64);
-    const size_t lds = lds_bytes(c);
+    // axes (+ the wave's scatter window of the transpose: iono_fermat_kernels.h)
+    const size_t lds = ((lds_bytes(c) + 15) & ~(size_t)15) + (adjoint ? sizeof(double) * FW * FW * FWZ : 0);
 #define LAUNCH_FT(K, B, A)                                                                                                              \
     hipLaunchKernelGGL((k_fermat_tec<K, B, A>), grid, block, lds, c->stream, g, c->d_nM, dO, dD, R, tmax, Ns, substeps, rule, independent,   \
                        kind_ne, ne_scale, dW, tec, grad, c->d_flags)

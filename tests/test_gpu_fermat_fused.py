@@ -95,8 +95,8 @@ def test_config3_fused_equals_trace_then_integrate_and_the_oracle(kind, O):
 
 
 def test_620k_bending_rays_through_256_cubed_in_one_launch():
-    """Config 4's ray count with the bending tracer: one launch, no 5.1 GB ray buffer; sampled against trace + integrate, the
-    transpose by the dot-product test on a subset (plain hardware atomics: the full batch is timed in profiles/)."""
+    """Config 4's ray count with the bending tracer: one launch, no 5.1 GB ray buffer; sampled against trace + integrate; the
+    transpose by the dot-product test on the full batch and entry by entry on a subset."""
     w = syn.make_workload("cfg4", margin_cells=16)
     eng = make_engine(w)
     eng.set_values(eng.tensor(w["ne"]))
@@ -118,8 +118,17 @@ def test_620k_bending_rays_through_256_cubed_in_one_launch():
     assert np.max(np.abs(tec[idx] - two) / two) < 1e-12
     straight = eng.forward(oi, di, w["tmax"], Ns).cpu().numpy() * 1e-13
     assert np.max(np.abs(two - straight) / straight) > 1e-6                       # the rays really bend
-    y = eng.tensor(np.random.default_rng(3).normal(size=len(idx)))
-    g = eng.adjoint_fermat(oi, di, y, w["tmax"], Ns, freq, bend=True, kind="linear", substeps=2, ne_scale=1e-13)
-    lhs, rhs = float((eng.tensor(tec[idx]) * y).sum()), float((g * eng.tensor(w["ne"])).sum())
-    assert abs(lhs - rhs) < 1e-10 * np.linalg.norm(tec[idx]) * float(y.norm())
+    # the transpose on the FULL batch (re-trace + scatter through each wave's LDS window): <G x, y> = <x, G^T y>
+    y = eng.tensor(np.random.default_rng(3).normal(size=R))
+    g = eng.adjoint_fermat(ot, dt, y, w["tmax"], Ns, freq, bend=True, kind="linear", substeps=2, ne_scale=1e-13)
+    lhs, rhs = float((eng.tensor(tec) * y).sum()), float((g * eng.tensor(w["ne"])).sum())
+    assert abs(lhs - rhs) < 1e-10 * np.linalg.norm(tec) * float(y.norm())
+    # ... and on a subset, entry by entry, against the explicit-ray transpose (plain atomics per corner)
+    from ionotomo_amd import _lib
+    ys = eng.tensor(np.random.default_rng(4).normal(size=len(idx)))
+    ref = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
+    eng.ctx.call("iono_adjoint_rays_dev", _lib._V(rays.data_ptr()), _lib._V(ys.data_ptr()), len(idx), Ns, eng.kind, eng.rule,
+                 _lib._V(ref.data_ptr()), _lib.F64)
+    got = eng.adjoint_fermat(oi, di, ys, w["tmax"], Ns, freq, bend=True, kind="linear", substeps=2)
+    assert float((got - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
     assert not eng.check_oob()
