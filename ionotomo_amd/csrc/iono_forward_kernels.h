@@ -553,6 +553,9 @@ static_assert(B_LEV8 == B_LEV * 8, "B_LEV8");
 #define B_CAPCOLS 120                            // columns per wave image
 #define B_WAVE_LDS (B_CAPCOLS * B_PPC * 16)      // 9 600 B per wave, 4 waves per workgroup
 #define B_SPLIT 4                                // z-parts of a ray = waves of a workgroup
+#ifndef B_LOOKAHEAD
+#define B_LOOKAHEAD 48                           // rejected rays a bundle looks past before it closes (plan, host side)
+#endif
 #ifndef B_UNROLL
 #define B_UNROLL 2
 #endif
@@ -662,6 +665,10 @@ __global__ __launch_bounds__(256) void k_bundle_keys(GridView g, const double *_
         }
         keys[r] = code, idx[r] = (int)r, rec[r] = h;
     }
+}
+__global__ __launch_bounds__(256) void k_bundle_permute(const int *__restrict__ sorted_idx, const int *__restrict__ perm, int64_t R,
+                                                        int *__restrict__ order) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < R; q += (int64_t)gridDim.x * blockDim.x) order[q] = sorted_idx[perm[q]];
 }
 __global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__restrict__ rec, const int *__restrict__ order, int64_t R,
                                                        BundleSummary *__restrict__ sorted) {

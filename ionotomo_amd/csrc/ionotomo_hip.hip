@@ -795,37 +795,60 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     std::vector<BundleSummary> hr((size_t)R);
     HIP_TRY(c, hipMemcpyAsync(hr.data(), r1, (size_t)R * sizeof(BundleSummary), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, plan_reserve(fp.d_order, fp.cap_order, (size_t)R * sizeof(int)));
-    HIP_TRY(c, hipMemcpyAsync(fp.d_order, i1, (size_t)R * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    std::vector<int> bstart;
+    // The cut: walk the sorted rays; a bundle takes the next rays that keep its window within the image, looking up to
+    // B_LOOKAHEAD rejected rays ahead (the Morton curve jumps: a ray that does not fit now often belongs to a later bundle, while
+    // the ones behind it still fit this one: 4 838 -> ~4 560 bundles at the bench shape).  perm = walk positions, bundle by bundle.
+    std::vector<int> bstart, perm;
     bstart.reserve((size_t)R / 32 + 2);
+    perm.reserve((size_t)R);
+    std::vector<unsigned char> used((size_t)R, 0);
     const float inf = 3.0e38f;
-    float x0lo = inf, x0hi = -inf, y0lo = inf, y0hi = -inf, xelo = inf, xehi = -inf, yelo = inf, yehi = -inf, zlo = inf, zhi = -inf, ax = 0, ay = 0, az = 0;
-    int cnt = 0;
-    bool cur_valid = true;
-    auto reset = [&]() { x0lo = y0lo = xelo = yelo = zlo = inf, x0hi = y0hi = xehi = yehi = zhi = -inf, ax = ay = az = 0, cnt = 0; };
     for (int64_t i = 0; i < R; ++i) {
-        const BundleSummary &h = hr[(size_t)i];                  // (walk order)
-        const bool valid = h.adx >= 0.0f;
-        // the bundle with this ray added
-        const float nx0lo = std::min(x0lo, h.fx0), nx0hi = std::max(x0hi, h.fx0), ny0lo = std::min(y0lo, h.fy0), ny0hi = std::max(y0hi, h.fy0);
-        const float nxelo = std::min(xelo, h.fxe), nxehi = std::max(xehi, h.fxe), nyelo = std::min(yelo, h.fye), nyehi = std::max(yehi, h.fye);
-        const float nzlo = std::min(zlo, h.fz0), nzhi = std::max(zhi, h.fz0), nax = std::max(ax, h.adx), nay = std::max(ay, h.ady), naz = std::max(az, h.dz);
-        const int wxb = (int)std::floor(std::max(nx0hi - nx0lo, nxehi - nxelo) + nax * (B_KC - 1) + 1e-3f) + 3;
-        const int wyb = (int)std::floor(std::max(ny0hi - ny0lo, nyehi - nyelo) + nay * (B_KC - 1) + 1e-3f) + 3;
-        const int nlb = (int)std::floor((nzhi - nzlo) + naz * (B_KC - 1) + 1e-3f) + 4;
-        const bool ok = cnt < 64 && valid == cur_valid && (!valid || (wxb * wyb <= B_CAPCOLS && wyb <= B_MAXWY && nlb <= B_LEV));
-        if (cnt == 0 || !ok) {            // (a single ray whose own window does not fit still gets a bundle: its chunks take the direct loads)
-            bstart.push_back((int)i);
-            reset();
-            cur_valid = valid;
-            x0lo = x0hi = h.fx0, y0lo = y0hi = h.fy0, xelo = xehi = h.fxe, yelo = yehi = h.fye, zlo = zhi = h.fz0, ax = h.adx, ay = h.ady, az = h.dz;
-            cnt = 1;
-        } else {
+        if (used[(size_t)i]) continue;
+        const BundleSummary &h0 = hr[(size_t)i];
+        const bool valid = h0.adx >= 0.0f;
+        float x0lo = h0.fx0, x0hi = h0.fx0, y0lo = h0.fy0, y0hi = h0.fy0, xelo = h0.fxe, xehi = h0.fxe, yelo = h0.fye, yehi = h0.fye, zlo = h0.fz0,
+              zhi = h0.fz0, ax = h0.adx, ay = h0.ady, az = h0.dz;
+        (void)inf;
+        bstart.push_back((int)perm.size());      // (a single ray whose own window does not fit still gets a bundle: its chunks take the direct loads)
+        perm.push_back((int)i);
+        used[(size_t)i] = 1;
+        int cnt = 1, miss = 0;
+        for (int64_t j = i + 1; j < R && cnt < 64 && miss <= B_LOOKAHEAD; ++j) {
+            if (used[(size_t)j]) continue;
+            const BundleSummary &h = hr[(size_t)j];
+            if ((h.adx >= 0.0f) != valid) break;               // rays that leave the grid sit at the end of the walk, in bundles of their own
+            bool ok = true;
+            float nx0lo = x0lo, nx0hi = x0hi, ny0lo = y0lo, ny0hi = y0hi, nxelo = xelo, nxehi = xehi, nyelo = yelo, nyehi = yehi, nzlo = zlo, nzhi = zhi,
+                  nax = ax, nay = ay, naz = az;
+            if (valid) {
+                nx0lo = std::min(x0lo, h.fx0), nx0hi = std::max(x0hi, h.fx0), ny0lo = std::min(y0lo, h.fy0), ny0hi = std::max(y0hi, h.fy0);
+                nxelo = std::min(xelo, h.fxe), nxehi = std::max(xehi, h.fxe), nyelo = std::min(yelo, h.fye), nyehi = std::max(yehi, h.fye);
+                nzlo = std::min(zlo, h.fz0), nzhi = std::max(zhi, h.fz0), nax = std::max(ax, h.adx), nay = std::max(ay, h.ady), naz = std::max(az, h.dz);
+                const int wxb = (int)std::floor(std::max(nx0hi - nx0lo, nxehi - nxelo) + nax * (B_KC - 1) + 1e-3f) + 3;
+                const int wyb = (int)std::floor(std::max(ny0hi - ny0lo, nyehi - nyelo) + nay * (B_KC - 1) + 1e-3f) + 3;
+                const int nlb = (int)std::floor((nzhi - nzlo) + naz * (B_KC - 1) + 1e-3f) + 4;
+                ok = wxb * wyb <= B_CAPCOLS && wyb <= B_MAXWY && nlb <= B_LEV;
+            }
+            if (!ok) {
+                ++miss;
+                continue;
+            }
             x0lo = nx0lo, x0hi = nx0hi, y0lo = ny0lo, y0hi = ny0hi, xelo = nxelo, xehi = nxehi, yelo = nyelo, yehi = nyehi;
             zlo = nzlo, zhi = nzhi, ax = nax, ay = nay, az = naz;
+            perm.push_back((int)j);
+            used[(size_t)j] = 1;
             ++cnt;
         }
+    }
+    // order[q] = sorted index at walk position perm[q]
+    {
+        int *d_perm = i0;                                         // (scratch: the unsorted index array is no longer needed)
+        HIP_TRY(c, hipMemcpyAsync(d_perm, perm.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_bundle_permute, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, i1, d_perm, R, fp.d_order);
+        HIP_TRY(c, hipGetLastError());
+        HIP_TRY(c, hipStreamSynchronize(c->stream));              // (perm is a host vector)
     }
     bstart.push_back((int)R);
     const int nb = (int)bstart.size() - 1, nchunks = (Ns + B_KC - 1) / B_KC;
