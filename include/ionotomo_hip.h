@@ -204,6 +204,9 @@ int iono_adjoint_plan_dev(iono_ctx *ctx, const double *origins_dev, const double
                           int Ns, int interp_kind);
 int iono_adjoint_plan_clear(iono_ctx *ctx);
 int iono_adjoint_plan_info(iono_ctx *ctx, int64_t *n_segments, int *n_units, double *outside_fraction);
+/* Lanes per segment the plan chose for this geometry (4, 8 or 16; 0 without a plan): the width that leaves the fewest lanes of
+ * the LDS atomics empty.  Geometry only; never changes which samples are summed (env IONOTOMO_SEG_LANES forces a width). */
+int iono_adjoint_plan_segment_lanes(iono_ctx *ctx, int *lanes);
 /* Device memory for hosts that keep operands resident between calls but have no torch (the reference-signature facade:
  * a line search calls forward_equation(rays, K_ne, m_tci, i0) again and again with the SAME rays,
  * inversion/line_search.py:56,71,83).  iono_dev_download is also the end of a chain of *_dev launches: it waits for the

@@ -94,6 +94,7 @@ _SIGNATURES = {
     "iono_adjoint_plan_dev": [_V, _V, _L, _D, _I, _I],
     "iono_adjoint_plan_clear": [],
     "iono_adjoint_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
+    "iono_adjoint_plan_segment_lanes": [ctypes.POINTER(ctypes.c_int)],
     "iono_dev_alloc": [ctypes.c_size_t, ctypes.POINTER(_V)],
     "iono_dev_free": [_V],
     "iono_dev_upload": [_V, _V, ctypes.c_size_t],

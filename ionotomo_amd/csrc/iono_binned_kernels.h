@@ -29,7 +29,8 @@ namespace {
 #define BIN_BY (BIN_SY + 2 * BIN_H + 1)
 #define BIN_BZ (BIN_SZ + 1)                  // 16 z nodes
 #define BIN_BZP 17                           // padded z stride (odd: columns start on different banks)
-#define BIN_SEG 16                           // samples per segment = lanes per segment
+#define BIN_SEG 16                           // most samples per segment = lanes per segment (a plan may use 4 or 8: `segl`)
+#define BIN_ENTRY_PAD 128                    // zero entries behind the list: the kernel prefetches two passes (of 256 / segl) ahead
 #ifndef BIN_UNIT
 #define BIN_UNIT 512                         // segments per work unit (256: +6 %, 1024: +3 % on the bench geometry)
 #endif
@@ -53,8 +54,11 @@ __global__ void k_plan_urays(GridView g, const double *__restrict__ origins, con
 }
 
 // The plan itself, on the device (one thread per ray; a host loop over R x Ns samples took 0.26 s at the bench shape, eight
-// times a 50-iteration inversion).  Segments: <= BIN_SEG consecutive samples of a ray inside one z-layer of boxes, filed under
+// times a 50-iteration inversion).  Segments: <= segl consecutive samples of a ray inside one z-layer of boxes, filed under
 // the (x, y) box around the middle of their extent; every sample of every valid ray lands in exactly one segment.
+// segl (4, 8 or 16) = the lanes a segment occupies in the back-projection: an LDS float atomic costs the same ~14 cycles
+// whatever its lane mask, so the plan picks the width that leaves the fewest lanes empty (64 samples through 256 cells
+// put 3.8 samples into a 15-cell layer: 16-lane segments ran the atomics 24 % full).
 //   pass 1 (EMIT = false): nseg[r] (-1: the ray leaves the grid) and the number of segments per box;
 //   pass 2 (EMIT = true, after an exclusive scan of the box counts on the host): entries[box_start + slot] = (ray, first
 //           sample | count << 16 | ordinal << 24), slot from an atomic counter of the box (order inside a box is immaterial:
@@ -92,7 +96,7 @@ __device__ __forceinline__ int wave_counter_add(int *__restrict__ ctr, int key, 
 }
 template <bool EMIT>
 __global__ __launch_bounds__(256) void k_plan_segments(const double *__restrict__ uray, int64_t R, int Ns, int nx, int ny, int nz,
-                                                       int nbx, int nby, int nbz, int *__restrict__ nseg,
+                                                       int nbx, int nby, int nbz, int segl, int *__restrict__ nseg,
                                                        int *__restrict__ box_count, const int *__restrict__ box_start,
                                                        int *__restrict__ box_fill, uint2 *__restrict__ entries,
                                                        unsigned long long *__restrict__ outside) {
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256) void k_plan_segments(const double *__restrict_
             if (active) {
                 const int zb = plan_cell(fz0, dfz, k, nz) / BIN_SZ;
                 ke = k + 1;
-                while (ke < Ns && ke - k < BIN_SEG && plan_cell(fz0, dfz, ke, nz) / BIN_SZ == zb) ++ke;
+                while (ke < Ns && ke - k < segl && plan_cell(fz0, dfz, ke, nz) / BIN_SZ == zb) ++ke;
                 const int xa = plan_cell(fx0, dfx, k, nx), xb = plan_cell(fx0, dfx, ke - 1, nx);
                 const int ya = plan_cell(fy0, dfy, k, ny), yb = plan_cell(fy0, dfy, ke - 1, ny);
                 const int bi = min(nbx - 1, (xa + xb + 1) / (2 * BIN_SX)), bj = min(nby - 1, (ya + yb + 1) / (2 * BIN_SY));
@@ -172,7 +176,7 @@ __device__ __forceinline__ double dpp_shr1(double v) {       // value of the pre
 // PNF > 0: transpose of the PHASE observable (inversion/iterative_newton.py:86-127) for PNF frequencies per pass: the ray weight
 // becomes a per-sample factor  sum_l wrf[r][l] / (2 n_p,l sqrt(1 - ne_k / n_p,l))  of the electron density ne_k interpolated at
 // the sample (gathered from the grid exactly as the forward kernel does), wray = wrf with row stride ldw.
-template <typename AT, bool CUBIC, int PNF = 0, typename GT = double>
+template <typename AT, bool CUBIC, int PNF = 0, typename GT = double, int SEGL = BIN_SEG>
 __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
                                                         const BinUnit *__restrict__ units, const double *__restrict__ wray,
                                                         int Ns, const double *__restrict__ unitw, AT *__restrict__ G, int field,
@@ -187,7 +191,8 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
     const BinUnit un = units[blockIdx.x];
     lds_barrier();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int sub = lane & (BIN_SEG - 1), grp = wid * 4 + (lane >> 4);          // 16 segments per pass of the workgroup
+    constexpr int PASS = 256 / SEGL;                                             // segments per pass of the workgroup
+    const int sub = lane & (SEGL - 1), grp = wid * (64 / SEGL) + lane / SEGL;
     // The segment list and the ray records are dependent gathers (entry -> ray id -> ray record): software-pipelined two
     // deep so that a pass computes while the next pass's ray records and the one after's entries are in flight.
     struct RayRec {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
         double w[PNF > 0 ? PNF : 1]; // ray weight (PNF: one per frequency)
     };
     const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
-    // (the entry array is padded by 32 zero entries: unconditional loads; a pass beyond the unit is masked by its count)
+    // (the entry array is padded by BIN_ENTRY_PAD zero entries: unconditional loads; a pass beyond the unit is masked by its count)
     auto load_entry = [&](int e) { return entries[e]; };
     auto load_ray = [&](const uint2 en) {
         const double2 *up = (const double2 *)(uray + (size_t)en.x * 8);
@@ -210,10 +215,10 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
         return r;
     };
     int e = un.e_lo + grp;
-    uint2 en0 = load_entry(e), en1 = load_entry(e + 16);
+    uint2 en0 = load_entry(e), en1 = load_entry(e + PASS);
     RayRec r0 = load_ray(en0);
-    for (; e < un.e_hi; e += 16) {
-        const uint2 en2 = load_entry(e + 32);
+    for (; e < un.e_hi; e += PASS) {
+        const uint2 en2 = load_entry(e + 2 * PASS);
         const RayRec r1 = load_ray(en1);
         const int cnt = e < un.e_hi ? (int)((en0.y >> 16) & 0xffu) : 0, k = min((int)(en0.y & 0xffffu) + sub, Ns - 1);
         // every lane computes (no divergence before the lane exchange below); inactive lanes carry zero weights
@@ -242,8 +247,10 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
         const double u00 = w00 * az1, u01 = w01 * az1, u10 = w10 * az1, u11 = w11 * az1;  // ... at level kz + 1
         // Consecutive samples of a ray mostly sit in consecutive z cells of the same (i, j) column: the upper-level
         // contributions of lane s then hit the very nodes of lane s + 1's lower level.  Pass them one lane up inside the
-        // 16-lane segment (DPP row_shr:1) and let the receiver add them to its own before its LDS atomics: 4 + (rarely 4)
-        // instead of 8 LDS atomics per sample -- the kernel is bound by LDS atomic throughput.
+        // 16-lane DPP row (row_shr:1) and let the receiver add them to its own before its LDS atomics: 4 + (rarely 4)
+        // instead of 8 LDS atomics per sample -- the kernel is bound by LDS atomic throughput.  (The test is on the NODE, not
+        // on the ray: with narrower segments lane s and lane s + 1 may belong to different rays of the unit; a contribution
+        // that meets the cell below its own is merged all the same, into the same LDS word it would have gone to.)
         const int lin = active ? (i * g.ny + j) * g.nz + kz : -7;
         const int prev = __builtin_amdgcn_update_dpp(-9, lin, 0x111, 0xf, 0xf, false);          // row_shr:1 (row lane 0 keeps -9)
         const bool accept = active && prev + 1 == lin;

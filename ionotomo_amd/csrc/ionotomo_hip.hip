@@ -86,6 +86,7 @@ struct iono_ctx {
     int comm_ranks = 0;
     int walk_mode = 0;               // env IONOTOMO_WALK: forward walk A/B (see wave_chunk); never changes results
     bool walk_mode_set = false;
+    int seg_lanes = 0;               // env IONOTOMO_SEG_LANES=4|8|16: lanes per segment of the back-projection plan (0: chosen per geometry)
     int fwd_plan = 0;                // env IONOTOMO_FWD_PLAN=1: the forward uses the ray plan too (node-stationary, A/B)
     int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
@@ -108,6 +109,7 @@ struct iono_ctx {
         const void *o_key = nullptr, *d_key = nullptr;     // the ray arrays it was built for (caller keeps them unchanged)
         int64_t R = -1, n_entries = 0;
         int Ns = 0, kind = -1, n_units = 0;
+        int segl = BIN_SEG;                               // lanes per segment of this plan (4, 8 or 16)
         double tmax = 0;
         double *d_uray = nullptr;
         uint2 *d_entries = nullptr;
@@ -451,6 +453,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
     if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 2 | 4), c->walk_mode_set = true;
     if (const char *e = getenv("IONOTOMO_FWD_PLAN")) c->fwd_plan = atoi(e);
+    if (const char *e = getenv("IONOTOMO_SEG_LANES")) c->seg_lanes = atoi(e);
     if (const char *e = getenv("IONOTOMO_ADJ_BUNDLE")) c->adj_mode = atoi(e) & (32 | 64 | 128);
 #ifdef IONO_ABLATION
     if (const char *e = getenv("IONOTOMO_ADJ_ABLATE")) c->adj_mode |= atoi(e) & (4 | 8);     // timing only: WRONG results
@@ -1171,16 +1174,53 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     char *sb = scratch.as<char>();
     int *d_nseg32 = (int *)sb, *d_cnt = (int *)(sb + off_cnt), *d_start = (int *)(sb + off_start), *d_fill = (int *)(sb + off_fill);
     unsigned long long *d_out = (unsigned long long *)(sb + off_out);
-    HIP_TRY(c, hipMemsetAsync(sb + off_cnt, 0, off_out + 16 - off_cnt, c->stream));
-    hipLaunchKernelGGL((k_plan_segments<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz, nbx,
-                       nby, nbz, d_nseg32, d_cnt, (const int *)nullptr, (int *)nullptr, (uint2 *)nullptr, d_out);
-    HIP_TRY(c, hipGetLastError());
     std::vector<int> h_nseg((size_t)R), h_cnt((size_t)nbox);
     unsigned long long outside = 0;
+    // The lanes a segment occupies (segl): the widest first; while the segments come out less than half full, count again with
+    // half the width; keep the width with the fewest lanes in total (an entry costs about two lanes' worth of gathers).
+    auto count_segments = [&](int width, int64_t *n_seg) -> int {
+        HIP_TRY(c, hipMemsetAsync(sb + off_cnt, 0, off_out + 16 - off_cnt, c->stream));
+        hipLaunchKernelGGL((k_plan_segments<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz,
+                           nbx, nby, nbz, width, d_nseg32, d_cnt, (const int *)nullptr, (int *)nullptr, (uint2 *)nullptr, d_out);
+        HIP_TRY(c, hipGetLastError());
+        if (n_seg) {
+            HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)nbox * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            *n_seg = 0;
+            for (int64_t q = 0; q < nbox; ++q) *n_seg += h_cnt[(size_t)q];
+        }
+        return IONO_OK;
+    };
+    int segl = BIN_SEG;
+    if (c->fwd_plan) {                                    // the node-stationary forward (A/B) reads 16-lane segments
+        rc = count_segments(segl, nullptr);
+        if (rc) return rc;
+    } else if (c->seg_lanes == 4 || c->seg_lanes == 8 || c->seg_lanes == 16) {      // forced width (A/B, tests)
+        segl = c->seg_lanes;
+        rc = count_segments(segl, nullptr);
+        if (rc) return rc;
+    } else {
+        double best = -1;
+        int counted = 0;
+        for (int width = BIN_SEG; width >= 4; width /= 2) {
+            int64_t n_seg = 0;
+            rc = count_segments(width, &n_seg);
+            if (rc) return rc;
+            counted = width;
+            const double cost = (double)n_seg * (width + 2);
+            if (best < 0 || cost < best) best = cost, segl = width;
+            if (n_seg == 0 || (double)R * Ns > 0.5 * (double)n_seg * width) break;      // at least half full: narrower cannot pay
+        }
+        if (counted != segl) {
+            rc = count_segments(segl, nullptr);
+            if (rc) return rc;
+        }
+    }
     HIP_TRY(c, hipMemcpyAsync(h_nseg.data(), d_nseg32, (size_t)R * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)nbox * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&outside, d_out, sizeof(outside), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const int unit_segs = BIN_UNIT * (BIN_SEG / segl);     // the same number of lane passes per work unit whatever the width
     std::vector<unsigned char> nseg((size_t)R, 0);
     int smax = 1;
     bool fwd_ok = true;
@@ -1213,16 +1253,16 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         const int64_t lo = start[(size_t)b], hi = start[(size_t)b + 1];
         if (lo == hi) continue;
         const int zb = (int)(b % nbz), bj = (int)((b / nbz) % nby), bi = (int)(b / ((int64_t)nbz * nby));
-        for (int64_t q = lo; q < hi; q += BIN_UNIT)
-            units.push_back(BinUnit{bi * BIN_SX - BIN_H, bj * BIN_SY - BIN_H, zb * BIN_SZ, (int)q, (int)std::min(hi, q + BIN_UNIT)});
+        for (int64_t q = lo; q < hi; q += unit_segs)
+            units.push_back(BinUnit{bi * BIN_SX - BIN_H, bj * BIN_SY - BIN_H, zb * BIN_SZ, (int)q, (int)std::min(hi, q + unit_segs)});
     }
     std::stable_sort(units.begin(), units.end(), [](const BinUnit &a, const BinUnit &b) { return a.e_hi - a.e_lo > b.e_hi - b.e_lo; });
-    // pass 2 on the device: the segments into their boxes (+ 32 zero entries: the kernel prefetches two passes ahead)
-    HIP_TRY(c, plan_reserve(pl.d_entries, pl.cap_entries, ((size_t)ne + 32) * sizeof(uint2)));
-    HIP_TRY(c, hipMemsetAsync(pl.d_entries + ne, 0, 32 * sizeof(uint2), c->stream));
+    // pass 2 on the device: the segments into their boxes (+ BIN_ENTRY_PAD zero entries: the kernel prefetches two passes ahead)
+    HIP_TRY(c, plan_reserve(pl.d_entries, pl.cap_entries, ((size_t)ne + BIN_ENTRY_PAD) * sizeof(uint2)));
+    HIP_TRY(c, hipMemsetAsync(pl.d_entries + ne, 0, BIN_ENTRY_PAD * sizeof(uint2), c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_start, start.data(), (size_t)nbox * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL((k_plan_segments<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz, nbx,
-                       nby, nbz, (int *)nullptr, (int *)nullptr, (const int *)d_start, d_fill, pl.d_entries, (unsigned long long *)nullptr);
+                       nby, nbz, segl, (int *)nullptr, (int *)nullptr, (const int *)d_start, d_fill, pl.d_entries, (unsigned long long *)nullptr);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, plan_reserve(pl.d_units, pl.cap_units, units.size() * sizeof(BinUnit)));
     HIP_TRY(c, hipMemcpyAsync(pl.d_units, units.data(), units.size() * sizeof(BinUnit), hipMemcpyHostToDevice, c->stream));
@@ -1233,7 +1273,7 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     if (pl.fwd_ok && c->fwd_plan) HIP_TRY(c, plan_reserve(pl.d_partial, pl.cap_partial, (size_t)R * smax * sizeof(double)));
     else pl.fwd_ok = false;      // (the node-stationary FORWARD is an opt-in A/B: no 40 MB of partial sums otherwise)
     pl.o_key = o, pl.d_key = d, pl.R = R, pl.Ns = Ns, pl.tmax = tmax, pl.kind = kind;
-    pl.n_entries = ne, pl.n_units = (int)units.size(), pl.n_invalid = n_invalid;
+    pl.n_entries = ne, pl.n_units = (int)units.size(), pl.n_invalid = n_invalid, pl.segl = segl;
     pl.outside_fraction = (double)outside / (double)ne;
     return IONO_OK;
 }
@@ -1246,7 +1286,28 @@ int iono_adjoint_plan_info(iono_ctx *c, int64_t *n_entries, int *n_units, double
     return IONO_OK;
 }
 
+int iono_adjoint_plan_segment_lanes(iono_ctx *c, int *lanes) {
+    if (!c || !lanes) return fail(c, IONO_ERR_ARG, "null argument");
+    *lanes = c->plan.R >= 0 ? c->plan.segl : 0;
+    return IONO_OK;
+}
+
 }  // extern "C"  (templates below need C++ linkage)
+
+// the node-stationary kernel instantiated for the plan's segment width: BY_SEGL(pl.segl, launch using SL)
+#define BY_SEGL(segl, ...)                                                                                                          \
+    do {                                                                                                                           \
+        if ((segl) == 4) {                                                                                                         \
+            constexpr int SL = 4;                                                                                                  \
+            __VA_ARGS__;                                                                                                           \
+        } else if ((segl) == 8) {                                                                                                  \
+            constexpr int SL = 8;                                                                                                  \
+            __VA_ARGS__;                                                                                                           \
+        } else {                                                                                                                   \
+            constexpr int SL = 16;                                                                                                 \
+            __VA_ARGS__;                                                                                                           \
+        }                                                                                                                          \
+    } while (0)
 
 // One launch of the LDS-tiled back-projection (ideal-uniform grids).  CUBIC: channel `field` of the tricubic transpose.
 template <typename AT, int MODE, bool CUBIC, bool PHASE = false, typename GT = double>
@@ -1300,8 +1361,8 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
     }
     const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);      // float64 box image for either AT
     if (planned && kind == IONO_INTERP_TRILINEAR) {
-        hipLaunchKernelGGL((k_adjoint_binned<AT, false>), dim3(pl.n_units), dim3(256), bin_lds, c->stream, g, pl.d_uray, pl.d_entries,
-                           pl.d_units, wr, Ns, c->d_unitw, grad, -1);
+        BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(pl.n_units), dim3(256), bin_lds, c->stream, g,
+                                            pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, grad, -1, PhaseFreqs{}, 0));
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }
@@ -1315,9 +1376,9 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
         for (int f = 0; f < LM_NF; ++f) {
             if (planned) {
-                hipLaunchKernelGGL((k_adjoint_binned<double, true>), dim3(pl.n_units), dim3(256),
-                                   sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE), c->stream, g, pl.d_uray, pl.d_entries,
-                                   pl.d_units, wr, Ns, c->d_unitw, c->d_G8 + (size_t)f * n, f);
+                BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, true, 0, double, SL>), dim3(pl.n_units), dim3(256), bin_lds,
+                                                    c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw,
+                                                    c->d_G8 + (size_t)f * n, f, PhaseFreqs{}, 0));
                 continue;
             }
             const int rc = launch_adjoint_tile<double, MODE, true>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns,
@@ -1505,8 +1566,8 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
             if (planned) {      // node-stationary: box images in LDS, ne gathered per sample (iono_binned_kernels.h)
                 const size_t bl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
 #define PHASE_BIN(NF)                                                                                                              \
-    hipLaunchKernelGGL((k_adjoint_binned<double, false, NF, GT>), dim3(pl.n_units), dim3(256), bl, c->stream, g, pl.d_uray,         \
-                       pl.d_entries, pl.d_units, wrf_work + f0, Ns, c->d_unitw, grad, -1, pf, Nf)
+    BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, NF, GT, SL>), dim3(pl.n_units), dim3(256), bl, c->stream, g, \
+                                        pl.d_uray, pl.d_entries, pl.d_units, wrf_work + f0, Ns, c->d_unitw, grad, -1, pf, Nf))
                 if (pf.nf == 1) PHASE_BIN(1);
                 else if (pf.nf == 2) PHASE_BIN(2);
                 else if (pf.nf <= 4) PHASE_BIN(4);

@@ -162,6 +162,13 @@ class RayEngine(object):
         self.ctx.call("iono_adjoint_plan_info", ctypes.byref(n), ctypes.byref(u), ctypes.byref(f))
         return n.value, u.value, f.value
 
+    def plan_segment_lanes(self):
+        """Lanes per segment of the current back-projection plan (4, 8 or 16; 0: no plan)."""
+        import ctypes
+        v = ctypes.c_int(0)
+        self.ctx.call("iono_adjoint_plan_segment_lanes", ctypes.byref(v))
+        return v.value
+
     def plan_forward(self, origins_t, dirs_t, tmax, Ns):
         """Bundle the rays ONCE (geometry only): later ``forward`` calls with these same two tensors give every workgroup a
         bundle of <= 64 nearly coincident rays whose voxel neighbourhood is staged in LDS

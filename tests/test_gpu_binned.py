@@ -102,6 +102,69 @@ def test_binned_adjoint_bench_shape_and_fused_modes(OC):
     assert not eng.check_oob()
 
 
+@pytest.mark.parametrize("lanes", [4, 8, 16])
+@pytest.mark.parametrize("Ns", [17, 64, 257])
+def test_binned_segment_widths(lanes, Ns, OC, monkeypatch):
+    """The plan packs a segment into 4, 8 or 16 lanes (IONOTOMO_SEG_LANES forces one; without it the width with the fewest empty
+    lanes is chosen per geometry): the trilinear, tricubic and phase back-projections are the same sums at every width --
+    also where a DPP row mixes segments of different rays (the z-neighbour merge is decided on the node, not on the ray)."""
+    monkeypatch.setenv("IONOTOMO_SEG_LANES", str(lanes))
+    w = syn.make_workload(antennas="lofar", na=20, nd=5, nt=3, n=72)
+    xv, yv, zv = w["xvec"], w["yvec"], w["zvec"]
+    M = w["ne"] / 1e13
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    rng = np.random.default_rng(lanes * 1000 + Ns)
+    y = rng.normal(size=len(o))
+    eng = engine(xv, yv, zv)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    segs, units, _ = eng.plan_adjoint(ot, dt, w["tmax"], Ns)
+    assert eng.plan_segment_lanes() == lanes and segs >= len(o) * ((Ns + lanes - 1) // lanes)
+    g = eng.adjoint(ot, dt, eng.tensor(y), w["tmax"], Ns).cpu().numpy()
+    gref = OC.adjoint_straight(xv, yv, zv, o, d, y, w["tmax"], Ns)
+    assert np.max(np.abs(g - gref)) < 1e-11 * np.max(np.abs(gref))
+    # phase transpose: planned against the ray-stationary kernel
+    freqs = np.array([120e6, 150e6, 180e6])
+    eng.set_values(eng.tensor(w["ne"]))
+    yp = eng.tensor(rng.normal(size=(20, 15, 3)))
+    gp = eng.adjoint_phase(ot, dt, yp, 20, w["tmax"], Ns, freqs, 2)
+    eng.clear_adjoint_plan()
+    assert eng.plan_segment_lanes() == 0
+    gq = eng.adjoint_phase(ot, dt, yp, 20, w["tmax"], Ns, freqs, 2)
+    assert float((gp - gq).abs().max()) < 1e-11 * float(gq.abs().max())
+    # tricubic channels
+    engc = engine(xv, yv, zv, interp="cubic")
+    engc.set_values(engc.tensor(M))
+    oc, dc = engc.tensor(o), engc.tensor(d)
+    gu = engc.adjoint(oc, dc, engc.tensor(y), w["tmax"], Ns)
+    engc.plan_adjoint(oc, dc, w["tmax"], Ns)
+    assert engc.plan_segment_lanes() == lanes
+    gc = engc.adjoint(oc, dc, engc.tensor(y), w["tmax"], Ns)
+    assert float((gc - gu).abs().max()) < 1e-11 * float(gu.abs().max())
+    assert not eng.check_oob() and not engc.check_oob()
+
+
+def test_binned_segment_width_is_chosen_per_geometry():
+    """65 samples through 256 cells leave 3.8 samples in a 15-cell layer: 4 lanes; one sample per cell (the bench shape) and 257
+    samples through 48 cells fill 16."""
+    import bench
+    w = bench.build_workload(0)
+    eng = engine(w["xvec"], w["yvec"], w["zvec"])
+    na, P = bench.NA, bench.NT * bench.ND
+    ot, dt = eng.tensor(w["origins"].reshape(-1, 3)[: 40 * P]), eng.tensor(w["directions"].reshape(-1, 3)[: 40 * P])
+    eng.plan_adjoint(ot, dt, bench.TMAX, 65)
+    assert eng.plan_segment_lanes() == 4
+    eng.plan_adjoint(ot, dt, bench.TMAX, 129)
+    assert eng.plan_segment_lanes() == 8
+    eng.plan_adjoint(ot, dt, bench.TMAX, bench.NS)
+    assert eng.plan_segment_lanes() == 16
+    v = syn.make_workload(antennas="lofar", na=62, nd=6, nt=4, n=48)
+    eng2 = engine(v["xvec"], v["yvec"], v["zvec"])
+    o2, d2 = eng2.tensor(v["origins"].reshape(-1, 3)), eng2.tensor(v["directions"].reshape(-1, 3))
+    eng2.plan_adjoint(o2, d2, v["tmax"], 257)
+    assert eng2.plan_segment_lanes() == 16
+
+
 def test_binned_tricubic_channels():
     from oracle import oracle as O
     w = syn.make_workload("cfg2")
