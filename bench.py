@@ -463,6 +463,8 @@ def main():
         def ca():
             gc.zero_()
             ec.adjoint(o_t, d_t, yc, TMAX, NS, out=gc, order=order_t)
+        if args.fwd_plan:          # bundles of neighbouring rays, one Lekien-Marsden field pair per wave (k_forward_bundle_lm)
+            ec.plan_forward(o_t, d_t, TMAX, NS)
         return ec, cf, ca, tc
 
     def solver_problem():
@@ -599,6 +601,18 @@ def main():
             del big_a, big_b
             # ---- tricubic (Lekien-Marsden derivative fields; config 2's interpolant) at the same shape
             _, kcf = time_steps(cf, k2, 1, torch, dist, 1)
+            if args.fwd_plan:
+                # with new node values every call (what an inversion iteration pays: the derivative fields are rebuilt), and lanes = samples
+                xc = torch.exp(m_t).mul_(w["K_ne"] / 1e13)
+
+                def cf_new_values():
+                    ec.set_values(xc)
+                    cf()
+                _, kcn = time_steps(cf_new_values, max(2, k2 // 2), 1, torch, dist, 1)
+                extra["tricubic_forward_new_values_ms"] = kcn * 1e3
+                ec.clear_forward_plan()
+                _, kcu = time_steps(cf, max(2, k2 // 2), 1, torch, dist, 1)
+                extra["tricubic_forward_unplanned_ms"] = kcu * 1e3
             if args.plan:
                 ec.plan_adjoint(o_t, d_t, TMAX, NS)
             _, kca = time_steps(ca, max(2, k2 // 4), 1, torch, dist, 1)

@@ -44,26 +44,6 @@ __global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, d
         Z[idx] = make_double2((double)row[0], dz);
     }
 }
-// pass y: Y4[node][q + 2 r] = (f, Dy f, Dz f, Dy Dz f) from Z = (f, Dz f);  pass x: F8[node][p + 2 (q + 2 r)]
-__global__ __launch_bounds__(256) void k_lm_fields_y(const double2 *__restrict__ Z, double *__restrict__ Y4, int nx, int ny, int nz) {
-    const int64_t n = (int64_t)nx * ny * nz;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int j = (int)((idx / nz) % ny);
-        const double2 z0 = Z[idx];
-        double dy0 = 0.0, dy1 = 0.0;
-        if (j >= 2 && j <= ny - 3) {
-#pragma unroll
-            for (int db = -2; db <= 2; ++db) {
-                if (db == 0) continue;
-                const double2 z = Z[idx + (int64_t)db * nz];
-                dy0 += fd_coef(db) * z.x, dy1 += fd_coef(db) * z.y;
-            }
-        }
-        double2 *o = (double2 *)(Y4 + idx * 4);
-        o[0] = make_double2(z0.x, dy0);          // r = 0: q = 0, 1
-        o[1] = make_double2(z0.y, dy1);          // r = 1
-    }
-}
 // z stride of F8 in nodes.  (Padding it to nz + 1 -- at 256^3 the column and plane strides, 16 KB and 4 MB, are powers of
 // two and TCP_READ_TAGCONFLICT_STALL is 15 % of the forward's cycles -- measured 8 % SLOWER: 2.07 vs 1.92 ms.)
 #ifndef LM_PAD_J
@@ -72,30 +52,72 @@ __global__ __launch_bounds__(256) void k_lm_fields_y(const double2 *__restrict__
 #endif
 #define LM_NZP(nz) ((nz) + LM_PAD_J)
 #define LM_SI(ny, nz) ((int64_t)(ny) * LM_NZP(nz) + LM_PAD_I)     // x-plane stride in nodes
-__global__ __launch_bounds__(256) void k_lm_fields_x(const double *__restrict__ Y4, double *__restrict__ F8, int nx, int ny, int nz) {
-    const int64_t n = (int64_t)nx * ny * nz, sx = (int64_t)ny * nz;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int i = (int)(idx / sx);
-        const double2 *c = (const double2 *)(Y4 + idx * 4);
-        const double2 a0 = c[0], a1 = c[1];
-        double2 d0 = make_double2(0.0, 0.0), d1 = d0;
-        if (i >= 2 && i <= nx - 3) {
+// passes y and x in one kernel: a thread owns a (j, k) line of nodes and marches along i through one of LM_XSEG stretches, keeping
+// Y4 = (f, Dy f, Dz f, Dy Dz f) of the five planes i - 2 .. i + 2 in registers (each formed from the five j-neighbours of Z = (f, Dz f):
+// rows 4 KB apart, L1 / L2 hits), so that every Z is read from memory once and no Y4 array exists.  (Three separate passes took
+// 0.09 + 0.26 + 0.68 ms at 256^3 -- the x pass re-read five planes 2 MB apart, beyond the L2.)  Lanes run along k: every load and
+// store of a wave is one contiguous run.  Output: F8[node][p + 2 (q + 2 r)] node-major (k_forward_straight_lm), or -- PAIRS -- the
+// same four (value, Dx value) pairs PAIR-major, FP[t = q + 2 r][node] (double2, node = the grid's own linear index, npad nodes per
+// pair array): the layout the bundle-stationary forward stages from (k_forward_bundle_lm).
+#define LM_XSEG 8
+template <bool PAIRS>
+__global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict__ Z, double *__restrict__ F8, int nx, int ny, int nz, int64_t npad) {
+    const int64_t sx = (int64_t)ny * nz, lines = sx * LM_XSEG;
+    const int seg_len = (nx + LM_XSEG - 1) / LM_XSEG;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < lines; t += (int64_t)gridDim.x * blockDim.x) {
+        const int seg = (int)(t / sx);
+        const int64_t jk = t - (int64_t)seg * sx;
+        const int j = (int)(jk / nz);
+        const int i0 = seg * seg_len, i1 = min(i0 + seg_len, nx);
+        const bool yslope = j >= 2 && j <= ny - 3;
+        double2 a[5], b[5];                      // a = (f, Dy f), b = (Dz f, Dy Dz f) of planes io - 2 .. io + 2 (slot 4 = the newest)
 #pragma unroll
-            for (int da = -2; da <= 2; ++da) {
-                if (da == 0) continue;
-                const double2 *t = (const double2 *)(Y4 + (idx + da * sx) * 4);
-                const double2 t0 = t[0], t1 = t[1];
-                const double cf = fd_coef(da);
-                d0.x += cf * t0.x, d0.y += cf * t0.y, d1.x += cf * t1.x, d1.y += cf * t1.y;
+        for (int q = 0; q < 5; ++q) a[q] = b[q] = make_double2(0.0, 0.0);
+        for (int ii = i0 - 2; ii < i1 + 2; ++ii) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] = a[q + 1], b[q] = b[q + 1];
+            a[4] = b[4] = make_double2(0.0, 0.0);
+            if (ii >= 0 && ii < nx) {
+                const double2 *zp = Z + (int64_t)ii * sx + jk;
+                const double2 z0 = zp[0];
+                double dy0 = 0.0, dy1 = 0.0;
+                if (yslope) {
+#pragma unroll
+                    for (int db = -2; db <= 2; ++db) {
+                        if (db == 0) continue;
+                        const double2 z = zp[(int64_t)db * nz];
+                        dy0 += fd_coef(db) * z.x, dy1 += fd_coef(db) * z.y;
+                    }
+                }
+                a[4] = make_double2(z0.x, dy0), b[4] = make_double2(z0.y, dy1);
+            }
+            const int io = ii - 2;
+            if (io < i0) continue;
+            double2 d0 = make_double2(0.0, 0.0), d1 = d0;
+            if (io >= 2 && io <= nx - 3) {
+#pragma unroll
+                for (int da = -2; da <= 2; ++da) {
+                    if (da == 0) continue;
+                    const double cf = fd_coef(da);
+                    d0.x += cf * a[2 + da].x, d0.y += cf * a[2 + da].y, d1.x += cf * b[2 + da].x, d1.y += cf * b[2 + da].y;
+                }
+            }
+            const double2 a0 = a[2], a1 = b[2];
+            if (PAIRS) {
+                double2 *o = (double2 *)F8 + (int64_t)io * sx + jk;
+                o[0] = make_double2(a0.x, d0.x);
+                o[npad] = make_double2(a0.y, d0.y);
+                o[2 * npad] = make_double2(a1.x, d1.x);
+                o[3 * npad] = make_double2(a1.y, d1.y);
+            } else {
+                // index p + 2 (q + 2 r): (value, Dx value) for (q, r) = 00, 10, 01, 11; padded z stride in the output
+                double2 *o = (double2 *)(F8 + (io * LM_SI(ny, nz) + (int64_t)j * LM_NZP(nz) + (jk - (int64_t)j * nz)) * LM_NF);
+                o[0] = make_double2(a0.x, d0.x);
+                o[1] = make_double2(a0.y, d0.y);
+                o[2] = make_double2(a1.x, d1.x);
+                o[3] = make_double2(a1.y, d1.y);
             }
         }
-        const int64_t col = idx / nz;                    // (i, j) column; padded z stride in the output
-        const int64_t jj = col - (int64_t)i * ny;
-        double2 *o = (double2 *)(F8 + (i * LM_SI(ny, nz) + jj * LM_NZP(nz) + (idx - col * nz)) * LM_NF);      // index p + 2 (q + 2 r): (value, Dx value) for (q, r) = 00, 10, 01, 11
-        o[0] = make_double2(a0.x, d0.x);
-        o[1] = make_double2(a0.y, d0.y);
-        o[2] = make_double2(a1.x, d1.x);
-        o[3] = make_double2(a1.y, d1.y);
     }
 }
 
@@ -378,6 +400,224 @@ __global__ __launch_bounds__(256, LM_WG) void k_forward_straight_lm(GridView g, 
         __builtin_amdgcn_wave_barrier();
     }
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
+}
+
+// ---- tricubic forward on the bundle plan (iono_forward_kernels.h: bundle-stationary forward) ---------------------------------------
+// k_forward_straight_lm moves 512 B per sample through 16-B loads whose lanes sit 64 B apart: one L1 tag look-up per lane and
+// load, 1.44 G per launch, which is what binds it.  The bundle plan of the trilinear forward -- <= 64 neighbouring rays
+// per workgroup, lane = ray, per B_KC samples a window of <= B_CAPCOLS columns x B_LEV levels that holds every cell the bundle
+// touches -- serves the Lekien-Marsden form: a sample still needs the 2 x 2 x 2 nodes of its cell, only 64 B of each.
+// The interpolant is a SUM over the four (q, r) field pairs of independent 8-corner contractions
+//     f = sum_{q,r} sum_{a,b,c} Hy[b][q](ty) Hz[c][r](tz) ( Hx[a][0](tx) F[0,q,r] + Hx[a][1](tx) F[1,q,r] )(i+a, j+b, k+c),
+// so the four waves of the workgroup take one pair each (the PAIR-major arrays FP[t = q + 2 r][node] = (value, Dx value): 16 B
+// per node, contiguous along z), stage ITS window with LDS-DMA (one node per lane, BL_CPL columns per wave-load) and walk ALL the
+// samples; the four partial integrals are added in a fixed order.  Per ray the arithmetic never depends on the bundling, and a
+// chunk whose window does not fit reads the same 16-B nodes from memory: results do not depend on the plan.
+// Chunks are BL_KC = 4 samples here (their own windows in the plan: BL_LEV = 6 levels >= 3 dfz + 2 + the spread of the lanes): an
+// image of 11.5 KB per wave, three workgroups = twelve waves per CU -- while one wave waits for its window the others compute.
+typedef double lm_d2 __attribute__((ext_vector_type(2)));
+#define BL_NODE 16
+#define BL_KC 4                                   // samples per chunk
+#define BL_LEV 6                                  // levels per staged column
+#define BL_COL (BL_LEV * BL_NODE)                 // 96 B per staged column
+#define BL_CPL (64 / BL_LEV)                      // columns per staging wave-load (10: 60 lanes, one node each)
+#define BL_WAVE_LDS (B_CAPCOLS * BL_COL)          // 11 520 B per wave
+#define BL_LDS_BYTES (B_SPLIT * BL_WAVE_LDS + B_SPLIT * 64 * (int)sizeof(double))
+
+struct LmPairW {          // weights of one sample for the wave's pair (q, r): x needs both kinds, y and z one kind each
+    double xh0, xh1, xs0, xs1, w00, w01, w10, w11;      // w[b][c] = Hy[b][q] Hz[c][r]
+};
+template <int Q, int RZ>
+__device__ __forceinline__ LmPairW lm_pair_weights(double tx, double ty, double tz) {
+    const Herm hx = hermite(tx), hy = hermite(ty), hz = hermite(tz);
+    const double y0 = Q ? hy.s0 : hy.h0, y1 = Q ? hy.s1 : hy.h1, z0 = RZ ? hz.s0 : hz.h0, z1 = RZ ? hz.s1 : hz.h1;
+    LmPairW w;
+    w.xh0 = hx.h0, w.xh1 = hx.h1, w.xs0 = hx.s0, w.xs1 = hx.s1;
+    w.w00 = y0 * z0, w.w01 = y0 * z1, w.w10 = y1 * z0, w.w11 = y1 * z1;
+    return w;
+}
+__device__ __forceinline__ double lm_pair_value(const LmPairW &w, const lm_d2 (&n)[8]) {      // n[a * 4 + b * 2 + c]
+    const lm_d2 s0 = w.w00 * n[0] + w.w01 * n[1] + w.w10 * n[2] + w.w11 * n[3];
+    const lm_d2 s1 = w.w00 * n[4] + w.w01 * n[5] + w.w10 * n[6] + w.w11 * n[7];
+    return (w.xh0 * s0.x + w.xs0 * s0.y) + (w.xh1 * s1.x + w.xs1 * s1.y);
+}
+
+// Staging is asynchronous (LDS-DMA, counted by vmcnt): while a wave interpolates chunk c out of one half of its image it copies
+// the window of chunk c + 1 into the other half, whenever both windows have at most BL_SLOT columns (nine in ten at the bench
+// geometry: the median window has 20 columns, the image 120); a larger window takes the whole image and is staged in line.
+// One wave-load moves 60 nodes = BL_CPL columns x BL_LEV levels: floor(BL_CPL / wy) whole rows of a window wy <= BL_CPL wide, or one
+// of the two column groups of a wider row.
+#define BL_SLOT (B_CAPCOLS / 2)
+struct LmWindow {
+    int imin, jmin, kz0, wx, wy, rpl, fits;      // rpl: rows per staging wave-load (bits 20..23 of the plan's window word)
+};
+__device__ __forceinline__ LmWindow lm_window(const uint4 *__restrict__ wb, int c) {
+    const uint4 w = wb[c];
+    LmWindow W;
+    W.imin = __builtin_amdgcn_readfirstlane((int)w.x), W.jmin = __builtin_amdgcn_readfirstlane((int)w.y);
+    W.kz0 = __builtin_amdgcn_readfirstlane((int)w.z);
+    const int wxy = __builtin_amdgcn_readfirstlane((int)w.w);
+    W.wx = wxy & 255, W.wy = (wxy >> 8) & 255, W.fits = (wxy >> 16) & 1, W.rpl = (wxy >> 20) & 15;
+    return W;
+}
+// copy window W of the pair array into the lane-linear image at `dst`: column (di, dj) at byte (di * wy + dj) * 96, level at + 16 l.
+// Lane = (staged column col = lane / 6, level lane % 6); a window at most BL_CPL columns wide puts rpl whole rows into one load
+// (col = dr * wy + dj), a wider one takes two loads per row.
+__device__ __forceinline__ void lm_stage(const GridView &g, const lm_d2 *__restrict__ FPt, const LmWindow &W, char *dst) {
+#if defined(IONO_BL_ABL) && IONO_BL_ABL == 1      // timing-only build (WRONG results): no staging
+    return;
+#endif
+    const int lane = threadIdx.x & 63;
+    const int col = (int)(((unsigned)lane * 10923u) >> 16), lev = lane - BL_LEV * col;       // lane / 6, lane % 6
+    const unsigned si = (unsigned)g.ny * (unsigned)g.nz;       // (field arrays below 4 GiB per pair: cubic_fast_ok)
+    const char *base = (const char *)FPt + ((size_t)((size_t)W.imin * g.ny + W.jmin) * g.nz + W.kz0) * BL_NODE;
+    if (W.wy <= BL_CPL) {
+        // dr = col / wy without an integer division: floor((col + 1/2) / wy) in float is exact for these small integers
+        const int dr = (int)(((float)col + 0.5f) * __builtin_amdgcn_rcpf((float)W.wy));
+        const int dj = col - dr * W.wy;
+        const unsigned off = ((unsigned)dr * si + (unsigned)dj * (unsigned)g.nz + (unsigned)lev) * BL_NODE;
+        const int lim = dr < W.rpl && lane < BL_CPL * BL_LEV ? W.wx - dr : 0;      // this lane copies rows di + dr for di < lim
+        const unsigned step = (unsigned)(W.rpl * W.wy) * BL_COL;
+        const size_t bstep = (size_t)W.rpl * si * BL_NODE;
+        for (int di = 0; di < W.wx; di += W.rpl) {
+            if (di < lim)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off),
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            base += bstep;
+            dst += step;
+        }
+    } else {
+        const unsigned off = ((unsigned)col * (unsigned)g.nz + (unsigned)lev) * BL_NODE;
+        const unsigned rstride = (unsigned)W.wy * BL_COL;
+        for (int di = 0; di < W.wx; ++di) {
+            if (col < BL_CPL)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off),
+                                                 (__attribute__((address_space(3))) void *)dst, 16, 0, 0);
+            if (col < BL_CPL && col + BL_CPL < W.wy)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + off + (size_t)BL_CPL * g.nz * BL_NODE),
+                                                 (__attribute__((address_space(3))) void *)(dst + BL_CPL * BL_COL), 16, 0, 0);
+            base += (size_t)si * BL_NODE;
+            dst += rstride;
+        }
+    }
+}
+
+template <int Q, int RZ>
+__device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 *__restrict__ FPt, const BundleRays &B, const uint4 *__restrict__ wb,
+                                                 int nchunks, int Ns, const double *__restrict__ unitw, char *img) {
+    const size_t sj = (size_t)g.nz, si = (size_t)g.ny * g.nz;
+    double acc = 0.0;
+    LmWindow W = lm_window(wb, 0);
+    int slot = 0;                 // half of the image the current window lives in (0 for a window that takes the whole image)
+    bool staged = false;          // the current window was copied (or is being copied) while the previous chunk was interpolated
+    for (int c = 0; c < nchunks; ++c) {
+        const int k0 = c * BL_KC;
+        int ke = min(k0 + BL_KC, Ns);
+        const double kd0 = (double)k0;
+        double fx = fma(kd0, B.dfx, B.fx0), fy = fma(kd0, B.dfy, B.fy0), fz = fma(kd0, B.dfz, B.fz0);
+        const bool small = W.wx * W.wy <= BL_SLOT;
+        LmWindow Wn = W;
+        if (c + 1 < nchunks) Wn = lm_window(wb, c + 1);
+        const bool prefetch = c + 1 < nchunks && W.fits && small && Wn.fits && Wn.wx * Wn.wy <= BL_SLOT;
+        if (W.fits) {
+            if (!staged) {
+                slot = small ? slot : 0;
+                lm_stage(g, FPt, W, img + slot * (BL_SLOT * BL_COL));
+            }
+            // (this chunk's window has landed; the previous chunk's LDS reads have returned before the next copy may overwrite their half)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            char *cur = img + slot * (BL_SLOT * BL_COL);
+            if (prefetch) lm_stage(g, FPt, Wn, img + (slot ^ 1) * (BL_SLOT * BL_COL));
+            const double cw = (double)(W.wy * BL_LEV), cj = (double)BL_LEV;
+            const unsigned ibase = (unsigned)(size_t)cur - (((unsigned)W.imin * (unsigned)W.wy + (unsigned)W.jmin) * BL_LEV + (unsigned)W.kz0) * BL_NODE;
+            const unsigned row2 = (unsigned)W.wy * BL_COL;
+            typedef const __attribute__((address_space(3))) lm_d2 *lds_node;
+            // one sample: weights, the LDS address of its cell's lower corner, eight ds_read_b128 (issued, not yet waited for)
+            auto fetch = [&](LmPairW &pw, lm_d2 (&n)[8]) {
+                const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
+                pw = lm_pair_weights<Q, RZ>(fx - fi, fy - fj, fz - fk);
+                const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * BL_NODE + ibase;
+                const __attribute__((address_space(3))) char *p0 = (const __attribute__((address_space(3))) char *)(size_t)a;
+                const __attribute__((address_space(3))) char *p1 = (const __attribute__((address_space(3))) char *)(size_t)(a + row2);
+                n[0] = *(lds_node)(p0), n[1] = *(lds_node)(p0 + BL_NODE), n[2] = *(lds_node)(p0 + BL_COL), n[3] = *(lds_node)(p0 + BL_COL + BL_NODE);
+                n[4] = *(lds_node)(p1), n[5] = *(lds_node)(p1 + BL_NODE), n[6] = *(lds_node)(p1 + BL_COL), n[7] = *(lds_node)(p1 + BL_COL + BL_NODE);
+                fx += B.dfx, fy += B.dfy, fz += B.dfz;
+            };
+            // the chunk's quadrature weights in one scalar load, BEFORE the LDS reads (scalar loads share their counter: waiting for
+            // one inside the loop would wait for every read in flight); weights beyond the last sample are zeros
+            const double w0 = unitw[k0], w1 = unitw[k0 + 1], w2 = unitw[k0 + 2], w3 = unitw[k0 + 3];
+            static_assert(BL_KC == 4, "four weights per chunk");
+            LmPairW pa, pb;
+            lm_d2 na[8], nb[8];
+            fetch(pa, na);
+#if defined(IONO_BL_ABL) && IONO_BL_ABL == 2      // timing-only build (WRONG results): staging only
+            acc = fma(w0, lm_pair_value(pa, na), acc);
+#else
+            if (ke - k0 == BL_KC) {                // (wave-uniform; a ray's last chunk may be shorter)
+                fetch(pb, nb);
+                acc = fma(w0, lm_pair_value(pa, na), acc);
+                fetch(pa, na);
+                acc = fma(w1, lm_pair_value(pb, nb), acc);
+                fetch(pb, nb);
+                acc = fma(w2, lm_pair_value(pa, na), acc);
+                acc = fma(w3, lm_pair_value(pb, nb), acc);
+            } else {
+                acc = fma(w0, lm_pair_value(pa, na), acc);
+                for (int k = k0 + 1; k < ke; ++k) {
+                    fetch(pa, na);
+                    acc = fma(unitw[k], lm_pair_value(pa, na), acc);
+                }
+            }
+#endif
+        } else {
+            for (int k = k0; k < ke; ++k) {
+                const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
+                const LmPairW pw = lm_pair_weights<Q, RZ>(fx - fi, fy - fj, fz - fk);
+                const lm_d2 *q0 = FPt + (size_t)__builtin_fma(fi, (double)si, __builtin_fma(fj, (double)sj, fk)), *q1 = q0 + si;
+                lm_d2 n[8];
+                n[0] = q0[0], n[1] = q0[1], n[2] = q0[sj], n[3] = q0[sj + 1], n[4] = q1[0], n[5] = q1[1], n[6] = q1[sj], n[7] = q1[sj + 1];
+                acc = fma(unitw[k], lm_pair_value(pw, n), acc);
+                fx += B.dfx, fy += B.dfy, fz += B.dfz;
+            }
+        }
+        staged = prefetch;
+        if (prefetch) slot ^= 1;
+        W = Wn;
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const double *__restrict__ FP, int64_t npad, const double *__restrict__ origins,
+                                                           const double *__restrict__ dirs, const int *__restrict__ order,
+                                                           const int *__restrict__ bstart, const uint4 *__restrict__ win, int nb, int nchunks,
+                                                           double tmax, int Ns, const double *__restrict__ unitw, double *__restrict__ tec,
+                                                           int *oob_flag) {
+    extern __shared__ __attribute__((aligned(16))) char blds[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);     // XCD-major
+    if (b >= nb) return;
+    const BundleRays B = load_bundle<true>(g, origins, dirs, order, bstart, b, tmax, Ns);
+    if (wid == 0 && __any(B.mine && !B.valid) && lane == 0) atomicOr(oob_flag, 1);
+    if (!B.any) {
+        if (wid == 0 && B.mine) tec[B.r] = nan("");
+        return;
+    }
+    char *img = blds + wid * BL_WAVE_LDS;
+    double *part = (double *)(blds + B_SPLIT * BL_WAVE_LDS);
+    const lm_d2 *FPt = (const lm_d2 *)FP + (size_t)wid * npad;
+    const uint4 *wb = win + (size_t)b * nchunks;
+    double acc;
+    if (wid == 0) acc = bundle_lm_walk<0, 0>(g, FPt, B, wb, nchunks, Ns, unitw, img);
+    else if (wid == 1) acc = bundle_lm_walk<1, 0>(g, FPt, B, wb, nchunks, Ns, unitw, img);
+    else if (wid == 2) acc = bundle_lm_walk<0, 1>(g, FPt, B, wb, nchunks, Ns, unitw, img);
+    else acc = bundle_lm_walk<1, 1>(g, FPt, B, wb, nchunks, Ns, unitw, img);
+    part[wid * 64 + lane] = acc;
+    __syncthreads();
+    if (wid == 0 && B.mine) {
+        const double *pl = part + lane;
+        tec[B.r] = B.valid ? (((pl[0] + pl[64]) + pl[128]) + pl[192]) * B.h : nan("");
+    }
 }
 
 // ---- general tier of the tricubic transpose: 216 hardware atomics per sample (any grid; explicit or straight rays) ----

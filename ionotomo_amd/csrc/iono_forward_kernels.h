@@ -611,6 +611,8 @@ struct BundleRays {          // the rays of a bundle, one per lane; lanes withou
     int64_t r;
     bool mine, valid, any;
 };
+__device__ __forceinline__ URay load_uray_cubic(const GridView &g, const double *origins, const double *dirs, int64_t r, double tmax, int Ns);
+template <bool CUBIC = false>      // CUBIC: valid = both end points inside the tricubic domain g[2] .. g[n-3] (iono_cubic_kernels.h)
 __device__ __forceinline__ BundleRays load_bundle(const GridView &g, const double *__restrict__ origins, const double *__restrict__ dirs,
                                                   const int *__restrict__ order, const int *__restrict__ bstart, int b, double tmax, int Ns) {
     const int lane = threadIdx.x & 63;
@@ -621,7 +623,7 @@ __device__ __forceinline__ BundleRays load_bundle(const GridView &g, const doubl
     B.mine = lane < cnt;
     if (B.mine) {
         B.r = order[q0 + lane];
-        u = load_uray(g, origins, dirs, B.r, tmax, Ns);
+        u = CUBIC ? load_uray_cubic(g, origins, dirs, B.r, tmax, Ns) : load_uray(g, origins, dirs, B.r, tmax, Ns);
     }
     B.valid = u.valid;
     const unsigned long long vmask = __ballot(u.valid);
@@ -675,7 +677,10 @@ __global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__re
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) sorted[i] = rec[order[i]];
 }
 
-// window of chunk c of bundle b: {imin, jmin, kz0 (even), wx | wy << 8 | fits << 16}; one wave per bundle
+// window of chunk c of bundle b: {imin, jmin, kz0, wx | wy << 8 | fits << 16 | rpl << 20}; one wave per bundle.  KC samples per chunk, an
+// image of LEV levels per column and MAXWY columns per row; EVEN: the window starts on an even level (8-byte values staged in 16-byte
+// pieces); rpl = whole rows of the window per staging wave-load of 64 / LEV columns (used by k_forward_bundle_lm)
+template <int KC, int LEV, int MAXWY, bool EVEN>
 __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs,
                                                        const int *__restrict__ order, const int *__restrict__ bstart, int nb, double tmax,
                                                        int Ns, int nchunks, uint4 *__restrict__ win) {
@@ -686,17 +691,19 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
     for (int c = 0; c < nchunks; ++c) {
         uint4 w = make_uint4(0, 0, 0, 0);
         if (B.any) {
-            const int k0 = c * B_KC, ke = min(k0 + B_KC, Ns);
+            const int k0 = c * KC, ke = min(k0 + KC, Ns);
             const double kd0 = (double)k0, kd1 = (double)(ke - 1);
             const double fx = fma(kd0, B.dfx, B.fx0), fy = fma(kd0, B.dfy, B.fy0), fz = fma(kd0, B.dfz, B.fz0);
             const double fxe = fma(kd1, B.dfx, B.fx0), fye = fma(kd1, B.dfy, B.fy0), fze = fma(kd1, B.dfz, B.fz0);
             const int imin = wave_minmax_i32<false>((int)fmax(fmin(fx, fxe) - eps, 0.0)), imax = wave_minmax_i32<true>((int)(fmax(fx, fxe) + eps));
             const int jmin = wave_minmax_i32<false>((int)fmax(fmin(fy, fye) - eps, 0.0)), jmax = wave_minmax_i32<true>((int)(fmax(fy, fye) + eps));
             const int kmin = wave_minmax_i32<false>((int)fmax(fmin(fz, fze) - eps, 0.0)), kmax = wave_minmax_i32<true>((int)(fmax(fz, fze) + eps));
-            const int kz0 = kmin & ~1;
+            const int kz0 = EVEN ? kmin & ~1 : kmin;
             const int wx = imax - imin + 2, wy = jmax - jmin + 2, nlev = kmax + 2 - kz0;
-            const bool fits = (g.nz & 1) == 0 && wx * wy <= B_CAPCOLS && wx < 256 && wy <= B_MAXWY && nlev <= B_LEV;
-            w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0, (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u));
+            const bool fits = (!EVEN || (g.nz & 1) == 0) && wx * wy <= B_CAPCOLS && wx < 256 && wy <= MAXWY && nlev <= LEV;
+            const int rpl = min(15, max(1, (64 / LEV) / wy));
+            w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0,
+                           (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u) | ((unsigned)rpl << 20));
         }
         if ((threadIdx.x & 63) == 0) win[(size_t)b * nchunks + c] = w;
     }
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
         const int imin = __builtin_amdgcn_readfirstlane((int)w.x), jmin = __builtin_amdgcn_readfirstlane((int)w.y),
                   kz0 = __builtin_amdgcn_readfirstlane((int)w.z), wxy = __builtin_amdgcn_readfirstlane((int)w.w);
         const int wx = wxy & 255, wy = (wxy >> 8) & 255;
-        if (wxy >> 16) {
+        if ((wxy >> 16) & 1) {
             // ---- stage the window row by row: lane = (column dj = lane / 5, piece pc = lane % 5 = levels kz0 + 2 pc, + 1) of row di;
             //      the image is lane-linear: row di at byte di * wy * 80, column dj at + 80 dj.  Source = a wave-uniform row base
             //      + a per-lane offset that never changes: no vector arithmetic per load.

@@ -100,6 +100,8 @@ struct iono_ctx {
     double c0[3] = {0, 0, 0}, clast[3] = {0, 0, 0};     // tricubic domain g[2] .. g[n-3] (n >= 6)
     double *d_F8 = nullptr;          // Lekien-Marsden derivative fields [node][8] of the current values (lazily built)
     bool F8_valid = false;
+    double *d_FP = nullptr;          // the same fields PAIR-major [4][padded nodes][2] for the bundle-stationary tricubic forward (lazily built)
+    bool FP_valid = false;
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
     double *d_LMw = nullptr;         // [nodes][6] scratch of the axis-by-axis field build / fold
     float4 *d_Q4 = nullptr;          // float32 storage: 2 x 2 (y, z) corner blocks for the 2-loads-per-sample forward (lazily built)
@@ -130,7 +132,9 @@ struct iono_ctx {
         double tmax = 0;
         int *d_order = nullptr, *d_bstart = nullptr;
         uint4 *d_win = nullptr;
-        size_t cap_order = 0, cap_bstart = 0, cap_win = 0;
+        uint4 *d_win_lm = nullptr;       // windows of the tricubic kernel's shorter chunks (BL_KC samples, BL_LEV levels of 16-byte nodes)
+        int nchunks_lm = 0;
+        size_t cap_order = 0, cap_bstart = 0, cap_win = 0, cap_win_lm = 0;
         double fit_fraction = 0;         // chunks whose window fits the LDS image
     } fplan;
     char *h_pinned = nullptr;        // pinned staging of small downloads (iono_dev_download): result + flags in one round trip
@@ -174,6 +178,7 @@ void fplan_free(iono_ctx *c) {
     if (c->fplan.d_order) (void)hipFree(c->fplan.d_order);
     if (c->fplan.d_bstart) (void)hipFree(c->fplan.d_bstart);
     if (c->fplan.d_win) (void)hipFree(c->fplan.d_win);
+    if (c->fplan.d_win_lm) (void)hipFree(c->fplan.d_win_lm);
     c->fplan = iono_ctx::FwdPlan();
 }
 
@@ -349,8 +354,9 @@ int ensure_unitw(iono_ctx *c, int Ns, int rule) {
         HIP_TRY(c, hipFree(c->d_unitw));
         c->d_unitw = nullptr;
     }
-    HIP_TRY(c, hipMalloc((void **)&c->d_unitw, sizeof(double) * Ns));
-    HIP_TRY(c, hipMemcpy(c->d_unitw, w.data(), sizeof(double) * Ns, hipMemcpyHostToDevice));
+    w.resize((size_t)Ns + 8, 0.0);      // (zero weights beyond the last sample: kernels may read a whole chunk's weights at once)
+    HIP_TRY(c, hipMalloc((void **)&c->d_unitw, sizeof(double) * w.size()));
+    HIP_TRY(c, hipMemcpy(c->d_unitw, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
     c->unitw_n = Ns;
     c->unitw_rule = rule;
     return IONO_OK;
@@ -476,6 +482,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_unitw) (void)hipFree(c->d_unitw);
     if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->d_F8) (void)hipFree(c->d_F8);
+    if (c->d_FP) (void)hipFree(c->d_FP);
     if (c->d_G8) (void)hipFree(c->d_G8);
     if (c->d_LMw) (void)hipFree(c->d_LMw);
     if (c->d_Q4) (void)hipFree(c->d_Q4);
@@ -556,6 +563,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     if (c->d_M) HIP_TRY(c, hipFree(c->d_M));
     if (c->d_nM) HIP_TRY(c, hipFree(c->d_nM));
     if (c->d_F8) HIP_TRY(c, hipFree(c->d_F8));
+    if (c->d_FP) HIP_TRY(c, hipFree(c->d_FP));
     if (c->d_G8) HIP_TRY(c, hipFree(c->d_G8));
     if (c->d_LMw) HIP_TRY(c, hipFree(c->d_LMw));
     if (c->d_Q4) HIP_TRY(c, hipFree(c->d_Q4));
@@ -564,11 +572,11 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     c->d_axes = nullptr;
     c->d_M = nullptr;
     c->d_nM = nullptr;
-    c->d_F8 = c->d_G8 = nullptr;
+    c->d_F8 = c->d_G8 = c->d_FP = nullptr;
     c->d_M_ext = nullptr;
     plan_free(c);
     fplan_free(c);
-    c->F8_valid = false;
+    c->F8_valid = c->FP_valid = false;
     c->nM_freq = -1.0;
     c->nx = nx;
     c->ny = ny;
@@ -598,7 +606,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
 static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, double scale) {
     const int64_t n = ncells(c);
     c->nM_freq = -1.0;
-    c->F8_valid = false;
+    c->F8_valid = c->FP_valid = false;
     c->Q4_valid = false;
     int rc = dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
@@ -701,27 +709,37 @@ static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks
     return IONO_OK;
 }
 
-// Lekien-Marsden derivative fields of the current grid values (iono_cubic_kernels.h): rebuilt after every change
-static int ensure_lm_fields(iono_ctx *c) {
-    const int64_t n = ncells(c);
-    if (!c->d_F8) {
+// Lekien-Marsden derivative fields of the current grid values (iono_cubic_kernels.h): rebuilt after every change.  Two layouts, each
+// built when a kernel first asks for it: node-major records F8 (k_forward_straight_lm) and pair-major arrays FP (k_forward_bundle_lm).
+static int ensure_lm_fields(iono_ctx *c, bool pairs = false) {
+    const int64_t n = ncells(c), npad = padded_count(c);
+    if (!pairs && !c->d_F8) {
         const size_t fb = (size_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double);
         HIP_TRY(c, hipMalloc((void **)&c->d_F8, fb));
         HIP_TRY(c, hipMemsetAsync(c->d_F8, 0, fb, c->stream));      // (pad nodes: never read by a valid sample)
     }
+    if (pairs && !c->d_FP) {
+        const size_t fb = (size_t)npad * 4 * 2 * sizeof(double);
+        HIP_TRY(c, hipMalloc((void **)&c->d_FP, fb));
+        HIP_TRY(c, hipMemsetAsync(c->d_FP, 0, fb, c->stream));      // (pad nodes: staged with a window's last levels, never weighed)
+    }
     if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
-    if (!c->F8_valid) {
+    if (!(pairs ? c->FP_valid : c->F8_valid)) {
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
             hipLaunchKernelGGL((k_lm_fields_z<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c),
                                (double2 *)c->d_LMw, c->nx, c->ny, c->nz);
             return IONO_OK;
         });
-        hipLaunchKernelGGL(k_lm_fields_y, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_LMw + 2 * n, c->nx,
-                           c->ny, c->nz);
-        hipLaunchKernelGGL(k_lm_fields_x, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_LMw + 2 * n, c->d_F8, c->nx, c->ny, c->nz);
+        const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
+        if (pairs)
+            hipLaunchKernelGGL((k_lm_fields_yx<true>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_FP,
+                               c->nx, c->ny, c->nz, npad);
+        else
+            hipLaunchKernelGGL((k_lm_fields_yx<false>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_F8,
+                               c->nx, c->ny, c->nz, npad);
         HIP_TRY(c, hipGetLastError());
-        c->F8_valid = true;
+        (pairs ? c->FP_valid : c->F8_valid) = true;
     }
     return IONO_OK;
 }
@@ -858,8 +876,29 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, plan_reserve(fp.d_bstart, fp.cap_bstart, bstart.size() * sizeof(int)));
     HIP_TRY(c, plan_reserve(fp.d_win, fp.cap_win, (size_t)nb * nchunks * sizeof(uint4)));
     HIP_TRY(c, hipMemcpy(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_bundle_windows, dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart, nb, tmax, Ns, nchunks, fp.d_win);
+    hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
+                       nb, tmax, Ns, nchunks, fp.d_win);
+    const int nchunks_lm = (Ns + BL_KC - 1) / BL_KC;
+    HIP_TRY(c, plan_reserve(fp.d_win_lm, fp.cap_win_lm, (size_t)nb * nchunks_lm * sizeof(uint4)));
+    hipLaunchKernelGGL((k_bundle_windows<BL_KC, BL_LEV, 2 * BL_CPL, false>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order,
+                       fp.d_bstart, nb, tmax, Ns, nchunks_lm, fp.d_win_lm);
+    fp.nchunks_lm = nchunks_lm;
     HIP_TRY(c, hipGetLastError());
+    if (getenv("IONOTOMO_PLAN_STATS")) {      // columns per window, both chunk lengths (stderr; tuning aid)
+        for (int which = 0; which < 2; ++which) {
+            std::vector<uint4> hv((size_t)nb * (which ? nchunks_lm : nchunks));
+            HIP_TRY(c, hipMemcpy(hv.data(), which ? fp.d_win_lm : fp.d_win, hv.size() * sizeof(uint4), hipMemcpyDeviceToHost));
+            std::vector<int> cols, wys;
+            size_t nfit = 0;
+            for (const uint4 &w : hv) cols.push_back((int)((w.w & 255u) * ((w.w >> 8) & 255u))), wys.push_back((int)((w.w >> 8) & 255u)), nfit += (w.w >> 16) & 1u;
+            std::sort(cols.begin(), cols.end());
+            std::sort(wys.begin(), wys.end());
+            auto q = [&](const std::vector<int> &v, double f) { return v.empty() ? 0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+            fprintf(stderr, "[plan] %s windows: %zu, fit %.4f, columns p10 %d p50 %d p90 %d p99 %d max %d; wy p50 %d p99 %d max %d\n",
+                    which ? "4-sample" : "8-sample", hv.size(), (double)nfit / hv.size(), q(cols, 0.1), q(cols, 0.5), q(cols, 0.9), q(cols, 0.99),
+                    cols.back(), q(wys, 0.5), q(wys, 0.99), wys.back());
+        }
+    }
     std::vector<uint4> hw((size_t)nb * nchunks);
     HIP_TRY(c, hipMemcpyAsync(hw.data(), fp.d_win, hw.size() * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -942,6 +981,19 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             if (rc2) return rc2;
             hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
                                wm, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
+        } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && fplan_serves(c, o, d, R, tmax, Ns)) {
+            // bundles of neighbouring rays, one field pair per wave, windows staged in LDS (iono_cubic_kernels.h:k_forward_bundle_lm)
+            const int rc2 = ensure_lm_fields(c, true);
+            if (rc2) return rc2;
+            const iono_ctx::FwdPlan &fp = c->fplan;
+            static bool lds_attr_set = false;
+            if (!lds_attr_set) {
+                HIP_TRY(c, hipFuncSetAttribute((const void *)k_forward_bundle_lm, hipFuncAttributeMaxDynamicSharedMemorySize, BL_LDS_BYTES));
+                lds_attr_set = true;
+            }
+            hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES, c->stream, g, c->d_FP,
+                               padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
+                               c->d_flags);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
@@ -1027,7 +1079,7 @@ int iono_grid_bind_values_dev(iono_ctx *c, double *values_dev) {
     if (values_dev && (((uintptr_t)values_dev) & 15)) return fail(c, IONO_ERR_ARG, "values must be 16-byte aligned");
     c->d_M_ext = values_dev;
     c->nM_freq = -1.0;
-    c->F8_valid = false;
+    c->F8_valid = c->FP_valid = false;
     return IONO_OK;
 }
 
@@ -1035,7 +1087,7 @@ int iono_grid_values_changed(iono_ctx *c) {
     int rc = need_grid(c);
     if (rc) return rc;
     c->nM_freq = -1.0;
-    c->F8_valid = false;
+    c->F8_valid = c->FP_valid = false;
     return IONO_OK;
 }
 
@@ -1220,7 +1272,17 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)nbox * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(&outside, d_out, sizeof(outside), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    const int unit_segs = BIN_UNIT * (BIN_SEG / segl);     // the same number of lane passes per work unit whatever the width
+    // Work-unit size: BIN_UNIT 16-lane segments' worth of lane passes whatever the width -- but a problem too small to give every
+    // workgroup slot (5 per CU) a unit of that size is cut finer, down to two passes per unit: the launch then lasts as long as its
+    // LONGEST unit (2 604 rays through 128^3: 26 040 segments, the hot boxes under the station core held 512 of them each).
+    int unit_segs = BIN_UNIT * (BIN_SEG / segl);
+    {
+        int64_t total = 0;
+        for (int64_t q = 0; q < nbox; ++q) total += h_cnt[(size_t)q];
+        const int64_t slots = (int64_t)c->num_cus * 5, pass = 256 / segl;
+        const int64_t even = (total + slots - 1) / slots;
+        if (even < unit_segs) unit_segs = (int)std::max<int64_t>(2 * pass, (even + pass - 1) / pass * pass);
+    }
     std::vector<unsigned char> nseg((size_t)R, 0);
     int smax = 1;
     bool fwd_ok = true;

@@ -248,3 +248,75 @@ def test_phase_observable_on_the_bundle_plan(OC):
     eng.plan_forward(ot, bt, bench.TMAX, bench.NS)
     g = eng.forward_phase(ot, bt, na, nt, nd, bench.TMAX, bench.NS, np.array([150e6]), clock, const, 2).cpu().numpy().reshape(-1)
     assert eng.check_oob() and np.isnan(g[7]) and np.isfinite(g[8])
+
+
+@pytest.mark.parametrize("seed", range(SOAK * 8))
+def test_bundle_tricubic_forward_random_geometries(seed):
+    """k_forward_bundle_lm (one Lekien-Marsden field pair per wave, windows staged from the pair-major arrays) against the
+    lanes = samples tricubic kernel and the numpy oracle: random clustered / scattered rays incl. rays outside the tricubic domain
+    (NaN + flag), windows that do not fit (steep rays), changed grid values (the pair arrays are rebuilt), every quadrature rule."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(7000 + seed)
+    n = [int(v) for v in rng.integers(8, 60, 3)]
+    n[2] += n[2] & 1
+    xv, yv, zv = (np.linspace(0.0, float(rng.uniform(20, 200)), m) for m in n)
+    R = int(rng.integers(1, 1200))
+    Ns = int(rng.choice([2, 7, 8, 9, 17, 64, 65, 129]))
+    steep = float(rng.choice([0.02, 0.3, 1.0]))
+    o, d, zhi, _ = random_rays(rng, xv, yv, zv, R, steep, cluster=bool(seed % 2))
+    zhi = min(zhi, zv[-3] - 1e-9)
+    o[:, 2] = np.maximum(o[:, 2], zv[2] + 1e-9)
+    end = o + d * ((zhi - o[:, 2]) / d[:, 2])[:, None]
+    lo, hi = np.array([xv[2], yv[2]]), np.array([xv[-3], yv[-3]])
+    inside = np.all((o[:, :2] >= lo) & (o[:, :2] <= hi) & (end[:, :2] >= lo) & (end[:, :2] <= hi), axis=1)
+    quad = ["avg", "scipy", "trapz"][seed % 3]
+    eng = engine(xv, yv, zv, quad=quad, interp="cubic")
+    M = rng.uniform(1, 2, size=n)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    direct = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    assert eng.check_oob() == (not inside.all())
+    nb, nchunks, fit = eng.plan_forward(ot, dt, zhi, Ns)
+    assert nb > 0
+    got = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    assert eng.check_oob() == (not inside.all())
+    assert np.all(np.isnan(got[~inside])) and np.all(np.isnan(direct[~inside]))
+    if inside.any():
+        scale = np.max(np.abs(direct[inside]))
+        assert np.max(np.abs(got[inside] - direct[inside])) < 1e-12 * scale, (n, R, Ns, steep, fit)
+        if Ns % 2 == 1 and quad != "trapz" and inside.sum() <= 400:
+            rays = O.straight_rays(o[inside], d[inside], zhi, Ns)
+            ref = O.forward_tec(rays, xv, yv, zv, M, kind=O.INTERP_TRICUBIC)
+            assert np.max(np.abs(got[inside] - ref)) < 1e-11 * np.max(np.abs(ref))
+    M2 = rng.uniform(1, 2, size=n)
+    eng.set_values(eng.tensor(M2))
+    got2 = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    eng.clear_forward_plan()
+    direct2 = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    eng.check_oob()
+    if inside.any():
+        assert np.max(np.abs(got2[inside] - direct2[inside])) < 1e-12 * np.max(np.abs(direct2[inside]))
+
+
+def test_bundle_tricubic_bench_shape():
+    import bench
+    w = bench.build_workload(0)
+    eng = engine(w["xvec"], w["yvec"], w["zvec"], force_bundle=False, interp="cubic")
+    eng.set_values(eng.tensor(np.exp(w["m"])))
+    ot, dt = eng.tensor(w["origins"].reshape(-1, 3)), eng.tensor(w["directions"].reshape(-1, 3))
+    direct = eng.forward(ot, dt, bench.TMAX, bench.NS)
+    nb, _, fit = eng.plan_forward(ot, dt, bench.TMAX, bench.NS)
+    assert nb > 2000 and fit > 0.9
+    got = eng.forward(ot, dt, bench.TMAX, bench.NS)
+    assert not eng.check_oob()
+    assert float((got - direct).abs().max()) < 1e-12 * float(direct.abs().max())
+    import time
+    for name, plan in (("bundle", True), ("direct", False)):
+        if not plan:
+            eng.clear_forward_plan()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(20):
+            eng.forward(ot, dt, bench.TMAX, bench.NS)
+        torch.cuda.synchronize()
+        print("tricubic forward %s: %.3f ms" % (name, (time.perf_counter() - t) / 20 * 1e3))
