@@ -246,7 +246,7 @@ def test_matern_field_matches_reference_realisation(golden):
     import ionotomo_amd as it
     sim = it.IonosphereSimulation(g["xvec"], g["yvec"], g["zvec"], float(g["sigma"]), float(g["corr"]), type='m52')
     assert np.array_equal(sim.realization(seed=int(g["seed"])), B)
-    assert it.a_priori_model_(np.array([110.0, 300.0]), 45.0).shape == (2,) and it.clock() > 0
+    assert it.a_priori_model_(np.array([110.0, 300.0]), 45.0).shape == (2,)
 
 
 def test_tricubic_matches_notebook_lekien_marsden_coefficients(golden):
