@@ -235,22 +235,13 @@ template <int KIND, bool BEND>
 __device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u, int stype) {
     double n, nx, ny, nz;
     if (KIND == IONO_INTERP_TRILINEAR) {
-        trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
+        // ideal-uniform grid, point not on a cell face: no axis tables, no divisions (iono_device_common.h)
+        if (!(g.ideal && trilinear_grad_ideal(g, nM, u.x, u.y, u.z, n, nx, ny, nz))) trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
     } else {
         tricubic_n_and_gradient(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
     }
     if (!BEND) nx = ny = nz = 0.0;
-    if (stype) return fermat_rates(n, nx, ny, nz, u, 1);
-    const double f = n / u.pz;
-    FState d;
-    d.px = nx * f;
-    d.py = ny * f;
-    d.pz = nz * f;
-    d.x = u.px / u.pz;
-    d.y = u.py / u.pz;
-    d.z = 1.0;
-    d.s = f;
-    return d;
+    return fermat_rates(n, nx, ny, nz, u, stype);
 }
 __device__ __forceinline__ FState axpy(const FState &u, double a, const FState &d) {
     FState r;

@@ -140,11 +140,15 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
     const double ztop = ax.z[ax.nz - 1] + 1e-9 * fabs(tmax);
     bool oob = false;
     // value of the integrand (forward) or "inside" marker (adjoint) of the samples in the window
+    const bool ideal_lin = g.ideal && kne == IONO_INTERP_TRILINEAR;       // (wave-uniform) no axis tables for the integrand either
     auto inside = [&](const FState &p) {
+        if (ideal_lin)
+            return p.x >= g.g0[0] && p.x <= g.glast[0] && p.y >= g.g0[1] && p.y <= g.glast[1] && p.z >= g.g0[2] && p.z <= g.glast[2];
         return !(kne == IONO_INTERP_TRILINEAR ? sample_outside<IONO_INTERP_TRILINEAR>(ax, p.x, p.y, p.z)
                                                : sample_outside<IONO_INTERP_TRICUBIC>(ax, p.x, p.y, p.z));
     };
     auto value = [&](const FState &p) {
+        if (ideal_lin) return trilinear_ideal(g, (const double *)g.M, p.x, p.y, p.z);
         return kne == IONO_INTERP_TRILINEAR ? sample_at<double, IONO_INTERP_TRILINEAR>(g, ax, p.x, p.y, p.z)
                                             : sample_at<double, IONO_INTERP_TRICUBIC>(g, ax, p.x, p.y, p.z);
     };

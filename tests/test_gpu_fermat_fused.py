@@ -132,3 +132,34 @@ def test_620k_bending_rays_through_256_cubed_in_one_launch():
     got = eng.adjoint_fermat(oi, di, ys, w["tmax"], Ns, freq, bend=True, kind="linear", substeps=2)
     assert float((got - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
     assert not eng.check_oob()
+
+
+@pytest.mark.parametrize("aligned", [False, True])
+def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, O, monkeypatch):
+    """On an ideal-uniform grid the tracer's right-hand side skips the axis tables and the divisions (trilinear_grad_ideal) except
+    within 1e-9 of a cell face, where the general form decides the cell as scipy does.  Traced rays and fused TEC equal the
+    general form's (IONOTOMO_VARIANT=13) to rounding and the oracle's RK4 -- also when EVERY sample sits on a z face (``aligned``:
+    samples one cell apart starting on a level, the case where the face rule decides which cell's gradient bends the ray)."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="example", na=6, nd=5, nt=2, n=33, margin_cells=10)
+    xv, yv, zv = w["xvec"], w["yvec"], w["zvec"]
+    o, d = w["origins"].reshape(-1, 3).copy(), w["directions"].reshape(-1, 3)
+    Ns, tmax = 21, float(zv[24])
+    if aligned:
+        o[:, 2] = zv[4]                                   # z_k = linspace(zv[4], zv[24], 21): every sample on a level of the grid
+    res = {}
+    for variant in ("0", "13"):
+        monkeypatch.setenv("IONOTOMO_VARIANT", variant)
+        eng = RayEngine(0)
+        eng.set_grid(xv, yv, zv)
+        eng.set_values(eng.tensor(w["ne"]))
+        ot, dt = eng.tensor(np.tile(o, (80, 1))), eng.tensor(np.tile(d, (80, 1)))      # 4 800 rays: the lanes = rays tracer
+        rays = eng.trace_fermat(ot, dt, tmax, Ns, 100e6, bend=True, kind="linear", substeps=2)
+        tec = eng.forward_fermat(ot, dt, tmax, Ns, 100e6, bend=True, kind="linear", substeps=2)
+        assert not eng.check_oob()
+        res[variant] = (rays.cpu().numpy()[: len(o)], tec.cpu().numpy()[: len(o)])
+    (r0, t0), (r1, t1) = res["0"], res["13"]
+    assert np.max(np.abs(r0 - r1)) < 1e-10 and np.max(np.abs(t0 - t1)) < 1e-11 * np.max(np.abs(t1))
+    field = O.n_field_trilinear(xv, yv, zv, O.ne_to_n(w["ne"], 100e6))
+    ref = O.fermat_trace(o, d, tmax, Ns, field, bend=True, substeps=2)
+    assert np.max(np.abs(r0 - ref)) < 1e-9
