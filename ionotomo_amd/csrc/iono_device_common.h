@@ -131,11 +131,12 @@ __device__ __forceinline__ bool trilinear_grad_ideal(const GridView &g, const do
     const double fi = __builtin_floor(ux), fj = __builtin_floor(uy), fk = __builtin_floor(uz);
     const double tx = ux - fi, ty = uy - fj, tz = uz - fk;
     const double eps = 1e-9;
-    const bool interior = tx > eps && tx < 1.0 - eps && ty > eps && ty < 1.0 - eps && tz > eps && tz < 1.0 - eps && fi >= 0.0 &&
-                          fi <= (double)(g.nx - 2) && fj >= 0.0 && fj <= (double)(g.ny - 2) && fk >= 0.0 && fk <= (double)(g.nz - 2);
+    // (one predicate, no short-circuit branches; `ideal` implies fewer than 2^32 nodes: a 32-bit node index)
+    const bool interior = (tx > eps) & (tx < 1.0 - eps) & (ty > eps) & (ty < 1.0 - eps) & (tz > eps) & (tz < 1.0 - eps) & (fi >= 0.0) &
+                          (fi <= (double)(g.nx - 2)) & (fj >= 0.0) & (fj <= (double)(g.ny - 2)) & (fk >= 0.0) & (fk <= (double)(g.nz - 2));
     if (!interior) return false;
     const size_t sj = (size_t)g.nz, si = (size_t)g.ny * g.nz;
-    const double *p = M + (size_t)__builtin_fma(fi, (double)si, __builtin_fma(fj, (double)sj, fk));
+    const double *p = M + (unsigned)__builtin_fma(fi, (double)si, __builtin_fma(fj, (double)sj, fk));
     const double c000 = p[0], c001 = p[1], c010 = p[sj], c011 = p[sj + 1];
     const double c100 = p[si], c101 = p[si + 1], c110 = p[si + sj], c111 = p[si + sj + 1];
     const double z00 = c001 - c000, z01 = c011 - c010, z10 = c101 - c100, z11 = c111 - c110;        // d/dz along the four columns
@@ -158,7 +159,7 @@ __device__ __forceinline__ double trilinear_ideal(const GridView &g, const doubl
                  fk = fmin(__builtin_floor(__builtin_fabs(uz)), (double)(g.nz - 2));
     const double tx = ux - fi, ty = uy - fj, tz = uz - fk;
     const size_t sj = (size_t)g.nz, si = (size_t)g.ny * g.nz;
-    const double *p = M + (size_t)__builtin_fma(fi, (double)si, __builtin_fma(fj, (double)sj, fk));
+    const double *p = M + (unsigned)__builtin_fma(fi, (double)si, __builtin_fma(fj, (double)sj, fk));
     const double v00 = __builtin_fma(tz, p[1] - p[0], p[0]), v01 = __builtin_fma(tz, p[sj + 1] - p[sj], p[sj]);
     const double v10 = __builtin_fma(tz, p[si + 1] - p[si], p[si]), v11 = __builtin_fma(tz, p[si + sj + 1] - p[si + sj], p[si + sj]);
     const double w0 = __builtin_fma(ty, v01 - v00, v00), w1 = __builtin_fma(ty, v11 - v10, v10);

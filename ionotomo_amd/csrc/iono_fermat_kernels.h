@@ -157,7 +157,13 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
         if (windowed) {
             int i = 0, j = 0, k = 0;
             double tx = 0, ty = 0, tz = 0;
-            if (on) {
+            if (on && g.ideal) {          // cell and weights as trilinear_ideal forms them (the transpose of that very interpolation)
+                const double ux = (p.x - g.g0[0]) * g.inv_h[0], uy = (p.y - g.g0[1]) * g.inv_h[1], uz = (p.z - g.g0[2]) * g.inv_h[2];
+                const double fi = fmin(__builtin_floor(__builtin_fabs(ux)), (double)(g.nx - 2)), fj = fmin(__builtin_floor(__builtin_fabs(uy)), (double)(g.ny - 2)),
+                             fk = fmin(__builtin_floor(__builtin_fabs(uz)), (double)(g.nz - 2));
+                i = (int)fi, j = (int)fj, k = (int)fk;
+                tx = ux - fi, ty = uy - fj, tz = uz - fk;
+            } else if (on) {
                 i = find_cell(ax.x, ax.nx, p.x, g.inv_h[0], g.uniform[0]), j = find_cell(ax.y, ax.ny, p.y, g.inv_h[1], g.uniform[1]);
                 k = find_cell(ax.z, ax.nz, p.z, g.inv_h[2], g.uniform[2]);
                 tx = (p.x - ax.x[i]) / (ax.x[i + 1] - ax.x[i]), ty = (p.y - ax.y[j]) / (ax.y[j + 1] - ax.y[j]);
@@ -180,11 +186,24 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
     for (int k = 1; k < Ns; ++k) {
         for (int sub = 0; sub < substeps; ++sub) {
             FState kprev = {}, sum = {};
+            if (KN == IONO_INTERP_TRILINEAR) {
+                // the four stages spelled out (same operations in the same order as the loop below: the loop only exists because
+                // four inlined tricubic evaluations do not fit the register file)
+                kprev = fermat_rhs<KN, BEND>(g, nM, axpy(u, 0.0, kprev), stype);
+                sum = axpy(sum, 1.0, kprev);
+                kprev = fermat_rhs<KN, BEND>(g, nM, axpy(u, 0.5 * h, kprev), stype);
+                sum = axpy(sum, 2.0, kprev);
+                kprev = fermat_rhs<KN, BEND>(g, nM, axpy(u, 0.5 * h, kprev), stype);
+                sum = axpy(sum, 2.0, kprev);
+                kprev = fermat_rhs<KN, BEND>(g, nM, axpy(u, h, kprev), stype);
+                sum = axpy(sum, 1.0, kprev);
+            } else {
 #pragma unroll 1
-            for (int st = 0; st < 4; ++st) {
-                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs<KN, BEND>(g, nM, axpy(u, ca, kprev), stype);
-                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+                for (int st = 0; st < 4; ++st) {
+                    const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                    kprev = fermat_rhs<KN, BEND>(g, nM, axpy(u, ca, kprev), stype);
+                    sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+                }
             }
             u = axpy(u, h / 6.0, sum);
         }

@@ -222,7 +222,7 @@ GridView view(const iono_ctx *c) {
         g.c0[a] = c->c0[a];
         g.clast[a] = c->clast[a];
     }
-    g.ideal = c->ideal && c->force_general == 0 && c->variant != 13;      // (IONOTOMO_VARIANT=13: the tracer's general right-hand side, A/B)
+    g.ideal = c->ideal && c->force_general == 0 && c->variant != 13 && (uint64_t)c->nx * c->ny * c->nz < ((uint64_t)1 << 32);      // (IONOTOMO_VARIANT=13: the tracer's general right-hand side, A/B)
     return g;
 }
 hipError_t DevBuf::alloc(size_t bytes) {

@@ -19,3 +19,11 @@ t = time.perf_counter()
 e4.forward_fermat(o4, d4, w4["tmax"], w4["Ns"], 150e6, bend=True, kind="linear", substeps=2, out=t4)
 torch.cuda.synchronize()
 print(json.dumps({"rays": o4.shape[0], "Ns": w4["Ns"], "fused_forward_ms": (time.perf_counter() - t) * 1e3}))
+y4 = torch.randn(o4.shape[0], dtype=torch.float64, device="cuda")
+g4 = torch.zeros(e4.shape, dtype=torch.float64, device="cuda")
+e4.adjoint_fermat(o4, d4, y4, w4["tmax"], w4["Ns"], 150e6, bend=True, kind="linear", substeps=2, out=g4)
+torch.cuda.synchronize()
+t = time.perf_counter()
+e4.adjoint_fermat(o4, d4, y4, w4["tmax"], w4["Ns"], 150e6, bend=True, kind="linear", substeps=2, out=g4)
+torch.cuda.synchronize()
+print(json.dumps({"fused_adjoint_ms": (time.perf_counter() - t) * 1e3}))
