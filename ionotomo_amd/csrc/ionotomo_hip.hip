@@ -92,8 +92,10 @@ struct iono_ctx {
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
                                            // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
     int fermat_coop_rpw = 0;               // rays per wave of that kernel, 1..8: 0 = default (env IONOTOMO_FERMAT_COOP_RPW)
-    int64_t fermat_lin4_max = 131072;   // trilinear tracer: 4 lanes per ray up to this many rays, lanes = rays beyond
-                                        // (measured crossover ~150k rays; env IONOTOMO_FERMAT_LIN4_MAX)
+    int64_t fermat_lin4_max = 4096;     // trilinear tracer: 4 lanes per ray up to this many rays, lanes = rays beyond (crossover
+                                        // ~5k rays since the lanes = rays right-hand side dropped the axis tables on ideal grids:
+                                        // 2 604 rays 1.05 vs 1.16 ms, 10 416: 1.33 vs 1.21, 78 120: 3.08 vs 1.87; it was ~150k rays
+                                        // before.  env IONOTOMO_FERMAT_LIN4_MAX)
     int fermat_lin4_rpw = 0;            // rays per wave of that kernel: 0 = by batch size (env IONOTOMO_FERMAT_LIN4_RPW)
     int ideal = 0;                   // every axis is g0 + i*h to within 2.5e-13 h (np.linspace)
     double g0[3] = {0, 0, 0}, glast[3] = {0, 0, 0};
