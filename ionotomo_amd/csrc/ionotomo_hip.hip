@@ -2012,7 +2012,9 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
 #define LAUNCH_F(K, B) \
     hipLaunchKernelGGL((k_trace_fermat<K, B>), grid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags, stype)
     const size_t axes_bytes = (size_t)(c->nx + c->ny + c->nz) * 8;
-    if (kind == IONO_INTERP_TRILINEAR && c->variant != 3 && R <= c->fermat_lin4_max && axes_bytes <= 48 * 1024) {
+    // (a grid that is not ideal-uniform keeps the general right-hand side in the lanes = rays kernel: crossover ~150k rays as before)
+    const int64_t lin4_max = g.ideal || c->fermat_lin4_max != 4096 ? c->fermat_lin4_max : 131072;
+    if (kind == IONO_INTERP_TRILINEAR && c->variant != 3 && R <= lin4_max && axes_bytes <= 48 * 1024) {
         // small batch: 4 lanes per ray, axes in LDS, corners cached per cell (latency-bound regime)
         const int rpw = c->fermat_lin4_rpw > 0 ? c->fermat_lin4_rpw : (R <= 4096 ? 4 : 16);   // measured
         const dim3 qgrid((unsigned)((R + rpw - 1) / rpw));
