@@ -1447,10 +1447,13 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             if (rc) return rc;
         }
         if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
-        hipLaunchKernelGGL(k_lm_fold_z, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_G8, c->d_LMw, c->nx, c->ny, c->nz);
-        hipLaunchKernelGGL(k_lm_fold_y, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_LMw, (double2 *)(c->d_LMw + 4 * n), c->nx, c->ny,
-                           c->nz);
-        hipLaunchKernelGGL((k_lm_fold_x<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double2 *)(c->d_LMw + 4 * n), grad, c->nx,
+        // scratch [6 n]: H0 | H1 (double2 each) | K0 | K1
+        double2 *H0 = (double2 *)c->d_LMw, *H1 = H0 + n;
+        double *K0 = c->d_LMw + 4 * n, *K1 = K0 + n;
+        hipLaunchKernelGGL(k_lm_fold_z, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_G8, H0, H1, c->nx, c->ny, c->nz);
+        hipLaunchKernelGGL(k_lm_fold_y, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double2 *)H0, (const double2 *)H1, K0, K1, c->nx,
+                           c->ny, c->nz);
+        hipLaunchKernelGGL((k_lm_fold_x<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double *)K0, (const double *)K1, grad, c->nx,
                            c->ny, c->nz);
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
