@@ -226,7 +226,9 @@ int iono_scale_by_grid_dev(iono_ctx *ctx, double *grad_dev);
  * bundle needs for 8 consecutive samples is copied to LDS once (LDS-DMA) and every ray interpolates from there.  The
  * caller must not modify the two arrays while the plan is in use.  TEC never depends on the plan: a chunk whose
  * neighbourhood does not fit the LDS image takes direct loads with bit-identical arithmetic, and a ray's partial sums are
- * added in a fixed order.  No plan is built (and the other forward kernels serve the call) on other grids / storage. */
+ * added in a fixed order.  No plan is built (and the other forward kernels serve the call) on other grids / storage.
+ * interp_kind = IONO_INTERP_TRICUBIC launches use the same plan (k_forward_bundle_lm, iono_cubic_kernels.h: the Lekien-Marsden
+ * derivative fields kept as four pair-major arrays, one pair per wave, windows of 4-sample chunks), so does the phase forward. */
 int iono_forward_plan_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R, double tmax, int Ns);
 int iono_forward_plan_clear(iono_ctx *ctx);
 int iono_forward_plan_info(iono_ctx *ctx, int64_t *n_bundles, int *n_chunks, double *fit_fraction);
