@@ -269,15 +269,31 @@ class RayEngine(object):
                       int(bool(bend)), _lib.interp_kind(kind), int(substeps), _lib.ray_type(type), _ptr(out))
         return out
 
+    # a tricubic refractive index is traced 13 x faster by the 8-lanes-per-ray tracer with its cached stencil than by the lanes = rays
+    # stepper of the fused kernel (config 3: 2.3 against 31 ms): below this many bytes of rays[R,4,Ns] the two-step path serves it
+    FUSED_CUBIC_ABOVE_BYTES = 8 << 30
+
+    def _two_step_fermat(self, R, Ns, kind, fused):
+        if fused is not None:
+            return not fused
+        return _lib.interp_kind(kind) == _lib.interp_kind("cubic") and R * 4 * int(Ns) * 8 <= self.FUSED_CUBIC_ABOVE_BYTES
+
     def forward_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=True, kind="linear", substeps=4, type="z", ne_kind=None,
-                       ne_scale=1.0, out=None):
+                       ne_scale=1.0, out=None, fused=None):
         """tec[R] along the Fermat rays WITHOUT materialising them: RK4 stepper + streaming non-uniform Simpson in one kernel
         (== ``forward_rays(trace_fermat(...))`` to rounding; include/ionotomo_hip.h:iono_forward_tec_fermat_dev).  The grid must
-        hold ne [m^-3]; ``kind`` interpolates the refractive index, ``ne_kind`` (default: the engine's) the integrand."""
+        hold ne [m^-3]; ``kind`` interpolates the refractive index, ``ne_kind`` (default: the engine's) the integrand.
+        ``fused``: None = the fused kernel, except for a tricubic index while the ray tensor fits (see above); True / False force."""
         self._sync_stream()
         R = origins_t.shape[0]
         if out is None:
             out = torch.empty(R, dtype=torch.float64, device=self.device)
+        if self._two_step_fermat(R, Ns, kind, fused):
+            rays = self.trace_fermat(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, substeps=substeps, type=type)
+            self.forward_rays(rays, out=out, kind=ne_kind)
+            if ne_scale != 1.0:
+                out.mul_(float(ne_scale))
+            return out
         nk = self.kind if ne_kind is None else _lib.interp_kind(ne_kind)
         order, res = None, out
         if R >= 4096:            # lanes = rays: neighbouring lanes on nearly coincident rays share the lines they load (27 -> 15 ms at 620 000 rays)
@@ -290,12 +306,21 @@ class RayEngine(object):
         return out
 
     def adjoint_fermat(self, origins_t, dirs_t, w_t, tmax, Ns, frequency, bend=True, kind="linear", substeps=4, type="z",
-                       ne_kind=None, ne_scale=1.0, out=None):
+                       ne_kind=None, ne_scale=1.0, out=None, fused=None):
         """out[nx,ny,nz] += transpose of ``forward_fermat`` applied to w (the ray paths held fixed): re-trace and scatter.
         Large batches are walked in ``locality_order`` (neighbouring lanes = nearly coincident rays, so the hardware atomics of a
-        wave-instruction fall into a few lines instead of 64: a sum over rays does not care about their order)."""
+        wave-instruction fall into a few lines instead of 64: a sum over rays does not care about their order).  ``fused`` as in
+        ``forward_fermat``."""
         self._sync_stream()
         R = origins_t.shape[0]
+        if self._two_step_fermat(R, Ns, kind, fused):
+            if out is None:
+                out = torch.zeros(self.shape, dtype=torch.float64, device=self.device)
+            rays = self.trace_fermat(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, substeps=substeps, type=type)
+            w = w_t.reshape(-1) if ne_scale == 1.0 else w_t.reshape(-1) * float(ne_scale)
+            nk = self.kind if ne_kind is None else _lib.interp_kind(ne_kind)
+            self.ctx.call("iono_adjoint_rays_dev", _ptr(rays), _ptr(w.contiguous()), R, int(Ns), nk, self.rule, _ptr(out), _lib.F64)
+            return out
         if R >= 4096:
             order = self._cached_locality_order(origins_t, dirs_t, tmax)
             origins_t, dirs_t, w_t = origins_t[order].contiguous(), dirs_t[order].contiguous(), w_t.reshape(-1)[order].contiguous()

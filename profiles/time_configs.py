@@ -86,7 +86,8 @@ e3.set_grid(w3["xvec"], w3["yvec"], w3["zvec"])
 e3.set_values(e3.tensor(w3["ne"]))
 o3, d3 = e3.tensor(w3["origins"].reshape(-1, 3)), e3.tensor(w3["directions"].reshape(-1, 3))
 for kind in ("linear", "cubic"):
-    out["cfg3_fused_forward_%s_ms" % kind] = timeit(lambda: e3.forward_fermat(o3, d3, w3["tmax"], w3["Ns"], 120e6, bend=True, kind=kind, substeps=4), 10, 2)
+    out["cfg3_fused_forward_%s_ms" % kind] = timeit(lambda: e3.forward_fermat(o3, d3, w3["tmax"], w3["Ns"], 120e6, bend=True, kind=kind, substeps=4, fused=True), 10, 2)
+    out["cfg3_forward_fermat_%s_default_path_ms" % kind] = timeit(lambda: e3.forward_fermat(o3, d3, w3["tmax"], w3["Ns"], 120e6, bend=True, kind=kind, substeps=4), 10, 2)
 y3 = torch.randn(o3.shape[0], dtype=torch.float64, device="cuda")
 g3 = torch.zeros(e3.shape, dtype=torch.float64, device="cuda")
 out["cfg3_fused_adjoint_linear_ms"] = timeit(lambda: e3.adjoint_fermat(o3, d3, y3, w3["tmax"], w3["Ns"], 120e6, bend=True, kind="linear", substeps=4, out=g3), 5, 1)

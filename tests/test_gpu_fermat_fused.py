@@ -38,13 +38,13 @@ def test_streaming_quadrature_equals_the_explicit_sample_kernels(quad, Ns):
         tmax = w["tmax"] if typ == "z" else 0.8 * w["tmax"]
         rays = eng.trace_fermat(ot, dt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ)
         two_step = eng.forward_rays(rays).cpu().numpy()
-        fused = eng.forward_fermat(ot, dt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ).cpu().numpy()
+        fused = eng.forward_fermat(ot, dt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ, fused=True).cpu().numpy()
         assert not eng.check_oob()
         assert np.max(np.abs(fused - two_step)) <= 1e-12 * np.max(np.abs(two_step)), (kind, typ)
         # transpose: re-trace + scatter == scatter along the stored rays, and <G x, y> = <x, G^T y>
         y = np.random.default_rng(Ns).normal(size=len(o))
         yt = eng.tensor(y)
-        g_f = eng.adjoint_fermat(ot, dt, yt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ)
+        g_f = eng.adjoint_fermat(ot, dt, yt, tmax, Ns, 60e6, bend=True, kind=kind, substeps=3, type=typ, fused=True)
         lhs, rhs = float((eng.tensor(fused) * yt).sum()), float((g_f * eng.tensor(w["ne"])).sum())
         assert abs(lhs - rhs) <= 1e-11 * np.linalg.norm(fused) * np.linalg.norm(y), (kind, typ)
         assert not eng.check_oob()
@@ -64,10 +64,10 @@ def test_fused_adjoint_equals_the_explicit_ray_adjoint():
         ref = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
         eng.ctx.call("iono_adjoint_rays_dev", _lib._V(rays.data_ptr()), _lib._V(yt.data_ptr()), len(o), 21, eng.kind, eng.rule,
                      _lib._V(ref.data_ptr()), _lib.F64)
-        got = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, bend=True, kind=kind, substeps=2, ne_scale=1.0)
+        got = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, bend=True, kind=kind, substeps=2, ne_scale=1.0, fused=True)
         assert float((got - ref).abs().max()) <= 1e-11 * float(ref.abs().max()), kind
         # ne_scale scales both directions
-        got2 = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, bend=True, kind=kind, substeps=2, ne_scale=1e-13)
+        got2 = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, bend=True, kind=kind, substeps=2, ne_scale=1e-13, fused=True)
         assert float((got2 * 1e13 - ref).abs().max()) <= 1e-11 * float(ref.abs().max())
         assert not eng.check_oob()
 
@@ -83,7 +83,9 @@ def test_config3_fused_equals_trace_then_integrate_and_the_oracle(kind, O):
     rays_t = eng.trace_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=4)
     for tk, ok in (("linear", O.INTERP_TRILINEAR), ("cubic", O.INTERP_TRICUBIC)):
         two_step = eng.forward_rays(rays_t, kind=tk).cpu().numpy()
-        fused = eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=4, ne_kind=tk).cpu().numpy()
+        fused = eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=4, ne_kind=tk, fused=True).cpu().numpy()
+        auto = eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=4, ne_kind=tk, ne_scale=0.5).cpu().numpy()
+        assert np.max(np.abs(auto - 0.5 * fused) / np.abs(fused)) < 1e-12       # (a tricubic index: trace + integrate; else the fused kernel)
         assert np.max(np.abs(fused - two_step) / np.abs(two_step)) < 1e-12
         idx = np.sort(np.random.default_rng(0).choice(len(o), 104, replace=False))
         nM = O.ne_to_n(w["ne"], freq)
@@ -163,3 +165,23 @@ def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, O, monkeypat
     field = O.n_field_trilinear(xv, yv, zv, O.ne_to_n(w["ne"], 100e6))
     ref = O.fermat_trace(o, d, tmax, Ns, field, bend=True, substeps=2)
     assert np.max(np.abs(r0 - ref)) < 1e-9
+
+
+def test_tricubic_index_takes_the_two_step_path_by_default():
+    """``fused=None``: a tricubic refractive index is traced by the 8-lanes-per-ray tracer and integrated along the stored rays
+    while rays[R,4,Ns] fits (13 x faster than the lanes = rays stepper of the fused kernel); forward and transpose equal the
+    fused kernels' to rounding, ne_scale included."""
+    w = syn.make_workload(antennas="example", na=6, nd=5, nt=2, n=24, margin_cells=8)
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"]))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    yt = eng.tensor(np.random.default_rng(4).normal(size=len(o)))
+    assert eng._two_step_fermat(len(o), 21, "cubic", None) and not eng._two_step_fermat(len(o), 21, "linear", None)
+    a = eng.forward_fermat(ot, dt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13)
+    b = eng.forward_fermat(ot, dt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
+    assert float((a - b).abs().max()) < 1e-12 * float(b.abs().max())
+    ga = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13)
+    gb = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
+    assert float((ga - gb).abs().max()) < 1e-12 * float(gb.abs().max())
+    assert not eng.check_oob()
