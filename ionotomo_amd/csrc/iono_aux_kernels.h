@@ -594,6 +594,102 @@ __global__ __launch_bounds__(64) void k_trace_fermat_lin4(GridView g, const doub
     if (oob && writer) atomicOr(oob_flag, 1);
 }
 
+// ---- small batches on ideal-uniform grids: one ray per lane, few lanes per wave, the cell's polynomial in registers -------------------
+// A single coherence window (config 3: 2 604 rays) cannot fill the chip whatever the mapping: the time is the dependent chain
+// of one ray -- 128 samples x 4 substeps x 4 stages -- and the 4-lanes-per-ray kernel spends it on DPP sums, cell-bound compares and
+// a reciprocal per stage (510 ns per evaluation).  Inside a cell the trilinear index is the polynomial
+//     n = k0 + k1 tx + k2 ty + k3 tz + k4 tx ty + k5 tx tz + k6 ty tz + k7 tx ty tz        (t = local coordinates in the cell)
+// whose value and gradient are 12 fused multiply-adds three deep; the eight coefficients are formed once per cell (a ray stays
+// ~16 stages in one) from four 16-byte loads.  The cell is floor((x - g0) / h) except within 1e-9 of a face, where the axis
+// tables decide as scipy does (find_cell: the gradient jumps there) -- the same rule, the same cell polynomial as
+// trilinear_grad_at, to rounding.  rays_per_wave lanes of a wave are used (16 measured best: a lone wave issues one instruction
+// per ~10 cycles whatever its lane count, 88 vector + 24 scalar instructions per stage -- the time IS that chain; more rays per
+// wave only add cell changes that stall their neighbours, fewer waste issue slots).
+struct CellPoly {
+    int i, j, k;          // cached cell (-1: none)
+    double k0, k1, k2, k3, k4, k5, k6, k7;
+};
+__device__ __forceinline__ void cell_poly_load(const GridView &g, const double *__restrict__ nM, int i, int j, int k, CellPoly &cp) {
+    const size_t sj = (size_t)g.nz, si = (size_t)g.ny * g.nz;
+    const double *p = nM + ((size_t)i * g.ny + j) * g.nz + k;
+    const double c000 = p[0], c001 = p[1], c010 = p[sj], c011 = p[sj + 1];
+    const double c100 = p[si], c101 = p[si + 1], c110 = p[si + sj], c111 = p[si + sj + 1];
+    cp.i = i, cp.j = j, cp.k = k;
+    cp.k0 = c000;
+    cp.k1 = c100 - c000, cp.k2 = c010 - c000, cp.k3 = c001 - c000;
+    cp.k4 = (c110 - c100) - (c010 - c000);
+    cp.k5 = (c101 - c100) - (c001 - c000);
+    cp.k6 = (c011 - c010) - (c001 - c000);
+    cp.k7 = ((c111 - c110) - (c101 - c100)) - ((c011 - c010) - (c001 - c000));
+}
+template <bool BEND>
+__device__ __forceinline__ FState fermat_rhs_poly(const GridView &g, const double *gx, const double *gy, const double *gz,
+                                                  const double *__restrict__ nM, const FState &u, CellPoly &cp, int stype) {
+    const double ux = (u.x - g.g0[0]) * g.inv_h[0], uy = (u.y - g.g0[1]) * g.inv_h[1], uz = (u.z - g.g0[2]) * g.inv_h[2];
+    double fi = __builtin_floor(ux), fj = __builtin_floor(uy), fk = __builtin_floor(uz);
+    const double eps = 1e-9;
+    {
+        const double tx = ux - fi, ty = uy - fj, tz = uz - fk;
+        // within eps of a face (or outside the grid): the axis tables name the cell, as scipy would
+        if (!((tx > eps) & (tx < 1.0 - eps) & (fi >= 0.0) & (fi <= (double)(g.nx - 2)))) fi = (double)find_cell(gx, g.nx, u.x, g.inv_h[0], g.uniform[0]);
+        if (!((ty > eps) & (ty < 1.0 - eps) & (fj >= 0.0) & (fj <= (double)(g.ny - 2)))) fj = (double)find_cell(gy, g.ny, u.y, g.inv_h[1], g.uniform[1]);
+        if (!((tz > eps) & (tz < 1.0 - eps) & (fk >= 0.0) & (fk <= (double)(g.nz - 2)))) fk = (double)find_cell(gz, g.nz, u.z, g.inv_h[2], g.uniform[2]);
+    }
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    if ((i != cp.i) | (j != cp.j) | (k != cp.k)) cell_poly_load(g, nM, i, j, k, cp);
+    const double tx = ux - fi, ty = uy - fj, tz = uz - fk;
+    const double a = __builtin_fma(cp.k7, tz, cp.k4);              // d2n / dtx dty
+    const double nxt = __builtin_fma(ty, a, __builtin_fma(cp.k5, tz, cp.k1));
+    const double b = __builtin_fma(cp.k6, tz, cp.k2);
+    const double nyt = __builtin_fma(tx, a, b);
+    const double nzt = __builtin_fma(ty, __builtin_fma(cp.k7, tx, cp.k6), __builtin_fma(cp.k5, tx, cp.k3));
+    const double n = __builtin_fma(tx, nxt, __builtin_fma(ty, b, __builtin_fma(cp.k3, tz, cp.k0)));
+    double nx = nxt * g.inv_h[0], ny = nyt * g.inv_h[1], nz = nzt * g.inv_h[2];
+    if (!BEND) nx = ny = nz = 0.0;
+    return fermat_rates(n, nx, ny, nz, u, stype);
+}
+template <bool BEND>
+__global__ __launch_bounds__(64) void k_trace_fermat_poly(GridView g, const double *__restrict__ nM, const double *__restrict__ origins,
+                                                          const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps,
+                                                          double *__restrict__ rays, int *oob_flag, int rays_per_wave, int stype) {
+    if ((int)threadIdx.x >= rays_per_wave) return;
+    const int64_t r = (int64_t)blockIdx.x * rays_per_wave + threadIdx.x;
+    if (r >= R) return;
+    const double *gx = g.axes, *gy = g.axes + g.nx, *gz = g.axes + g.nx + g.ny;
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm, u.py = dy / nrm, u.pz = dz / nrm;
+    u.x = origins[3 * r], u.y = origins[3 * r + 1], u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
+    double *o = rays + (size_t)r * 4 * Ns;
+    o[0] = u.x, o[Ns] = u.y, o[2 * Ns] = u.z, o[3 * Ns] = u.s;
+    CellPoly cp;
+    cp.i = cp.j = cp.k = -1;
+    const double ztop = g.glast[2] + 1e-9 * fabs(tmax);
+    bool oob = false;
+    for (int k = 1; k < Ns; ++k) {
+        for (int sub = 0; sub < substeps; ++sub) {
+            // the four stages spelled out (same operations in the same order as the stage loop of k_trace_fermat)
+            FState kprev = {}, sum = {};
+            kprev = fermat_rhs_poly<BEND>(g, gx, gy, gz, nM, axpy(u, 0.0, kprev), cp, stype);
+            sum = axpy(sum, 1.0, kprev);
+            kprev = fermat_rhs_poly<BEND>(g, gx, gy, gz, nM, axpy(u, 0.5 * h, kprev), cp, stype);
+            sum = axpy(sum, 2.0, kprev);
+            kprev = fermat_rhs_poly<BEND>(g, gx, gy, gz, nM, axpy(u, 0.5 * h, kprev), cp, stype);
+            sum = axpy(sum, 2.0, kprev);
+            kprev = fermat_rhs_poly<BEND>(g, gx, gy, gz, nM, axpy(u, h, kprev), cp, stype);
+            sum = axpy(sum, 1.0, kprev);
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= !(u.x >= g.g0[0] && u.x <= g.glast[0] && u.y >= g.g0[1] && u.y <= g.glast[1] && u.z >= g.g0[2] && u.z <= ztop);
+        o[k] = u.x, o[Ns + k] = u.y, o[2 * Ns + k] = u.z, o[3 * Ns + k] = u.s;
+    }
+    if (oob) atomicOr(oob_flag, 1);
+}
+
+
 }  // namespace
 
 #endif

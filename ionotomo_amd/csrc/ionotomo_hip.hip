@@ -92,6 +92,9 @@ struct iono_ctx {
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
                                            // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
     int fermat_coop_rpw = 0;               // rays per wave of that kernel, 1..8: 0 = default (env IONOTOMO_FERMAT_COOP_RPW)
+    int64_t fermat_poly_max = 4096;     // trilinear tracer on ideal grids: cell-polynomial kernel (few rays per wave) up to this many rays
+                                        // (env IONOTOMO_FERMAT_POLY_MAX, _RPW; IONOTOMO_VARIANT=15: the 4-lanes-per-ray kernel instead)
+    int fermat_poly_rpw = 0;
     int64_t fermat_lin4_max = 4096;     // trilinear tracer: 4 lanes per ray up to this many rays, lanes = rays beyond (crossover
                                         // ~5k rays since the lanes = rays right-hand side dropped the axis tables on ideal grids:
                                         // 2 604 rays 1.05 vs 1.16 ms, 10 416: 1.33 vs 1.21, 78 120: 3.08 vs 1.87; it was ~150k rays
@@ -470,6 +473,8 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_FERMAT_COOP_MAX")) c->fermat_coop_max = atoll(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_COOP_RPW")) c->fermat_coop_rpw = std::min(8, std::max(1, atoi(e)));
     if (const char *e = getenv("IONOTOMO_FERMAT_LIN4_MAX")) c->fermat_lin4_max = atoll(e);
+    if (const char *e = getenv("IONOTOMO_FERMAT_POLY_MAX")) c->fermat_poly_max = atoll(e);
+    if (const char *e = getenv("IONOTOMO_FERMAT_POLY_RPW")) c->fermat_poly_rpw = atoi(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_LIN4_RPW")) c->fermat_lin4_rpw = std::min(16, std::max(1, atoi(e)));
     *out = c;
     return IONO_OK;
@@ -2017,7 +2022,19 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
     const size_t axes_bytes = (size_t)(c->nx + c->ny + c->nz) * 8;
     // (a grid that is not ideal-uniform keeps the general right-hand side in the lanes = rays kernel: crossover ~150k rays as before)
     const int64_t lin4_max = g.ideal || c->fermat_lin4_max != 4096 ? c->fermat_lin4_max : 131072;
-    if (kind == IONO_INTERP_TRILINEAR && c->variant != 3 && R <= lin4_max && axes_bytes <= 48 * 1024) {
+    if (kind == IONO_INTERP_TRILINEAR && g.ideal && c->variant != 3 && c->variant != 15 && R <= c->fermat_poly_max) {
+        // small batch on an ideal-uniform grid: the cell's polynomial in registers, no DPP sums (iono_aux_kernels.h).  16 rays per
+        // wave measured best from 600 to 4 096 rays (0.91-0.94 ms at config 3's 129 samples x 4 substeps; 8: 0.89-1.14, 32: 0.93-0.96,
+        // 1: 3.0 -- a lone lane still pays the whole wave's issue slots; the 4-lanes-per-ray kernel: 1.08-1.18)
+        const int rpw = c->fermat_poly_rpw > 0 ? c->fermat_poly_rpw : 16;
+        const dim3 pgrid((unsigned)((R + rpw - 1) / rpw));
+        if (bend)
+            hipLaunchKernelGGL((k_trace_fermat_poly<true>), pgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags,
+                               rpw, stype);
+        else
+            hipLaunchKernelGGL((k_trace_fermat_poly<false>), pgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags,
+                               rpw, stype);
+    } else if (kind == IONO_INTERP_TRILINEAR && c->variant != 3 && R <= lin4_max && axes_bytes <= 48 * 1024) {
         // small batch: 4 lanes per ray, axes in LDS, corners cached per cell (latency-bound regime)
         const int rpw = c->fermat_lin4_rpw > 0 ? c->fermat_lin4_rpw : (R <= 4096 ? 4 : 16);   // measured
         const dim3 qgrid((unsigned)((R + rpw - 1) / rpw));

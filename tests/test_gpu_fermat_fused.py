@@ -136,12 +136,15 @@ def test_620k_bending_rays_through_256_cubed_in_one_launch():
     assert not eng.check_oob()
 
 
+@pytest.mark.parametrize("rep", [1, 80])
 @pytest.mark.parametrize("aligned", [False, True])
-def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, O, monkeypatch):
+def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, rep, O, monkeypatch):
     """On an ideal-uniform grid the tracer's right-hand side skips the axis tables and the divisions (trilinear_grad_ideal) except
     within 1e-9 of a cell face, where the general form decides the cell as scipy does.  Traced rays and fused TEC equal the
     general form's (IONOTOMO_VARIANT=13) to rounding and the oracle's RK4 -- also when EVERY sample sits on a z face (``aligned``:
-    samples one cell apart starting on a level, the case where the face rule decides which cell's gradient bends the ray)."""
+    samples one cell apart starting on a level, the case where the face rule decides which cell's gradient bends the ray).
+    ``rep`` = 1: 60 rays, the small-batch tracer that keeps the cell's polynomial in registers (k_trace_fermat_poly) against the
+    4-lanes-per-ray kernel it replaced on ideal grids (IONOTOMO_VARIANT=15); 80: 4 800 rays, the lanes = rays tracer."""
     from ionotomo_amd.engine import RayEngine
     w = syn.make_workload(antennas="example", na=6, nd=5, nt=2, n=33, margin_cells=10)
     xv, yv, zv = w["xvec"], w["yvec"], w["zvec"]
@@ -150,17 +153,18 @@ def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, O, monkeypat
     if aligned:
         o[:, 2] = zv[4]                                   # z_k = linspace(zv[4], zv[24], 21): every sample on a level of the grid
     res = {}
-    for variant in ("0", "13"):
+    other = "13" if rep > 1 else "15"
+    for variant in ("0", other):
         monkeypatch.setenv("IONOTOMO_VARIANT", variant)
         eng = RayEngine(0)
         eng.set_grid(xv, yv, zv)
         eng.set_values(eng.tensor(w["ne"]))
-        ot, dt = eng.tensor(np.tile(o, (80, 1))), eng.tensor(np.tile(d, (80, 1)))      # 4 800 rays: the lanes = rays tracer
+        ot, dt = eng.tensor(np.tile(o, (rep, 1))), eng.tensor(np.tile(d, (rep, 1)))
         rays = eng.trace_fermat(ot, dt, tmax, Ns, 100e6, bend=True, kind="linear", substeps=2)
         tec = eng.forward_fermat(ot, dt, tmax, Ns, 100e6, bend=True, kind="linear", substeps=2)
         assert not eng.check_oob()
         res[variant] = (rays.cpu().numpy()[: len(o)], tec.cpu().numpy()[: len(o)])
-    (r0, t0), (r1, t1) = res["0"], res["13"]
+    (r0, t0), (r1, t1) = res["0"], res[other]
     assert np.max(np.abs(r0 - r1)) < 1e-10 and np.max(np.abs(t0 - t1)) < 1e-11 * np.max(np.abs(t1))
     field = O.n_field_trilinear(xv, yv, zv, O.ne_to_n(w["ne"], 100e6))
     ref = O.fermat_trace(o, d, tmax, Ns, field, bend=True, substeps=2)
