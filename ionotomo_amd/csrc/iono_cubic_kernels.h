@@ -446,12 +446,14 @@ __device__ __forceinline__ double lm_pair_value(const LmPairW &w, const lm_d2 (&
     return (w.xh0 * s0.x + w.xs0 * s0.y) + (w.xh1 * s1.x + w.xs1 * s1.y);
 }
 
-// Staging is asynchronous (LDS-DMA, counted by vmcnt): while a wave interpolates chunk c out of one half of its image it copies
-// the window of chunk c + 1 into the other half, whenever both windows have at most BL_SLOT columns (nine in ten at the bench
-// geometry: the median window has 20 columns, the image 120); a larger window takes the whole image and is staged in line.
+// Two ways through a chunk, chosen by the size of its window (wave-uniform, from the plan):
+//  * at most BL_ALL = 30 columns (the median window has 20): ONE wave -- wave c mod 4 -- copies the windows of all four pairs into
+//    the four quarters of its image and evaluates the whole interpolant for its lanes: position, floor and the three Hermite
+//    sets are then computed once per sample instead of once per sample and wave (31 of the 67 vector instructions);
+//  * larger: every wave copies the window of ITS pair and adds its quarter of the interpolant, as above.
 // One wave-load moves 60 nodes = BL_CPL columns x BL_LEV levels: floor(BL_CPL / wy) whole rows of a window wy <= BL_CPL wide, or one
 // of the two column groups of a wider row.
-#define BL_SLOT (B_CAPCOLS / 2)
+#define BL_ALL (B_CAPCOLS / 4)
 struct LmWindow {
     int imin, jmin, kz0, wx, wy, rpl, fits;      // rpl: rows per staging wave-load (bits 20..23 of the plan's window word)
 };
@@ -506,51 +508,83 @@ __device__ __forceinline__ void lm_stage(const GridView &g, const lm_d2 *__restr
     }
 }
 
+typedef const __attribute__((address_space(3))) lm_d2 *lm_lds_node;
+__device__ __forceinline__ void lm_read8(lm_d2 (&n)[8], unsigned a, unsigned row2) {
+    const __attribute__((address_space(3))) char *p0 = (const __attribute__((address_space(3))) char *)(size_t)a;
+    const __attribute__((address_space(3))) char *p1 = (const __attribute__((address_space(3))) char *)(size_t)(a + row2);
+    n[0] = *(lm_lds_node)(p0), n[1] = *(lm_lds_node)(p0 + BL_NODE), n[2] = *(lm_lds_node)(p0 + BL_COL), n[3] = *(lm_lds_node)(p0 + BL_COL + BL_NODE);
+    n[4] = *(lm_lds_node)(p1), n[5] = *(lm_lds_node)(p1 + BL_NODE), n[6] = *(lm_lds_node)(p1 + BL_COL), n[7] = *(lm_lds_node)(p1 + BL_COL + BL_NODE);
+}
 template <int Q, int RZ>
-__device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 *__restrict__ FPt, const BundleRays &B, const uint4 *__restrict__ wb,
-                                                 int nchunks, int Ns, const double *__restrict__ unitw, char *img) {
+__device__ __forceinline__ double lm_pair_of(const Herm &hx, const Herm &hy, const Herm &hz, const lm_d2 (&n)[8]) {
+    const double y0 = Q ? hy.s0 : hy.h0, y1 = Q ? hy.s1 : hy.h1, z0 = RZ ? hz.s0 : hz.h0, z1 = RZ ? hz.s1 : hz.h1;
+    LmPairW w;
+    w.xh0 = hx.h0, w.xh1 = hx.h1, w.xs0 = hx.s0, w.xs1 = hx.s1;
+    w.w00 = y0 * z0, w.w01 = y0 * z1, w.w10 = y1 * z0, w.w11 = y1 * z1;
+    return lm_pair_value(w, n);
+}
+
+template <int Q, int RZ>
+__device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 *__restrict__ FP, int64_t npad, const BundleRays &B,
+                                                 const uint4 *__restrict__ wb, int nchunks, int Ns, const double *__restrict__ unitw, char *img,
+                                                 int wid, int allpairs) {
+    const lm_d2 *FPt = FP + (size_t)wid * npad;          // this wave's pair (q, r) = (Q, RZ)
     const size_t sj = (size_t)g.nz, si = (size_t)g.ny * g.nz;
     double acc = 0.0;
-    LmWindow W = lm_window(wb, 0);
-    int slot = 0;                 // half of the image the current window lives in (0 for a window that takes the whole image)
-    bool staged = false;          // the current window was copied (or is being copied) while the previous chunk was interpolated
     for (int c = 0; c < nchunks; ++c) {
         const int k0 = c * BL_KC;
         int ke = min(k0 + BL_KC, Ns);
+        const LmWindow W = lm_window(wb, c);
+        const bool all = allpairs && W.fits && W.wx * W.wy <= BL_ALL;
+        if (all && (c & (B_SPLIT - 1)) != wid) continue;          // another wave takes the whole chunk
         const double kd0 = (double)k0;
         double fx = fma(kd0, B.dfx, B.fx0), fy = fma(kd0, B.dfy, B.fy0), fz = fma(kd0, B.dfz, B.fz0);
-        const bool small = W.wx * W.wy <= BL_SLOT;
-        LmWindow Wn = W;
-        if (c + 1 < nchunks) Wn = lm_window(wb, c + 1);
-        const bool prefetch = c + 1 < nchunks && W.fits && small && Wn.fits && Wn.wx * Wn.wy <= BL_SLOT;
-        if (W.fits) {
-            if (!staged) {
-                slot = small ? slot : 0;
-                lm_stage(g, FPt, W, img + slot * (BL_SLOT * BL_COL));
+        // the chunk's quadrature weights in one scalar load, BEFORE the LDS reads (scalar loads share their counter: waiting for
+        // one inside the loop would wait for every read in flight); weights beyond the last sample are zeros
+        const double w0 = unitw[k0], w1 = unitw[k0 + 1], w2 = unitw[k0 + 2], w3 = unitw[k0 + 3];
+        static_assert(BL_KC == 4, "four weights per chunk");
+        const double cw = (double)(W.wy * BL_LEV), cj = (double)BL_LEV;
+        const unsigned ibase = (unsigned)(size_t)img - (((unsigned)W.imin * (unsigned)W.wy + (unsigned)W.jmin) * BL_LEV + (unsigned)W.kz0) * BL_NODE;
+        const unsigned row2 = (unsigned)W.wy * BL_COL;
+        if (all) {
+            // ---- all four pairs by this wave: pair t in quarter t of the image -------------------------------------------------------
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the previous chunk's LDS reads have returned: the image may be overwritten
+#pragma unroll
+            for (int t = 0; t < 4; ++t) lm_stage(g, FP + (size_t)t * npad, W, img + t * (BL_ALL * BL_COL));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            constexpr unsigned PS = BL_ALL * BL_COL;
+#if defined(IONO_BL_ABL) && IONO_BL_ABL == 2      // timing-only build (WRONG results): staging only
+            ke = k0 + 1;
+#endif
+            for (int k = k0; k < ke; ++k) {
+                const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
+                const Herm hx = hermite(fx - fi), hy = hermite(fy - fj), hz = hermite(fz - fk);
+                const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * BL_NODE + ibase;
+                lm_d2 na[8], nb[8];
+                lm_read8(na, a, row2);
+                lm_read8(nb, a + PS, row2);
+                double v = lm_pair_of<0, 0>(hx, hy, hz, na);
+                lm_read8(na, a + 2 * PS, row2);
+                v += lm_pair_of<1, 0>(hx, hy, hz, nb);
+                lm_read8(nb, a + 3 * PS, row2);
+                v += lm_pair_of<0, 1>(hx, hy, hz, na);
+                v += lm_pair_of<1, 1>(hx, hy, hz, nb);
+                const int dk = k - k0;
+                acc = fma(dk == 0 ? w0 : dk == 1 ? w1 : dk == 2 ? w2 : w3, v, acc);
+                fx += B.dfx, fy += B.dfy, fz += B.dfz;
             }
-            // (this chunk's window has landed; the previous chunk's LDS reads have returned before the next copy may overwrite their half)
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            char *cur = img + slot * (BL_SLOT * BL_COL);
-            if (prefetch) lm_stage(g, FPt, Wn, img + (slot ^ 1) * (BL_SLOT * BL_COL));
-            const double cw = (double)(W.wy * BL_LEV), cj = (double)BL_LEV;
-            const unsigned ibase = (unsigned)(size_t)cur - (((unsigned)W.imin * (unsigned)W.wy + (unsigned)W.jmin) * BL_LEV + (unsigned)W.kz0) * BL_NODE;
-            const unsigned row2 = (unsigned)W.wy * BL_COL;
-            typedef const __attribute__((address_space(3))) lm_d2 *lds_node;
+        } else if (W.fits) {
+            // ---- this wave's pair --------------------------------------------------------------------------------------------------------
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            lm_stage(g, FPt, W, img);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             // one sample: weights, the LDS address of its cell's lower corner, eight ds_read_b128 (issued, not yet waited for)
             auto fetch = [&](LmPairW &pw, lm_d2 (&n)[8]) {
                 const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
                 pw = lm_pair_weights<Q, RZ>(fx - fi, fy - fj, fz - fk);
-                const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * BL_NODE + ibase;
-                const __attribute__((address_space(3))) char *p0 = (const __attribute__((address_space(3))) char *)(size_t)a;
-                const __attribute__((address_space(3))) char *p1 = (const __attribute__((address_space(3))) char *)(size_t)(a + row2);
-                n[0] = *(lds_node)(p0), n[1] = *(lds_node)(p0 + BL_NODE), n[2] = *(lds_node)(p0 + BL_COL), n[3] = *(lds_node)(p0 + BL_COL + BL_NODE);
-                n[4] = *(lds_node)(p1), n[5] = *(lds_node)(p1 + BL_NODE), n[6] = *(lds_node)(p1 + BL_COL), n[7] = *(lds_node)(p1 + BL_COL + BL_NODE);
+                lm_read8(n, (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * BL_NODE + ibase, row2);
                 fx += B.dfx, fy += B.dfy, fz += B.dfz;
             };
-            // the chunk's quadrature weights in one scalar load, BEFORE the LDS reads (scalar loads share their counter: waiting for
-            // one inside the loop would wait for every read in flight); weights beyond the last sample are zeros
-            const double w0 = unitw[k0], w1 = unitw[k0 + 1], w2 = unitw[k0 + 2], w3 = unitw[k0 + 3];
-            static_assert(BL_KC == 4, "four weights per chunk");
             LmPairW pa, pb;
             lm_d2 na[8], nb[8];
             fetch(pa, na);
@@ -584,9 +618,6 @@ __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 
                 fx += B.dfx, fy += B.dfy, fz += B.dfz;
             }
         }
-        staged = prefetch;
-        if (prefetch) slot ^= 1;
-        W = Wn;
     }
     return acc;
 }
@@ -595,7 +626,7 @@ __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const dou
                                                            const double *__restrict__ dirs, const int *__restrict__ order,
                                                            const int *__restrict__ bstart, const uint4 *__restrict__ win, int nb, int nchunks,
                                                            double tmax, int Ns, const double *__restrict__ unitw, double *__restrict__ tec,
-                                                           int *oob_flag) {
+                                                           int *oob_flag, int allpairs) {
     extern __shared__ __attribute__((aligned(16))) char blds[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int b = blockIdx.x;
@@ -609,13 +640,13 @@ __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const dou
     }
     char *img = blds + wid * BL_WAVE_LDS;
     double *part = (double *)(blds + B_SPLIT * BL_WAVE_LDS);
-    const lm_d2 *FPt = (const lm_d2 *)FP + (size_t)wid * npad;
+    const lm_d2 *FPd = (const lm_d2 *)FP;
     const uint4 *wb = win + (size_t)b * nchunks;
     double acc;
-    if (wid == 0) acc = bundle_lm_walk<0, 0>(g, FPt, B, wb, nchunks, Ns, unitw, img);
-    else if (wid == 1) acc = bundle_lm_walk<1, 0>(g, FPt, B, wb, nchunks, Ns, unitw, img);
-    else if (wid == 2) acc = bundle_lm_walk<0, 1>(g, FPt, B, wb, nchunks, Ns, unitw, img);
-    else acc = bundle_lm_walk<1, 1>(g, FPt, B, wb, nchunks, Ns, unitw, img);
+    if (wid == 0) acc = bundle_lm_walk<0, 0>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 0, allpairs);
+    else if (wid == 1) acc = bundle_lm_walk<1, 0>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 1, allpairs);
+    else if (wid == 2) acc = bundle_lm_walk<0, 1>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 2, allpairs);
+    else acc = bundle_lm_walk<1, 1>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 3, allpairs);
     part[wid * 64 + lane] = acc;
     __syncthreads();
     if (wid == 0 && B.mine) {

@@ -997,7 +997,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             static_assert(BL_LDS_BYTES <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
             hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES, c->stream, g, c->d_FP,
                                padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
-                               c->d_flags);
+                               c->d_flags, c->variant == 16 ? 0 : 1);      // (IONOTOMO_VARIANT=16: one pair per wave for every window, A/B)
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
