@@ -797,6 +797,21 @@ int iono_forward_plan_clear(iono_ctx *c) {
     return IONO_OK;
 }
 
+// window set of the tricubic bundle kernel (chunks of BL_KC samples, BL_LEV levels of 16-byte nodes): computed on its first launch,
+// so that a trilinear inversion does not pay for it (0.1 ms of kernel + 4.8 MB at the bench shape)
+static int ensure_lm_windows(iono_ctx *c) {
+    iono_ctx::FwdPlan &fp = c->fplan;
+    if (fp.R < 0 || fp.nchunks_lm > 0) return IONO_OK;
+    const int nchunks_lm = (fp.Ns + BL_KC - 1) / BL_KC;
+    HIP_TRY(c, plan_reserve(fp.d_win_lm, fp.cap_win_lm, (size_t)fp.nb * nchunks_lm * sizeof(uint4)));
+    hipLaunchKernelGGL((k_bundle_windows<BL_KC, BL_LEV, 2 * BL_CPL, false>), dim3(fp.nb), dim3(64), 0, c->stream, view(c),
+                       (const double *)fp.o_key, (const double *)fp.d_key, fp.d_order, fp.d_bstart, fp.nb, fp.tmax, fp.Ns, nchunks_lm,
+                       fp.d_win_lm);
+    HIP_TRY(c, hipGetLastError());
+    fp.nchunks_lm = nchunks_lm;
+    return IONO_OK;
+}
+
 int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns) {
     int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, 0);
     if (rc) return rc;
@@ -886,13 +901,13 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipMemcpy(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
     hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
                        nb, tmax, Ns, nchunks, fp.d_win);
-    const int nchunks_lm = (Ns + BL_KC - 1) / BL_KC;
-    HIP_TRY(c, plan_reserve(fp.d_win_lm, fp.cap_win_lm, (size_t)nb * nchunks_lm * sizeof(uint4)));
-    hipLaunchKernelGGL((k_bundle_windows<BL_KC, BL_LEV, 2 * BL_CPL, false>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order,
-                       fp.d_bstart, nb, tmax, Ns, nchunks_lm, fp.d_win_lm);
-    fp.nchunks_lm = nchunks_lm;
+    fp.nchunks_lm = 0;      // the tricubic kernel's window set is computed by its first launch (ensure_lm_windows)
     HIP_TRY(c, hipGetLastError());
     if (getenv("IONOTOMO_PLAN_STATS")) {      // columns per window, both chunk lengths (stderr; tuning aid)
+        fp.o_key = o, fp.d_key = d, fp.R = R, fp.Ns = Ns, fp.tmax = tmax, fp.nb = nb, fp.nchunks = nchunks;
+        rc = ensure_lm_windows(c);
+        if (rc) return rc;
+        const int nchunks_lm = fp.nchunks_lm;
         for (int which = 0; which < 2; ++which) {
             std::vector<uint4> hv((size_t)nb * (which ? nchunks_lm : nchunks));
             HIP_TRY(c, hipMemcpy(hv.data(), which ? fp.d_win_lm : fp.d_win, hv.size() * sizeof(uint4), hipMemcpyDeviceToHost));
@@ -991,7 +1006,9 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                                wm, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && fplan_serves(c, o, d, R, tmax, Ns)) {
             // bundles of neighbouring rays, one field pair per wave, windows staged in LDS (iono_cubic_kernels.h:k_forward_bundle_lm)
-            const int rc2 = ensure_lm_fields(c, true);
+            int rc2 = ensure_lm_fields(c, true);
+            if (rc2) return rc2;
+            rc2 = ensure_lm_windows(c);
             if (rc2) return rc2;
             const iono_ctx::FwdPlan &fp = c->fplan;
             static_assert(BL_LDS_BYTES <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
