@@ -683,11 +683,12 @@ __global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__re
 template <int KC, int LEV, int MAXWY, bool EVEN>
 __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs,
                                                        const int *__restrict__ order, const int *__restrict__ bstart, int nb, double tmax,
-                                                       int Ns, int nchunks, uint4 *__restrict__ win) {
+                                                       int Ns, int nchunks, uint4 *__restrict__ win, unsigned long long *__restrict__ fit_count) {
     const int b = blockIdx.x;
     if (b >= nb) return;
     const BundleRays B = load_bundle(g, origins, dirs, order, bstart, b, tmax, Ns);
     const double eps = 1e-9;       // the samples of a chunk are reached by accumulation from its first one: margin of the window
+    int nfit = 0;
     for (int c = 0; c < nchunks; ++c) {
         uint4 w = make_uint4(0, 0, 0, 0);
         if (B.any) {
@@ -704,9 +705,11 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
             const int rpl = min(15, max(1, (64 / LEV) / wy));
             w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0,
                            (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u) | ((unsigned)rpl << 20));
+            nfit += fits;
         }
         if ((threadIdx.x & 63) == 0) win[(size_t)b * nchunks + c] = w;
     }
+    if (fit_count && (threadIdx.x & 63) == 0 && nfit) atomicAdd(fit_count, (unsigned long long)nfit);      // one update per bundle
 }
 
 // NF = 0: TEC (tec[r]).  NF > 0: the phase observable's per-frequency integrals of 1 - sqrt(1 - ne / n_p) for NF frequencies per

@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -144,6 +145,8 @@ struct iono_ctx {
     } fplan;
     char *h_pinned = nullptr;        // pinned staging of small downloads (iono_dev_download): result + flags in one round trip
     size_t pinned_cap = 0;
+    char *h_plan = nullptr;          // pinned staging of the plan builders' host round trips (ray summaries, walk order: 8 MB at the
+    size_t plan_pinned_cap = 0;      // bench shape; from pageable memory those copies were half of the 3 ms a forward plan took)
     double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
     int64_t rayw_cap = 0;
     double *d_freqs = nullptr;       // frequencies of the phase observable on the device (cached copy of h_freqs)
@@ -499,6 +502,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     plan_free(c);
     fplan_free(c);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_plan) (void)hipHostFree(c->h_plan);
     if (c->d_kern) (void)hipFree(c->d_kern);
     if (c->d_work) (void)hipFree(c->d_work);
     for (auto &wp : c->walk) {
@@ -797,6 +801,18 @@ int iono_forward_plan_clear(iono_ctx *c) {
     return IONO_OK;
 }
 
+static int plan_pinned(iono_ctx *c, size_t bytes, char **out) {
+    if (c->plan_pinned_cap < bytes) {
+        if (c->h_plan) (void)hipHostFree(c->h_plan);
+        c->h_plan = nullptr, c->plan_pinned_cap = 0;
+        const size_t cap = bytes + bytes / 4 + 4096;
+        HIP_TRY(c, hipHostMalloc((void **)&c->h_plan, cap, hipHostMallocDefault));
+        c->plan_pinned_cap = cap;
+    }
+    *out = c->h_plan;
+    return IONO_OK;
+}
+
 // window set of the tricubic bundle kernel (chunks of BL_KC samples, BL_LEV levels of 16-byte nodes): computed on its first launch,
 // so that a trilinear inversion does not pay for it (0.1 ms of kernel + 4.8 MB at the bench shape)
 static int ensure_lm_windows(iono_ctx *c) {
@@ -806,7 +822,7 @@ static int ensure_lm_windows(iono_ctx *c) {
     HIP_TRY(c, plan_reserve(fp.d_win_lm, fp.cap_win_lm, (size_t)fp.nb * nchunks_lm * sizeof(uint4)));
     hipLaunchKernelGGL((k_bundle_windows<BL_KC, BL_LEV, 2 * BL_CPL, false>), dim3(fp.nb), dim3(64), 0, c->stream, view(c),
                        (const double *)fp.o_key, (const double *)fp.d_key, fp.d_order, fp.d_bstart, fp.nb, fp.tmax, fp.Ns, nchunks_lm,
-                       fp.d_win_lm);
+                       fp.d_win_lm, (unsigned long long *)nullptr);
     HIP_TRY(c, hipGetLastError());
     fp.nchunks_lm = nchunks_lm;
     return IONO_OK;
@@ -836,71 +852,91 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, rocprim::radix_sort_pairs(sb + off_tmp, tmp_bytes, k0, k1, i0, i1, (size_t)R, 0, 64, c->stream));
     hipLaunchKernelGGL(k_bundle_gather, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, r0, i1, R, r1);
     HIP_TRY(c, hipGetLastError());
-    std::vector<BundleSummary> hr((size_t)R);
-    HIP_TRY(c, hipMemcpyAsync(hr.data(), r1, (size_t)R * sizeof(BundleSummary), hipMemcpyDeviceToHost, c->stream));
+    // (pinned: [R summaries | R walk positions])
+    char *hp = nullptr;
+    rc = plan_pinned(c, (size_t)R * (sizeof(BundleSummary) + sizeof(int)) + 64, &hp);
+    if (rc) return rc;
+    const BundleSummary *hr = (const BundleSummary *)hp;
+    int *perm = (int *)(hp + (size_t)R * sizeof(BundleSummary));
+    HIP_TRY(c, hipMemcpyAsync(hp, r1, (size_t)R * sizeof(BundleSummary), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, plan_reserve(fp.d_order, fp.cap_order, (size_t)R * sizeof(int)));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // The cut: walk the sorted rays; a bundle takes the next rays that keep its window within the image, looking up to
     // B_LOOKAHEAD rejected rays ahead (the Morton curve jumps: a ray that does not fit now often belongs to a later bundle, while
     // the ones behind it still fit this one: 4 838 -> ~4 560 bundles at the bench shape).  perm = walk positions, bundle by bundle.
-    std::vector<int> bstart, perm;
-    bstart.reserve((size_t)R / 32 + 2);
-    perm.reserve((size_t)R);
+    // The walk is cut in up to 16 stretches by as many host threads (a bundle never crosses a stretch: 15 bundles in 4 600 end early);
+    // the sequential cut was 1.5 of the 2.8 ms a plan took.
+    const int nthreads = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(16, (int64_t)std::thread::hardware_concurrency()), R / 8192));
+    std::vector<std::vector<int>> starts((size_t)nthreads);
     std::vector<unsigned char> used((size_t)R, 0);
-    const float inf = 3.0e38f;
-    for (int64_t i = 0; i < R; ++i) {
-        if (used[(size_t)i]) continue;
-        const BundleSummary &h0 = hr[(size_t)i];
-        const bool valid = h0.adx >= 0.0f;
-        float x0lo = h0.fx0, x0hi = h0.fx0, y0lo = h0.fy0, y0hi = h0.fy0, xelo = h0.fxe, xehi = h0.fxe, yelo = h0.fye, yehi = h0.fye, zlo = h0.fz0,
-              zhi = h0.fz0, ax = h0.adx, ay = h0.ady, az = h0.dz;
-        (void)inf;
-        bstart.push_back((int)perm.size());      // (a single ray whose own window does not fit still gets a bundle: its chunks take the direct loads)
-        perm.push_back((int)i);
-        used[(size_t)i] = 1;
-        int cnt = 1, miss = 0;
-        for (int64_t j = i + 1; j < R && cnt < 64 && miss <= B_LOOKAHEAD; ++j) {
-            if (used[(size_t)j]) continue;
-            const BundleSummary &h = hr[(size_t)j];
-            if ((h.adx >= 0.0f) != valid) break;               // rays that leave the grid sit at the end of the walk, in bundles of their own
-            bool ok = true;
-            float nx0lo = x0lo, nx0hi = x0hi, ny0lo = y0lo, ny0hi = y0hi, nxelo = xelo, nxehi = xehi, nyelo = yelo, nyehi = yehi, nzlo = zlo, nzhi = zhi,
-                  nax = ax, nay = ay, naz = az;
-            if (valid) {
-                nx0lo = std::min(x0lo, h.fx0), nx0hi = std::max(x0hi, h.fx0), ny0lo = std::min(y0lo, h.fy0), ny0hi = std::max(y0hi, h.fy0);
-                nxelo = std::min(xelo, h.fxe), nxehi = std::max(xehi, h.fxe), nyelo = std::min(yelo, h.fye), nyehi = std::max(yehi, h.fye);
-                nzlo = std::min(zlo, h.fz0), nzhi = std::max(zhi, h.fz0), nax = std::max(ax, h.adx), nay = std::max(ay, h.ady), naz = std::max(az, h.dz);
-                const int wxb = (int)std::floor(std::max(nx0hi - nx0lo, nxehi - nxelo) + nax * (B_KC - 1) + 1e-3f) + 3;
-                const int wyb = (int)std::floor(std::max(ny0hi - ny0lo, nyehi - nyelo) + nay * (B_KC - 1) + 1e-3f) + 3;
-                const int nlb = (int)std::floor((nzhi - nzlo) + naz * (B_KC - 1) + 1e-3f) + 4;
-                ok = wxb * wyb <= B_CAPCOLS && wyb <= B_MAXWY && nlb <= B_LEV;
+    auto cut = [&](int t) {
+        const int64_t lo = R * t / nthreads, hi = R * (t + 1) / nthreads;
+        std::vector<int> &bs = starts[(size_t)t];
+        bs.reserve((size_t)(hi - lo) / 32 + 2);
+        int64_t np = lo;              // walk positions filed so far (a stretch permutes its own positions)
+        for (int64_t i = lo; i < hi; ++i) {
+            if (used[(size_t)i]) continue;
+            const BundleSummary &h0 = hr[(size_t)i];
+            const bool valid = h0.adx >= 0.0f;
+            float x0lo = h0.fx0, x0hi = h0.fx0, y0lo = h0.fy0, y0hi = h0.fy0, xelo = h0.fxe, xehi = h0.fxe, yelo = h0.fye, yehi = h0.fye, zlo = h0.fz0,
+                  zhi = h0.fz0, ax = h0.adx, ay = h0.ady, az = h0.dz;
+            bs.push_back((int)np);      // (a single ray whose own window does not fit still gets a bundle: its chunks take the direct loads)
+            perm[np++] = (int)i;
+            used[(size_t)i] = 1;
+            int cnt = 1, miss = 0;
+            for (int64_t j = i + 1; j < hi && cnt < 64 && miss <= B_LOOKAHEAD; ++j) {
+                if (used[(size_t)j]) continue;
+                const BundleSummary &h = hr[(size_t)j];
+                if ((h.adx >= 0.0f) != valid) break;               // rays that leave the grid sit at the end of the walk, in bundles of their own
+                bool ok = true;
+                float nx0lo = x0lo, nx0hi = x0hi, ny0lo = y0lo, ny0hi = y0hi, nxelo = xelo, nxehi = xehi, nyelo = yelo, nyehi = yehi, nzlo = zlo, nzhi = zhi,
+                      nax = ax, nay = ay, naz = az;
+                if (valid) {
+                    nx0lo = std::min(x0lo, h.fx0), nx0hi = std::max(x0hi, h.fx0), ny0lo = std::min(y0lo, h.fy0), ny0hi = std::max(y0hi, h.fy0);
+                    nxelo = std::min(xelo, h.fxe), nxehi = std::max(xehi, h.fxe), nyelo = std::min(yelo, h.fye), nyehi = std::max(yehi, h.fye);
+                    nzlo = std::min(zlo, h.fz0), nzhi = std::max(zhi, h.fz0), nax = std::max(ax, h.adx), nay = std::max(ay, h.ady), naz = std::max(az, h.dz);
+                    const int wxb = (int)std::floor(std::max(nx0hi - nx0lo, nxehi - nxelo) + nax * (B_KC - 1) + 1e-3f) + 3;
+                    const int wyb = (int)std::floor(std::max(ny0hi - ny0lo, nyehi - nyelo) + nay * (B_KC - 1) + 1e-3f) + 3;
+                    const int nlb = (int)std::floor((nzhi - nzlo) + naz * (B_KC - 1) + 1e-3f) + 4;
+                    ok = wxb * wyb <= B_CAPCOLS && wyb <= B_MAXWY && nlb <= B_LEV;
+                }
+                if (!ok) {
+                    ++miss;
+                    continue;
+                }
+                x0lo = nx0lo, x0hi = nx0hi, y0lo = ny0lo, y0hi = ny0hi, xelo = nxelo, xehi = nxehi, yelo = nyelo, yehi = nyehi;
+                zlo = nzlo, zhi = nzhi, ax = nax, ay = nay, az = naz;
+                perm[np++] = (int)j;
+                used[(size_t)j] = 1;
+                ++cnt;
             }
-            if (!ok) {
-                ++miss;
-                continue;
-            }
-            x0lo = nx0lo, x0hi = nx0hi, y0lo = ny0lo, y0hi = ny0hi, xelo = nxelo, xehi = nxehi, yelo = nyelo, yehi = nyehi;
-            zlo = nzlo, zhi = nzhi, ax = nax, ay = nay, az = naz;
-            perm.push_back((int)j);
-            used[(size_t)j] = 1;
-            ++cnt;
         }
+    };
+    if (nthreads == 1) {
+        cut(0);
+    } else {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < nthreads; ++t) pool.emplace_back(cut, t);
+        for (std::thread &th : pool) th.join();
     }
+    std::vector<int> bstart;
+    for (const std::vector<int> &bs : starts) bstart.insert(bstart.end(), bs.begin(), bs.end());
     // order[q] = sorted index at walk position perm[q]
     {
         int *d_perm = i0;                                         // (scratch: the unsorted index array is no longer needed)
-        HIP_TRY(c, hipMemcpyAsync(d_perm, perm.data(), (size_t)R * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(d_perm, perm, (size_t)R * sizeof(int), hipMemcpyHostToDevice, c->stream));
         hipLaunchKernelGGL(k_bundle_permute, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, i1, d_perm, R, fp.d_order);
         HIP_TRY(c, hipGetLastError());
-        HIP_TRY(c, hipStreamSynchronize(c->stream));              // (perm is a host vector)
     }
     bstart.push_back((int)R);
     const int nb = (int)bstart.size() - 1, nchunks = (Ns + B_KC - 1) / B_KC;
     HIP_TRY(c, plan_reserve(fp.d_bstart, fp.cap_bstart, bstart.size() * sizeof(int)));
     HIP_TRY(c, plan_reserve(fp.d_win, fp.cap_win, (size_t)nb * nchunks * sizeof(uint4)));
-    HIP_TRY(c, hipMemcpy(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(c, hipMemcpyAsync(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    unsigned long long *d_fits = (unsigned long long *)k0;        // (scratch: the key arrays are no longer needed)
+    HIP_TRY(c, hipMemsetAsync(d_fits, 0, sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
-                       nb, tmax, Ns, nchunks, fp.d_win);
+                       nb, tmax, Ns, nchunks, fp.d_win, d_fits);
     fp.nchunks_lm = 0;      // the tricubic kernel's window set is computed by its first launch (ensure_lm_windows)
     HIP_TRY(c, hipGetLastError());
     if (getenv("IONOTOMO_PLAN_STATS")) {      // columns per window, both chunk lengths (stderr; tuning aid)
@@ -922,12 +958,10 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
                     cols.back(), q(wys, 0.5), q(wys, 0.99), wys.back());
         }
     }
-    std::vector<uint4> hw((size_t)nb * nchunks);
-    HIP_TRY(c, hipMemcpyAsync(hw.data(), fp.d_win, hw.size() * sizeof(uint4), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    size_t fits = 0;
-    for (const uint4 &w : hw) fits += (w.w >> 16) & 1u;
-    fp.fit_fraction = hw.empty() ? 0.0 : (double)fits / (double)hw.size();
+    unsigned long long *h_fits = (unsigned long long *)hp;        // (the summaries are no longer needed)
+    HIP_TRY(c, hipMemcpyAsync(h_fits, d_fits, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));                  // (bstart is a host vector; the walk positions sit in pinned memory)
+    fp.fit_fraction = nb > 0 ? (double)*h_fits / ((double)nb * nchunks) : 0.0;
     fp.o_key = o, fp.d_key = d, fp.R = R, fp.Ns = Ns, fp.tmax = tmax, fp.nb = nb, fp.nchunks = nchunks;
     return IONO_OK;
 }
@@ -1855,6 +1889,7 @@ int iono_dev_download(iono_ctx *c, void *dst_host, const void *src_dev, size_t b
         // small results (a [Na,Nt,Nd] dTEC is 20 kB): payload and flags through pinned memory, ONE wait on the stream
         if (c->pinned_cap < bytes + 16) {
             if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->h_plan) (void)hipHostFree(c->h_plan);
             c->h_pinned = nullptr, c->pinned_cap = 0;
             HIP_TRY(c, hipHostMalloc((void **)&c->h_pinned, ((size_t)1 << 20) + 16, hipHostMallocDefault));
             c->pinned_cap = ((size_t)1 << 20) + 16;

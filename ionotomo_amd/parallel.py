@@ -118,12 +118,9 @@ class ShardedRays(object):
         self.R_local = self.Na * self.P_local
         self.dobs = None if dobs is None else self.slice(dobs)
         self.cdct = None if cdct is None else self.slice(cdct)
-        # walk order for the kernels (speed only): spatial neighbours next to each other
-        self.order = engine.locality_order(self.origins, self.dirs, self.tmax) if (
-            hasattr(engine, "locality_order") and self.R_local > 0) else None
-        # ... and for the forward kernels: nearly identical rays (one line of sight a few seconds apart) next to each other
-        self.forward_order = engine.coherent_order(self.origins, self.dirs) if (
-            hasattr(engine, "coherent_order") and self.R_local > 0) else None
+        # walk orders for the unplanned kernels (speed only; ``order`` / ``forward_order``): computed on first use -- some 250 small
+        # launches and a sort, 2-3 ms at the bench shape, which a planned geometry never needs
+        self._order = self._forward_order = None
         # node-stationary back-projection plan (speed only, once per geometry; engine.plan_adjoint): when the grid is
         # uniform every later adjoint of THESE two tensors reduces each grid box in LDS and flushes it once
         self.plan = None
@@ -150,10 +147,30 @@ class ShardedRays(object):
         if self.world > 1 and exchange != "dense":
             self.exchange.plan(self._touched())
 
+    @property
+    def order(self):
+        """Walk order of the ray-stationary back-projection: spatial neighbours next to each other (``engine.locality_order``)."""
+        if self._order is None and hasattr(self.engine, "locality_order") and self.R_local > 0:
+            self._order = self.engine.locality_order(self.origins, self.dirs, self.tmax)
+        return self._order
+
+    @property
+    def forward_order(self):
+        """Walk order of the unplanned forward: nearly identical rays (one line of sight a few seconds apart) next to each other."""
+        if self._forward_order is None and hasattr(self.engine, "coherent_order") and self.R_local > 0:
+            self._forward_order = self.engine.coherent_order(self.origins, self.dirs)
+        return self._forward_order
+
+    def _adjoint_order(self):
+        return None if (self.plan and self.plan[0]) else self.order          # the node-stationary kernel has its own order
+
+    def _fwd_order(self):
+        return None if (self.forward_plan and self.forward_plan[0]) else self.forward_order
+
     def _touched(self):
         """this rank's back-projection of unit ray weights: non-zero exactly at the nodes its rays reach"""
         ones = torch.ones(self.R_local, dtype=torch.float64, device=self.engine.device)
-        return self.engine.adjoint(self.origins, self.dirs, ones, self.tmax, self.Ns, order=self.order)
+        return self.engine.adjoint(self.origins, self.dirs, ones, self.tmax, self.Ns, order=self._adjoint_order())
 
     def active_index(self):
         """Sorted int32 indices of the grid nodes ANY rank's rays reach (identical on every rank; computed once per
@@ -177,7 +194,7 @@ class ShardedRays(object):
     def backproject_differential(self, v, scale, out_full):
         """out_full += (local rays) A^T (scale o v): fused differential weights + back-projection, no exchange."""
         return self.engine.adjoint_differential(self.origins, self.dirs, v, scale, self.Na, self.i0, self.tmax, self.Ns,
-                                                out=out_full, order=self.order)
+                                                out=out_full, order=self._adjoint_order())
 
     # -- sharded model update (SURVEY 8e: "reduce-scatter by slab and keep the model update sharded") ------------------------
     def shard_len(self, n):
@@ -224,7 +241,7 @@ class ShardedRays(object):
         # walked in the coherent order (engine.coherent_order): the waves of an XCD then work on nearly identical rays at the
         # same time and share lines in the L1 (trilinear 0.224 -> 0.210 ms, float32 blocks 0.172 -> 0.142 ms, tricubic 1.62 ->
         # 1.45 ms at the bench shape); results do not depend on it
-        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns, order=self.forward_order)
+        return self.engine.forward(self.origins, self.dirs, self.tmax, self.Ns, order=self._fwd_order())
 
     def forward(self):
         """differential TEC of the current grid values, local rays: A x = G x - (G x)[i0]."""
@@ -235,14 +252,14 @@ class ShardedRays(object):
         """A^T y summed over all ranks: differential weights, back-projection, all-reduce."""
         w = y.view(self.Na, self.P_local).clone()
         w[self.i0] -= y.view(self.Na, self.P_local).sum(dim=0)
-        g = self.engine.adjoint(self.origins, self.dirs, w.reshape(-1), self.tmax, self.Ns, order=self.order)
+        g = self.engine.adjoint(self.origins, self.dirs, w.reshape(-1), self.tmax, self.Ns, order=self._adjoint_order())
         return self.exchange.sum_(g)
 
     def gradient_from_tec(self, tec):
         """Fused residual -> weights -> back-projection (one launch) + all-reduce:
         G^T diff((tec - tec[i0] - dobs)/(CdCt + 1e-15))."""
         g = self.engine.adjoint_residual(self.origins, self.dirs, tec, self.dobs, self.cdct, self.Na, self.i0,
-                                         self.tmax, self.Ns, order=self.order)
+                                         self.tmax, self.Ns, order=self._adjoint_order())
         return self.exchange.sum_(g)
 
     def dot_rays(self, a, b):

@@ -97,7 +97,7 @@ def parallel_adjoint_raw(problem, w):
     """G^T w (no differencing), summed over ranks."""
     from .parallel import all_reduce_sum_
     return all_reduce_sum_(problem.engine.adjoint(problem.origins, problem.dirs, w, problem.tmax, problem.Ns,
-                                                  order=problem.order))
+                                                  order=problem._adjoint_order()))
 
 
 def _cgls_dense(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL):
