@@ -1273,7 +1273,9 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         plan_reset(c);
         return IONO_OK;
     }
-    // pass 1 on the device: segments per ray and per box (iono_binned_kernels.h:k_plan_segments)
+    // pass 1 on the device: segments per ray and per box (iono_binned_kernels.h:k_plan_segments), walking the rays in the forward
+    // plan's order when one exists for these very arrays (neighbours in it share boxes)
+    const int *walk = c->fplan.R == R && c->fplan.o_key == (const void *)o && c->fplan.d_key == (const void *)d ? c->fplan.d_order : nullptr;
     DevBuf scratch(c);
     const size_t off_cnt = ((size_t)R * sizeof(int) + 15) & ~(size_t)15, off_start = off_cnt + (size_t)nbox * sizeof(int),
                  off_fill = off_start + (size_t)nbox * sizeof(int), off_out = (off_fill + (size_t)nbox * sizeof(int) + 7) & ~(size_t)7;
@@ -1288,7 +1290,7 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     auto count_segments = [&](int width, int64_t *n_seg) -> int {
         HIP_TRY(c, hipMemsetAsync(sb + off_cnt, 0, off_out + 16 - off_cnt, c->stream));
         hipLaunchKernelGGL((k_plan_segments<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz,
-                           nbx, nby, nbz, width, d_nseg32, d_cnt, (const int *)nullptr, (int *)nullptr, (uint2 *)nullptr, d_out);
+                           nbx, nby, nbz, width, d_nseg32, d_cnt, (const int *)nullptr, (int *)nullptr, (uint2 *)nullptr, d_out, walk);
         HIP_TRY(c, hipGetLastError());
         if (n_seg) {
             HIP_TRY(c, hipMemcpyAsync(h_cnt.data(), d_cnt, (size_t)nbox * sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1379,7 +1381,8 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipMemsetAsync(pl.d_entries + ne, 0, BIN_ENTRY_PAD * sizeof(uint2), c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_start, start.data(), (size_t)nbox * sizeof(int), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL((k_plan_segments<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz, nbx,
-                       nby, nbz, segl, (int *)nullptr, (int *)nullptr, (const int *)d_start, d_fill, pl.d_entries, (unsigned long long *)nullptr);
+                       nby, nbz, segl, (int *)nullptr, d_cnt, (const int *)d_start, d_fill, pl.d_entries, (unsigned long long *)nullptr,
+                       walk);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, plan_reserve(pl.d_units, pl.cap_units, units.size() * sizeof(BinUnit)));
     HIP_TRY(c, hipMemcpyAsync(pl.d_units, units.data(), units.size() * sizeof(BinUnit), hipMemcpyHostToDevice, c->stream));

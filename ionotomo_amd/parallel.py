@@ -121,16 +121,17 @@ class ShardedRays(object):
         # walk orders for the unplanned kernels (speed only; ``order`` / ``forward_order``): computed on first use -- some 250 small
         # launches and a sort, 2-3 ms at the bench shape, which a planned geometry never needs
         self._order = self._forward_order = None
+        # bundle plan of the forward (speed only, once per geometry; engine.plan_forward): every later forward of THESE two
+        # tensors gives a workgroup <= 64 nearly coincident rays and stages their voxel neighbourhood in LDS.  First: the
+        # back-projection plan below is built along its walk (2.2 -> 1 ms)
+        self.forward_plan = None
+        if plan and hasattr(engine, "plan_forward") and self.R_local > 0:
+            self.forward_plan = engine.plan_forward(self.origins, self.dirs, self.tmax, self.Ns)
         # node-stationary back-projection plan (speed only, once per geometry; engine.plan_adjoint): when the grid is
         # uniform every later adjoint of THESE two tensors reduces each grid box in LDS and flushes it once
         self.plan = None
         if plan and hasattr(engine, "plan_adjoint") and self.R_local > 0:
             self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns)
-        # bundle plan of the forward (speed only, once per geometry; engine.plan_forward): every later forward of THESE two
-        # tensors gives a workgroup <= 64 nearly coincident rays and stages their voxel neighbourhood in LDS
-        self.forward_plan = None
-        if plan and hasattr(engine, "plan_forward") and self.R_local > 0:
-            self.forward_plan = engine.plan_forward(self.origins, self.dirs, self.tmax, self.Ns)
         # measured load balance of the ray-stationary back-projection (used when no plan could be built)
         self.partition = None
         if tune and not (self.plan and self.plan[0]) and hasattr(engine, "tune_adjoint_partition") and self.R_local > 0:
