@@ -1338,7 +1338,17 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         for (int64_t q = 0; q < nbox; ++q) total += h_cnt[(size_t)q];
         const int64_t slots = (int64_t)c->num_cus * 5, pass = 256 / segl;
         const int64_t even = (total + slots - 1) / slots;
-        if (even < unit_segs) unit_segs = (int)std::max<int64_t>(2 * pass, (even + pass - 1) / pass * pass);
+        if (even < unit_segs) {
+            const int full = unit_segs;
+            unit_segs = (int)std::max<int64_t>(2 * pass, (even + pass - 1) / pass * pass);
+            // ... but no finer than one round of workgroups: boxes do not fill their last unit, so the count is taken, not estimated
+            auto n_units = [&](int64_t size) {
+                int64_t u = 0;
+                for (int64_t q = 0; q < nbox; ++q) u += (h_cnt[(size_t)q] + size - 1) / size;
+                return u;
+            };
+            while (unit_segs < full && n_units(unit_segs) > slots) unit_segs += (int)pass;
+        }
     }
     std::vector<unsigned char> nseg((size_t)R, 0);
     int smax = 1;
