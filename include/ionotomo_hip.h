@@ -278,6 +278,15 @@ int iono_grid_values_changed(iono_ctx *ctx);
 int iono_rays_combine_dev(iono_ctx *ctx, const double *tec_dev, const double *dobs_dev, const double *s1_dev,
                           const double *s2_dev, int Na, int64_t NtNd, int i0, double a_coef, double b_coef,
                           double *out_dev, double *partial_dev);
+/* One coherence window (Na * NtNd <= 32768 rays): the ray-sized passes of a CG (mode 0) or SIRT (mode 1) iteration in one launch of one
+ * workgroup -- iono_rays_combine_dev, iono_vec_axpby_dot_dev and the reference-antenna sums of the differential back-projection,
+ * element for element (inversion/iterative_newton.py:542-554; geometry/oct_trees/Inversion.py:533,559,564):
+ *   mode 0: q = scale (tec - tec[i0]), dot1 = <q, q>;  r -= (gamma / dot1) q, dot2 = <r, r>;  w = differential weights of (r scale)
+ *   mode 1: r = dobs - (tec - tec[i0]), dot1 = sum r^2 weight;                              w = differential weights of (r scale)
+ * gamma: device scalar as (pointer, count) like iono_vec_axpby_dot_dev.  w feeds iono_adjoint_straight_dev directly. */
+int iono_small_ray_pass_dev(iono_ctx *ctx, int mode, const double *tec_dev, const double *dobs_dev, const double *scale_dev,
+                            const double *weight_dev, double *r_dev, double *q_dev, int Na, int64_t NtNd, int i0, const double *gamma,
+                            int gamma_count, double *dot1_dev, double *dot2_dev, double *w_dev);
 /* y = (a_sign an / ad) x + (bn / bd) y;  partial[blk] = sum y^2 */
 int iono_vec_axpby_dot_dev(iono_ctx *ctx, double *y_dev, const double *x_dev, int64_t n, const double *an, int an_count,
                            const double *ad, int ad_count, double a_sign, const double *bn, int bn_count,

@@ -85,6 +85,7 @@ _SIGNATURES = {
     "iono_grid_values_changed": [],
     "iono_rays_combine_dev": [_V, _V, _V, _V, _I, _L, _I, _D, _D, _V, _V],
     "iono_vec_axpby_dot_dev": [_V, _V, _L, _V, _I, _V, _I, _D, _V, _I, _V, _I, _V],
+    "iono_small_ray_pass_dev": [_I, _V, _V, _V, _V, _V, _V, _I, _L, _I, _V, _I, _V, _V, _V],
     "iono_compact_gather_dev": [_V, _V, _L, _V, _I, _V],
     "iono_compact_scatter_dev": [_V, _V, _L, _V],
     "iono_compact_cg_update_dev": [_V, _V, _V, _V, _L, _V, _V, _I, _V, _I, _V, _I, _V, _I],

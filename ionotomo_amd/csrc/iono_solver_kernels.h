@@ -77,6 +77,85 @@ __global__ __launch_bounds__(256) void k_axpby_dot(double *__restrict__ y, const
     }
 }
 
+// ---- one coherence window (<= IONO_SMALL_RAYS rays): the ray-sized passes of an iteration in ONE launch -----------------------------
+// At that size every pass is a few microseconds of launch and the dot products between them are what forces separate kernels; a
+// single workgroup holds all the rays, so the dots are workgroup reductions and the three passes become phases of one kernel:
+//   CG   (MODE 0): q = Wh (tec - tec[i0]), qq = <q, q>;  r -= (gamma / qq) q, rr = <r, r>;  w = differential weights of (r Wh)
+//   SIRT (MODE 1): r = dobs - (tec - tec[i0]), S2 = sum r^2 Wt;                             w = differential weights of (r L)
+// with the arithmetic of k_rays_combine, k_axpby_dot and k_ray_weights<2> element for element.  The weights feed the back-projection directly
+// (iono_adjoint_straight_dev), which then needs no k_ray_weights launch either: three launches fewer per CG iteration.
+#define IONO_SMALL_RAYS 32768
+__device__ __forceinline__ double block_sum_bcast_1024(double v) {
+    __shared__ double red16[16];
+    const double w = wave_sum_dpp(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = w;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red16[i];
+    return t;
+}
+template <int MODE>
+__global__ __launch_bounds__(1024) void k_small_ray_pass(const double *__restrict__ tec, const double *__restrict__ dobs,
+                                                         const double *__restrict__ s1, const double *__restrict__ s2, double *__restrict__ r,
+                                                         double *__restrict__ q, int Na, int64_t NtNd, int i0, const double *gam, int gamn,
+                                                         double *__restrict__ dot1, double *__restrict__ dot2, double *__restrict__ w) {
+    const int64_t n = (int64_t)Na * NtNd;
+    if (MODE == 0) {
+        double acc = 0.0;
+        for (int64_t t = threadIdx.x; t < n; t += blockDim.x) {
+            const int64_t p = t % NtNd;
+            double v = 1.0 * (tec[t] - tec[(int64_t)i0 * NtNd + p]);
+            v *= s1[t];
+            q[t] = v;
+            acc += v * v;
+        }
+        const double qq = block_sum_bcast_1024(acc);
+        if (threadIdx.x == 0) dot1[0] = qq;
+        // gamma: a plain scalar or a partials array of at most IONO_NPART entries, summed in the order read_scalar uses
+        double gs = 0.0;
+        if (gamn == 1) gs = gam[0];
+        else {
+            for (int t = threadIdx.x; t < gamn; t += blockDim.x) gs += gam[t];
+            gs = block_sum_bcast_1024(gs);
+        }
+        const double alpha = -1.0 * gs / qq;
+        acc = 0.0;
+        for (int64_t t = threadIdx.x; t < n; t += blockDim.x) {
+            const double v = fma(alpha, q[t], 1.0 * r[t]);
+            r[t] = v;
+            acc += v * v;
+        }
+        const double rr = block_sum_bcast_1024(acc);
+        if (threadIdx.x == 0) dot2[0] = rr;
+    } else {
+        double acc = 0.0;
+        for (int64_t t = threadIdx.x; t < n; t += blockDim.x) {
+            const int64_t p = t % NtNd;
+            double v = -1.0 * (tec[t] - tec[(int64_t)i0 * NtNd + p]);
+            v += 1.0 * dobs[t];
+            r[t] = v;
+            acc += v * v * s2[t];
+        }
+        const double S2 = block_sum_bcast_1024(acc);
+        if (threadIdx.x == 0) dot1[0] = S2;
+    }
+    __syncthreads();      // r is complete (written by this workgroup: visible after the barrier)
+    // differential weights of v = r * scale, as k_ray_weights<2> forms them: one wave per (time, direction) pair, lanes = antennas
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = threadIdx.x >> 6; p < NtNd; p += blockDim.x >> 6) {
+        double s = 0.0;
+        for (int a = lane; a < Na; a += 64) s += r[(int64_t)a * NtNd + p] * s1[(int64_t)a * NtNd + p];
+        s = wave_sum_dpp(s);
+        for (int a = lane; a < Na; a += 64) {
+            const int64_t t = (int64_t)a * NtNd + p;
+            const double v = r[t] * s1[t];
+            w[t] = a == i0 ? v - s : v;
+        }
+    }
+}
+
 // out[t] = full[idx[t]] (then full[idx[t]] = 0 if `zero`);  partial[blk] = sum out^2
 __global__ __launch_bounds__(256) void k_compact_gather(double *__restrict__ full, const int *__restrict__ idx, int64_t n,
                                                         double *__restrict__ out, int zero, double *__restrict__ partial) {

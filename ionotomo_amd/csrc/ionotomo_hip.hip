@@ -1166,6 +1166,27 @@ int iono_vec_axpby_dot_dev(iono_ctx *c, double *y, const double *x, int64_t n, c
     return IONO_OK;
 }
 
+int iono_small_ray_pass_dev(iono_ctx *c, int mode, const double *tec, const double *dobs, const double *scale, const double *weight, double *r,
+                            double *q, int Na, int64_t NtNd, int i0, const double *gamma, int gamma_count, double *dot1, double *dot2,
+                            double *w) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (Na < 1 || NtNd < 1 || i0 < 0 || i0 >= Na || (int64_t)Na * NtNd > IONO_SMALL_RAYS) return fail(c, IONO_ERR_ARG, "iono_small_ray_pass_dev: need 1 <= Na * NtNd <= 32768");
+    if (!tec || !scale || !r || !dot1 || !w || gamma_count > IONO_NPART) return fail(c, IONO_ERR_ARG, "iono_small_ray_pass_dev: bad argument");
+    if (mode == 0) {
+        if (!q || !gamma || gamma_count < 1 || !dot2) return fail(c, IONO_ERR_ARG, "iono_small_ray_pass_dev: CG needs q, gamma, dot2");
+        hipLaunchKernelGGL((k_small_ray_pass<0>), dim3(1), dim3(1024), 0, c->stream, tec, dobs, scale, weight, r, q, Na, NtNd, i0, gamma,
+                           gamma_count, dot1, dot2, w);
+    } else if (mode == 1) {
+        if (!dobs || !weight) return fail(c, IONO_ERR_ARG, "iono_small_ray_pass_dev: SIRT needs dobs, weight");
+        hipLaunchKernelGGL((k_small_ray_pass<1>), dim3(1), dim3(1024), 0, c->stream, tec, dobs, scale, weight, r, q, Na, NtNd, i0, gamma,
+                           gamma_count, dot1, dot2, w);
+    } else {
+        return fail(c, IONO_ERR_ARG, "iono_small_ray_pass_dev: mode 0 (CG) or 1 (SIRT)");
+    }
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
 static int compact_args_ok(iono_ctx *c, const int *idx, int64_t n) {
     if (n < 0 || (n > 0 && !idx)) return fail(c, IONO_ERR_ARG, "compact op: bad index");
     return IONO_OK;

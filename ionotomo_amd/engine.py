@@ -496,6 +496,23 @@ class RayEngine(object):
                       float(a), float(b), _ptr(out), opt(part))
         return out, part
 
+    SMALL_RAYS = 32768
+
+    def small_ray_pass(self, mode, tec, scale, r, Na, i0, q=None, gamma=None, dobs=None, weight=None, w=None):
+        """The ray-sized passes of one CG (``mode`` 0) or SIRT (1) iteration for at most ``SMALL_RAYS`` rays in ONE launch
+        (include/ionotomo_hip.h:iono_small_ray_pass_dev): CG: q = scale (tec - tec[i0]), <q, q>; r -= (gamma / <q, q>) q, <r, r>;
+        SIRT: r = dobs - (tec - tec[i0]), sum r^2 weight; both: w = the differential back-projection's ray weights of r * scale
+        (feed ``adjoint(origins, dirs, w, ...)``).  Returns (dot1, dot2, w): one-element device tensors + the weights."""
+        self._sync_stream()
+        R = tec.numel()
+        w = torch.empty(R, dtype=torch.float64, device=self.device) if w is None else w
+        dots = torch.empty(2, dtype=torch.float64, device=self.device)
+        gp, gn = self._sc(gamma)
+        opt = lambda t: _lib._V(0) if t is None else _ptr(t)
+        self.ctx.call("iono_small_ray_pass_dev", int(mode), _ptr(tec), opt(dobs), _ptr(scale), opt(weight), _ptr(r), opt(q), int(Na),
+                      R // int(Na), int(i0), gp, gn, _ptr(dots), _lib._V(dots.data_ptr() + 8), _ptr(w))
+        return dots[0:1], dots[1:2], w
+
     def axpby_dot_(self, y, x, an=None, ad=None, a_sign=1.0, bn=None, bd=None, want_dot=True):
         """y = (a_sign an / ad) x + (bn / bd) y in place; returns the partials of sum y^2 (or None)."""
         self._sync_stream()

@@ -27,4 +27,12 @@ for graph in (False, True):
     solvers.cgls(prob, x0, n_iter=300, graph=graph)
     torch.cuda.synchronize()
     out["cgls_us_per_iteration_%s" % ("graph" if graph else "eager")] = (time.perf_counter() - t0) / 300 * 1e6
+for name, kw in (("sirt_us_per_iteration_eager", {}), ("sirt_us_per_iteration_separate_passes", {"small_pass": False}), ("cgls_us_per_iteration_separate_passes", {"small_pass": False})):
+    fn = solvers.sirt if name.startswith("sirt") else solvers.cgls
+    fn(prob, x0, n_iter=5, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    fn(prob, x0, n_iter=300, **kw)
+    torch.cuda.synchronize()
+    out[name] = (time.perf_counter() - t0) / 300 * 1e6
 print(json.dumps(out))

@@ -405,6 +405,40 @@ def test_graph_captured_solver_iterations_equal_the_eager_loop(interp):
         assert float((xa - xb).abs().max()) < 1e-9 * scale and float((xa - xc).abs().max()) < 1e-9 * scale
 
 
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_small_problem_ray_pass_equals_the_separate_passes(interp):
+    """At most 32 768 rays on one rank: residual / search-direction pass, dot products and the differential back-projection's ray
+    weights run as ONE launch of one workgroup (iono_small_ray_pass_dev) instead of three kernels + k_ray_weights.  Iterates and
+    objective history of CGLS and SIRT equal the separate passes' (``small_pass=False``) to the rounding of the back-projection's
+    atomics, eager and graph-replayed; the entry point refuses larger problems."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="lofar", na=62, nd=6, nt=3, n=40)
+    eng = RayEngine(0, interp=interp)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    o, d = w["origins"].reshape(62, -1, 3), w["directions"].reshape(62, -1, 3)
+    rng = np.random.default_rng(5)
+    x_true = w["ne"] / 1e13
+    eng.set_values(eng.tensor(x_true))
+    P = o.shape[1]
+    tmax = w["tmax"] if interp == "linear" else w["zvec"][-3]
+    t = eng.forward(eng.tensor(o.reshape(-1, 3)), eng.tensor(d.reshape(-1, 3)), tmax, 41).cpu().numpy().reshape(62, P)
+    dobs = t - t[3] + rng.normal(size=t.shape) * 1e-3
+    cdct = rng.uniform(0.5e-6, 2e-6, size=t.shape)
+    prob = parallel.ShardedRays(eng, o, d, tmax, 41, dobs=dobs, cdct=cdct, i0=3)
+    assert solvers._small(prob, True) and not solvers._small(prob, False)          # (cgls: on by default; sirt: opt-in)
+    x0 = eng.tensor(x_true * 0.8)
+    for solve in (solvers.cgls, solvers.sirt):
+        xa, ha = solve(prob, x0, n_iter=8, small_pass=False)
+        for graph in (False, True):
+            xb, hb = solve(prob, x0, n_iter=8, small_pass=True, graph=graph)
+            assert len(ha) == len(hb) == 8
+            assert np.allclose(ha, hb, rtol=1e-9, atol=1e-9 * ha[0]), (solve.__name__, graph)
+            assert float((xa - xb).abs().max()) < 1e-9 * float(xa.abs().max()), (solve.__name__, graph)
+    big = torch.zeros(40000, dtype=torch.float64, device=eng.device)
+    with pytest.raises(ValueError):
+        eng.small_ray_pass(1, big, big, big.clone(), 4, 0, dobs=big, weight=big)
+
+
 def test_coherent_order_is_a_permutation_and_never_changes_results():
     """RayEngine.coherent_order (rays grouped by antenna, direction along a Morton curve; the forward then interleaves the
     waves of an XCD in it): a permutation, and TEC per ray is bit-identical with and without it, for float64, float32
