@@ -550,7 +550,9 @@ struct PhaseFreqs {
 #define B_LEV8 80                                 // B_LEV * 8 and + 8, as literals for the asm offsets
 #define B_LEV8P 88
 static_assert(B_LEV8 == B_LEV * 8, "B_LEV8");
+#ifndef B_CAPCOLS
 #define B_CAPCOLS 120                            // columns per wave image
+#endif
 #define B_WAVE_LDS (B_CAPCOLS * B_PPC * 16)      // 9 600 B per wave, 4 waves per workgroup
 #define B_SPLIT 4                                // z-parts of a ray = waves of a workgroup
 #ifndef B_LOOKAHEAD
