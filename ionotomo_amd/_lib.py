@@ -258,12 +258,20 @@ class Context(object):
         return (float(f[:64].sum()), float(f[mid:mid + 64].sum()), float(f[-64:].sum()), float(f[::max(1, n // 128)].sum()), n)
 
     def set_values_exp_cached(self, M, scale):
-        """grid values <- scale * exp(M) unless they already are (same object, same fingerprint, same scale)."""
+        """grid values <- scale * exp(M) unless they already are (the same LIVE object, same fingerprint, same scale)."""
+        import weakref
+        src = M
         M = as_f64(M)
-        key = (id(M), M.ctypes.data, M.shape, float(scale), self._fingerprint(M), self.grid_shape, self.storage)
-        if key != self._values_key:
-            self.set_values_exp(M, scale)
-            self._values_key = key
+        # identity = a WEAK REFERENCE to the caller's array: id() and the data address are reused by the allocator as soon as an array
+        # dies (a finite difference builds m + e, drops it, builds m - e at the same address: one node apart, between the probes)
+        key = (M.shape, float(scale), self._fingerprint(M), self.grid_shape, self.storage)
+        if self._values_key is not None and self._values_key[0]() is src and M is src and self._values_key[1] == key:
+            return
+        self.set_values_exp(M, scale)
+        try:
+            self._values_key = (weakref.ref(src), key) if M is src else None       # (a converted copy is never the same object twice)
+        except TypeError:
+            self._values_key = None
 
     def __del__(self):
         try:

@@ -85,3 +85,26 @@ def test_gradient_on_resident_rays_equals_the_plain_path(cfg2):
     ref = uncached(lambda: compute_gradient(np.array(rays), *args[1:]))          # a fresh rays object on a fresh cache
     assert grad.shape == tci.M.shape
     assert np.max(np.abs(grad - ref)) <= 1e-12 * np.max(np.abs(ref))             # (atomics: summation order differs run to run)
+
+
+def test_short_lived_models_never_alias_in_the_cache():
+    """A finite difference builds m + e, drops it and builds m - e: CPython hands the second array the id AND the data address of
+    the first, and one perturbed node sits between the fingerprint's probes -- the cache must key the model on a weak reference
+    to the live object, not on id() / address (it returned the m + e answer for m - e: a zero derivative)."""
+    w = syn.make_workload(antennas="example", na=4, nd=3, nt=1, n=12)
+    from oracle import oracle as O
+    rays = np.ascontiguousarray(O.straight_rays(w["origins"], w["directions"], w["tmax"], 13))
+    m = w["m"]
+    node = int(np.argmax(np.abs(compute_gradient(rays, forward_equation(rays, w["K_ne"], it.TriCubic(w["xvec"], w["yvec"], w["zvec"], m), 1),
+                                                 np.zeros((4, 1, 3)), 1, w["K_ne"], it.TriCubic(w["xvec"], w["yvec"], w["zvec"], m), None,
+                                                 np.full((4, 1, 3), 1e-4), None, None, None))))
+
+    def g_of(mm):
+        return forward_equation(rays, w["K_ne"], it.TriCubic(w["xvec"], w["yvec"], w["zvec"], mm), 1)
+    e = np.zeros(m.size)
+    e[node] = 1e-3
+    e = e.reshape(m.shape)
+    for _ in range(30):
+        gp, gm = g_of(m + e), g_of(m - e)          # the temporaries die between the calls
+        assert np.max(np.abs(gp - gm)) > 0.0
+        assert np.array_equal(gp, uncached(g_of, m + e)) and np.array_equal(gm, uncached(g_of, m - e))
