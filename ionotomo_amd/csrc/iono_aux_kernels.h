@@ -474,6 +474,95 @@ __global__ __launch_bounds__(64) void k_trace_fermat_coop(GridView g, const doub
     if (oob && writer) atomicOr(oob_flag, 1);
 }
 
+// ---- tricubic tracer on ideal-uniform grids: 8 lanes per ray, ONE NODE of the cell per lane (Lekien-Marsden records) ---------------
+// k_trace_fermat_coop gives a lane one x-tap plane of the 6 x 6 x 6 stencil: 36 values, 90 multiply-adds and the three 6-tap weight
+// sets per stage (250 vector instructions, which IS its time: a lone wave issues one instruction per ~10 cycles).  With the
+// derivative records of the refractive index (F8[node][p + 2 q + 4 r] = Dx^p Dy^q Dz^r n: the forward kernels' layout, built from
+// the n nodes) a cell is eight 64-byte records, one per lane (a, b, c) = bits of the lane's index in its group of eight:
+//     n = sum_lanes sum_pqr Hx[a][p](tx) Hy[b][q](ty) Hz[c][r](tz) F[pqr],   dn/dx = the same with Hx' / h, ...
+// -- 40 multiply-adds per lane and stage, the record reloaded when the cell changes.  Same interpolant as the 216-tap form to
+// rounding (iono_cubic_kernels.h); it is C1, so the cell rule on faces is immaterial: cell = floor, clamped to the tricubic domain.
+template <bool BEND>
+__device__ __forceinline__ FState fermat_rhs_lm(const GridView &g, const double *__restrict__ F8, const FState &u, int sub, int &ci, int &cj,
+                                                int &ck, double (&rec)[8], int stype) {
+    const double ux = (u.x - g.g0[0]) * g.inv_h[0], uy = (u.y - g.g0[1]) * g.inv_h[1], uz = (u.z - g.g0[2]) * g.inv_h[2];
+    const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(g.nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(g.ny - 4)),
+                 fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(g.nz - 4));
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    const int a = sub >> 2, b = (sub >> 1) & 1, c = sub & 1;
+    if ((i != ci) | (j != cj) | (k != ck)) {          // (the eight lanes of a ray hold the same state: they reload together)
+        const double2 *p = (const double2 *)(F8 + ((size_t)(i + a) * LM_SI(g.ny, g.nz) + (size_t)(j + b) * LM_NZP(g.nz) + (size_t)(k + c)) * LM_NF);
+        const double2 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+        rec[0] = r0.x, rec[1] = r0.y, rec[2] = r1.x, rec[3] = r1.y, rec[4] = r2.x, rec[5] = r2.y, rec[6] = r3.x, rec[7] = r3.y;
+        ci = i, cj = j, ck = k;
+    }
+    // Hermite value / slope weights of THIS lane's node along each axis, and their t-derivatives
+    auto axis = [](double t, int hi, double &w0, double &w1, double &d0, double &d1) {
+        const double t2 = t * t, t3 = t2 * t;
+        if (hi) {
+            w0 = 3.0 * t2 - 2.0 * t3, w1 = t3 - t2;                 // node 1: value weight h1, slope weight s1
+            d0 = 6.0 * t - 6.0 * t2, d1 = 3.0 * t2 - 2.0 * t;
+        } else {
+            w0 = 1.0 - (3.0 * t2 - 2.0 * t3), w1 = t3 - 2.0 * t2 + t;      // node 0: h0, s0
+            d0 = 6.0 * t2 - 6.0 * t, d1 = 3.0 * t2 - 4.0 * t + 1.0;
+        }
+    };
+    double X0, X1, dX0, dX1, Y0, Y1, dY0, dY1, Z0, Z1, dZ0, dZ1;
+    axis(ux - fi, a, X0, X1, dX0, dX1);
+    axis(uy - fj, b, Y0, Y1, dY0, dY1);
+    axis(uz - fk, c, Z0, Z1, dZ0, dZ1);
+    // contract p (x), then q (y), then r (z): rec[p + 2 q + 4 r]
+    const double g00 = X0 * rec[0] + X1 * rec[1], g10 = X0 * rec[2] + X1 * rec[3], g01 = X0 * rec[4] + X1 * rec[5], g11 = X0 * rec[6] + X1 * rec[7];
+    const double x00 = dX0 * rec[0] + dX1 * rec[1], x10 = dX0 * rec[2] + dX1 * rec[3], x01 = dX0 * rec[4] + dX1 * rec[5],
+                 x11 = dX0 * rec[6] + dX1 * rec[7];
+    const double h0 = Y0 * g00 + Y1 * g10, h1 = Y0 * g01 + Y1 * g11;             // r = 0, 1
+    const double hx0 = Y0 * x00 + Y1 * x10, hx1 = Y0 * x01 + Y1 * x11;
+    const double hy0 = dY0 * g00 + dY1 * g10, hy1 = dY0 * g01 + dY1 * g11;
+    const double n = sum8(Z0 * h0 + Z1 * h1);
+    double nx = sum8(Z0 * hx0 + Z1 * hx1) * g.inv_h[0], ny = sum8(Z0 * hy0 + Z1 * hy1) * g.inv_h[1], nz = sum8(dZ0 * h0 + dZ1 * h1) * g.inv_h[2];
+    if (!BEND) nx = ny = nz = 0.0;
+    return fermat_rates(n, nx, ny, nz, u, stype);
+}
+template <bool BEND>
+__global__ __launch_bounds__(64) void k_trace_fermat_lm(GridView g, const double *__restrict__ F8, const double *__restrict__ origins,
+                                                        const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps,
+                                                        double *__restrict__ rays, int *oob_flag, int rays_per_wave, int stype) {
+    if ((int)(threadIdx.x >> 3) >= rays_per_wave) return;
+    const int sub = threadIdx.x & 7;
+    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x >> 3);
+    const bool live = r < R;
+    if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm, u.py = dy / nrm, u.pz = dz / nrm;
+    u.x = origins[3 * r], u.y = origins[3 * r + 1], u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
+    double *o = rays + (size_t)r * 4 * Ns;
+    const bool writer = live && sub == 0;
+    if (writer) o[0] = u.x, o[Ns] = u.y, o[2 * Ns] = u.z, o[3 * Ns] = u.s;
+    bool oob = false;
+    int ci = -1, cj = -1, ck = -1;
+    double rec[8] = {};
+    const double ztop = g.glast[2] + 1e-9 * fabs(tmax);
+    for (int k = 1; k < Ns; ++k) {
+        for (int s2 = 0; s2 < substeps; ++s2) {
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs_lm<BEND>(g, F8, axpy(u, ca, kprev), sub, ci, cj, ck, rec, stype);
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= !(u.x >= g.g0[0] && u.x <= g.glast[0] && u.y >= g.g0[1] && u.y <= g.glast[1] && u.z >= g.g0[2] && u.z <= ztop);
+        if (writer) o[k] = u.x, o[Ns + k] = u.y, o[2 * Ns + k] = u.z, o[3 * Ns + k] = u.s;
+    }
+    if (oob && writer) atomicOr(oob_flag, 1);
+}
+
 // ---- trilinear tracer for small batches: 4 lanes per ray, axes in LDS, cell-cached corners ---------------
 // With lanes = rays every RK4 stage is a chain of dependent global loads (axis look-ups for the cell, then 8
 // corners spread over 4 cache lines per lane: 64 lanes x 4 lines = the whole 32 KB L1), ~1.4 us per stage and

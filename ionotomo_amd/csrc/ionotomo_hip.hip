@@ -81,6 +81,8 @@ struct iono_ctx {
     int kern_cap = 0;
     double *d_nM = nullptr;          // refractive-index nodes for the tracer (device-pointer entry), lazily built
     double nM_freq = -1.0;           // frequency d_nM was built for; < 0 = stale
+    double *d_nF8 = nullptr;         // Lekien-Marsden records of the refractive index (tricubic tracer on ideal grids), lazily built
+    double nF8_freq = -1.0;          // frequency they were built for; < 0 = stale
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     ncclComm_t comm = nullptr;       // iono_comm_init
@@ -494,6 +496,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_nM) (void)hipFree(c->d_nM);
     if (c->d_F8) (void)hipFree(c->d_F8);
     if (c->d_FP) (void)hipFree(c->d_FP);
+    if (c->d_nF8) (void)hipFree(c->d_nF8);
     if (c->d_G8) (void)hipFree(c->d_G8);
     if (c->d_LMw) (void)hipFree(c->d_LMw);
     if (c->d_Q4) (void)hipFree(c->d_Q4);
@@ -576,6 +579,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     if (c->d_nM) HIP_TRY(c, hipFree(c->d_nM));
     if (c->d_F8) HIP_TRY(c, hipFree(c->d_F8));
     if (c->d_FP) HIP_TRY(c, hipFree(c->d_FP));
+    if (c->d_nF8) HIP_TRY(c, hipFree(c->d_nF8));
     if (c->d_G8) HIP_TRY(c, hipFree(c->d_G8));
     if (c->d_LMw) HIP_TRY(c, hipFree(c->d_LMw));
     if (c->d_Q4) HIP_TRY(c, hipFree(c->d_Q4));
@@ -584,12 +588,12 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     c->d_axes = nullptr;
     c->d_M = nullptr;
     c->d_nM = nullptr;
-    c->d_F8 = c->d_G8 = c->d_FP = nullptr;
+    c->d_F8 = c->d_G8 = c->d_FP = c->d_nF8 = nullptr;
     c->d_M_ext = nullptr;
     plan_free(c);
     fplan_free(c);
     c->F8_valid = c->FP_valid = false;
-    c->nM_freq = -1.0;
+    c->nM_freq = c->nF8_freq = -1.0;
     c->nx = nx;
     c->ny = ny;
     c->nz = nz;
@@ -617,7 +621,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
 
 static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, double scale) {
     const int64_t n = ncells(c);
-    c->nM_freq = -1.0;
+    c->nM_freq = c->nF8_freq = -1.0;
     c->F8_valid = c->FP_valid = false;
     c->Q4_valid = false;
     int rc = dispatch_storage(c, [&](auto *tag) {
@@ -752,6 +756,27 @@ static int ensure_lm_fields(iono_ctx *c, bool pairs = false) {
                                c->nx, c->ny, c->nz, npad);
         HIP_TRY(c, hipGetLastError());
         (pairs ? c->FP_valid : c->F8_valid) = true;
+    }
+    return IONO_OK;
+}
+// the same records of the refractive-index nodes d_nM (built for `frequency`): what the tricubic tracer on ideal grids reads
+static int ensure_n_fields(iono_ctx *c, double frequency) {
+    const int64_t n = ncells(c);
+    if (!c->d_nF8) {
+        const size_t fb = (size_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double);
+        HIP_TRY(c, hipMalloc((void **)&c->d_nF8, fb));
+        HIP_TRY(c, hipMemsetAsync(c->d_nF8, 0, fb, c->stream));
+        c->nF8_freq = -1.0;
+    }
+    if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
+    if (c->nF8_freq != frequency) {
+        hipLaunchKernelGGL((k_lm_fields_z<double>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double *)c->d_nM, (double2 *)c->d_LMw,
+                           c->nx, c->ny, c->nz);
+        const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
+        hipLaunchKernelGGL((k_lm_fields_yx<false>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_nF8,
+                           c->nx, c->ny, c->nz, padded_count(c));
+        HIP_TRY(c, hipGetLastError());
+        c->nF8_freq = frequency;
     }
     return IONO_OK;
 }
@@ -1133,7 +1158,7 @@ int iono_grid_bind_values_dev(iono_ctx *c, double *values_dev) {
     if (values_dev && c->storage != IONO_F64) return fail(c, IONO_ERR_ARG, "caller-owned values need float64 storage");
     if (values_dev && (((uintptr_t)values_dev) & 15)) return fail(c, IONO_ERR_ARG, "values must be 16-byte aligned");
     c->d_M_ext = values_dev;
-    c->nM_freq = -1.0;
+    c->nM_freq = c->nF8_freq = -1.0;
     c->F8_valid = c->FP_valid = false;
     return IONO_OK;
 }
@@ -1141,7 +1166,7 @@ int iono_grid_bind_values_dev(iono_ctx *c, double *values_dev) {
 int iono_grid_values_changed(iono_ctx *c) {
     int rc = need_grid(c);
     if (rc) return rc;
-    c->nM_freq = -1.0;
+    c->nM_freq = c->nF8_freq = -1.0;
     c->F8_valid = c->FP_valid = false;
     return IONO_OK;
 }
@@ -2099,6 +2124,7 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
             return IONO_OK;
         });
         c->nM_freq = frequency;
+        c->nF8_freq = -1.0;
     }
     const GridView g = view(c);
     const dim3 grid((unsigned)((R + 63) / 64)), block(64);
@@ -2134,6 +2160,19 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
         if (bend) LAUNCH_F(IONO_INTERP_TRILINEAR, true); else LAUNCH_F(IONO_INTERP_TRILINEAR, false);
     } else if (c->variant == 3 || R > c->fermat_coop_max) {   // lanes = rays: enough rays to fill the chip without splitting them
         if (bend) LAUNCH_F(IONO_INTERP_TRICUBIC, true); else LAUNCH_F(IONO_INTERP_TRICUBIC, false);
+    } else if (g.ideal && cubic_fast_ok(c, 2) && c->variant != 17) {
+        // ideal-uniform grid: 8 lanes per ray, one Lekien-Marsden record of n per lane (iono_aux_kernels.h:k_trace_fermat_lm;
+        // IONOTOMO_VARIANT=17 keeps the 216-tap kernel below for A/B)
+        const int rcf = ensure_n_fields(c, frequency);
+        if (rcf) return rcf;
+        const int rpw = c->fermat_coop_rpw > 0 ? c->fermat_coop_rpw : 8;
+        const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
+        if (bend)
+            hipLaunchKernelGGL((k_trace_fermat_lm<true>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps,
+                               dR, c->d_flags, rpw, stype);
+        else
+            hipLaunchKernelGGL((k_trace_fermat_lm<false>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps,
+                               dR, c->d_flags, rpw, stype);
     } else {                                // 8 lanes per ray: the 6x6x6 stencil of one ray spread over 8 lanes
         const int rpw = c->fermat_coop_rpw > 0 ? c->fermat_coop_rpw : 8;
         const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));

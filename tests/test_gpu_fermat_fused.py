@@ -189,3 +189,34 @@ def test_tricubic_index_takes_the_two_step_path_by_default():
     gb = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
     assert float((ga - gb).abs().max()) < 1e-12 * float(gb.abs().max())
     assert not eng.check_oob()
+
+
+@pytest.mark.parametrize("typ", ["z", "s"])
+def test_tricubic_tracer_on_node_records_equals_the_216_tap_kernel(typ, O, monkeypatch):
+    """On ideal-uniform grids the tricubic tracer reads the Lekien-Marsden records of the refractive index, one node per lane
+    (k_trace_fermat_lm), instead of a 6 x 6 plane of taps per lane (k_trace_fermat_coop, IONOTOMO_VARIANT=17): the same interpolant,
+    so the rays agree to rounding -- both independent variables, a changed model (the records are rebuilt), a second frequency --
+    and with the oracle's RK4 on its 216-tap form."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="example", na=6, nd=5, nt=2, n=33, margin_cells=10)
+    xv, yv, zv = w["xvec"], w["yvec"], w["zvec"]
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    Ns = 21
+    tmax = float(zv[24]) if typ == "z" else 0.7 * float(zv[24])
+    res = {}
+    for variant in ("0", "17"):
+        monkeypatch.setenv("IONOTOMO_VARIANT", variant)
+        eng = RayEngine(0, interp="cubic")
+        eng.set_grid(xv, yv, zv)
+        out = []
+        for ne, freq in ((w["ne"], 100e6), (w["ne"] * 1.3, 100e6), (w["ne"] * 1.3, 140e6)):
+            eng.set_values(eng.tensor(ne))
+            out.append(eng.trace_fermat(eng.tensor(o), eng.tensor(d), tmax, Ns, freq, bend=True, kind="cubic", substeps=2, type=typ).cpu().numpy())
+        assert not eng.check_oob()
+        res[variant] = out
+    for a, b in zip(res["0"], res["17"]):
+        assert np.max(np.abs(a - b)) < 1e-10
+    assert np.max(np.abs(res["0"][0] - res["0"][1])) > 1e-6          # the model change was seen
+    field = O.n_field_tricubic(xv, yv, zv, O.ne_to_n(w["ne"], 100e6))
+    ref = O.fermat_trace(o, d, tmax, Ns, field, bend=True, substeps=2, type=typ)
+    assert np.max(np.abs(res["0"][0] - ref)) < 1e-9
