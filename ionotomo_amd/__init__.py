@@ -17,6 +17,7 @@ from .tomography.linear_operators import RayOp, TECForwardEquation
 from .ionosphere.covariance import Covariance
 from .ionosphere.simulation import IonosphereSimulation
 from .ionosphere.iri import a_priori_model_
+from .utils.timer import clock
 from ._lib import Context, default_context
 
 __all__ = ["TriCubic", "bisection", "calc_rays", "calc_rays_dask", "cast_ray", "Fermat", "forward_equation",
@@ -24,4 +25,4 @@ __all__ = ["TriCubic", "bisection", "calc_rays", "calc_rays_dask", "cast_ray", "
            "generate_example_radio_array", "DataPack", "generate_example_datapack",
            "phase_screen_datapack", "simulate_phase", "create_initial_model", "create_turbulent_model",
            "determine_inversion_domain", "RayOp", "TECForwardEquation", "Covariance", "IonosphereSimulation",
-           "a_priori_model_", "Context", "default_context"]
+           "a_priori_model_", "clock", "Context", "default_context"]

@@ -180,7 +180,6 @@ class Context(object):
         self.grid_shape = None
         self.storage = None
         self._axes = (None, None, None)
-        self._axes_ids, self._axes_objs = None, (None, None, None)
         self._dev_arrays = []          # facade cache: [(weakref to a host array, shape, device pointer, bytes)], most recent first
         self._values_key = None        # facade cache: what the device grid values were computed from
         self._scratch = {}
@@ -201,9 +200,18 @@ class Context(object):
         self.call("iono_dev_alloc", int(nbytes), ctypes.byref(p))
         return _V(p.value)
 
+    def staged(self, name, a):
+        """Device pointer of a FRESH copy of the float64 C-contiguous host array ``a`` in the named grow-only buffer: uploaded on
+        every call, so whatever the caller did to ``a`` since the last call (in place or not) is seen.  This is what the
+        reference-signature facade does by default."""
+        ptr = self.scratch(name, a.nbytes)
+        self.call("iono_dev_upload", ptr, _V(a.ctypes.data), a.nbytes)
+        return ptr
+
     def resident(self, a, keep=3, max_bytes=4 << 30):
-        """Device pointer of a copy of the float64 host array ``a``, uploaded once per OBJECT: the key is the array's identity
-        (a weak reference) and shape -- a caller that overwrites the array in place must pass a new object (or call
+        """OPT-IN (``assume_unchanged=True`` of the facade functions): device pointer of a copy of the float64 host array ``a``,
+        uploaded once per OBJECT.  The key is the array's identity (a weak reference) and shape ONLY -- no content check of any
+        kind: an in-place edit of ``a`` after the first call is NOT seen, the caller promises there is none (or calls
         ``forget``).  The ``keep`` most recently used arrays stay resident."""
         import weakref
         for i, (ref, shape, ptr, nb) in enumerate(self._dev_arrays):
@@ -248,17 +256,19 @@ class Context(object):
 
     @staticmethod
     def _fingerprint(M):
-        """Cheap content check of a grid-sized array (identity alone would miss ``m_tci.M += step``): three contiguous runs of
-        64 values (start, middle, end) + 128 evenly spaced ones, ~3 us.  An in-place change confined to nodes between the probes
-        is NOT seen -- assign a new array (``m_tci.M = ...``, which is what the reference's solvers do) or call
-        ``Context.forget()``."""
+        """SAMPLED content check of a grid-sized array, used ONLY on the opt-in path (``assume_unchanged=True``) as a safety net
+        for whole-array in-place updates (``m_tci.M += step``): three contiguous runs of 64 values (start, middle, end) + 128
+        evenly spaced ones, ~3 us.  An in-place change confined to nodes between the probes (one perturbed node of a
+        finite-difference loop) is NOT seen: that is why the default path never consults it."""
         f = M.reshape(-1)
         n = f.size
         mid = n >> 1
         return (float(f[:64].sum()), float(f[mid:mid + 64].sum()), float(f[-64:].sum()), float(f[::max(1, n // 128)].sum()), n)
 
     def set_values_exp_cached(self, M, scale):
-        """grid values <- scale * exp(M) unless they already are (the same LIVE object, same fingerprint, same scale)."""
+        """OPT-IN path: grid values <- scale * exp(M) unless they already are (the same LIVE object, same sampled fingerprint,
+        same scale).  Not exact against single-node in-place edits (see ``_fingerprint``); the default facade path calls
+        ``set_values_exp`` every time."""
         import weakref
         src = M
         M = as_f64(M)
@@ -297,8 +307,6 @@ class Context(object):
 
     # -- grid ------------------------------------------------------------------------------------
     def set_grid(self, xvec, yvec, zvec, M=None, storage="f64"):
-        if M is None and self._axes_ids == (id(xvec), id(yvec), id(zvec), storage) and self._axes_objs[0] is xvec:
-            return                        # the very arrays of the last call (a TriCubic's own axes): nothing to compare
         xv, yv, zv = as_f64(xvec).ravel(), as_f64(yvec).ravel(), as_f64(zvec).ravel()
         Mp = None
         if M is not None:
@@ -308,7 +316,6 @@ class Context(object):
             Mp = _dp(M)
         same = (self.grid_shape == (xv.size, yv.size, zv.size) and self.storage == storage_code(storage)
                 and all(np.array_equal(a, b) for a, b in zip(self._axes, (xv, yv, zv))))
-        self._axes_ids, self._axes_objs = (id(xvec), id(yvec), id(zvec), storage), (xvec, yvec, zvec)
         if same:                      # same axes: keep the device allocation, refresh the values only
             if Mp is not None:
                 self._values_key = None

@@ -1948,7 +1948,6 @@ int iono_dev_download(iono_ctx *c, void *dst_host, const void *src_dev, size_t b
         // small results (a [Na,Nt,Nd] dTEC is 20 kB): payload and flags through pinned memory, ONE wait on the stream
         if (c->pinned_cap < bytes + 16) {
             if (c->h_pinned) (void)hipHostFree(c->h_pinned);
-    if (c->h_plan) (void)hipHostFree(c->h_plan);
             c->h_pinned = nullptr, c->pinned_cap = 0;
             HIP_TRY(c, hipHostMalloc((void **)&c->h_pinned, ((size_t)1 << 20) + 16, hipHostMallocDefault));
             c->pinned_cap = ((size_t)1 << 20) + 16;

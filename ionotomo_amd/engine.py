@@ -274,9 +274,17 @@ class RayEngine(object):
     FUSED_CUBIC_ABOVE_BYTES = 8 << 30
 
     def _two_step_fermat(self, R, Ns, kind, fused):
+        """True: trace into a TEMPORARY rays[R,4,Ns] tensor (32 R Ns bytes of device memory) and integrate along it."""
         if fused is not None:
             return not fused
-        return _lib.interp_kind(kind) == _lib.interp_kind("cubic") and R * 4 * int(Ns) * 8 <= self.FUSED_CUBIC_ABOVE_BYTES
+        need = R * 4 * int(Ns) * 8
+        if _lib.interp_kind(kind) != _lib.interp_kind("cubic") or need > self.FUSED_CUBIC_ABOVE_BYTES:
+            return False
+        try:                                   # never a hidden allocation beyond half of what the device has free
+            free = torch.cuda.mem_get_info(self.device)[0]
+        except Exception:
+            free = 0
+        return need <= free // 2
 
     def forward_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=True, kind="linear", substeps=4, type="z", ne_kind=None,
                        ne_scale=1.0, out=None, fused=None):

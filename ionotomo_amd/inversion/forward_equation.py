@@ -30,25 +30,33 @@ def do_forward_equation(rays, ne_tci, quad="avg"):
     return ctx.forward_tec_rays(rays, kind=ne_tci.kind, rule=quad)
 
 
-def forward_equation(rays, K_ne, m_tci, i0, quad="avg"):
+def forward_equation(rays, K_ne, m_tci, i0, quad="avg", assume_unchanged=False):
     """dtec[Na,Nt,Nd] using reference antenna ``i0`` (forward_equation.py:36-51).
 
-    A line search calls this again and again with the SAME ``rays`` array and a new model each time
-    (inversion/line_search.py:56,71,83): the rays stay resident on the device (keyed on the array OBJECT and its shape:
-    ``Context.resident``), the node values are recomputed only when the model changed (``Context.set_values_exp_cached``),
-    and only the [Na,Nt,Nd] result crosses PCIe -- a repeated call costs three small launches and one 20 kB copy."""
-    rays_in = rays
+    DEFAULT (exact): ``rays`` and ``m_tci.M`` are uploaded on EVERY call -- whatever the caller did to them since the last
+    call, in place or not, is seen (the reference's own finite-difference loop perturbs one node of ``m_tci.M`` in place and
+    calls again: tests/test_inversion.py:81-82).  Only the device buffers are kept between calls; the [Na,Nt,Nd] result
+    comes back through pinned memory.
+
+    ``assume_unchanged=True`` (opt-in, for a line search that passes the SAME ``rays`` object again and again:
+    inversion/line_search.py:56,71,83): the caller promises that arrays handed over before have not been edited IN PLACE
+    since.  ``rays`` is then keyed on the array OBJECT (a weak reference + shape, no content check: ``Context.resident``)
+    and the node values are recomputed only when the model object, the scale or a sampled fingerprint of it changed
+    (``Context.set_values_exp_cached``) -- a single-node in-place edit is NOT seen on this path.  For device-resident
+    inversion loops use ``engine.RayEngine`` instead."""
     rays = np.asarray(rays, dtype=np.float64)
-    Na, Nt, Nd, _, Ns = rays.shape
+    rays_c = np.ascontiguousarray(rays)
+    Na, Nt, Nd, _, Ns = rays_c.shape
     ctx = _lib.default_context()
     ctx.set_grid(m_tci.xvec, m_tci.yvec, m_tci.zvec, None, storage=m_tci.storage)
-    ctx.set_values_exp_cached(m_tci.M, K_ne / TECU)
-    rays_dev = ctx.resident(rays) if rays is rays_in else None        # (a converted copy has no identity to key on)
+    if assume_unchanged:
+        ctx.set_values_exp_cached(m_tci.M, K_ne / TECU)
+        rays_dev = ctx.resident(rays_c) if rays_c is rays else None    # (a converted copy has no identity to key on)
+    else:
+        ctx.set_values_exp(m_tci.M, K_ne / TECU)
+        rays_dev = None
     if rays_dev is None:
-        tec = ctx.forward_tec_rays(rays, kind=m_tci.kind, rule=quad)
-        tec = np.ascontiguousarray(tec.reshape(Na, Nt * Nd))
-        ctx.call("iono_subtract_reference", _lib._dp(tec), Na, Nt * Nd, int(i0))
-        return tec.reshape(Na, Nt, Nd)
+        rays_dev = ctx.staged("rays", rays_c)
     R = Na * Nt * Nd
     tec_dev = ctx.scratch("tec", R * 8)
     ctx.call("iono_forward_tec_rays_dev", rays_dev, R, int(Ns), _lib.interp_kind(m_tci.kind), _lib.quad_rule(quad), tec_dev)
@@ -58,7 +66,7 @@ def forward_equation(rays, K_ne, m_tci, i0, quad="avg"):
     return tec
 
 
-def forward_equation_dask(rays, K_ne, m_tci, i0, quad="avg"):
+def forward_equation_dask(rays, K_ne, m_tci, i0, quad="avg", assume_unchanged=False):
     """The reference's dask-multiprocessing variant computes the same numbers
     (tests/test_forward_equation.py:27 asserts exact equality); one GPU needs no task split."""
-    return forward_equation(rays, K_ne, m_tci, i0, quad=quad)
+    return forward_equation(rays, K_ne, m_tci, i0, quad=quad, assume_unchanged=assume_unchanged)

@@ -23,32 +23,39 @@ def differential_weights(dd, i0):
 
 
 def compute_gradient(rays, g, dobs, i0, K_ne, m_tci, m_prior, CdCt, sigma_m, Nkernel, size_cell, cov_obj=None,
-                     quad="avg", method="transpose"):
+                     quad="avg", method="transpose", assume_unchanged=False):
     """``method="transpose"`` (default): the exact transpose of the forward model (module docstring).
     ``method="chords"``: the reference's own discretisation, ``do_gradient`` = einsum(dirac, ne, dd) over voxel chord
     lengths (inversion/gradient.py:15-20, geometry/ray_dirac.py), pinned to the reference's output in
     tests/golden/ray_dirac.npz -- for comparison with the shipped code, not for optimisation.  (The reference then
     subtracts ``gradient[i0, ...]``, i.e. indexes the GRID's first axis with an antenna index (:62); that slip is not
-    reproduced.)"""
-    rays_in = rays
+    reproduced.)
+
+    ``rays`` and ``m_tci.M`` are uploaded on every call (exact against in-place edits) unless ``assume_unchanged=True``
+    (opt-in, same contract as ``forward_equation``: operands keyed on the array OBJECTS, the rays ``forward_equation`` left
+    on the device are re-used)."""
     rays = np.asarray(rays, dtype=np.float64)
     dd = g - dobs
     dd /= (CdCt + 1e-15)                       # inversion/gradient.py:77-81
     ctx = _lib.default_context()
     ctx.set_grid(m_tci.xvec, m_tci.yvec, m_tci.zvec, None, storage=m_tci.storage)
-    ctx.set_values_exp_cached(m_tci.M, K_ne / TECU)
+    if assume_unchanged:
+        ctx.set_values_exp_cached(m_tci.M, K_ne / TECU)
+    else:
+        ctx.set_values_exp(m_tci.M, K_ne / TECU)
     if method == "chords":
         return ctx.gradient_chords(rays, dd)
     w = np.ascontiguousarray(differential_weights(dd, i0).reshape(-1))
-    rays_dev = ctx.resident(rays) if rays is rays_in else None        # the rays of forward_equation: already on the device
+    rays_c = np.ascontiguousarray(rays)
+    rays_dev = ctx.resident(rays_c) if (assume_unchanged and rays_c is rays) else None
     if rays_dev is None:
-        return ctx.adjoint_rays(rays, w, rule=quad, scale_by_grid=True, kind=m_tci.kind)
+        rays_dev = ctx.staged("rays", rays_c)
     n = int(np.prod(ctx.grid_shape))
     w_dev, g_dev = ctx.scratch("w", w.nbytes), ctx.scratch("grad", n * 8)
     ctx.call("iono_dev_upload", w_dev, _lib._V(w.ctypes.data), w.nbytes)
     ctx.call("iono_dev_zero", g_dev, n * 8)
-    ctx.call("iono_adjoint_rays_dev", rays_dev, w_dev, w.size, int(rays.shape[-1]), _lib.interp_kind(m_tci.kind), _lib.quad_rule(quad),
-             g_dev, _lib.F64)
+    ctx.call("iono_adjoint_rays_dev", rays_dev, w_dev, w.size, int(rays_c.shape[-1]), _lib.interp_kind(m_tci.kind),
+             _lib.quad_rule(quad), g_dev, _lib.F64)
     ctx.call("iono_scale_by_grid_dev", g_dev)
     grad = np.empty(ctx.grid_shape, dtype=np.float64)
     ctx.call("iono_dev_download", _lib._V(grad.ctypes.data), g_dev, n * 8)

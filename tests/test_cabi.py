@@ -82,6 +82,8 @@ def test_tricubic_container_semantics():
     ref_odd = simpson(simpson(simpson(odd.M * odd.M, x=zv[:11], axis=2), x=yv, axis=1), x=xv[:9], axis=0)
     assert abs(odd.inner(odd.M) - ref_odd) < 1e-12 * abs(ref_odd)
     assert abs(tci.inner(M) - ref) < 1e-2 * abs(ref)      # even axes: 'avg' rule vs scipy-1.15 rule
+    t0 = it.clock()                                    # the reference exports its wall timer at top level (__init__.py:26)
+    assert isinstance(t0, float) and it.clock() >= t0
     assert it.bisection(xv, xv[3] + 1e-3) == 3 and it.bisection(xv, -5) == -1 and it.bisection(xv, 5) == 10
 
 

@@ -139,6 +139,32 @@ def test_failed_grid_set_leaves_context_intact(OC):
     c.close()
 
 
+def test_plan_then_small_download_then_plan_on_one_context(OC):
+    """the first small iono_dev_download on a ctx must not free the plan builders' pinned staging buffer (a stray
+    hipHostFree left h_plan dangling: the next plan of a size that fits the stale capacity copied into freed memory, and
+    iono_ctx_destroy freed it twice).  One ctx: forward plan, download, forward plan, forward, destroy."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="lofar", na=62, nd=8, nt=4, n=64)
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    eng = RayEngine(0)
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    eng.set_values(eng.tensor(w["ne"] / 1e13))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    eng.plan_forward(ot, dt, w["tmax"], 65)
+    first = eng.forward(ot, dt, w["tmax"], 65)
+    host = np.empty(len(o))
+    eng.ctx.call("iono_dev_download", _lib._V(host.ctypes.data), _lib._V(first.data_ptr()), host.nbytes)     # first small download of this ctx
+    assert np.array_equal(host, first.cpu().numpy())
+    eng.clear_forward_plan()
+    ot2, dt2 = ot.clone(), dt.clone()
+    eng.plan_forward(ot2, dt2, w["tmax"], 65)          # same size: fits the capacity recorded for the staging buffer
+    again = eng.forward(ot2, dt2, w["tmax"], 65).cpu().numpy()
+    assert np.array_equal(again, host)
+    ref = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], w["ne"] / 1e13, o, d, w["tmax"], 65)
+    assert np.max(np.abs(again - ref)) < 1e-12 * np.max(np.abs(ref))
+    eng.ctx.close()
+
+
 def test_library_walk_order_and_host_adjoint(OC):
     w = syn.make_workload(antennas="lofar", na=62, nd=8, nt=4, n=64)
     c = _lib.Context(0)
