@@ -60,57 +60,86 @@ __global__ __launch_bounds__(256) void k_read(const char *__restrict__ base, siz
 
 // LDS read rates, one instruction form per kernel (inline asm: the compiler picks its own mix otherwise).  KIND 0: ds_read2_b64 on
 // 8-B-aligned (not 16-B-aligned) pairs; 1: ds_read_b64; 2: ds_read_b128 on 16-B-aligned addresses; 3: ds_read_b128 on addresses
-// that are only 8-B aligned (what a (level, level + 1) pair of float64 nodes is).  Lanes read consecutive 16-B (8-B) words.
-typedef double dbl2 __attribute__((ext_vector_type(2)));
+// that are only 8-B aligned (what a (level, level + 1) pair of float64 nodes is).  Lanes read consecutive 16-B (8-B) words:
+// conflict-free in every lane group of MI355X_MICROARCH.md's LDS table.
+// Round 4: the round-3 loop drained lgkmcnt(0) and issued 8 v_add_f64 after every 8 reads on 4 waves per
+// SIMD -- issue-bound, 64 % of the array's rate.  Now: 16 reads per loop body in ONE asm block, every one with its own
+// immediate offset (no address arithmetic between them), NO s_waitcnt and no vector instruction inside the loop (LDS data
+// returns in order, so re-using the destination registers while older reads are in flight is safe for a rate measurement;
+// issue stalls only when the 4-bit lgkmcnt is full = 15 reads in flight), 8 workgroups of 4 waves per CU = 8 waves per SIMD
+// (18 KB of LDS per workgroup).  The registers are consumed once, after the loop, by integer XORs.  s_memtime (shader clock)
+// and s_memrealtime (100 MHz) around the loop give the clock the CU actually held: B/clk/CU = bytes / (cycles x CUs).
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+#define R16(OP, T, O0, ST)                                                                                                   \
+    asm volatile(OP " %0, %16 offset:%17\n\t" OP " %1, %16 offset:%18\n\t" OP " %2, %16 offset:%19\n\t" OP " %3, %16 offset:%20\n\t" \
+                 OP " %4, %16 offset:%21\n\t" OP " %5, %16 offset:%22\n\t" OP " %6, %16 offset:%23\n\t" OP " %7, %16 offset:%24\n\t" \
+                 OP " %8, %16 offset:%25\n\t" OP " %9, %16 offset:%26\n\t" OP " %10, %16 offset:%27\n\t" OP " %11, %16 offset:%28\n\t" \
+                 OP " %12, %16 offset:%29\n\t" OP " %13, %16 offset:%30\n\t" OP " %14, %16 offset:%31\n\t" OP " %15, %16 offset:%32" \
+                 : "=&v"(T[0]), "=&v"(T[1]), "=&v"(T[2]), "=&v"(T[3]), "=&v"(T[4]), "=&v"(T[5]), "=&v"(T[6]), "=&v"(T[7]),      \
+                   "=&v"(T[8]), "=&v"(T[9]), "=&v"(T[10]), "=&v"(T[11]), "=&v"(T[12]), "=&v"(T[13]), "=&v"(T[14]), "=&v"(T[15]) \
+                 : "v"(addr), "n"(O0), "n"(O0 + ST), "n"(O0 + 2 * ST), "n"(O0 + 3 * ST), "n"(O0 + 4 * ST), "n"(O0 + 5 * ST),       \
+                   "n"(O0 + 6 * ST), "n"(O0 + 7 * ST), "n"(O0 + 8 * ST), "n"(O0 + 9 * ST), "n"(O0 + 10 * ST), "n"(O0 + 11 * ST),    \
+                   "n"(O0 + 12 * ST), "n"(O0 + 13 * ST), "n"(O0 + 14 * ST), "n"(O0 + 15 * ST)                                       \
+                 : "memory")
 template <int KIND>
-__global__ __launch_bounds__(256) void k_lds(int iters, unsigned *__restrict__ sink) {
-    __shared__ __attribute__((aligned(16))) double buf[4096 + 64];
-    for (int i = threadIdx.x; i < 4096 + 64; i += 256) buf[i] = 0.0;
+__global__ __launch_bounds__(256) void k_lds(int iters, unsigned *__restrict__ sink, unsigned long long *__restrict__ clk) {
+    __shared__ __attribute__((aligned(16))) double buf[2304];                      // 18 KB: 8 workgroups per CU
+    for (int i = threadIdx.x; i < 2304; i += 256) buf[i] = 0.0;
     __syncthreads();
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    unsigned pos = wid * 512;
-    const unsigned base = (unsigned)(size_t)buf;
-    double acc = 0.0;
+    const int lane = threadIdx.x & 63;
+    const unsigned addr = (unsigned)(size_t)buf + (KIND == 1 ? lane * 8 : lane * 16);
+    u32x2 w[16];
+    u32x4 v[16];
+    unsigned long long c0 = 0, c1 = 0, r0 = 0, r1 = 0;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c0), "=s"(r0)::"memory");
     for (int it = 0; it < iters; ++it) {
-        dbl2 v[8];
-        double w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const unsigned a16 = base + (((pos + 2 * lane) & 4094) << 3), a8 = base + (((pos + lane) & 4095) << 3);
-            if (KIND == 0) asm volatile("ds_read2_b64 %0, %1 offset0:1 offset1:2" : "=v"(v[u]) : "v"(a8));        // (lanes 8 B apart: no bank conflict)
-            else if (KIND == 1) asm volatile("ds_read_b64 %0, %1" : "=v"(w[u]) : "v"(a8));
-            else if (KIND == 2) asm volatile("ds_read_b128 %0, %1" : "=v"(v[u]) : "v"(a16));
-            else asm volatile("ds_read_b128 %0, %1 offset:8" : "=v"(v[u]) : "v"(a16));
-            pos += 130;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (KIND == 1) {
-                asm volatile("" : "+v"(w[u]));
-                acc += w[u];
-            } else {
-                asm volatile("" : "+v"(v[u]));
-                acc += v[u].x + v[u].y;
-            }
+        if (KIND == 1) R16("ds_read_b64", w, 0, 520);                              // 15 * 520 + 512 = 8 312 B
+        else if (KIND == 2) R16("ds_read_b128", v, 0, 1040);                       // 15 * 1040 + 1024 = 16 624 B
+        else if (KIND == 3) R16("ds_read_b128", v, 8, 1040);
+        else {                                                                     // ds_read2_b64: two 8-B words at +8 and +16
+            asm volatile("ds_read2_b64 %0, %8 offset0:1 offset1:2\n\tds_read2_b64 %1, %8 offset0:3 offset1:4\n\t"
+                         "ds_read2_b64 %2, %8 offset0:5 offset1:6\n\tds_read2_b64 %3, %8 offset0:7 offset1:8\n\t"
+                         "ds_read2_b64 %4, %8 offset0:9 offset1:10\n\tds_read2_b64 %5, %8 offset0:11 offset1:12\n\t"
+                         "ds_read2_b64 %6, %8 offset0:13 offset1:14\n\tds_read2_b64 %7, %8 offset0:15 offset1:16"
+                         : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                         : "v"(addr)
+                         : "memory");
         }
     }
-    if (acc == 1.2345) sink[0] = 1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
+    unsigned acc = 0;
+    const int nreg = KIND == 0 ? 8 : 16;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        if (u >= nreg) break;
+        if (KIND == 1) {
+            asm volatile("" : "+v"(w[u]));                  // (orders the XORs behind the final wait)
+            acc ^= w[u].x ^ w[u].y;
+        } else {
+            asm volatile("" : "+v"(v[u]));
+            acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+        }
+    }
+    if (acc == 0x12345678u) sink[0] = 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = c1 - c0, clk[1] = r1 - r0;
 }
+struct LdsRate { double seconds, shader_mhz; };
 template <int KIND>
-double run_lds(int blocks, int iters, unsigned *sink, hipStream_t s) {
+LdsRate run_lds(int blocks, int iters, unsigned *sink, unsigned long long *clk, hipStream_t s) {
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k_lds<KIND>), dim3(blocks), dim3(256), 0, s, iters, sink);
+    hipLaunchKernelGGL((k_lds<KIND>), dim3(blocks), dim3(256), 0, s, iters, sink, clk);
     CK(hipEventRecord(a, s));
     const int reps = 5;
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_lds<KIND>), dim3(blocks), dim3(256), 0, s, iters, sink);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_lds<KIND>), dim3(blocks), dim3(256), 0, s, iters, sink, clk);
     CK(hipEventRecord(b, s));
     CK(hipEventSynchronize(b));
     float ms = 0;
     CK(hipEventElapsedTime(&ms, a, b));
-    return ms / reps * 1e-3;
+    unsigned long long h[2];
+    CK(hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost));
+    return {ms / reps * 1e-3, h[1] ? (double)h[0] / ((double)h[1] / 100.0) : 0.0};      // s_memrealtime ticks at 100 MHz
 }
 
 template <int SHAPE>
@@ -162,12 +191,21 @@ int main() {
                wl * 1024 / t3 / 1e9);
     }
     {
-        const int iters = 2048;
-        const double lanes = (double)blocks * 256 * iters * 8;
-        const double t0 = run_lds<0>(blocks, iters, sink, s), t1 = run_lds<1>(blocks, iters, sink, s), t2 = run_lds<2>(blocks, iters, sink, s),
-                     t3 = run_lds<3>(blocks, iters, sink, s);
-        printf(", \"lds\": {\"read2_b64_gbs\": %.1f, \"read_b64_gbs\": %.1f, \"read_b128_gbs\": %.1f, \"read_b128_8B_aligned_gbs\": %.1f}",
-               lanes * 16 / t0 / 1e9, lanes * 8 / t1 / 1e9, lanes * 16 / t2 / 1e9, lanes * 16 / t3 / 1e9);
+        unsigned long long *clk;
+        CK(hipMalloc((void **)&clk, 16));
+        CK(hipMemset(clk, 0, 16));
+        const int iters = 4096;
+        const double reads = (double)blocks * 256 * iters * 16;          // lane-reads per launch (ds_read2_b64: 8 instructions of 2 words)
+        const LdsRate t0 = run_lds<0>(blocks, iters, sink, clk, s), t1 = run_lds<1>(blocks, iters, sink, clk, s),
+                      t2 = run_lds<2>(blocks, iters, sink, clk, s), t3 = run_lds<3>(blocks, iters, sink, clk, s);
+        const double g0 = reads * 8 / t0.seconds / 1e9, g1 = reads * 8 / t1.seconds / 1e9, g2 = reads * 16 / t2.seconds / 1e9,
+                     g3 = reads * 16 / t3.seconds / 1e9;
+        printf(", \"lds\": {\"read2_b64_gbs\": %.1f, \"read_b64_gbs\": %.1f, \"read_b128_gbs\": %.1f, \"read_b128_8B_aligned_gbs\": %.1f, "
+               "\"read_b64_shader_mhz\": %.0f, \"read_b128_shader_mhz\": %.0f, \"read_b64_bytes_per_clk_per_cu\": %.1f, "
+               "\"read_b128_bytes_per_clk_per_cu\": %.1f, \"waves_per_simd\": 8, \"reads_in_flight_per_wave\": 15, "
+               "\"method\": \"16 reads per loop body, immediate offsets, no s_waitcnt / VALU in the loop; clock = s_memtime / s_memrealtime\"}",
+               g0, g1, g2, g3, t1.shader_mhz, t2.shader_mhz, t1.shader_mhz > 0 ? g1 * 1e3 / (t1.shader_mhz * cus) : 0.0,
+               t2.shader_mhz > 0 ? g2 * 1e3 / (t2.shader_mhz * cus) : 0.0);
     }
     printf("}\n");
     return 0;
