@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_lds(int iters, unsigned *__restrict__ s
     for (int i = threadIdx.x; i < 2304; i += 256) buf[i] = 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
-    const unsigned addr = (unsigned)(size_t)buf + (KIND == 1 ? lane * 8 : lane * 16);
+    const unsigned addr = (unsigned)(size_t)buf + (KIND <= 1 ? lane * 8 : lane * 16);      // (ds_read2_b64: pairs 8 B apart)
     u32x2 w[16];
     u32x4 v[16];
     unsigned long long c0 = 0, c1 = 0, r0 = 0, r1 = 0;
