@@ -325,6 +325,13 @@ int iono_adjoint_fermat_dev(iono_ctx *ctx, const double *origins_dev, const doub
                             double tmax, int Ns, double frequency, int bend, int interp_kind_n, int substeps, int independent,
                             int interp_kind_ne, int quad_rule, double ne_scale, double *grad_dev);
 int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
+/* Plans (iono_forward_plan_dev, iono_adjoint_plan_dev) are keyed on device pointers, but every planned launch re-hashes the rays
+ * it is handed (64 bits per ray) against the hashes recorded when the plan was built.  If a planned array was edited in place:
+ * the forward falls back to direct loads for the bundles concerned (its TEC is exact for ANY bundling, so the result is still
+ * correct), the back-projection -- which works from the plan's own ray records -- poisons the edited rays (every node they touch
+ * comes out NaN), and both raise a sticky flag.  iono_plan_stale synchronises, reads and clears it; the Python layer raises
+ * ValueError (IONO_ERR_ARG semantics) and asks for a new plan.  Replaces no reference code (the reference has no plans). */
+int iono_plan_stale(iono_ctx *ctx, int *stale_out);
 
 /* ---- model-covariance smoothing C_m: Covariance.smooth =
  *      scipy.ndimage.convolve(phi, c_stencil, mode='nearest') (ionosphere/covariance.py:46-63,383-385) with the

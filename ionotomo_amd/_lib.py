@@ -110,6 +110,7 @@ _SIGNATURES = {
     "iono_forward_tec_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],
     "iono_adjoint_fermat_dev": [_V, _V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
+    "iono_plan_stale": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],
     "iono_smooth_separable_dev": [_V, _V, _V, _P, _P, _P, _I],
     "iono_comm_unique_id": [ctypes.c_char_p],
@@ -362,6 +363,13 @@ class Context(object):
     def check_oob(self):
         v = ctypes.c_int(0)
         self.call("iono_check_oob", ctypes.byref(v))
+        return bool(v.value)
+
+    def plan_stale(self):
+        """True (and the flag is cleared) if a planned launch since the last call met rays its plan was not made for: a planned
+        array was edited in place (include/ionotomo_hip.h:iono_plan_stale).  Synchronises."""
+        v = ctypes.c_int(0)
+        self.call("iono_plan_stale", ctypes.byref(v))
         return bool(v.value)
 
     # -- measured load balance of the chunked kernels (include/ionotomo_hip.h) -----------------------------

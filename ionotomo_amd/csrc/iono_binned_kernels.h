@@ -45,9 +45,10 @@ struct BinUnit {
 // so that validity and sample positions are those of the forward kernels: uray[r] = fx0, dfx, fy0, dfy, fz0, dfz, h, valid
 template <bool CUBIC>
 __global__ void k_plan_urays(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
-                             int Ns, double *__restrict__ uray) {
+                             int Ns, double *__restrict__ uray, uint2 *__restrict__ hash) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
         const URay u = CUBIC ? load_uray_cubic(g, origins, dirs, r, tmax, Ns) : load_uray(g, origins, dirs, r, tmax, Ns);
+        hash[r] = ray_hash(origins, dirs, r);
         double *o = uray + r * 8;
         o[0] = u.fx0, o[1] = u.dfx, o[2] = u.fy0, o[3] = u.dfy, o[4] = u.fz0, o[5] = u.dfz, o[6] = u.h, o[7] = u.valid ? 1.0 : 0.0;
     }
@@ -157,15 +158,38 @@ __global__ __launch_bounds__(256) void k_plan_segments(const double *__restrict_
     }
 }
 
+// The back-projection works from the plan's OWN ray records (uray), so a planned array edited in place would silently give the
+// old rays' answer.  Every planned launch therefore re-hashes the rays it is handed (12.5 MB read at the bench shape, 3 us) against
+// the hashes the plan recorded: a ray that differs has its record poisoned (h = NaN: every node it touches comes out NaN, never a
+// plausible number) and raises flags[2] (iono_plan_stale -> the host layer turns it into IONO_ERR_ARG).
+__device__ __forceinline__ void plan_verify_ray(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t r,
+                                                const uint2 *__restrict__ hash, double *__restrict__ uray, int *__restrict__ flags) {
+    const uint2 want = hash[r], have = ray_hash(origins, dirs, r);
+    if ((want.x != have.x) | (want.y != have.y)) {
+        uray[r * 8 + 6] = nan("");
+        atomicOr(flags + 2, 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_plan_verify(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R,
+                                                     const uint2 *__restrict__ hash, double *__restrict__ uray, int *__restrict__ flags) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x)
+        plan_verify_ray(origins, dirs, r, hash, uray, flags);
+}
+
 // per-ray weights of the fused modes (residual / differential), one value per ray: the binned kernel visits a ray once
 // per segment, so the reference-antenna sums are formed here, once.  One wave per (time, direction) pair p, lanes =
 // antennas: the column sum over antennas is a wave reduction instead of a 62-step loop in the i0 threads.
+// (+ the plan's ray check of the launch that follows, in the same pass over the rays: `origins` non-null)
 template <int MODE>
 __global__ __launch_bounds__(256) void k_ray_weights(const double *__restrict__ tec, const double *__restrict__ dobs,
                                                      const double *__restrict__ cdct, int Na, int64_t NtNd, int i0,
-                                                     double *__restrict__ w) {
+                                                     double *__restrict__ w, const double *__restrict__ origins = nullptr,
+                                                     const double *__restrict__ dirs = nullptr, const uint2 *__restrict__ hash = nullptr,
+                                                     double *__restrict__ uray = nullptr, int *__restrict__ flags = nullptr) {
     const int lane = threadIdx.x & 63;
     for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < NtNd; p += (int64_t)gridDim.x * 4) {
+        if (origins)
+            for (int a = lane; a < Na; a += 64) plan_verify_ray(origins, dirs, (int64_t)a * NtNd + p, hash, uray, flags);
         const double tref = MODE == 2 ? 0.0 : tec[(int64_t)i0 * NtNd + p];
         double s = 0.0;
         for (int a = lane; a < Na; a += 64) s += dd_of<MODE>(tec, dobs, cdct, tref, (int64_t)a * NtNd + p);

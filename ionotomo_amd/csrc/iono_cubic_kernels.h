@@ -534,7 +534,8 @@ __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 
     for (int c = 0; c < nchunks; ++c) {
         const int k0 = c * BL_KC;
         int ke = min(k0 + BL_KC, Ns);
-        const LmWindow W = lm_window(wb, c);
+        LmWindow W = lm_window(wb, c);
+        if (B.stale) W.fits = 0;          // rays edited since the plan was made: every chunk reads its nodes from memory (exact for any bundling)
         const bool all = allpairs && W.fits && W.wx * W.wy <= BL_ALL;
         if (all && (c & (B_SPLIT - 1)) != wid) continue;          // another wave takes the whole chunk
         const double kd0 = (double)k0;
@@ -624,16 +625,17 @@ __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 
 
 __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const double *__restrict__ FP, int64_t npad, const double *__restrict__ origins,
                                                            const double *__restrict__ dirs, const int *__restrict__ order,
-                                                           const int *__restrict__ bstart, const uint4 *__restrict__ win, int nb, int nchunks,
-                                                           double tmax, int Ns, const double *__restrict__ unitw, double *__restrict__ tec,
-                                                           int *oob_flag, int allpairs) {
+                                                           const int *__restrict__ bstart, const uint4 *__restrict__ win, const uint2 *__restrict__ rhash,
+                                                           int nb, int nchunks, double tmax, int Ns, const double *__restrict__ unitw,
+                                                           double *__restrict__ tec, int *oob_flag, int allpairs) {
     extern __shared__ __attribute__((aligned(16))) char blds[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);     // XCD-major
     if (b >= nb) return;
-    const BundleRays B = load_bundle<true>(g, origins, dirs, order, bstart, b, tmax, Ns);
+    const BundleRays B = load_bundle<true>(g, origins, dirs, order, bstart, b, tmax, Ns, rhash);
     if (wid == 0 && __any(B.mine && !B.valid) && lane == 0) atomicOr(oob_flag, 1);
+    if (wid == 0 && B.stale && lane == 0) atomicOr(oob_flag + 2, 1);
     if (!B.any) {
         if (wid == 0 && B.mine) tec[B.r] = nan("");
         return;

@@ -598,6 +598,15 @@ __device__ __forceinline__ void lds_read8(Corners<double> &c, unsigned a, unsign
                  : "v"(a), "v"(a2)
                  : "memory");
 }
+// the same, issued only after `dep` has been computed (an in/out operand that costs no instruction): keeps the compiler from
+// sinking the previous sample's interpolation below this sample's reads and the wait that follows them
+__device__ __forceinline__ void lds_read8_after(Corners<double> &c, unsigned a, unsigned a2, double &dep) {
+    asm volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:" IONO_STR(B_LEV8) "\n\tds_read_b64 %3, %9 offset:" IONO_STR(B_LEV8P) "\n\t"
+                 "ds_read_b64 %4, %10\n\tds_read_b64 %5, %10 offset:8\n\tds_read_b64 %6, %10 offset:" IONO_STR(B_LEV8) "\n\tds_read_b64 %7, %10 offset:" IONO_STR(B_LEV8P)
+                 : "=&v"(c.c000), "=&v"(c.c001), "=&v"(c.c010), "=&v"(c.c011), "=&v"(c.c100), "=&v"(c.c101), "=&v"(c.c110), "=&v"(c.c111), "+v"(dep)
+                 : "v"(a), "v"(a2)
+                 : "memory");
+}
 // all but the n youngest LDS reads of this wave have returned (n is a constant after unrolling: one s_waitcnt remains)
 __device__ __forceinline__ void lds_wait(int n) {
     if (n == 0) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -612,21 +621,47 @@ struct BundleRays {          // the rays of a bundle, one per lane; lanes withou
     double fx0, fy0, fz0, dfx, dfy, dfz, h;
     int64_t r;
     bool mine, valid, any;
+    bool stale;              // wave-uniform: some ray of the bundle is not the ray the plan was made for (its 64-bit hash differs)
 };
+// 64-bit checksum of a ray's six doubles as the caller's arrays hold them (bit patterns, so -0.0 != 0.0 and NaNs are told apart):
+// Fletcher's two running sums over the 12 dwords (a += w, b += a: position-sensitive, 24 integer adds).  Any edit of ONE double
+// changes it with certainty, an edit of several slips through only if both 32-bit sums cancel.  A plan records it per ray when
+// it is built and every planned launch recomputes it from the arrays it is handed: the forward then takes the direct loads (exact
+// for ANY bundling), the back-projection poisons that ray with NaN, and both raise flags[2] (iono_plan_stale).
+__device__ __forceinline__ uint2 ray_hash6(double ox, double oy, double oz, double dx, double dy, double dz) {
+    unsigned a = 0x9e3779b9u, b = 0x85ebca6bu;
+    const double v[6] = {ox, oy, oz, dx, dy, dz};
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        a += (unsigned)__double2loint(v[i]), b += a;
+        a += (unsigned)__double2hiint(v[i]), b += a;
+    }
+    return make_uint2(a, b);
+}
+__device__ __forceinline__ uint2 ray_hash(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t r) {
+    return ray_hash6(origins[3 * r], origins[3 * r + 1], origins[3 * r + 2], dirs[3 * r], dirs[3 * r + 1], dirs[3 * r + 2]);
+}
 __device__ __forceinline__ URay load_uray_cubic(const GridView &g, const double *origins, const double *dirs, int64_t r, double tmax, int Ns);
 template <bool CUBIC = false>      // CUBIC: valid = both end points inside the tricubic domain g[2] .. g[n-3] (iono_cubic_kernels.h)
 __device__ __forceinline__ BundleRays load_bundle(const GridView &g, const double *__restrict__ origins, const double *__restrict__ dirs,
-                                                  const int *__restrict__ order, const int *__restrict__ bstart, int b, double tmax, int Ns) {
+                                                  const int *__restrict__ order, const int *__restrict__ bstart, int b, double tmax, int Ns,
+                                                  const uint2 *__restrict__ rhash = nullptr) {
     const int lane = threadIdx.x & 63;
     const int q0 = bstart[b], cnt = bstart[b + 1] - q0;
     BundleRays B;
     URay u = {};
     B.r = 0;
     B.mine = lane < cnt;
+    bool differs = false;
     if (B.mine) {
         B.r = order[q0 + lane];
         u = CUBIC ? load_uray_cubic(g, origins, dirs, B.r, tmax, Ns) : load_uray(g, origins, dirs, B.r, tmax, Ns);
+        if (rhash) {
+            const uint2 want = rhash[q0 + lane], have = ray_hash(origins, dirs, B.r);
+            differs = (want.x != have.x) | (want.y != have.y);
+        }
     }
+    B.stale = __any(differs);
     B.valid = u.valid;
     const unsigned long long vmask = __ballot(u.valid);
     B.any = vmask != 0;
@@ -639,15 +674,43 @@ __device__ __forceinline__ BundleRays load_bundle(const GridView &g, const doubl
     return B;
 }
 
+// ---- plan, device part 3: the rays of every bundle as the kernels want them, 64 B per (bundle, lane) in one contiguous 4-KB run per
+// bundle: grid coordinates of the foot, increments per sample, arc length per sample and a tag (ray index | flags), computed ONCE
+// with load_bundle's arithmetic.  A planned launch reads its 64 rays with four coalesced wave-loads instead of the chain
+// bstart -> order -> origins / directions -> normalisation (a square root and five divisions per ray and wave): 7 500 of the 38 000
+// cycles a wave of k_forward_bundle lived (profiles/r04_bundle_stamps.json).  + the checksum of (origin, direction) per (bundle, lane).
+struct BundleRec {
+    double fx0, fy0, fz0, dfx, dfy, dfz, h;
+    unsigned long long tag;      // ray index | BREC_*
+};
+#define BREC_MINE (1ull << 62)      // the lane holds a ray
+#define BREC_VALID (1ull << 61)     // ... that stays inside the grid
+#define BREC_ANY (1ull << 60)       // the bundle has a valid ray (wave-uniform)
+#define BREC_RMASK ((1ull << 40) - 1ull)
+template <bool CUBIC>
+__global__ __launch_bounds__(64) void k_bundle_records(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                       const int *__restrict__ order, const int *__restrict__ bstart, int nb, double tmax, int Ns,
+                                                       BundleRec *__restrict__ rec, uint2 *__restrict__ hash) {
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
+    if (b >= nb) return;
+    const BundleRays B = load_bundle<CUBIC>(g, origins, dirs, order, bstart, b, tmax, Ns);
+    BundleRec o;
+    o.fx0 = B.fx0, o.fy0 = B.fy0, o.fz0 = B.fz0, o.dfx = B.dfx, o.dfy = B.dfy, o.dfz = B.dfz, o.h = B.h;
+    o.tag = (unsigned long long)B.r | (B.mine ? BREC_MINE : 0ull) | (B.valid ? BREC_VALID : 0ull) | (B.any ? BREC_ANY : 0ull);
+    rec[(size_t)b * 64 + lane] = o;
+    if (hash) hash[(size_t)b * 64 + lane] = B.mine ? ray_hash(origins, dirs, B.r) : make_uint2(0u, 0u);
+}
+
 // ---- plan, device part 1: per ray a 4-D Morton key of foot and end point (3/4-cell quanta) and a 32-byte summary for the cut ----
 struct BundleSummary {          // grid coordinates of foot and end, |drift| per sample, first level; adx < 0: the ray leaves the grid
     float fx0, fy0, fxe, fye, fz0, adx, ady, dz;
 };
 __global__ __launch_bounds__(256) void k_bundle_keys(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R,
                                                      double tmax, int Ns, unsigned long long *__restrict__ keys, int *__restrict__ idx,
-                                                     BundleSummary *__restrict__ rec) {
+                                                     BundleSummary *__restrict__ rec, uint2 *__restrict__ hash_by_ray) {
     for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
         const URay u = load_uray(g, origins, dirs, r, tmax, Ns);
+        if (hash_by_ray) hash_by_ray[r] = ray_hash(origins, dirs, r);
         BundleSummary h;
         const double n1 = (double)(Ns - 1);
         h.fx0 = (float)u.fx0, h.fy0 = (float)u.fy0, h.fxe = (float)fma(n1, u.dfx, u.fx0), h.fye = (float)fma(n1, u.dfy, u.fy0);
@@ -671,8 +734,12 @@ __global__ __launch_bounds__(256) void k_bundle_keys(GridView g, const double *_
     }
 }
 __global__ __launch_bounds__(256) void k_bundle_permute(const int *__restrict__ sorted_idx, const int *__restrict__ perm, int64_t R,
-                                                        int *__restrict__ order) {
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < R; q += (int64_t)gridDim.x * blockDim.x) order[q] = sorted_idx[perm[q]];
+                                                        int *__restrict__ order, const uint2 *__restrict__ hash_by_ray, uint2 *__restrict__ rhash) {
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < R; q += (int64_t)gridDim.x * blockDim.x) {
+        const int r = sorted_idx[perm[q]];
+        order[q] = r;
+        if (rhash) rhash[q] = hash_by_ray[r];           // in walk order: a bundle's hashes are one contiguous run
+    }
 }
 __global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__restrict__ rec, const int *__restrict__ order, int64_t R,
                                                        BundleSummary *__restrict__ sorted) {
@@ -682,7 +749,10 @@ __global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__re
 // window of chunk c of bundle b: {imin, jmin, kz0, wx | wy << 8 | fits << 16 | rpl << 20}; one wave per bundle.  KC samples per chunk, an
 // image of LEV levels per column and MAXWY columns per row; EVEN: the window starts on an even level (8-byte values staged in 16-byte
 // pieces); rpl = whole rows of the window per staging wave-load of 64 / LEV columns (used by k_forward_bundle_lm)
-template <int KC, int LEV, int MAXWY, bool EVEN>
+// PACK (the trilinear kernel's record): {element offset of the window origin (imin, jmin, kz0) in the values array, byte offset of that
+// origin in an image of rows of wy columns x LEV levels, bit pattern of (float)(1 / wy), flags} with rpl = whole rows per wave-load
+// of 64 / (LEV / 2) columns: everything the staging loop needs comes out of one scalar load without 64-bit scalar arithmetic
+template <int KC, int LEV, int MAXWY, bool EVEN, bool PACK = false>
 __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs,
                                                        const int *__restrict__ order, const int *__restrict__ bstart, int nb, double tmax,
                                                        int Ns, int nchunks, uint4 *__restrict__ win, unsigned long long *__restrict__ fit_count) {
@@ -704,9 +774,14 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
             const int kz0 = EVEN ? kmin & ~1 : kmin;
             const int wx = imax - imin + 2, wy = jmax - jmin + 2, nlev = kmax + 2 - kz0;
             const bool fits = (!EVEN || (g.nz & 1) == 0) && wx * wy <= B_CAPCOLS && wx < 256 && wy <= MAXWY && nlev <= LEV;
-            const int rpl = min(15, max(1, (64 / LEV) / wy));
-            w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0,
-                           (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u) | ((unsigned)rpl << 20));
+            const int rpl = min(15, max(1, (PACK ? 64 / (LEV / 2) : 64 / LEV) / wy));
+            unsigned flags = (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u) | ((unsigned)rpl << 20);
+            if (PACK) flags |= (unsigned)min(31, (wx + rpl - 1) / rpl) << 24;      // wave-loads of the copy
+            if (PACK)
+                w = make_uint4(((unsigned)imin * (unsigned)g.ny + (unsigned)jmin) * (unsigned)g.nz + (unsigned)kz0,
+                               (((unsigned)imin * (unsigned)wy + (unsigned)jmin) * LEV + (unsigned)kz0) * 8u, __float_as_uint(1.0f / (float)wy), flags);
+            else
+                w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0, flags);
             nfit += fits;
         }
         if ((threadIdx.x & 63) == 0) win[(size_t)b * nchunks + c] = w;
@@ -714,37 +789,120 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
     if (fit_count && (threadIdx.x & 63) == 0 && nfit) atomicAdd(fit_count, (unsigned long long)nfit);      // one update per bundle
 }
 
+// LDS byte address of a sample's lower corner (+ its three weights) WITHOUT integer instructions: `magic` = 2^49 + (image byte
+// address - byte offset of the window origin) / 8.  With an exponent of 49 one unit of the last place is 2^-3, so the low dword of
+// magic + node offset IS 8 * (node offset) + that byte address: the v_cvt_u32_f64 and the shift-add of bundle_addr() become one add.
+__device__ __forceinline__ unsigned bundle_addr_magic(Corners<double> &c, double fx, double fy, double fz, double cw, double cj, double magic) {
+    const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
+    c.tx = fx - fi, c.ty = fy - fj, c.tz = fz - fk;
+    return (unsigned)__double2loint(__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk + magic)));
+}
+
 // NF = 0: TEC (tec[r]).  NF > 0: the phase observable's per-frequency integrals of 1 - sqrt(1 - ne / n_p) for NF frequencies per
 // pass (out[r * ldf + l]; inversion/iterative_newton.py:108-119), same traversal, NF accumulators per lane.
+// Round 4, after in-kernel stamps (profiles/r04_bundle_stamps.json: of the 38 000 cycles a wave lived, 7 500 went into the bundle
+// prologue, 7 600 into ISSUING the LDS-DMA copies -- 150 cycles per instruction, as the guide's price list says -- 2 700 + 2 600
+// into waiting for window records and copies, 17 900 into the samples):
+//  (1) the rays come out of the plan's records (k_bundle_records: four coalesced wave-loads, no arithmetic);
+//  (2) the window of the NEXT chunk travels through registers: up to B_NPF plain 16-B wave-loads are issued before a chunk's
+//      samples and written to the image (ds_write_b128) after them -- a prefetch with ONE image per wave, since a wave's LDS
+//      operations execute in order; windows of more rows finish with LDS-DMA, `rpl` whole rows per load;
+//  (3) window records are read one chunk ahead, the chunk's eight weights in ONE scalar load; the sample loop is a software
+//      pipeline over the chunk (the reads of sample u + 1 are in flight while sample u is interpolated);
+//  (4) the LDS address falls out of the float64 node offset without a conversion (bundle_addr_magic);
+//  (5) wave 0 checks that the arrays still hold the planned rays (ray_hash); if not, the workgroup recomputes its bundle from the
+//      arrays with direct loads (exact for any bundling) and raises flags[2].
+#ifndef B_NPF
+#define B_NPF 6
+#endif
+#ifdef IONO_B_STAMP      // timing-only build: in-kernel stamps (s_memtime) of every wave, summed per phase (profiles/tools/bundle_stamps.py)
+__device__ unsigned long long g_bstamp[8 * 4 * 8192];
+#define BST(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); st[i] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define BST(i) do { } while (0)
+#endif
+struct BWin {                  // a window record of the plan, decoded (all wave-uniform)
+    unsigned woff, wib;        // element offset of the window origin in the values array; byte offset of that origin in the image
+    int winv, wx, wy, rpl, fits, nl;
+};
+__device__ __forceinline__ BWin bwin_decode(uint4 w) {
+    BWin W;
+    W.woff = (unsigned)__builtin_amdgcn_readfirstlane((int)w.x), W.wib = (unsigned)__builtin_amdgcn_readfirstlane((int)w.y);
+    W.winv = __builtin_amdgcn_readfirstlane((int)w.z);
+    const int f = __builtin_amdgcn_readfirstlane((int)w.w);
+    W.wx = f & 255, W.wy = (f >> 8) & 255, W.fits = (f >> 16) & 1, W.rpl = (f >> 20) & 15, W.nl = (f >> 24) & 31;
+    return W;
+}
+typedef double dbl8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 template <int NF>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) void k_forward_bundle(
-    GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, const int *__restrict__ order,
-    const int *__restrict__ bstart, const uint4 *__restrict__ win, int nb, int nchunks, double tmax, int Ns,
-    const double *__restrict__ unitw, double *__restrict__ tec, int *oob_flag, PhaseFreqs pf, int ldf) {
+    GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, const BundleRec *__restrict__ brec,
+    const uint2 *__restrict__ bhash, const uint4 *__restrict__ win, int nb, int nchunks, double tmax, int Ns,
+    const double *__restrict__ unitw, double *__restrict__ tec, int *flags, PhaseFreqs pf, int ldf) {
     constexpr int NA = NF > 0 ? NF : 1;
     extern __shared__ __attribute__((aligned(16))) char blds[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform: scalar loop control)
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0) b = (int)(blockIdx.x & 7) * (int)(gridDim.x >> 3) + (int)(blockIdx.x >> 3);     // XCD-major: neighbouring bundles share an L2
     if (b >= nb) return;
+#ifdef IONO_B_STAMP
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
+    const unsigned long long tstart = tlast;
+#endif
     const double *M = (const double *)g.M;
     const double *b00 = M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
-    const BundleRays B = load_bundle(g, origins, dirs, order, bstart, b, tmax, Ns);
-    if (wid == 0 && __any(B.mine && !B.valid) && lane == 0) atomicOr(oob_flag, 1);
-    if (!B.any) {
-        if (wid == 0 && B.mine) {
-            if (NF == 0) tec[B.r] = nan("");
-            else
-                for (int l = 0; l < pf.nf; ++l) tec[(size_t)B.r * ldf + l] = nan("");
-        }
-        return;
+    // ---- the bundle's rays: one 64-byte record per lane ------------------------------------------------------------------------
+    BundleRays B;
+    {
+        const double2 *rp = (const double2 *)(brec + (size_t)b * 64 + lane);
+        const double2 q0 = rp[0], q1 = rp[1], q2 = rp[2], q3 = rp[3];
+        B.fx0 = q0.x, B.fy0 = q0.y, B.fz0 = q1.x, B.dfx = q1.y, B.dfy = q2.x, B.dfz = q2.y, B.h = q3.x;
+        const unsigned long long tag = (unsigned long long)__double_as_longlong(q3.y);
+        B.r = (int64_t)(tag & BREC_RMASK), B.mine = (tag & BREC_MINE) != 0, B.valid = (tag & BREC_VALID) != 0;
+        B.any = __builtin_amdgcn_readfirstlane((int)(tag >> 60) & 1) != 0;
+        B.stale = false;
     }
     char *img = blds + wid * B_WAVE_LDS;
     double *part = (double *)(blds + B_SPLIT * B_WAVE_LDS);
-    const int lane_dj = (int)(((unsigned)lane * 52429u) >> 18);                 // lane / 5
-    const unsigned lane_off = ((unsigned)lane_dj * (unsigned)g.nz + 2u * (unsigned)(lane - B_PPC * lane_dj)) * 8u;
+    int *sflag = (int *)(part + NA * B_SPLIT * 64);
+    const int lane_q = (int)(((unsigned)lane * 52429u) >> 18);                  // lane / 5: column slot of a wave-load
+    const int lane_pc = lane - B_PPC * lane_q;                                   // piece = levels kz0 + 2 pc, + 1
+    const float lane_qf = (float)lane_q + 0.5f;
     const uint4 *wb = win + (size_t)b * nchunks;
     const int c0 = nchunks * wid / B_SPLIT, c1 = nchunks * (wid + 1) / B_SPLIT;
+    const unsigned plane8 = (unsigned)g.ny * (unsigned)g.nz * 8u;              // bytes between two rows (i, i + 1) of a window in memory
+    // ---- window copy, part 1: the first B_NPF wave-loads of a window into registers (lane = (row r, column dj, piece pc) of a
+    //      load of rpl rows; the image is lane-linear: row di at byte di * wy * 80, column dj at + 80 dj) ----------------------------
+    u32x4 pre[B_NPF], pre_last = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int n = 0; n < B_NPF; ++n) pre[n] = u32x4{0u, 0u, 0u, 0u};
+    bool act = false, act_last = false;                                          // lanes of the pending copy (all loads / its last one)
+    auto issue = [&](const BWin &W) {
+        int r = 0, dj = lane_q;
+        if (W.rpl > 1) {                                                         // (wave-uniform)
+            r = (int)(lane_qf * __uint_as_float((unsigned)W.winv));               // lane_q / wy, exact: lane_q <= 12, wy <= 12
+            dj = lane_q - r * W.wy;
+        }
+        const unsigned loff = (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
+        const char *rowp = (const char *)M + (size_t)W.woff * 8;
+        const size_t gstep = (size_t)W.rpl * plane8;
+        act = lane_q < W.rpl * W.wy;
+        act_last = act && r < W.wx - (W.nl - 1) * W.rpl;
+        // (all full loads under ONE execution mask, the last -- possibly partial -- group of rows under another: per-load predicates
+        //  cost four vector instructions each.  Plain loads: the compiler tracks them; the s_waitcnt builtin at the top of a chunk
+        //  tells it that nothing is pending there, otherwise it cannot prove across the loop's branches that a destination's
+        //  previous load has landed and puts vmcnt(0) in front of every load of a window)
+        if (act) {
+#pragma unroll
+            for (int n = 0; n < B_NPF; ++n)
+                if (n < W.nl - 1) pre[n] = *(const u32x4 *)(rowp + (size_t)n * gstep + loff);
+        }
+        // (the last group in a register of its own: a slot that either block may write would make the compiler wait for the first
+        //  block's loads before the second's)
+        if (act_last && W.nl - 1 <= B_NPF) pre_last = *(const u32x4 *)(rowp + (size_t)(W.nl - 1) * gstep + loff);
+    };
     double inv_np_max = 0.0;                                  // the lowest frequency of the pass has the largest ne / n_p
 #pragma unroll
     for (int l = 0; l < NA; ++l) inv_np_max = NF > 0 ? fmax(inv_np_max, pf.inv_np[l]) : 0.0;
@@ -762,62 +920,120 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
             for (int l = 0; l < NA; ++l) acc[l] = fma(wk, phase_one_minus_sqrt(ne * pf.inv_np[l], small), acc[l]);
         }
     };
-    for (int c = c0; c < c1; ++c) {
+    BWin Wc = bwin_decode(B.any && c0 < c1 ? wb[c0] : make_uint4(0, 0, 0, 0));
+    if (Wc.fits) issue(Wc);
+    // ---- wave 0: do the arrays still hold the rays this plan was made for?  (its loads overlap with the first window's) -------------
+    if (wid == 0) {
+        bool differs = false;
+        if (B.mine) {
+            const uint2 want = bhash[(size_t)b * 64 + lane], have = ray_hash(origins, dirs, B.r);
+            differs = (want.x != have.x) | (want.y != have.y);
+        }
+        B.stale = __any(differs);
+        const bool leaves = __any(B.mine && !B.valid);
+        if (lane == 0) {
+            sflag[0] = B.stale ? 1 : 0;
+            if (B.stale) atomicOr(flags + 2, 1);
+            else if (leaves) atomicOr(flags, 1);
+        }
+    }
+    asm volatile("" ::"v"(B.fx0), "v"(B.dfx), "v"(B.h));
+    BST(0);                                                                    // 0: bundle prologue (records, first window, checksum)
+    for (int c = c0; c < c1 && B.any; ++c) {
         const int k0 = c * B_KC, ke = min(k0 + B_KC, Ns);
         const double kd0 = (double)k0;
         double fx = fma(kd0, B.dfx, B.fx0), fy = fma(kd0, B.dfy, B.fy0), fz = fma(kd0, B.dfz, B.fz0);
-        const uint4 w = wb[c];
-        const int imin = __builtin_amdgcn_readfirstlane((int)w.x), jmin = __builtin_amdgcn_readfirstlane((int)w.y),
-                  kz0 = __builtin_amdgcn_readfirstlane((int)w.z), wxy = __builtin_amdgcn_readfirstlane((int)w.w);
-        const int wx = wxy & 255, wy = (wxy >> 8) & 255;
-        if ((wxy >> 16) & 1) {
-            // ---- stage the window row by row: lane = (column dj = lane / 5, piece pc = lane % 5 = levels kz0 + 2 pc, + 1) of row di;
-            //      the image is lane-linear: row di at byte di * wy * 80, column dj at + 80 dj.  Source = a wave-uniform row base
-            //      + a per-lane offset that never changes: no vector arithmetic per load.
-            if (lane_dj < wy) {
-                const char *rowp = (const char *)M + ((size_t)((size_t)imin * g.ny + jmin) * g.nz + kz0) * 8;
-                const unsigned rstride = (unsigned)wy * (B_PPC * 16);
-                for (int di = 0; di < wx; ++di) {
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + lane_off),
-                                                     (__attribute__((address_space(3))) void *)(img + di * rstride), 16, 0, 0);
-                    rowp += (size_t)g.ny * g.nz * 8;
-                }
+        // the next chunk's window record and this chunk's eight weights: two scalar loads, waited for once, below (unitw is padded
+        // with B_KC zeros: ensure_unitw; the record array is read one element beyond a wave's range only inside the bundle's own row)
+        dbl8 wq;
+        u32x4 wn;
+        static_assert(B_KC == 8, "one s_load_dwordx16 holds the weights of a chunk");
+        asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0" : "=&s"(wq), "=&s"(wn) : "s"(unitw + k0), "s"(wb + min(c + 1, c1 - 1)) : "memory");
+        // vmcnt(0): this chunk's window rows, issued a whole chunk ago, have landed.  (On EVERY path through the loop: the compiler
+        // then knows that no load is pending into a register the next window's loads and their address arithmetic overwrite)
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        if (Wc.fits) {
+            // ---- window copy, part 2: registers -> image (after the previous chunk's reads: a wave's LDS operations run in order)
+            const unsigned lstep = (unsigned)(Wc.rpl * Wc.wy) * (B_PPC * 16);
+            char *dst = img + lane * 16;
+            if (act) {
+#pragma unroll
+                for (int n = 0; n < B_NPF; ++n)
+                    if (n < Wc.nl - 1) *(u32x4 *)(dst + n * lstep) = pre[n];
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (act_last && Wc.nl - 1 <= B_NPF) *(u32x4 *)(dst + (Wc.nl - 1) * lstep) = pre_last;
+            if (Wc.nl - 1 > B_NPF) {                                              // the rest of a tall window: LDS-DMA, not prefetched
+                int r = 0, dj = lane_q;
+                if (Wc.rpl > 1) {
+                    r = (int)(lane_qf * __uint_as_float((unsigned)Wc.winv));
+                    dj = lane_q - r * Wc.wy;
+                }
+                const unsigned loff = (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
+                const size_t gstep = (size_t)Wc.rpl * plane8;
+                const char *rowp = (const char *)M + (size_t)Wc.woff * 8 + (size_t)B_NPF * gstep;
+                char *dd = img + B_NPF * lstep;
+                if (act) {
+                    for (int n = B_NPF; n < Wc.nl - 1; ++n) {
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + loff),
+                                                         (__attribute__((address_space(3))) void *)dd, 16, 0, 0);
+                        rowp += gstep, dd += lstep;
+                    }
+                    if (act_last)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + loff),
+                                                         (__attribute__((address_space(3))) void *)dd, 16, 0, 0);
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        BST(1);                                                                // 1: registers -> image (incl. the wait for the loads)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wq), "+s"(wn)::"memory");
+        BST(2);                                                                // 2: wait for weights + next record (+ the LDS writes)
+        const BWin Wn = bwin_decode(make_uint4(wn.x, wn.y, wn.z, c + 1 < c1 ? wn.w : 0u));
+        const BWin Wuse = Wc;
+        // ---- window copy, part 1 for the NEXT chunk: in flight during this chunk's samples
+        if (Wn.fits) issue(Wn);
+        Wc = Wn;
+        BST(3);                                                                // 3: issue of the next window's loads
+        if (Wuse.fits) {
             // ---- B_KC samples per lane from the image; the window origin only shifts the (integer) node offset ------------
-            const double cw = (double)(wy * B_LEV), cj = (double)B_LEV;
-            // (node offset of the window origin: subtracted from the LDS byte address with 32-bit wrap-around)
-            const unsigned ibase = (unsigned)(size_t)img - (((unsigned)imin * (unsigned)wy + (unsigned)jmin) * B_LEV + (unsigned)kz0) * 8u;
-            const unsigned row2 = (unsigned)wy * (B_LEV * 8);
-            // eight ds_read_b64 per sample (2 LDS cycles each) instead of the four ds_read2_b64 (8 each) the compiler forms from
-            // plain loads: 0.133 -> 0.111 ms.  B_UNROLL samples' reads in flight; the asm loads are waited for by hand.
+            const double cw = (double)(Wuse.wy * B_LEV), cj = (double)B_LEV;
+            // (image address minus the byte offset of the window origin, in 8-byte units, riding on 2^49: bundle_addr_magic)
+            const double magic = 0x1p49 + (double)(int)((unsigned)(size_t)img - Wuse.wib) * 0.125;
+            const unsigned row2 = (unsigned)Wuse.wy * (B_LEV * 8);
             int k = k0;
-            for (; k + B_UNROLL <= ke; k += B_UNROLL) {
-                Corners<double> cc[B_UNROLL];
-                unsigned aa[B_UNROLL];
-#pragma unroll
-                for (int u = 0; u < B_UNROLL; ++u) {
-                    aa[u] = bundle_addr(cc[u], fx, fy, fz, cw, cj, ibase);
-                    fx += B.dfx, fy += B.dfy, fz += B.dfz;
-                }
-#pragma unroll
-                for (int u = 0; u < B_UNROLL; ++u) lds_read8(cc[u], aa[u], aa[u] + row2);
-#pragma unroll
-                for (int u = 0; u < B_UNROLL; ++u) {
-                    lds_wait(8 * (B_UNROLL - 1 - u));
-                    lds_pin8(cc[u]);
-                    add(unitw[k + u], lerp_corners<double>(cc[u]));
-                }
-            }
-            for (; k < ke; ++k) {
-                Corners<double> ca;
-                const unsigned a0 = bundle_addr(ca, fx, fy, fz, cw, cj, ibase);
+            if (ke - k0 == B_KC) {
+                // software pipeline over the whole chunk: the reads of sample u + 1 are in flight while sample u is interpolated
+                // (LDS data returns in order: lgkmcnt(8) right after issuing 8 reads = the previous 8 have landed)
+                Corners<double> cq[2];
+                unsigned a0 = bundle_addr_magic(cq[0], fx, fy, fz, cw, cj, magic);
                 fx += B.dfx, fy += B.dfy, fz += B.dfz;
-                lds_read8(ca, a0, a0 + row2);
+                lds_read8(cq[0], a0, a0 + row2);
+#pragma unroll
+                for (int u = 0; u < B_KC; ++u) {
+                    if (u + 1 < B_KC) {
+                        a0 = bundle_addr_magic(cq[(u + 1) & 1], fx, fy, fz, cw, cj, magic);
+                        fx += B.dfx, fy += B.dfy, fz += B.dfz;
+                        lds_read8_after(cq[(u + 1) & 1], a0, a0 + row2, acc[0]);
+                        lds_wait(8);
+                    } else {
+                        lds_wait(0);
+                    }
+                    lds_pin8(cq[u & 1]);
+                    add(wq[u], lerp_corners<double>(cq[u & 1]));
+                }
+                k = ke;
+            }
+            for (; k < ke; ++k) {                                             // (the last chunk of a ray: Ns = 32 x 8 + 1)
+                Corners<double> ca;
+                const unsigned a1 = bundle_addr_magic(ca, fx, fy, fz, cw, cj, magic);
+                fx += B.dfx, fy += B.dfy, fz += B.dfz;
+                lds_read8(ca, a1, a1 + row2);
                 lds_wait(0);
                 lds_pin8(ca);
                 add(unitw[k], lerp_corners<double>(ca));
             }
+            asm volatile("" ::"v"(acc[0]));
+            BST(4);                                                            // 4: the chunk's samples
         } else {
             for (int k = k0; k < ke; ++k) {
                 add(unitw[k], trilinear_u<double>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz));
@@ -828,16 +1044,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
         }
     }
     // ---- the four z-parts of a ray, added in a fixed order ------------------------------------------------------------------
+#ifdef IONO_B_STAMP
+    if (blockIdx.x < 8192 && lane == 0) {
+        unsigned long long *o_ = g_bstamp + ((size_t)blockIdx.x * 4 + wid) * 8;
+        for (int i = 0; i < 5; ++i) o_[i] = st[i];
+        o_[5] = tlast - tstart, o_[6] = tstart, o_[7] = tlast;
+    }
+#endif
 #pragma unroll
     for (int l = 0; l < NA; ++l) part[(l * B_SPLIT + wid) * 64 + lane] = acc[l];
     __syncthreads();
+    double hscale = B.h;
+    bool valid = B.valid;
+    if (sflag[0]) {
+        // the arrays do not hold the planned rays: the whole bundle again FROM THE ARRAYS with direct loads (the same arithmetic
+        // position for position, so the result is the one an unplanned launch gives)
+        URay u = {};
+        if (B.mine) u = load_uray(g, origins, dirs, B.r, tmax, Ns);
+        valid = u.valid, hscale = u.h;
+#pragma unroll
+        for (int l = 0; l < NA; ++l) acc[l] = 0.0;
+        if (B.mine && u.valid) {
+            for (int c = c0; c < c1; ++c) {
+                const int k0 = c * B_KC, ke = min(k0 + B_KC, Ns);
+                const double kd0 = (double)k0;
+                double fx = fma(kd0, u.dfx, u.fx0), fy = fma(kd0, u.dfy, u.fy0), fz = fma(kd0, u.dfz, u.fz0);
+                for (int k = k0; k < ke; ++k) {
+                    add(unitw[k], trilinear_u<double>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz));
+                    fx += u.dfx, fy += u.dfy, fz += u.dfz;
+                }
+            }
+        }
+        if (wid == 0 && __any(B.mine && !u.valid) && lane == 0) atomicOr(flags, 1);
+        __syncthreads();
+#pragma unroll
+        for (int l = 0; l < NA; ++l) part[(l * B_SPLIT + wid) * 64 + lane] = acc[l];
+        __syncthreads();
+    }
     if (wid == 0 && B.mine) {
 #pragma unroll
         for (int l = 0; l < NA; ++l) {
             const double *pl = part + l * B_SPLIT * 64 + lane;
             const double tot = ((pl[0] + pl[64]) + pl[128]) + pl[192];
-            if (NF == 0) tec[B.r] = B.valid ? tot * B.h : nan("");
-            else if (l < pf.nf) tec[(size_t)B.r * ldf + l] = B.valid ? tot * B.h : nan("");
+            if (NF == 0) tec[B.r] = valid ? tot * hscale : nan("");
+            else if (l < pf.nf) tec[(size_t)B.r * ldf + l] = valid ? tot * hscale : nan("");
         }
     }
 }

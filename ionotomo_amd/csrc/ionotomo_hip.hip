@@ -59,7 +59,7 @@ struct iono_ctx {
     double *d_M_ext = nullptr;       // caller-owned float64 values bound with iono_grid_bind_values_dev (takes precedence)
     double inv_h[3] = {0, 0, 0};
     int uniform[3] = {0, 0, 0};
-    int *d_flags = nullptr;          // [0] out-of-bounds, [1] non-finite
+    int *d_flags = nullptr;          // [0] out-of-bounds, [1] non-finite, [2] a planned launch met rays its plan was not made for, [3] spare
     double *d_unitw = nullptr;       // cached unit-spacing quadrature weights
     int unitw_n = 0, unitw_rule = -1;
     std::string err;
@@ -122,6 +122,7 @@ struct iono_ctx {
         int segl = BIN_SEG;                               // lanes per segment of this plan (4, 8 or 16)
         double tmax = 0;
         double *d_uray = nullptr;
+        uint2 *d_hash = nullptr;                          // ray_hash of every ray as planned, by ray index (checked by every planned launch)
         uint2 *d_entries = nullptr;
         BinUnit *d_units = nullptr;
         unsigned char *d_nseg = nullptr;                  // segments per ray (forward: partial sums per ray)
@@ -130,7 +131,7 @@ struct iono_ctx {
         bool fwd_ok = false;                              // every ray has <= 255 segments
         double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
         int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
-        size_t cap_uray = 0, cap_entries = 0, cap_units = 0, cap_nseg = 0, cap_partial = 0;      // bytes (grow-only: a new geometry reuses them)
+        size_t cap_uray = 0, cap_hash = 0, cap_entries = 0, cap_units = 0, cap_nseg = 0, cap_partial = 0;      // bytes (grow-only: a new geometry reuses them)
     } plan;
     // bundle plan of the forward (iono_forward_plan_dev; k_forward_bundle): geometry only, library-owned
     struct FwdPlan {
@@ -140,6 +141,11 @@ struct iono_ctx {
         double tmax = 0;
         int *d_order = nullptr, *d_bstart = nullptr;
         uint4 *d_win = nullptr;
+        uint2 *d_rhash = nullptr;        // 64-bit checksum of every ray's six doubles, in walk order: checked by every planned launch (ray_hash)
+        size_t cap_rhash = 0;
+        BundleRec *d_brec = nullptr;     // the rays of every bundle as the trilinear kernel wants them, 64 B per (bundle, lane) (k_bundle_records)
+        uint2 *d_bhash = nullptr;        // ... and their checksums in the same layout
+        size_t cap_brec = 0, cap_bhash = 0;
         uint4 *d_win_lm = nullptr;       // windows of the tricubic kernel's shorter chunks (BL_KC samples, BL_LEV levels of 16-byte nodes)
         int nchunks_lm = 0;
         size_t cap_order = 0, cap_bstart = 0, cap_win = 0, cap_win_lm = 0;
@@ -159,6 +165,7 @@ namespace {
 
 void plan_free(iono_ctx *c) {
     if (c->plan.d_uray) (void)hipFree(c->plan.d_uray);
+    if (c->plan.d_hash) (void)hipFree(c->plan.d_hash);
     if (c->plan.d_entries) (void)hipFree(c->plan.d_entries);
     if (c->plan.d_units) (void)hipFree(c->plan.d_units);
     if (c->plan.d_nseg) (void)hipFree(c->plan.d_nseg);
@@ -172,6 +179,7 @@ void plan_reset(iono_ctx *c) {
     fresh.d_uray = p.d_uray, fresh.d_entries = p.d_entries, fresh.d_units = p.d_units, fresh.d_nseg = p.d_nseg, fresh.d_partial = p.d_partial;
     fresh.cap_uray = p.cap_uray, fresh.cap_entries = p.cap_entries, fresh.cap_units = p.cap_units, fresh.cap_nseg = p.cap_nseg;
     fresh.cap_partial = p.cap_partial;
+    fresh.d_hash = p.d_hash, fresh.cap_hash = p.cap_hash;
     p = fresh;
 }
 template <typename T>
@@ -188,6 +196,9 @@ void fplan_free(iono_ctx *c) {
     if (c->fplan.d_order) (void)hipFree(c->fplan.d_order);
     if (c->fplan.d_bstart) (void)hipFree(c->fplan.d_bstart);
     if (c->fplan.d_win) (void)hipFree(c->fplan.d_win);
+    if (c->fplan.d_rhash) (void)hipFree(c->fplan.d_rhash);
+    if (c->fplan.d_brec) (void)hipFree(c->fplan.d_brec);
+    if (c->fplan.d_bhash) (void)hipFree(c->fplan.d_bhash);
     if (c->fplan.d_win_lm) (void)hipFree(c->fplan.d_win_lm);
     c->fplan = iono_ctx::FwdPlan();
 }
@@ -385,7 +396,7 @@ int check_common(iono_ctx *c, int64_t R, int Ns, int kind, int rule) {
 }
 
 int read_flag(iono_ctx *c, int which, int *out) {
-    int v[2] = {0, 0};
+    int v[4] = {0, 0, 0, 0};
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(v, c->d_flags, sizeof(v), hipMemcpyDeviceToHost));
     *out = v[which];
@@ -454,8 +465,8 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     c->device = device_id;
     hipError_t e = hipSetDevice(device_id);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flags, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flags, 4 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flags, 0, 4 * sizeof(int));
     if (e != hipSuccess) {
         std::string m = std::string("iono_ctx_create: ") + hipGetErrorString(e);
         delete c;
@@ -864,7 +875,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     DevBuf scratch(c);
     const size_t off_k0 = 0, off_k1 = off_k0 + (size_t)R * 8, off_i0 = off_k1 + (size_t)R * 8, off_i1 = off_i0 + (size_t)R * 4,
                  off_r0 = (off_i1 + (size_t)R * 4 + 31) & ~(size_t)31, off_r1 = off_r0 + (size_t)R * sizeof(BundleSummary),
-                 off_tmp = off_r1 + (size_t)R * sizeof(BundleSummary);
+                 off_h = off_r1 + (size_t)R * sizeof(BundleSummary), off_tmp = off_h + (size_t)R * sizeof(uint2);
     size_t tmp_bytes = 0;
     HIP_TRY(c, rocprim::radix_sort_pairs(nullptr, tmp_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (int *)nullptr,
                                          (int *)nullptr, (size_t)R, 0, 64, c->stream));
@@ -873,7 +884,8 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     unsigned long long *k0 = (unsigned long long *)(sb + off_k0), *k1 = (unsigned long long *)(sb + off_k1);
     int *i0 = (int *)(sb + off_i0), *i1 = (int *)(sb + off_i1);
     BundleSummary *r0 = (BundleSummary *)(sb + off_r0), *r1 = (BundleSummary *)(sb + off_r1);
-    hipLaunchKernelGGL(k_bundle_keys, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, view(c), o, d, R, tmax, Ns, k0, i0, r0);
+    uint2 *hash_by_ray = (uint2 *)(sb + off_h);
+    hipLaunchKernelGGL(k_bundle_keys, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, view(c), o, d, R, tmax, Ns, k0, i0, r0, hash_by_ray);
     HIP_TRY(c, rocprim::radix_sort_pairs(sb + off_tmp, tmp_bytes, k0, k1, i0, i1, (size_t)R, 0, 64, c->stream));
     hipLaunchKernelGGL(k_bundle_gather, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, r0, i1, R, r1);
     HIP_TRY(c, hipGetLastError());
@@ -885,6 +897,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     int *perm = (int *)(hp + (size_t)R * sizeof(BundleSummary));
     HIP_TRY(c, hipMemcpyAsync(hp, r1, (size_t)R * sizeof(BundleSummary), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, plan_reserve(fp.d_order, fp.cap_order, (size_t)R * sizeof(int)));
+    HIP_TRY(c, plan_reserve(fp.d_rhash, fp.cap_rhash, (size_t)R * sizeof(uint2)));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // The cut: walk the sorted rays; a bundle takes the next rays that keep its window within the image, looking up to
     // B_LOOKAHEAD rejected rays ahead (the Morton curve jumps: a ray that does not fit now often belongs to a later bundle, while
@@ -950,7 +963,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     {
         int *d_perm = i0;                                         // (scratch: the unsorted index array is no longer needed)
         HIP_TRY(c, hipMemcpyAsync(d_perm, perm, (size_t)R * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_bundle_permute, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, i1, d_perm, R, fp.d_order);
+        hipLaunchKernelGGL(k_bundle_permute, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, i1, d_perm, R, fp.d_order, hash_by_ray, fp.d_rhash);
         HIP_TRY(c, hipGetLastError());
     }
     bstart.push_back((int)R);
@@ -960,8 +973,12 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipMemcpyAsync(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     unsigned long long *d_fits = (unsigned long long *)k0;        // (scratch: the key arrays are no longer needed)
     HIP_TRY(c, hipMemsetAsync(d_fits, 0, sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
+    hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
                        nb, tmax, Ns, nchunks, fp.d_win, d_fits);
+    HIP_TRY(c, plan_reserve(fp.d_brec, fp.cap_brec, (size_t)nb * 64 * sizeof(BundleRec)));
+    HIP_TRY(c, plan_reserve(fp.d_bhash, fp.cap_bhash, (size_t)nb * 64 * sizeof(uint2)));
+    hipLaunchKernelGGL((k_bundle_records<false>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart, nb, tmax, Ns,
+                       fp.d_brec, fp.d_bhash);
     fp.nchunks_lm = 0;      // the tricubic kernel's window set is computed by its first launch (ensure_lm_windows)
     HIP_TRY(c, hipGetLastError());
     if (getenv("IONOTOMO_PLAN_STATS")) {      // columns per window, both chunk lengths (stderr; tuning aid)
@@ -978,6 +995,19 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
             std::sort(cols.begin(), cols.end());
             std::sort(wys.begin(), wys.end());
             auto q = [&](const std::vector<int> &v, double f) { return v.empty() ? 0 : v[std::min(v.size() - 1, (size_t)(f * v.size()))]; };
+            if (!which) {      // wave-loads per window at rpl rows per load (the trilinear kernel's copy)
+                std::vector<int> nl, wxs;
+                for (const uint4 &w : hv) {
+                    const int wx = (int)(w.w & 255u), rpl = std::max(1, (int)((w.w >> 20) & 15u));
+                    nl.push_back((wx + rpl - 1) / rpl), wxs.push_back(wx);
+                }
+                std::sort(nl.begin(), nl.end());
+                std::sort(wxs.begin(), wxs.end());
+                double mean = 0;
+                for (int v : nl) mean += v;
+                fprintf(stderr, "[plan] wave-loads per window: mean %.2f p50 %d p75 %d p90 %d p95 %d p99 %d max %d; wx p50 %d p90 %d p99 %d max %d\n", mean / nl.size(),
+                        q(nl, 0.5), q(nl, 0.75), q(nl, 0.9), q(nl, 0.95), q(nl, 0.99), nl.back(), q(wxs, 0.5), q(wxs, 0.9), q(wxs, 0.99), wxs.back());
+            }
             fprintf(stderr, "[plan] %s windows: %zu, fit %.4f, columns p10 %d p50 %d p90 %d p99 %d max %d; wy p50 %d p99 %d max %d\n",
                     which ? "4-sample" : "8-sample", hv.size(), (double)nfit / hv.size(), q(cols, 0.1), q(cols, 0.5), q(cols, 0.9), q(cols, 0.99),
                     cols.back(), q(wys, 0.5), q(wys, 0.99), wys.back());
@@ -1043,9 +1073,9 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             //  not fit the LDS image, or bundles of a few rays.  IONOTOMO_VARIANT=12 forces the bundle kernel)
             // bundle-stationary: one workgroup per planned bundle of <= 64 rays, windows staged in LDS (iono_forward_plan_dev)
             const iono_ctx::FwdPlan &fp = c->fplan;
-            hipLaunchKernelGGL((k_forward_bundle<0>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double),
-                               c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec, c->d_flags,
-                               PhaseFreqs{}, 0);
+            hipLaunchKernelGGL((k_forward_bundle<0>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double) + 16,
+                               c->stream, g, o, d, fp.d_brec, fp.d_bhash, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec,
+                               c->d_flags, PhaseFreqs{}, 0);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c) && lanes_are_rays(c, R, order)) {
             // lanes = 64 neighbouring rays of the walk order; one wave-task per 64 rays (A/B: IONOTOMO_VARIANT=11)
             const int64_t tasks = (R + 63) / 64;
@@ -1072,7 +1102,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             const iono_ctx::FwdPlan &fp = c->fplan;
             static_assert(BL_LDS_BYTES <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
             hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES, c->stream, g, c->d_FP,
-                               padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
+                               padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.d_rhash, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
                                c->d_flags, c->variant == 16 ? 0 : 1);      // (IONOTOMO_VARIANT=16: one pair per wave for every window, A/B)
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
@@ -1307,11 +1337,12 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         return IONO_OK;                                  // no plan: the ray-stationary kernels serve this case
     iono_ctx::AdjPlan &pl = c->plan;
     HIP_TRY(c, plan_reserve(pl.d_uray, pl.cap_uray, (size_t)R * 8 * sizeof(double)));
+    HIP_TRY(c, plan_reserve(pl.d_hash, pl.cap_hash, (size_t)R * sizeof(uint2)));
     const GridView g = view(c);
     if (cubic)
-        hipLaunchKernelGGL((k_plan_urays<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray);
+        hipLaunchKernelGGL((k_plan_urays<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray, pl.d_hash);
     else
-        hipLaunchKernelGGL((k_plan_urays<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray);
+        hipLaunchKernelGGL((k_plan_urays<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray, pl.d_hash);
     HIP_TRY(c, hipGetLastError());
     const int nbx = (c->nx - 1 + BIN_SX - 1) / BIN_SX, nby = (c->ny - 1 + BIN_SY - 1) / BIN_SY, nbz = (c->nz - 1 + BIN_SZ - 1) / BIN_SZ;
     const int64_t nbox = (int64_t)nbx * nby * nbz;
@@ -1531,9 +1562,12 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             HIP_TRY(c, hipMalloc((void **)&c->d_rayw, (size_t)R * sizeof(double)));
             c->rayw_cap = R;
         }
+        // (+ the check that the rays are still the planned ones, in the same pass: plan_verify_ray)
         hipLaunchKernelGGL((k_ray_weights<MODE == 0 ? 1 : MODE>), dim3(ew_blocks(c, NtNd * 64)), dim3(256), 0, c->stream, tec, dobs,
-                           cdct, Na, NtNd, i0, c->d_rayw);
+                           cdct, Na, NtNd, i0, c->d_rayw, o, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
         wr = c->d_rayw;
+    } else if (planned) {
+        hipLaunchKernelGGL(k_plan_verify, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, o, d, R, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
     }
     const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);      // float64 box image for either AT
     if (planned && kind == IONO_INTERP_TRILINEAR) {
@@ -1688,8 +1722,8 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
             const iono_ctx::FwdPlan &fp = c->fplan;
 #define PHASE_B(NF)                                                                                                                        \
     hipLaunchKernelGGL((k_forward_bundle<NF>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block,                                               \
-                       B_SPLIT * B_WAVE_LDS + NF * B_SPLIT * 64 * sizeof(double), c->stream, g, o, d, fp.d_order, fp.d_bstart, fp.d_win, fp.nb, \
-                       fp.nchunks, tmax, Ns, c->d_unitw, phi_work + f0, c->d_flags, pf, Nf)
+                       B_SPLIT * B_WAVE_LDS + NF * B_SPLIT * 64 * sizeof(double) + 16, c->stream, g, o, d, fp.d_brec, fp.d_bhash, fp.d_win, \
+                       fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, phi_work + f0, c->d_flags, pf, Nf)
             if (pf.nf == 1) PHASE_B(1);
             else if (pf.nf <= 4) PHASE_B(4);
             else PHASE_B(8);
@@ -1738,6 +1772,8 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
     const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax &&
                          pl.kind == IONO_INTERP_TRILINEAR && c->variant != 2 && c->variant != 7;
     if (planned && pl.n_invalid > 0) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_flags, 1, 1, c->stream));   // out-of-grid rays
+    if (planned)      // the rays handed over are still the planned ones? (plan_verify_ray)
+        hipLaunchKernelGGL(k_plan_verify, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, o, d, R, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
     for (int f0 = 0; f0 < Nf; f0 += 8) {
         const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
         rc = dispatch_storage(c, [&](auto *tag) -> int {
@@ -1814,6 +1850,20 @@ int iono_gradient_chords(iono_ctx *c, const double *rays, const double *dd, int6
 int iono_check_oob(iono_ctx *c, int *oob) {
     if (!c || !oob) return fail(c, IONO_ERR_ARG, "null argument");
     return read_flag(c, 0, oob);
+}
+// 1 (and the flag is cleared) if a planned launch since the last call met rays that are not the ones its plan was made for -- the
+// caller edited a planned array in place.  The forward then took the direct loads (its results are exact whatever the bundling); a
+// back-projection poisoned the edited rays' weights with NaN.  Waits for the ctx stream.
+#ifdef IONO_B_STAMP      // timing-only build: the forward bundle kernel's in-kernel stamps (8 x uint64 per wave, 4 waves per workgroup)
+extern "C" int iono_debug_bundle_stamps(iono_ctx *c, unsigned long long *out, size_t count) {
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bstamp), count * sizeof(unsigned long long)));
+    return IONO_OK;
+}
+#endif
+int iono_plan_stale(iono_ctx *c, int *stale) {
+    if (!c || !stale) return fail(c, IONO_ERR_ARG, "null argument");
+    return read_flag(c, 2, stale);
 }
 
 // ---- host-pointer wrappers --------------------------------------------------------------------

@@ -182,7 +182,8 @@ class RayEngine(object):
         """Bundle the rays ONCE (geometry only): later ``forward`` calls with these same two tensors give every workgroup a
         bundle of <= 64 nearly coincident rays whose voxel neighbourhood is staged in LDS
         (include/ionotomo_hip.h:iono_forward_plan_dev).  Returns (bundles, chunks per ray, fraction of chunks served from LDS)
-        -- (0, 0, 0.0) when no plan applies (non-uniform grid, float32 storage).  Keep the tensors alive and unchanged."""
+        -- (0, 0, 0.0) when no plan applies (non-uniform grid, float32 storage).  Keep the tensors alive; a planned launch checks a
+        64-bit checksum per ray and falls back to direct loads (exact) for bundles whose rays were edited in place: ``plan_stale``."""
         import ctypes
         self._sync_stream()
         self.ctx.call("iono_forward_plan_dev", _ptr(origins_t), _ptr(dirs_t), origins_t.shape[0], float(tmax), int(Ns))
@@ -557,3 +558,17 @@ class RayEngine(object):
 
     def check_oob(self):
         return self.ctx.check_oob()
+
+    def plan_stale(self):
+        """True (flag cleared) if a planned launch since the last call was handed rays that are not the ones its plan was made
+        for -- a planned tensor was edited in place (``o_t.copy_(new)``).  The forward took the direct loads for the bundles
+        concerned (its TEC is exact whatever the bundling: the result is still correct, just slower); a back-projection poisoned
+        the edited rays, so its result holds NaN.  Synchronises the stream (include/ionotomo_hip.h:iono_plan_stale)."""
+        return self.ctx.plan_stale()
+
+    def check_plans(self):
+        """Raise ``ValueError`` (IONO_ERR_ARG semantics) if ``plan_stale()``: re-plan (``plan_forward`` / ``plan_adjoint``) after
+        changing planned ray tensors in place."""
+        if self.plan_stale():
+            raise ValueError("a planned ray tensor was modified in place after plan_forward / plan_adjoint: forward results were "
+                             "computed without the plan, back-projections of the modified rays are NaN; build the plans again")

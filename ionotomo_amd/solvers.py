@@ -193,6 +193,14 @@ def _backproject_weights(problem, w, s_full):
     return eng.adjoint(problem.origins, problem.dirs, w, problem.tmax, problem.Ns, out=s_full, order=problem._adjoint_order())
 
 
+def _check_plans(eng):
+    """A solve ends with a read-back anyway: raise if any planned launch in it was handed rays its plan was not made for (a planned
+    tensor edited in place: engine.RayEngine.check_plans; engines without plans -- the CPU test engine -- have nothing to check)."""
+    chk = getattr(eng, "check_plans", None)
+    if chk is not None:
+        chk()
+
+
 def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=None, pgtol=PGTOL, graph=False, small_pass=False):
     """x_{k+1} = x_k + relax * C A^T L (d - A x_k),  A = differenced ray operator; L, C from row / column sums of |A|
     bounded by the un-differenced sums (keeps rho <= 1; geometry/oct_trees/Inversion.py:559,564).
@@ -309,6 +317,7 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
         eng.bind_values(None)
     out = x_full.clone(), _history(hist, problem if defer else None)
     del held
+    _check_plans(eng)
     return out
 
 
@@ -427,6 +436,7 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
     x.view(-1).index_copy_(0, il, x_c)
     out = x, _history(hist, problem if multi else None)
     del held
+    _check_plans(eng)
     return out
 
 
@@ -466,6 +476,7 @@ def steepest_descent_log_model(problem, m0, K_scale, m_prior=None, prior_weight=
         m.addcmul_(dm, eps, value=-1.0)                              # m -= eps dm
         if k >= min_iter and float(eps.abs() * torch.linalg.vector_norm(dm, ord=float("inf"))) <= PGTOL:   # read-back 2
             break
+    _check_plans(problem.engine)
     return m, hist
 
 
@@ -512,4 +523,5 @@ def steepest_descent_phase(eng, origins, dirs, Na, Nt, Nd, tmax, Ns, freqs, cloc
         step = eps * dm
         step_max = float(step.abs().max())
         mu -= step
+    _check_plans(eng)
     return mu, hist

@@ -62,7 +62,7 @@ for rnd in range(7):
         times[spec].append(a.elapsed_time(b) / 10)
         if ref is None:
             ref = out.clone()
-        elif "f32" not in spec:
+        elif "f32" not in spec and not os.environ.get("IONO_AB_NOCHECK"):
             assert float((out - ref).abs().max() / ref.abs().max()) < 1e-12, spec
 for spec in times:
     t = np.array(times[spec])

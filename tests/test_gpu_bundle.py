@@ -343,3 +343,64 @@ def test_bundle_tricubic_one_pair_per_wave_variant(monkeypatch):
     for got, direct in res.values():
         assert float((got - direct).abs().max()) < 1e-12 * scale
     assert float((res["0"][0] - res["16"][0]).abs().max()) < 1e-12 * scale
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_planned_tensors_edited_in_place_never_give_garbage(OC, interp):
+    """a plan is keyed on device pointers -- ``o_t.copy_(new)`` into planned tensors used to make k_forward_bundle
+    interpolate from LDS addresses outside the staged window.  Every planned launch now checks a 64-bit checksum per ray against the
+    plan's: the forward recomputes the bundles concerned from the arrays with direct loads (exact), the back-projection poisons
+    the edited rays (NaN, never a plausible number), both raise the flag ``plan_stale`` / ``check_plans`` report."""
+    import bench
+    from oracle import oracle as O
+    w = bench.build_workload(0)
+    sel = np.arange(bench.NA * bench.NT * bench.ND).reshape(bench.NA, bench.NT, bench.ND)[:, :10].reshape(-1)      # 26 040 rays
+    o, d = w["origins"][sel].copy(), w["directions"][sel].copy()
+    eng = engine(w["xvec"], w["yvec"], w["zvec"], interp=interp)
+    eng.set_log_model(eng.tensor(w["m"]), w["K_ne"] / 1e13)
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    nb, _, fit = eng.plan_forward(ot, dt, bench.TMAX, bench.NS)
+    assert nb > 0 and fit > 0.9
+    planned = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
+    assert not eng.plan_stale()
+    # (1) a handful of rays edited in place: other directions, one moved to another station
+    rng = np.random.default_rng(3)
+    o2, d2 = o.copy(), d.copy()
+    hit = rng.choice(len(o), size=40, replace=False)
+    d2[hit, :2] += rng.normal(size=(40, 2)) * 0.02
+    o2[hit[0]] = o[(hit[0] + 5000) % len(o)]
+    ot.copy_(eng.tensor(o2))
+    dt.copy_(eng.tensor(d2))
+    got = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
+    assert eng.plan_stale() and not eng.plan_stale()                        # raised once, cleared by the read
+    eng2 = engine(w["xvec"], w["yvec"], w["zvec"], interp=interp)            # the same rays on a context that never saw a plan
+    eng2.set_log_model(eng2.tensor(w["m"]), w["K_ne"] / 1e13)
+    fresh = eng2.forward(eng2.tensor(o2), eng2.tensor(d2), bench.TMAX, bench.NS).cpu().numpy()
+    assert np.all(np.isfinite(got))
+    assert np.max(np.abs(got - fresh)) <= 1e-12 * np.max(np.abs(fresh))
+    assert np.max(np.abs(got[hit] - planned[hit])) > 1e-6 * np.max(np.abs(planned))          # (the edit did change those rays)
+    keep = np.setdiff1d(np.arange(len(o)), hit)
+    assert np.max(np.abs(got[keep] - planned[keep])) <= 1e-12 * np.max(np.abs(planned))
+    # (2) a full rewrite: every ray another ray
+    ot.copy_(eng.tensor(o[::-1].copy()))
+    dt.copy_(eng.tensor(d[::-1].copy()))
+    got = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
+    assert np.max(np.abs(got - planned[::-1])) <= 1e-12 * np.max(np.abs(planned))
+    with pytest.raises(ValueError):
+        eng.check_plans()
+    # (3) a new plan on the rewritten tensors: planned path again, no flag
+    eng.plan_forward(ot, dt, bench.TMAX, bench.NS)
+    again = eng.forward(ot, dt, bench.TMAX, bench.NS).cpu().numpy()
+    assert not eng.plan_stale()
+    assert np.max(np.abs(again - planned[::-1])) <= 1e-12 * np.max(np.abs(planned))
+    # (4) the back-projection works from the plan's own ray records: edited rays come out as NaN + flag, never as the old rays' answer
+    eng.plan_adjoint(ot, dt, bench.TMAX, bench.NS)
+    y = eng.tensor(rng.normal(size=len(o)))
+    g0 = eng.adjoint(ot, dt, y, bench.TMAX, bench.NS).cpu().numpy()
+    assert np.all(np.isfinite(g0)) and not eng.plan_stale()
+    dt[hit[1], 0] += 0.01                                                     # ONE ray, in place
+    g1 = eng.adjoint(ot, dt, y, bench.TMAX, bench.NS).cpu().numpy()
+    assert eng.plan_stale() and np.isnan(g1).any()
+    eng.plan_adjoint(ot, dt, bench.TMAX, bench.NS)
+    g2 = eng.adjoint(ot, dt, y, bench.TMAX, bench.NS).cpu().numpy()
+    assert np.all(np.isfinite(g2)) and not eng.plan_stale() and np.max(np.abs(g2 - g0)) > 0.0
