@@ -28,13 +28,22 @@ namespace {
 #define BIN_BX (BIN_SX + 2 * BIN_H + 1)      // nodes of the box image along x (15)
 #define BIN_BY (BIN_SY + 2 * BIN_H + 1)
 #define BIN_BZ (BIN_SZ + 1)                  // 16 z nodes
-#define BIN_BZP 17                           // padded z stride (odd: columns start on different banks)
+#ifndef BIN_BZP
+#define BIN_BZP 16                           // z stride of the image in words.  NOT padded: ds_add_f64 is served in four groups of 16 lanes
+#endif                                       // with bank = word mod 16, a segment = one group = 16 consecutive levels, and a segment that
+                                             // changes column half-way keeps distinct banks only if the column strides are multiples of 16
+                                             // words (17: every such segment met a 2-way conflict: 16.2 against 8.2 cycles per instruction,
+                                             // profiles/r04_lds_atomic_probe.json; nine segments in ten change column at the bench geometry)
 #define BIN_SEG 16                           // most samples per segment = lanes per segment (a plan may use 4 or 8: `segl`)
-#define BIN_ENTRY_PAD 128                    // zero entries behind the list: the kernel prefetches two passes (of 256 / segl) ahead
+#define BIN_ENTRY_PAD 512                    // zero entries behind the list: the kernel prefetches three passes (of BIN_THREADS / segl <= 128) ahead
 #ifndef BIN_UNIT
-#define BIN_UNIT 512                         // segments per work unit (256: +6 %, 1024: +3 % on the bench geometry)
+#define BIN_UNIT 1024                        // segments per work unit (round 4, bench geometry, ms per back-projection: 256: 0.401, 512: 0.337, 1024: 0.322,
+                                             // 2048: 0.325, 4096: 0.324: zeroing + flushing a 29-KB image per unit against load balance)
 #endif
 #define BIN_TILE (BIN_BX * BIN_BY * BIN_BZP)
+#ifndef BIN_THREADS
+#define BIN_THREADS 256                      // threads per workgroup of k_adjoint_binned (one box image per workgroup)
+#endif
 
 struct BinUnit {
     int x0, y0, z0;      // first node of the box image
@@ -213,7 +222,7 @@ __device__ __forceinline__ double dpp_shr1(double v) {       // value of the pre
 // becomes a per-sample factor  sum_l wrf[r][l] / (2 n_p,l sqrt(1 - ne_k / n_p,l))  of the electron density ne_k interpolated at
 // the sample (gathered from the grid exactly as the forward kernel does), wray = wrf with row stride ldw.
 template <typename AT, bool CUBIC, int PNF = 0, typename GT = double, int SEGL = BIN_SEG>
-__global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
+__global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
                                                         const BinUnit *__restrict__ units, const double *__restrict__ wray,
                                                         int Ns, const double *__restrict__ unitw, AT *__restrict__ G, int field,
                                                         PhaseFreqs pf = PhaseFreqs{}, int ldw = 0) {
@@ -227,12 +236,14 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
     const BinUnit un = units[blockIdx.x];
     lds_barrier();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    constexpr int PASS = 256 / SEGL;                                             // segments per pass of the workgroup
+    constexpr int PASS = BIN_THREADS / SEGL;                                     // segments per pass of the workgroup
     const int sub = lane & (SEGL - 1), grp = wid * (64 / SEGL) + lane / SEGL;
     // The segment list and the ray records are dependent gathers (entry -> ray id -> ray record): software-pipelined two
     // deep so that a pass computes while the next pass's ray records and the one after's entries are in flight.
     struct RayRec {
-        double2 ux, uy, uz, uh;      // (f0, df) per axis in grid coordinates; (h, valid)
+        double2 ux, uy, uz;          // (f0, df) per axis in grid coordinates
+        double uh;                   // arc length per sample (the record's "valid" is not needed: only valid rays have segments;
+                                     //  8 bytes instead of 16 through the texture path, which returns 64 B per clock to a wave)
         double w[PNF > 0 ? PNF : 1]; // ray weight (PNF: one per frequency)
     };
     const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
@@ -241,7 +252,7 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
     auto load_ray = [&](const uint2 en) {
         const double2 *up = (const double2 *)(uray + (size_t)en.x * 8);
         RayRec r;
-        r.ux = up[0], r.uy = up[1], r.uz = up[2], r.uh = up[3];
+        r.ux = up[0], r.uy = up[1], r.uz = up[2], r.uh = ((const double *)up)[6];
         if (PNF > 0) {
 #pragma unroll
             for (int l = 0; l < (PNF > 0 ? PNF : 1); ++l) r.w[l] = wray[(size_t)en.x * ldw + l];
@@ -253,9 +264,35 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
     int e = un.e_lo + grp;
     uint2 en0 = load_entry(e), en1 = load_entry(e + PASS);
     RayRec r0 = load_ray(en0);
-    for (; e < un.e_hi; e += PASS) {
-        const uint2 en2 = load_entry(e + 2 * PASS);
-        const RayRec r1 = load_ray(en1);
+    // (round 4: the instruction diet of this loop -- 105 -> ~85 vector instructions per pass: clamps without the NaN canonicalisation
+    //  fmin() implies, node and image indices by 24-bit multiply-adds instead of 64-bit ones (nx ny <= 2^24 is a condition of the plan),
+    //  (1 - t) weights as differences, two passes per loop body so that the software pipeline's registers rename instead of moving)
+    const double lim_x = (double)(g.nx - 2), lim_y = (double)(g.ny - 2), lim_z = (double)(g.nz - 2);
+    // a * b + c on 24-bit operands, ONE full-rate instruction (the compiler turns small-integer index arithmetic into v_mad_u64_u32 +
+    // v_mul_lo_u32: quarter rate); b is wave-uniform
+    auto mad24 = [](unsigned a, unsigned b, unsigned c) {
+        unsigned o;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(o) : "v"(a), "s"(b), "v"(c));
+        return o;
+    };
+    // the box image's four columns at one level, as LDS atomics the compiler cannot merge with the global ones of the other branch
+    // (it formed ONE flat atomic out of the two branches' last atomics: flat atomics are slower than either kind)
+    auto tile_add4 = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:%5\n\tds_add_f64 %0, %3 offset:%6\n\tds_add_f64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8), "n"(BIN_BY * BIN_BZP * 8), "n"((BIN_BY + 1) * BIN_BZP * 8) : "memory");
+    };
+    auto tile_add4_up = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_f64 %0, %1 offset:8\n\tds_add_f64 %0, %2 offset:%5\n\tds_add_f64 %0, %3 offset:%6\n\tds_add_f64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8 + 8), "n"(BIN_BY * BIN_BZP * 8 + 8), "n"((BIN_BY + 1) * BIN_BZP * 8 + 8) : "memory");
+    };
+    const unsigned tile_base = (unsigned)(size_t)tile;
+    auto clampf = [](double v, double lim) {
+        double o;
+        asm("v_min_f64 %0, %1, %2" : "=v"(o) : "v"(v), "v"(lim));
+        return o;
+    };
+    // one pass: the 256 / SEGL segments en0 (ray records r0) of this workgroup, entry index e
+    auto pass = [&](const uint2 en0, const RayRec &r0, const int e) {
         const int cnt = e < un.e_hi ? (int)((en0.y >> 16) & 0xffu) : 0, k = min((int)(en0.y & 0xffffu) + sub, Ns - 1);
         // every lane computes (no divergence before the lane exchange below); inactive lanes carry zero weights
         const double kd = (double)k;
@@ -267,27 +304,36 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
 #pragma unroll
             for (int l = 0; l < (PNF > 0 ? PNF : 1); ++l) wr += r0.w[l] * (0.5 * pf.inv_np[l]) * rsqrt(1.0 - ne * pf.inv_np[l]);
         }
-        const double c = sub < cnt ? wr * r0.uh.x * wlds[k] : 0.0;
+        const double c = sub < cnt ? wr * r0.uh * wlds[k] : 0.0;
         const bool active = c != 0.0;
-        const double fi = fmin(__builtin_floor(__builtin_fabs(fx)), (double)(g.nx - 2)),
-                     fj = fmin(__builtin_floor(__builtin_fabs(fy)), (double)(g.ny - 2)),
-                     fk = fmin(__builtin_floor(__builtin_fabs(fz)), (double)(g.nz - 2));
-        double ax0, ax1, ay0, ay1, az0, az1;
-        axis_pair(fx - fi, field & 1, CUBIC, ax0, ax1);
-        axis_pair(fy - fj, field & 2, CUBIC, ay0, ay1);
-        axis_pair(fz - fk, field & 4, CUBIC, az0, az1);
-        const double w0 = c * ax0, w1 = c * ax1;
-        const double w00 = w0 * ay0, w01 = w0 * ay1, w10 = w1 * ay0, w11 = w1 * ay1;
+        const double fi = clampf(__builtin_floor(__builtin_fabs(fx)), lim_x), fj = clampf(__builtin_floor(__builtin_fabs(fy)), lim_y),
+                     fk = clampf(__builtin_floor(__builtin_fabs(fz)), lim_z);
+        double w00, w01, w10, w11, l00, l01, l10, l11, u00, u01, u10, u11;
+        if (CUBIC) {
+            double ax0, ax1, ay0, ay1, az0, az1;
+            axis_pair(fx - fi, field & 1, CUBIC, ax0, ax1);
+            axis_pair(fy - fj, field & 2, CUBIC, ay0, ay1);
+            axis_pair(fz - fk, field & 4, CUBIC, az0, az1);
+            const double w0 = c * ax0, w1 = c * ax1;
+            w00 = w0 * ay0, w01 = w0 * ay1, w10 = w1 * ay0, w11 = w1 * ay1;
+            l00 = w00 * az0, l01 = w01 * az0, l10 = w10 * az0, l11 = w11 * az0;      // to the 4 columns at level kz
+            u00 = w00 * az1, u01 = w01 * az1, u10 = w10 * az1, u11 = w11 * az1;      // ... at level kz + 1
+        } else {
+            // trilinear: weights (1 - t, t) per axis as x (1 - t) = x - x t: one multiply and one subtraction per split
+            const double tx = fx - fi, ty = fy - fj, tz = fz - fk;
+            const double w1 = c * tx, w0 = c - w1;
+            w01 = w0 * ty, w00 = w0 - w01, w11 = w1 * ty, w10 = w1 - w11;
+            u00 = w00 * tz, u01 = w01 * tz, u10 = w10 * tz, u11 = w11 * tz;
+            l00 = w00 - u00, l01 = w01 - u01, l10 = w10 - u10, l11 = w11 - u11;
+        }
         const int i = (int)fi, j = (int)fj, kz = (int)fk;
-        double l00 = w00 * az0, l01 = w01 * az0, l10 = w10 * az0, l11 = w11 * az0;      // to the 4 columns at level kz
-        const double u00 = w00 * az1, u01 = w01 * az1, u10 = w10 * az1, u11 = w11 * az1;  // ... at level kz + 1
         // Consecutive samples of a ray mostly sit in consecutive z cells of the same (i, j) column: the upper-level
         // contributions of lane s then hit the very nodes of lane s + 1's lower level.  Pass them one lane up inside the
         // 16-lane DPP row (row_shr:1) and let the receiver add them to its own before its LDS atomics: 4 + (rarely 4)
         // instead of 8 LDS atomics per sample -- the kernel is bound by LDS atomic throughput.  (The test is on the NODE, not
         // on the ray: with narrower segments lane s and lane s + 1 may belong to different rays of the unit; a contribution
         // that meets the cell below its own is merged all the same, into the same LDS word it would have gone to.)
-        const int lin = active ? (i * g.ny + j) * g.nz + kz : -7;
+        const int lin = active ? (int)mad24(mad24((unsigned)i, (unsigned)g.ny, (unsigned)j), (unsigned)g.nz, (unsigned)kz) : -7;
         const int prev = __builtin_amdgcn_update_dpp(-9, lin, 0x111, 0xf, 0xf, false);          // row_shr:1 (row lane 0 keeps -9)
         const bool accept = active && prev + 1 == lin;
         const double p00 = dpp_shr1(u00), p01 = dpp_shr1(u01), p10 = dpp_shr1(u10), p11 = dpp_shr1(u11);
@@ -297,28 +343,30 @@ __global__ __launch_bounds__(256) void k_adjoint_binned(GridView g, const double
         if (active) {
             const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
             if ((a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1))) {
-                double *t = tile + ((int)a * BIN_BY + (int)b) * BIN_BZP + (int)m;
-                atomicAdd(t, l00);
-                atomicAdd(t + BIN_BZP, l01);
-                atomicAdd(t + BIN_BY * BIN_BZP, l10);
-                atomicAdd(t + (BIN_BY + 1) * BIN_BZP, l11);
-                if (upper) {
-                    atomicAdd(t + 1, u00);
-                    atomicAdd(t + BIN_BZP + 1, u01);
-                    atomicAdd(t + BIN_BY * BIN_BZP + 1, u10);
-                    atomicAdd(t + (BIN_BY + 1) * BIN_BZP + 1, u11);
-                }
+                const unsigned t = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
+                tile_add4(t, l00, l01, l10, l11);
+                if (upper) tile_add4_up(t, u00, u01, u10, u11);
             } else {
                 global_add4<AT>(G, i, j, kz, g.ny, g.nz, l00, l01, l10, l11);
                 if (upper) global_add4<AT>(G, i, j, kz + 1, g.ny, g.nz, u00, u01, u10, u11);
             }
         }
-        en0 = en1, en1 = en2, r0 = r1;
+    };
+    // two passes per loop body (the DPP exchange is a convergent operation: the compiler does not unroll such a loop by itself), so
+    // that the registers of the software pipeline -- entries three passes ahead, ray records one -- rename instead of moving
+    for (; e < un.e_hi; e += 2 * PASS) {
+        const uint2 en2 = load_entry(e + 2 * PASS);
+        const RayRec r1 = load_ray(en1);
+        pass(en0, r0, e);
+        const uint2 en3 = load_entry(e + 3 * PASS);
+        r0 = load_ray(en2);
+        pass(en1, r1, e + PASS);
+        en0 = en2, en1 = en3;
     }
     lds_barrier();
     // ---- flush the box once: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
     const int m = threadIdx.x & 15;
-    for (int col = threadIdx.x >> 4; col < BIN_BX * BIN_BY; col += 16) {
+    for (int col = threadIdx.x >> 4; col < BIN_BX * BIN_BY; col += BIN_THREADS / 16) {
         const double v = tile[col * BIN_BZP + m];
         if (v != 0.0) {
             const int a = col / BIN_BY, b = col - a * BIN_BY;

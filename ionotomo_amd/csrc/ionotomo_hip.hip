@@ -1333,7 +1333,8 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     plan_reset(c);
     const bool cubic = kind == IONO_INTERP_TRICUBIC;
-    if (R == 0 || R > (int64_t)UINT32_MAX || Ns > 65535 || !(cubic ? cubic_fast_ok(c, Ns) : ideal_path_ok(c, Ns)))
+    if (R == 0 || R > (int64_t)UINT32_MAX || Ns > 65535 || !(cubic ? cubic_fast_ok(c, Ns) : ideal_path_ok(c, Ns)) ||
+        (int64_t)c->nx * c->ny > ((int64_t)1 << 24) || c->nz >= (1 << 24))      // (k_adjoint_binned forms node indices with 24-bit multiply-adds)
         return IONO_OK;                                  // no plan: the ray-stationary kernels serve this case
     iono_ctx::AdjPlan &pl = c->plan;
     HIP_TRY(c, plan_reserve(pl.d_uray, pl.cap_uray, (size_t)R * 8 * sizeof(double)));
@@ -1571,7 +1572,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
     }
     const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);      // float64 box image for either AT
     if (planned && kind == IONO_INTERP_TRILINEAR) {
-        BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(pl.n_units), dim3(256), bin_lds, c->stream, g,
+        BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds, c->stream, g,
                                             pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, grad, -1, PhaseFreqs{}, 0));
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
@@ -1586,7 +1587,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
         for (int f = 0; f < LM_NF; ++f) {
             if (planned) {
-                BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, true, 0, double, SL>), dim3(pl.n_units), dim3(256), bin_lds,
+                BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, true, 0, double, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds,
                                                     c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw,
                                                     c->d_G8 + (size_t)f * n, f, PhaseFreqs{}, 0));
                 continue;
@@ -1781,7 +1782,7 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
             if (planned) {      // node-stationary: box images in LDS, ne gathered per sample (iono_binned_kernels.h)
                 const size_t bl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
 #define PHASE_BIN(NF)                                                                                                              \
-    BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, NF, GT, SL>), dim3(pl.n_units), dim3(256), bl, c->stream, g, \
+    BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, NF, GT, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bl, c->stream, g, \
                                         pl.d_uray, pl.d_entries, pl.d_units, wrf_work + f0, Ns, c->d_unitw, grad, -1, pf, Nf))
                 if (pf.nf == 1) PHASE_BIN(1);
                 else if (pf.nf == 2) PHASE_BIN(2);
