@@ -35,7 +35,7 @@ namespace {
                                              // words (17: every such segment met a 2-way conflict: 16.2 against 8.2 cycles per instruction,
                                              // profiles/r04_lds_atomic_probe.json; nine segments in ten change column at the bench geometry)
 #define BIN_SEG 16                           // most samples per segment = lanes per segment (a plan may use 4 or 8: `segl`)
-#define BIN_ENTRY_PAD 512                    // zero entries behind the list: the kernel prefetches three passes (of BIN_THREADS / segl <= 128) ahead
+#define BIN_ENTRY_PAD 1024                   // zero entries behind the list: the kernels prefetch three passes (of <= 1024 / 4 segments) ahead
 #ifndef BIN_UNIT
 #define BIN_UNIT 1024                        // segments per work unit (round 4, bench geometry, ms per back-projection: 256: 0.401, 512: 0.337, 1024: 0.322,
                                              // 2048: 0.325, 4096: 0.324: zeroing + flushing a 29-KB image per unit against load balance)
@@ -373,6 +373,136 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
             const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + m;
             if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz)
                 atomicAdd(G + ((size_t)gi * g.ny + gj) * g.nz + gk, (AT)v);
+        }
+    }
+}
+
+// ---- tricubic transpose: FOUR derivative channels per traversal ---------------------------------------------------------------------
+// The Lekien-Marsden transpose scatters, per sample, Hermite weights X_p[cx] Y_q[cy] Z_r[cz] into channel (p, q, r) of the 8 corner
+// nodes (iono_cubic_kernels.h).  One k_adjoint_binned<.., CUBIC> pass per channel repeats everything that is NOT an LDS atomic eight
+// times -- entry and ray-record gathers through the texture path (0.6 busy), positions, clamps, the unit's zeroing and flush -- and
+// the LDS atomics are only half of a pass (profiles/r04_adjoint_pmc.json).  Here a workgroup of LM4_THREADS threads keeps the box images of
+// the four channels (p, q) in {0, 1}^2 of ONE z kind r (4 x 28.8 KB) and every lane scatters its sample into all four: positions,
+// records and the x / y Hermite sets once per sample, the z pair once, 4 x (4 + 4) LDS atomics with the same DPP hand-over of the
+// upper level.  Two launches (r = 0, 1) replace eight.
+#ifndef LM4_THREADS
+#define LM4_THREADS 1024
+#endif
+#define LM4_LDS_BYTES(Ns) (sizeof(double) * ((((size_t)(Ns) + 1) & ~(size_t)1) + 4 * (size_t)BIN_TILE))
+template <int SEGL>
+__global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
+                                                                    const BinUnit *__restrict__ units, const double *__restrict__ wray, int Ns,
+                                                                    const double *__restrict__ unitw, double *__restrict__ G8, int64_t nstride,
+                                                                    int rbit) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *wlds = (double *)smem;                                   // [Ns] quadrature weights
+    double *tile = wlds + ((Ns + 1) & ~1);                           // [4][BIN_BX * BIN_BY][BIN_BZP]: channel c = p + 2 q
+    for (int t = threadIdx.x; t < Ns; t += LM4_THREADS) wlds[t] = unitw[t];
+    for (int t = threadIdx.x; t < 4 * BIN_TILE; t += LM4_THREADS) tile[t] = 0.0;
+    const BinUnit un = units[blockIdx.x];
+    lds_barrier();
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int PASS = LM4_THREADS / SEGL;
+    const int sub = lane & (SEGL - 1), grp = wid * (64 / SEGL) + lane / SEGL;
+    struct RayRec {
+        double2 ux, uy, uz;
+        double uh, w;
+    };
+    auto load_ray = [&](const uint2 en) {
+        const double2 *up = (const double2 *)(uray + (size_t)en.x * 8);
+        RayRec r;
+        r.ux = up[0], r.uy = up[1], r.uz = up[2], r.uh = ((const double *)up)[6], r.w = wray[en.x];
+        return r;
+    };
+    const double lim_x = (double)(g.nx - 2), lim_y = (double)(g.ny - 2), lim_z = (double)(g.nz - 2);
+    auto clampf = [](double v, double lim) {
+        double o;
+        asm("v_min_f64 %0, %1, %2" : "=v"(o) : "v"(v), "v"(lim));
+        return o;
+    };
+    auto mad24 = [](unsigned a, unsigned b, unsigned c) {
+        unsigned o;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(o) : "v"(a), "s"(b), "v"(c));
+        return o;
+    };
+    auto tile_add4 = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %2 offset:%5\n\tds_add_f64 %0, %3 offset:%6\n\tds_add_f64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8), "n"(BIN_BY * BIN_BZP * 8), "n"((BIN_BY + 1) * BIN_BZP * 8) : "memory");
+    };
+    auto tile_add4_up = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_f64 %0, %1 offset:8\n\tds_add_f64 %0, %2 offset:%5\n\tds_add_f64 %0, %3 offset:%6\n\tds_add_f64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8 + 8), "n"(BIN_BY * BIN_BZP * 8 + 8), "n"((BIN_BY + 1) * BIN_BZP * 8 + 8) : "memory");
+    };
+    const unsigned tile_base = (unsigned)(size_t)tile;
+    auto pass = [&](const uint2 en0, const RayRec &r0, const int e) {
+        const int cnt = e < un.e_hi ? (int)((en0.y >> 16) & 0xffu) : 0, k = min((int)(en0.y & 0xffffu) + sub, Ns - 1);
+        const double kd = (double)k;
+        const double fx = fma(kd, r0.ux.y, r0.ux.x), fy = fma(kd, r0.uy.y, r0.uy.x), fz = fma(kd, r0.uz.y, r0.uz.x);
+        const double c = sub < cnt ? r0.w * r0.uh * wlds[k] : 0.0;
+        const bool active = c != 0.0;
+        const double fi = clampf(__builtin_floor(__builtin_fabs(fx)), lim_x), fj = clampf(__builtin_floor(__builtin_fabs(fy)), lim_y),
+                     fk = clampf(__builtin_floor(__builtin_fabs(fz)), lim_z);
+        // Hermite value (bit 0) and slope (bit 1) weights of the two nodes per axis: axis_pair (iono_adjoint_kernels.h)
+        double xv0, xv1, xs0, xs1, yv0, yv1, ys0, ys1, z0, z1;
+        axis_pair(fx - fi, 0, true, xv0, xv1);
+        axis_pair(fx - fi, 1, true, xs0, xs1);
+        axis_pair(fy - fj, 0, true, yv0, yv1);
+        axis_pair(fy - fj, 1, true, ys0, ys1);
+        axis_pair(fz - fk, rbit, true, z0, z1);
+        const int i = (int)fi, j = (int)fj, kz = (int)fk;
+        const int lin = active ? (int)mad24(mad24((unsigned)i, (unsigned)g.ny, (unsigned)j), (unsigned)g.nz, (unsigned)kz) : -7;
+        const int prev = __builtin_amdgcn_update_dpp(-9, lin, 0x111, 0xf, 0xf, false);          // row_shr:1 (row lane 0 keeps -9)
+        const bool accept = active && prev + 1 == lin;
+        const int taken = __builtin_amdgcn_update_dpp(0, (int)accept, 0x101, 0xf, 0xf, false);  // row_shl:1: did lane s + 1 take mine?
+        const bool upper = active && !taken;
+        const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
+        const bool inside = (a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1));
+        const unsigned t0 = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
+        const double cz0 = c * z0, cz1 = c * z1;
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+            const double x0 = (ch & 1) ? xs0 : xv0, x1 = (ch & 1) ? xs1 : xv1, y0 = (ch & 2) ? ys0 : yv0, y1 = (ch & 2) ? ys1 : yv1;
+            const double w00 = x0 * y0, w01 = x0 * y1, w10 = x1 * y0, w11 = x1 * y1;
+            double l00 = w00 * cz0, l01 = w01 * cz0, l10 = w10 * cz0, l11 = w11 * cz0;
+            const double u00 = w00 * cz1, u01 = w01 * cz1, u10 = w10 * cz1, u11 = w11 * cz1;
+            const double p00 = dpp_shr1(u00), p01 = dpp_shr1(u01), p10 = dpp_shr1(u10), p11 = dpp_shr1(u11);
+            if (accept) l00 += p00, l01 += p01, l10 += p10, l11 += p11;
+            if (active) {
+                if (inside) {
+                    const unsigned t = t0 + (unsigned)ch * (BIN_TILE * 8u);
+                    tile_add4(t, l00, l01, l10, l11);
+                    if (upper) tile_add4_up(t, u00, u01, u10, u11);
+                } else {
+                    double *G = G8 + (size_t)(4 * rbit + ch) * nstride;
+                    global_add4<double>(G, i, j, kz, g.ny, g.nz, l00, l01, l10, l11);
+                    if (upper) global_add4<double>(G, i, j, kz + 1, g.ny, g.nz, u00, u01, u10, u11);
+                }
+            }
+        }
+    };
+    int e = un.e_lo + grp;
+    uint2 en0 = entries[e], en1 = entries[e + PASS];
+    RayRec r0 = load_ray(en0);
+    for (; e < un.e_hi; e += 2 * PASS) {
+        const uint2 en2 = entries[e + 2 * PASS];
+        const RayRec r1 = load_ray(en1);
+        pass(en0, r0, e);
+        const uint2 en3 = entries[e + 3 * PASS];
+        r0 = load_ray(en2);
+        pass(en1, r1, e + PASS);
+        en0 = en2, en1 = en3;
+    }
+    lds_barrier();
+    // ---- flush the four images: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
+    const int mz = threadIdx.x & 15;
+    for (int cc = threadIdx.x >> 4; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / 16) {
+        const double v = tile[cc * BIN_BZP + mz];
+        if (v != 0.0) {
+            const int ch = cc / (BIN_BX * BIN_BY), col = cc - ch * (BIN_BX * BIN_BY);
+            const int a = col / BIN_BY, b = col - a * BIN_BY;
+            const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + mz;
+            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz)
+                atomicAdd(G8 + (size_t)(4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk, v);
         }
     }
 }

@@ -155,6 +155,7 @@ struct iono_ctx {
     size_t pinned_cap = 0;
     char *h_plan = nullptr;          // pinned staging of the plan builders' host round trips (ray summaries, walk order: 8 MB at the
     size_t plan_pinned_cap = 0;      // bench shape; from pageable memory those copies were half of the 3 ms a forward plan took)
+    bool lm4_attr[3] = {false, false, false};      // k_adjoint_binned_lm4<SEGL>: > 64 KB of dynamic LDS allowed (hipFuncSetAttribute, once per context)
     double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
     int64_t rayw_cap = 0;
     double *d_freqs = nullptr;       // frequencies of the phase observable on the device (cached copy of h_freqs)
@@ -1585,7 +1586,22 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         const int64_t n = ncells(c);
         if (!c->d_G8) HIP_TRY(c, hipMalloc((void **)&c->d_G8, (size_t)n * LM_NF * sizeof(double)));
         HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
+        if (planned && c->variant != 21) {
+            // four channels (one z kind) per traversal: two launches instead of eight (k_adjoint_binned_lm4; IONOTOMO_VARIANT=21: A/B)
+            const size_t l4 = LM4_LDS_BYTES(Ns);
+            BY_SEGL(pl.segl, {
+                if (!c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2]) {
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_adjoint_binned_lm4<SL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                    c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2] = true;
+                }
+                for (int rb = 0; rb < 2; ++rb)
+                    hipLaunchKernelGGL((k_adjoint_binned_lm4<SL>), dim3(pl.n_units), dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray, pl.d_entries,
+                                       pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb);
+            });
+            HIP_TRY(c, hipGetLastError());
+        }
         for (int f = 0; f < LM_NF; ++f) {
+            if (planned && c->variant != 21) break;
             if (planned) {
                 BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, true, 0, double, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds,
                                                     c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw,

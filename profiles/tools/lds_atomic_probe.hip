@@ -16,7 +16,7 @@
 #include <cstdlib>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-template <int PAT>
+template <int PAT, int OP = 0>
 __global__ __launch_bounds__(256) void k_atom(int iters, double *out, unsigned long long *clk) {
     __shared__ double tile[15 * 15 * 19 + 512];
     for (int i = threadIdx.x; i < 15 * 15 * 19 + 512; i += 256) tile[i] = 0.0;
@@ -44,10 +44,14 @@ __global__ __launch_bounds__(256) void k_atom(int iters, double *out, unsigned l
         if (act) {
             const double v = 1.0;
             // the kernel's 8 atomics: 4 columns x 2 levels
-            asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %1 offset:8" ::"v"((unsigned)(size_t)t), "v"(v) : "memory");
-            asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %1 offset:8" ::"v"((unsigned)(size_t)(t + s17)), "v"(v) : "memory");
-            asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %1 offset:8" ::"v"((unsigned)(size_t)(t + s15)), "v"(v) : "memory");
-            asm volatile("ds_add_f64 %0, %1\n\tds_add_f64 %0, %1 offset:8" ::"v"((unsigned)(size_t)(t + s15 + s17)), "v"(v) : "memory");
+#define ATOM2(INS, A, V) asm volatile(INS " %0, %1\n\t" INS " %0, %1 offset:8" ::"v"((unsigned)(size_t)(A)), "v"(V) : "memory")
+            const float vf = 1.0f;
+            if (OP == 0) { ATOM2("ds_add_f64", t, v); ATOM2("ds_add_f64", t + s17, v); ATOM2("ds_add_f64", t + s15, v); ATOM2("ds_add_f64", t + s15 + s17, v); }
+            if (OP == 1) { ATOM2("ds_add_u64", t, v); ATOM2("ds_add_u64", t + s17, v); ATOM2("ds_add_u64", t + s15, v); ATOM2("ds_add_u64", t + s15 + s17, v); }
+            if (OP == 2) { ATOM2("ds_add_f32", t, vf); ATOM2("ds_add_f32", t + s17, vf); ATOM2("ds_add_f32", t + s15, vf); ATOM2("ds_add_f32", t + s15 + s17, vf); }
+            if (OP == 3) { ATOM2("ds_add_u32", t, vf); ATOM2("ds_add_u32", t + s17, vf); ATOM2("ds_add_u32", t + s15, vf); ATOM2("ds_add_u32", t + s15 + s17, vf); }
+            if (OP == 4) { ATOM2("ds_write_b64", t, v); ATOM2("ds_write_b64", t + s17, v); ATOM2("ds_write_b64", t + s15, v); ATOM2("ds_write_b64", t + s15 + s17, v); }
+            if (OP == 5) { ATOM2("ds_max_f64", t, v); ATOM2("ds_max_f64", t + s17, v); ATOM2("ds_max_f64", t + s15, v); ATOM2("ds_max_f64", t + s15 + s17, v); }
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1), "=s"(r1)::"memory");
@@ -55,15 +59,15 @@ __global__ __launch_bounds__(256) void k_atom(int iters, double *out, unsigned l
     if (threadIdx.x == 0) out[blockIdx.x] = tile[100];
     if (blockIdx.x == 0 && threadIdx.x == 0) clk[0] = c1 - c0, clk[1] = r1 - r0;
 }
-template <int PAT>
+template <int PAT, int OP = 0>
 void run(const char *name, int cus, int iters, double *out, unsigned long long *clk) {
     const int blocks = cus * 5;
     hipEvent_t a, b;
     CK(hipEventCreate(&a));
     CK(hipEventCreate(&b));
-    hipLaunchKernelGGL((k_atom<PAT>), dim3(blocks), dim3(256), 0, 0, iters, out, clk);
+    hipLaunchKernelGGL((k_atom<PAT, OP>), dim3(blocks), dim3(256), 0, 0, iters, out, clk);
     CK(hipEventRecord(a, 0));
-    hipLaunchKernelGGL((k_atom<PAT>), dim3(blocks), dim3(256), 0, 0, iters, out, clk);
+    hipLaunchKernelGGL((k_atom<PAT, OP>), dim3(blocks), dim3(256), 0, 0, iters, out, clk);
     CK(hipEventRecord(b, 0));
     CK(hipEventSynchronize(b));
     float ms = 0;
@@ -94,6 +98,12 @@ int main() {
     run<8>("seg16_stride17_column_change_i", cus, 4000, out, clk);
     run<9>("seg16_stride16_column_change_i", cus, 4000, out, clk);
     run<3>("same_word", cus, 500, out, clk);
+    run<7, 1>("u64_seg16_stride16_column_change", cus, 4000, out, clk);
+    run<0, 1>("u64_linear", cus, 4000, out, clk);
+    run<0, 2>("f32_linear", cus, 4000, out, clk);
+    run<0, 3>("u32_linear", cus, 4000, out, clk);
+    run<0, 4>("write_b64_linear", cus, 4000, out, clk);
+    run<0, 5>("max_f64_linear", cus, 4000, out, clk);
     printf("}\n");
     return 0;
 }
