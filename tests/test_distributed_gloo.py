@@ -1,5 +1,7 @@
-"""world_size-2 (and 3) gloo runs of the sharded path on CPU: partition by (time,direction)
-pair, forward without collective, adjoint + all-reduce, CGLS/SIRT iterates identical to one rank."""
+"""world_size-2, 3 and 8 gloo runs of the sharded path on CPU: partition by (time,direction)
+pair, forward without collective, adjoint + all-reduce, CGLS/SIRT iterates identical to one rank.  The world-8 cases shard
+config 4's layout (Na antennas x (Nt x Nd) pairs, pair blocks per rank) the way the 8-GPU SCALE run will, with every exchange
+mode."""
 import os
 import socket
 import sys
@@ -70,22 +72,28 @@ def _worker(rank, world, port, q, exchange, engine="oracle", size=None):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,exchange", [(2, "dense"), (2, "compact"), (3, "auto"), (2, "sharded"), (3, "sharded")])
-def test_sharded_path_matches_single_rank(world, exchange):
+SIZE8 = dict(na=5, nd=6, nt=4, n=12, Ns=13)          # 24 (time, direction) pairs: three per rank at world 8
+
+
+@pytest.mark.parametrize("world,exchange,size", [(2, "dense", None), (2, "compact", None), (3, "auto", None), (2, "sharded", None),
+                                                 (3, "sharded", None), (8, "dense", SIZE8), (8, "compact", SIZE8),
+                                                 (8, "sharded", SIZE8), (8, "auto", SIZE8)])
+def test_sharded_path_matches_single_rank(world, exchange, size):
     """``exchange``: the gradient all-reduce over the whole grid, or only over the nodes some ray touches."""
-    ref = _run(1)
+    ref = _run(1, size=size)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, "oracle", size)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=240) for _ in range(world))
+    res = dict(q.get(timeout=400) for _ in range(world))
     for p in procs:
-        p.join(timeout=60)
+        p.join(timeout=120)
         assert p.exitcode == 0
     blocks = [res[r]["block"] for r in range(world)]
-    assert blocks[0][0] == 0 and blocks[-1][1] == 10 and all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    assert blocks[0][0] == 0 and blocks[-1][1] == ref["P"] and all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+    assert all(b[1] > b[0] for b in blocks)                           # every rank holds pairs
     for r in range(world):
         assert np.allclose(res[r]["fwd"], ref["fwd"], rtol=1e-13, atol=1e-15)
         assert np.allclose(res[r]["adj"], ref["adj"], rtol=1e-11, atol=1e-14)
