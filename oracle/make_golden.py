@@ -332,6 +332,21 @@ def round2_fixtures(R, w, rays, m_tci, K_ne, ne_tci):
         outcome, detail = "raised " + type(exc).__name__, str(exc)
     np.savez_compressed(os.path.join(OUT, "covariance_contract_behaviour.npz"), phi=phi, d=np.array([5.0, 6.0, 7.0]),
                         outcome=outcome, detail=detail, meta=meta())
+    a_priori_fixture()
+
+
+def a_priori_fixture():
+    """SURVEY 8(c) golden item 8: the reference's self-contained Chapman-layer prior ``a_priori_model_`` (ionosphere/iri.py:20-68),
+    on which every synthetic benchmark input is built.  The module imports pyiri2016 (Fortran, absent) at its top for the OTHER
+    function: an inert stand-in lets the module load; ``a_priori_model_`` itself is pure numpy and runs unmodified."""
+    import importlib
+    sys.modules["pyiri2016"] = _Inert("pyiri2016")
+    iri = importlib.import_module("ionotomo.ionosphere.iri")
+    h = np.linspace(0.0, 1000.0, 401)
+    zen = np.array([0.0, 45.0, 80.0, 110.0])
+    thick = np.stack([iri.a_priori_model_(h, float(z)) for z in zen])
+    thin = np.stack([iri.a_priori_model_(h, float(z), thin_f=True) for z in zen])
+    np.savez_compressed(os.path.join(OUT, "a_priori_model.npz"), h=h, zenith=zen, ne=thick, ne_thin_f=thin, meta=meta())
 
 
 if __name__ == "__main__":

@@ -7,13 +7,16 @@ library.
 
 Pinned against the reference itself: tests/test_oracle_golden.py checks every
 function below against tests/golden/*.npz, which oracle/make_golden.py produced
-by running the reference's own functions in the build container.  Two pieces
-have no runnable reference and are "parity unpinned" by it (stated in
-DESIGN.md): the reference-era even-N ``simps(even='avg')`` rule (restated from
-the in-tree spec tomography/integrate.py:50-74,130-153) and the truly bending
-Fermat tracer (the shipped one zeroes its gradients, inversion/fermat.py:54-55;
-spec: notebooks/FermatClass.ipynb c0:60-96), which is cross-checked against
-scipy's LSODA on the same right-hand side instead.
+by running the reference's own functions in the build container -- including
+the reference-era even-N ``simps(even='avg')`` rule, pinned since round 3 by
+running the UNMODIFIED inversion/forward_equation.py on scipy 1.7.1
+(oracle/make_golden_conda.py -> forward_tec_even_simps_unmodified.npz; the
+rule itself is restated from tomography/integrate.py:50-74,130-153).  ONE
+piece has no runnable reference and stays "parity unpinned" (stated in
+DESIGN.md): the truly bending Fermat tracer (the shipped one zeroes its
+gradients, inversion/fermat.py:54-55; spec: notebooks/FermatClass.ipynb
+c0:60-96), which is cross-checked against scipy's LSODA on the same right-hand
+side instead.
 
 All ``file:line`` citations are relative to /root/reference/src/ionotomo/.
 """

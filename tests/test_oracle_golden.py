@@ -249,6 +249,20 @@ def test_matern_field_matches_reference_realisation(golden):
     assert it.a_priori_model_(np.array([110.0, 300.0]), 45.0).shape == (2,)
 
 
+def test_a_priori_chapman_profile_matches_the_reference(golden):
+    """ionosphere/iri.py:20-68 run unmodified (oracle/make_golden.py:a_priori_fixture): 401 heights x 4 solar zenith angles, thick
+    and thin F layers.  Every synthetic benchmark input is built on this profile (synthetic.make_workload)."""
+    import ionotomo_amd as it
+    g = golden("a_priori_model")
+    for iz, z in enumerate(g["zenith"]):
+        for key, thin in (("ne", False), ("ne_thin_f", True)):
+            got = it.a_priori_model_(g["h"], float(z), thin_f=thin)
+            assert got.shape == g["h"].shape
+            assert np.array_equal(got, g[key][iz]), (float(z), thin, float(np.max(np.abs(got - g[key][iz]) / g[key][iz])))
+    from ionotomo_amd.ionosphere.iri import chapman_profile
+    assert np.array_equal(syn.chapman_profile(g["h"], 45.0) if hasattr(syn, "chapman_profile") else chapman_profile(g["h"], 45.0), g["ne"][1])
+
+
 def test_tricubic_matches_notebook_lekien_marsden_coefficients(golden):
     g = golden("lm_tricubic")
     xv, yv, zv, M = g["xvec"], g["yvec"], g["zvec"], g["M"]
