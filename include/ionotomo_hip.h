@@ -166,6 +166,21 @@ int iono_adjoint_differential_straight_dev(iono_ctx *ctx, const double *origins_
                                            const int *order_dev, const double *v_dev, const double *scale_dev,
                                            int Na, int64_t NtNd, int i0, double tmax, int Ns, int interp_kind,
                                            int quad_rule, void *grad_dev, int accum_dtype);
+/* A solver iteration's ray-sized pass FUSED with the differential-weights pass of the back-projection that follows it: one small
+ * launch + the back-projection instead of two or three small launches + the back-projection (round 4; the loop these replace:
+ * inversion/iterative_newton.py:993-1000 -- forward, residual, gradient).  All vectors in ray layout [Na][NtNd]; `partial`
+ * (nullable): IONO_NPART per-workgroup partial sums, to be summed in order by the consumer (iono_vec_axpby_dot_dev et al.).
+ *   cg_step  : r -= (sum an / sum ad) q in place, partial = sum r^2; grad += A^T (scale o r)          (A = differenced operator)
+ *   sirt_step: v = dobs - (tec - tec[i0]); partial = sum v^2 weight; grad += A^T (scale o v); r_out (nullable) = v
+ * an / ad: device scalars given as (pointer, count) like iono_vec_axpby_dot_dev's. */
+int iono_adjoint_cg_step_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, const int *order_dev,
+                             double *r_dev, const double *q_dev, const double *an_dev, int an_count, const double *ad_dev, int ad_count,
+                             const double *scale_dev, int Na, int64_t NtNd, int i0, double tmax, int Ns, int interp_kind,
+                             int quad_rule, double *partial_dev, void *grad_dev, int accum_dtype);
+int iono_adjoint_sirt_step_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, const int *order_dev,
+                               const double *tec_dev, const double *dobs_dev, const double *scale_dev, const double *weight_dev, int Na,
+                               int64_t NtNd, int i0, double tmax, int Ns, int interp_kind, int quad_rule, double *r_out_dev,
+                               double *partial_dev, void *grad_dev, int accum_dtype);
 int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);
 /* Measured load balance of the two chunked kernels.  The straight-ray forward gives every resident wave one
  * contiguous chunk of the ray walk, the LDS-tiled adjoint every resident workgroup; the cost per ray varies with where

@@ -211,6 +211,55 @@ __global__ __launch_bounds__(256) void k_ray_weights(const double *__restrict__ 
     }
 }
 
+// ---- one pass over the rays where an iteration had two or three (round 4: launches per iteration) -----------------------------------
+//  MODE 0 (CGLS): r -= (an / ad) q, partial = sum r^2;                        w = differential weights of r * scale
+//                 (= k_axpby_dot + k_ray_weights<2>: 7 -> 6 launches per iteration)
+//  MODE 1 (SIRT): v = dobs - (tec - tec[i0]), partial = sum v^2 * weight;    w = differential weights of v * scale; r (nullable) = v
+//                 (= k_rays_combine + k_ray_weights<2>: 5 -> 4)
+// + the plan's ray check of the back-projection that follows (origins non-null).  One wave per (time, direction) pair, lanes =
+// antennas; one partial per workgroup, summed in a fixed order by the consumer (no atomics: identical bits on every rank).
+template <int MODE>
+__global__ __launch_bounds__(256) void k_rays_step(const double *__restrict__ tq, const double *__restrict__ dobs,
+                                                   const double *__restrict__ scale, const double *__restrict__ weight, double *__restrict__ r,
+                                                   const double *an, int ann, const double *ad, int adn, int Na, int64_t NtNd, int i0,
+                                                   double *__restrict__ w, double *__restrict__ partial, const double *__restrict__ origins,
+                                                   const double *__restrict__ dirs, const uint2 *__restrict__ hash, double *__restrict__ uray,
+                                                   int *__restrict__ flags) {
+    const double alpha = MODE == 0 ? -1.0 * read_scalar(an, ann) / read_scalar(ad, adn) : 0.0;
+    const int lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < NtNd; p += (int64_t)gridDim.x * 4) {
+        const double tref = MODE == 1 ? tq[(int64_t)i0 * NtNd + p] : 0.0;
+        double s = 0.0;
+        for (int a = lane; a < Na; a += 64) {
+            const int64_t i = (int64_t)a * NtNd + p;
+            if (origins) plan_verify_ray(origins, dirs, i, hash, uray, flags);
+            double v;
+            if (MODE == 0) {
+                v = fma(alpha, tq[i], 1.0 * r[i]);
+                r[i] = v;
+                acc += v * v;
+            } else {
+                v = -1.0 * (tq[i] - tref) + 1.0 * dobs[i];
+                if (r) r[i] = v;
+                acc += weight ? v * v * weight[i] : v * v;
+            }
+            const double vs = scale ? v * scale[i] : v;
+            w[i] = vs;                                       // (the reference-antenna row is corrected below)
+            s += vs;
+        }
+        s = wave_sum_dpp(s);
+        if (i0 % 64 == lane) {                               // the lane that wrote w[i0, p] (its own store: no fence needed)
+            const int64_t i = (int64_t)i0 * NtNd + p;
+            w[i] = w[i] - s;
+        }
+    }
+    if (partial) {
+        const double t = block_sum_bcast(acc);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
 __device__ __forceinline__ double dpp_shr1(double v) {       // value of the previous lane of the 16-lane row (0 for its first lane)
     // (bound_ctrl: the row's first lane reads 0 without an initialised destination -- eight v_mov fewer per pass)
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, true);

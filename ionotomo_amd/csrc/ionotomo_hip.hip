@@ -155,6 +155,7 @@ struct iono_ctx {
     size_t pinned_cap = 0;
     char *h_plan = nullptr;          // pinned staging of the plan builders' host round trips (ray summaries, walk order: 8 MB at the
     size_t plan_pinned_cap = 0;      // bench shape; from pageable memory those copies were half of the 3 ms a forward plan took)
+    bool plan_verified = false;      // the ray pass in front of a planned back-projection already checked the rays (k_rays_step)
     bool lm4_attr[3] = {false, false, false};      // k_adjoint_binned_lm4<SEGL>: > 64 KB of dynamic LDS allowed (hipFuncSetAttribute, once per context)
     double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
     int64_t rayw_cap = 0;
@@ -1568,9 +1569,10 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         hipLaunchKernelGGL((k_ray_weights<MODE == 0 ? 1 : MODE>), dim3(ew_blocks(c, NtNd * 64)), dim3(256), 0, c->stream, tec, dobs,
                            cdct, Na, NtNd, i0, c->d_rayw, o, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
         wr = c->d_rayw;
-    } else if (planned) {
+    } else if (planned && !c->plan_verified) {
         hipLaunchKernelGGL(k_plan_verify, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, o, d, R, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
     }
+    c->plan_verified = false;
     const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);      // float64 box image for either AT
     if (planned && kind == IONO_INTERP_TRILINEAR) {
         BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds, c->stream, g,
@@ -1674,6 +1676,53 @@ int iono_adjoint_differential_straight_dev(iono_ctx *c, const double *o, const d
     if (Na < 1 || NtNd < 0 || i0 < 0 || i0 >= Na || !v) return fail(c, IONO_ERR_ARG, "bad [Na][NtNd]/i0/v");
     return adjoint_straight_launch(c, 2, o, d, order, nullptr, v, nullptr, scale, Na, NtNd, i0, (int64_t)Na * NtNd, tmax, Ns,
                                    kind, rule, grad, accum);
+}
+
+// ---- a solver iteration's ray pass + back-projection: one small launch + the back-projection (include/ionotomo_hip.h) ----------
+static int rays_step_then_adjoint(iono_ctx *c, int mode, const double *o, const double *d, const int *order, const double *tq,
+                                  const double *dobs, const double *scale, const double *weight, double *r, const double *an, int ann,
+                                  const double *ad, int adn, int Na, int64_t NtNd, int i0, double tmax, int Ns, int kind, int rule,
+                                  double *partial, void *grad, int accum) {
+    const int64_t R = (int64_t)Na * NtNd;
+    int rc = check_common(c, R, Ns, kind, rule);
+    if (rc) return rc;
+    if (Na < 1 || NtNd < 0 || i0 < 0 || i0 >= Na || !tq) return fail(c, IONO_ERR_ARG, "bad [Na][NtNd] / i0 / vector");
+    if (ann > IONO_NPART || adn > IONO_NPART) return fail(c, IONO_ERR_ARG, "scalar count too large");
+    if (R == 0) return IONO_OK;
+    if (c->rayw_cap < R) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (c->d_rayw) (void)hipFree(c->d_rayw);
+        c->d_rayw = nullptr, c->rayw_cap = 0;
+        HIP_TRY(c, hipMalloc((void **)&c->d_rayw, (size_t)R * sizeof(double)));
+        c->rayw_cap = R;
+    }
+    const iono_ctx::AdjPlan &pl = c->plan;
+    const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax && pl.kind == kind &&
+                         c->variant != 2 && c->variant != 7;
+    const double *vo = planned ? o : nullptr;
+    if (mode == 0)
+        hipLaunchKernelGGL((k_rays_step<0>), dim3(IONO_NPART), dim3(256), 0, c->stream, tq, dobs, scale, weight, r, an, ann, ad, adn, Na, NtNd,
+                           i0, c->d_rayw, partial, vo, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
+    else
+        hipLaunchKernelGGL((k_rays_step<1>), dim3(IONO_NPART), dim3(256), 0, c->stream, tq, dobs, scale, weight, r, an, ann, ad, adn, Na, NtNd,
+                           i0, c->d_rayw, partial, vo, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
+    HIP_TRY(c, hipGetLastError());
+    c->plan_verified = planned;
+    return adjoint_straight_launch(c, 0, o, d, order, c->d_rayw, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, kind, rule, grad, accum);
+}
+int iono_adjoint_cg_step_dev(iono_ctx *c, const double *o, const double *d, const int *order, double *r, const double *q,
+                             const double *an, int ann, const double *ad, int adn, const double *scale, int Na, int64_t NtNd, int i0,
+                             double tmax, int Ns, int kind, int rule, double *partial, void *grad, int accum) {
+    if (!r || !an || !ad) return fail(c, IONO_ERR_ARG, "iono_adjoint_cg_step_dev: r, an, ad are required");
+    return rays_step_then_adjoint(c, 0, o, d, order, q, nullptr, scale, nullptr, r, an, ann, ad, adn, Na, NtNd, i0, tmax, Ns, kind, rule,
+                                  partial, grad, accum);
+}
+int iono_adjoint_sirt_step_dev(iono_ctx *c, const double *o, const double *d, const int *order, const double *tec, const double *dobs,
+                               const double *scale, const double *weight, int Na, int64_t NtNd, int i0, double tmax, int Ns, int kind,
+                               int rule, double *r_out, double *partial, void *grad, int accum) {
+    if (!dobs) return fail(c, IONO_ERR_ARG, "iono_adjoint_sirt_step_dev: dobs is required");
+    return rays_step_then_adjoint(c, 1, o, d, order, tec, dobs, scale, weight, r_out, nullptr, 0, nullptr, 0, Na, NtNd, i0, tmax, Ns, kind,
+                                  rule, partial, grad, accum);
 }
 
 int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int64_t R, int Ns, int kind, int rule, void *grad,

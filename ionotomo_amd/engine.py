@@ -216,6 +216,34 @@ class RayEngine(object):
                       _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 
+    def adjoint_cg_step(self, origins_t, dirs_t, r_t, q_t, an, ad, scale_t, Na, i0, tmax, Ns, out, order=None, want_dot=True):
+        """CGLS: r -= (an / ad) q in place, partials of <r, r>, out += A^T (scale o r) -- the residual update fused with the
+        back-projection's differential-weights pass (include/ionotomo_hip.h:iono_adjoint_cg_step_dev).  Returns the partials."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        assert R % Na == 0 and r_t.numel() == R and q_t.numel() == R
+        part = self._partial(want_dot)
+        (anp, ann), (adp, adn) = self._sc(an), self._sc(ad)
+        opt = lambda t: _lib._V(0) if t is None else _ptr(t)
+        self.ctx.call("iono_adjoint_cg_step_dev", _ptr(origins_t), _ptr(dirs_t), opt(order), _ptr(r_t), _ptr(q_t), anp, ann, adp, adn,
+                      opt(scale_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.kind, self.rule, opt(part), _ptr(out),
+                      _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+        return part
+
+    def adjoint_sirt_step(self, origins_t, dirs_t, tec_t, dobs_t, scale_t, weight_t, Na, i0, tmax, Ns, out, order=None, r_out=None,
+                          want_dot=True):
+        """SIRT: v = dobs - (tec - tec[i0]), partials of sum v^2 weight, out += A^T (scale o v) -- residual, objective and the
+        back-projection's differential-weights pass in one launch (iono_adjoint_sirt_step_dev).  Returns the partials."""
+        self._sync_stream()
+        R = origins_t.shape[0]
+        assert R % Na == 0 and tec_t.numel() == R and dobs_t.numel() == R
+        part = self._partial(want_dot)
+        opt = lambda t: _lib._V(0) if t is None else _ptr(t)
+        self.ctx.call("iono_adjoint_sirt_step_dev", _ptr(origins_t), _ptr(dirs_t), opt(order), _ptr(tec_t), _ptr(dobs_t), opt(scale_t),
+                      opt(weight_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.kind, self.rule, opt(r_out), opt(part),
+                      _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+        return part
+
     def adjoint_residual(self, origins_t, dirs_t, tec_t, dobs_t, cdct_t, Na, i0, tmax, Ns, out=None,
                          accum=torch.float64, order=None):
         """One launch: dd = (tec - tec[i0] - dobs)/(CdCt + 1e-15) -> differential weights -> G^T.

@@ -197,6 +197,21 @@ class ShardedRays(object):
         return self.engine.adjoint_differential(self.origins, self.dirs, v, scale, self.Na, self.i0, self.tmax, self.Ns,
                                                 out=out_full, order=self._adjoint_order())
 
+    def fused_steps(self):
+        """The engine fuses a solver's ray-sized pass with the back-projection's differential-weights pass (RayEngine does; the
+        CPU test engine does not)."""
+        return hasattr(self.engine, "adjoint_cg_step")
+
+    def backproject_cg_step(self, r, q, an, ad, scale, out_full):
+        """r -= (an / ad) q in place; out_full += (local rays) A^T (scale o r); returns the partials of <r, r>."""
+        return self.engine.adjoint_cg_step(self.origins, self.dirs, r, q, an, ad, scale, self.Na, self.i0, self.tmax, self.Ns,
+                                           out_full, order=self._adjoint_order())
+
+    def backproject_sirt_step(self, tec, scale, weight, out_full, r_out=None):
+        """v = dobs - (tec - tec[i0]); out_full += (local rays) A^T (scale o v); returns the partials of sum v^2 weight."""
+        return self.engine.adjoint_sirt_step(self.origins, self.dirs, tec, self.dobs, scale, weight, self.Na, self.i0, self.tmax,
+                                             self.Ns, out_full, order=self._adjoint_order(), r_out=r_out)
+
     # -- sharded model update (SURVEY 8e: "reduce-scatter by slab and keep the model update sharded") ------------------------
     def shard_len(self, n):
         """per-rank chunk length of a compact vector of n entries (even, so that chunk starts stay 16-byte aligned)"""

@@ -205,7 +205,8 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
     """x_{k+1} = x_k + relax * C A^T L (d - A x_k),  A = differenced ray operator; L, C from row / column sums of |A|
     bounded by the un-differenced sums (keeps rho <= 1; geometry/oct_trees/Inversion.py:559,564).
     One iteration = forward launch, ONE pass over the rays (residual + objective), fused differential back-projection,
-    ONE pass over the active nodes (update + re-zero + refresh of the grid the forward reads): 4 launches
+    ONE pass over the active nodes (update + re-zero + refresh of the grid the forward reads): 4 launches -- forward, ray pass
+    (k_rays_step: residual, objective, differential weights), back-projection, update
     (``_sirt_dense`` is the same arithmetic with full-grid torch vectors; used when a ``callback`` wants the iterate).
     ``stop="reference"``: the reference's stopping rule (``reference_stop``; ``n_iter`` is its max_iter) on the
     objective S = 1/2 sum r^2/CdCt and the largest model change per update -- one host read-back per iteration;
@@ -258,6 +259,9 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
     eng.bind_values(x_pad)
     hist, r, step = [], None, None
     small = _small(problem, small_pass)
+    # residual + objective + the back-projection's ray weights in ONE ray pass (4 launches per iteration instead of 5); with a
+    # stopping rule the objective is read back BEFORE the back-projection is started, so the passes stay apart there
+    fused = not small and not stop and problem.fused_steps()
     wbuf = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device) if small else None
     defer = multi and not stop                  # objective history: ONE stacked all-reduce at the end instead of one per iteration
     held = None
@@ -271,6 +275,8 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
                 if small:
                     S2, _, _ = eng.small_ray_pass(1, problem.forward_tec(), L, r, problem.Na, problem.i0, dobs=problem.dobs, weight=Wt, w=wbuf)
                     _backproject_weights(problem, wbuf, s_full)
+                elif fused:
+                    S2 = problem.backproject_sirt_step(problem.forward_tec(), L, Wt, s_full)
                 else:
                     _, S2 = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, -1.0, 1.0, dobs=problem.dobs, s2=Wt, out=r)
                     problem.backproject_differential(r, L, s_full)
@@ -286,6 +292,8 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
                 if r is None:
                     r = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device)
                 S2, _, _ = eng.small_ray_pass(1, tec, L, r, problem.Na, problem.i0, dobs=problem.dobs, weight=Wt, w=wbuf)   # r = d - A x, weights
+            elif fused:
+                S2 = problem.backproject_sirt_step(tec, L, Wt, s_full)          # r = d - A x, S, s_full += A^T (L r): one ray pass
             else:
                 r, S2 = eng.rays_combine(tec, problem.Na, problem.i0, -1.0, 1.0, dobs=problem.dobs, s2=Wt, out=r)   # r = d - A x
             hist.append(S2.sum().reshape(1) if defer else problem.scalar(S2))
@@ -293,7 +301,7 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
                 break
             if small:
                 _backproject_weights(problem, wbuf, s_full)
-            else:
+            elif not fused:
                 problem.backproject_differential(r, L, s_full)
             if sharded:
                 eng.compact_gather(s_full, idx, out=s_c[:n], zero=True, want_dot=False)
@@ -331,7 +339,8 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
     One iteration = forward launch (reads the search direction IN PLACE), one pass over the rays (q = W^1/2 A p and
     <q, q>), one (r -= alpha q and <r, r>), the fused differential back-projection, one gather over the active nodes
     (s and <s, s>, re-zeroing the back-projection buffer) and one update (x += alpha p, p = s + beta p, refresh of the
-    grid the forward reads): 6 launches, all scalars on the device as per-workgroup partial sums.
+    grid the forward reads): 6 launches (the second ray pass also forms the back-projection's differential weights: k_rays_step),
+    all scalars on the device as per-workgroup partial sums.
     ``damp`` > 0 (Tikhonov term: the gradient is then non-zero off the ray fan) or a ``callback`` use the dense-vector
     form ``_cgls_dense``.  ``stop="reference"``: the reference's stopping rule as in ``sirt``.  ``graph=True`` (one rank): iterations
     1 .. n-1 replayed from one hipGraph (``_run_iterations``).  ``small_pass``: at most 32 768 rays on one rank -- the three ray-sized
@@ -370,6 +379,7 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
         x_loc, p_loc = xg[lo:lo + per].clone(), pg[lo:lo + per].clone()
     hist, q = [rr.sum().reshape(1) if multi else rr], None
     small = _small(problem, small_pass)
+    fused = not small and problem.fused_steps()      # r -= alpha q, <r, r> and the back-projection's ray weights in ONE ray pass (6 launches, not 7)
     wbuf = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device) if small else None
     held = None
     try:
@@ -383,6 +393,9 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
                 if small:
                     qq, rr, _ = eng.small_ray_pass(0, problem.forward_tec(), Wh, r, problem.Na, problem.i0, q=q, gamma=gam, w=wbuf)
                     _backproject_weights(problem, wbuf, s_full)
+                elif fused:
+                    _, qq = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, 1.0, 0.0, s1=Wh, out=q)
+                    rr = problem.backproject_cg_step(r, q, gam, qq, Wh, s_full)
                 else:
                     _, qq = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, 1.0, 0.0, s1=Wh, out=q)
                     rr = eng.axpby_dot_(r, q, an=gam, ad=qq, a_sign=-1.0)
@@ -403,12 +416,15 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
             else:
                 q, qq = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, 1.0, 0.0, s1=Wh, out=q)      # W^1/2 A p
                 qq = problem.scalar(qq)
-                rr = eng.axpby_dot_(r, q, an=gamma, ad=qq, a_sign=-1.0)         # r -= alpha q
+                if fused:
+                    rr = problem.backproject_cg_step(r, q, gamma, qq, Wh, s_full)   # r -= alpha q, <r, r>, s_full += A^T (W^1/2 r)
+                else:
+                    rr = eng.axpby_dot_(r, q, an=gamma, ad=qq, a_sign=-1.0)         # r -= alpha q
             if k + 1 < n_iter:
                 hist.append(rr.sum().reshape(1) if multi else rr)           # sharded rays: summed over ranks once, at the end
             if small:
                 _backproject_weights(problem, wbuf, s_full)
-            else:
+            elif not fused:
                 problem.backproject_differential(r, Wh, s_full)
             if sharded:
                 eng.compact_gather(s_full, idx, out=sg[:n], zero=True, want_dot=False)
