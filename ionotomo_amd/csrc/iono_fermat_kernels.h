@@ -232,6 +232,124 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
     if (oob && lane_on) atomicOr(oob_flag, 1);
 }
 
+// ---- fused curved-ray TEC through a TRICUBIC refractive index on ideal-uniform grids: 8 lanes per ray ---------------------------------
+// k_fermat_tec<tricubic> steps lanes = rays with 216 taps per right-hand side out of line: 31 ms at config 3 against 1.13 ms for
+// k_trace_fermat_lm + k_forward_rays, which is why curved rays through a tricubic index used to be traced into rays[R][4][Ns] (5.1 GB at
+// 620 000 rays) and integrated in a second launch.  Here the record-per-lane stepper of k_trace_fermat_lm (same right-hand side, same
+// order of operations: the samples are bit-identical to the traced ones) feeds the streaming quadrature directly.  The integrand at
+// a sample is shared by the ray's eight lanes: trilinear -- every lane one corner; tricubic -- every lane a 3 x 3 x 3 block of the
+// 6 x 6 x 6 taps (a, b, c = the lane's bits) -- summed with three DPP steps (sum8).  No ray tensor, any batch size.
+__device__ __forceinline__ void cubic_taps_ideal(double t, double (&w)[6]) {        // cubic_axis on a uniform axis: c0 = c1 = 1 / 12
+    const double t2 = t * t, t3 = t2 * t;
+    const double b0 = 2 * t3 - 3 * t2 + 1, b1 = -2 * t3 + 3 * t2, b2 = (t3 - 2 * t2 + t) * (1.0 / 12.0), b3 = (t3 - t2) * (1.0 / 12.0);
+    w[0] = b2, w[1] = -8.0 * b2 + b3, w[2] = b0 - 8.0 * b3, w[3] = b1 + 8.0 * b2, w[4] = -b2 + 8.0 * b3, w[5] = -b3;
+}
+template <bool BEND>
+__global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *__restrict__ F8, const double *__restrict__ origins,
+                                                      const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps, int rule,
+                                                      int stype, int kne, double ne_scale, double *__restrict__ tec, int *oob_flag,
+                                                      int rays_per_wave) {
+    if ((int)(threadIdx.x >> 3) >= rays_per_wave) return;
+    const int sub = threadIdx.x & 7;
+    const int la = sub >> 2, lb = (sub >> 1) & 1, lc = sub & 1;
+    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x >> 3);
+    const bool live = r < R;
+    if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
+    const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
+    const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
+    FState u;
+    u.px = dx / nrm, u.py = dy / nrm, u.pz = dz / nrm;
+    u.x = origins[3 * r], u.y = origins[3 * r + 1], u.z = origins[3 * r + 2];
+    u.s = 0.0;
+    const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
+    const double *M = (const double *)g.M;
+    const size_t sj = (size_t)g.nz, si = (size_t)g.ny * g.nz;
+    const bool cubic = kne == IONO_INTERP_TRICUBIC;                    // (wave-uniform)
+    // a sample is integrated if it lies inside the integrand's domain (the whole grid / the tricubic domain g[2] .. g[n-3]), as
+    // k_forward_rays decides it; samples outside are skipped and flagged
+    auto inside = [&](const FState &p) {
+        if (cubic) return p.x >= g.c0[0] && p.x <= g.clast[0] && p.y >= g.c0[1] && p.y <= g.clast[1] && p.z >= g.c0[2] && p.z <= g.clast[2];
+        return p.x >= g.g0[0] && p.x <= g.glast[0] && p.y >= g.g0[1] && p.y <= g.glast[1] && p.z >= g.g0[2] && p.z <= g.glast[2];
+    };
+    auto value = [&](const FState &p) {          // called by all eight lanes of a ray with the same p
+        const double ux = (p.x - g.g0[0]) * g.inv_h[0], uy = (p.y - g.g0[1]) * g.inv_h[1], uz = (p.z - g.g0[2]) * g.inv_h[2];
+        if (!cubic) {
+            const double fi = fmin(__builtin_floor(__builtin_fabs(ux)), (double)(g.nx - 2)), fj = fmin(__builtin_floor(__builtin_fabs(uy)), (double)(g.ny - 2)),
+                         fk = fmin(__builtin_floor(__builtin_fabs(uz)), (double)(g.nz - 2));
+            const double tx = ux - fi, ty = uy - fj, tz = uz - fk;
+            const double v = M[((size_t)((int)fi + la) * g.ny + (size_t)((int)fj + lb)) * g.nz + (size_t)((int)fk + lc)];
+            return sum8(v * (la ? tx : 1.0 - tx) * (lb ? ty : 1.0 - ty) * (lc ? tz : 1.0 - tz));
+        }
+        const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(g.nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(g.ny - 4)),
+                     fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(g.nz - 4));
+        double wx[6], wy[6], wz[6];
+        cubic_taps_ideal(ux - fi, wx);
+        cubic_taps_ideal(uy - fj, wy);
+        cubic_taps_ideal(uz - fk, wz);
+        // this lane's half of each axis' six taps (selects, not indexed arrays: no scratch)
+        const double x3[3] = {la ? wx[3] : wx[0], la ? wx[4] : wx[1], la ? wx[5] : wx[2]};
+        const double y3[3] = {lb ? wy[3] : wy[0], lb ? wy[4] : wy[1], lb ? wy[5] : wy[2]};
+        const double z3[3] = {lc ? wz[3] : wz[0], lc ? wz[4] : wz[1], lc ? wz[5] : wz[2]};
+        const double *base = M + ((size_t)((int)fi - 2 + 3 * la) * g.ny + (size_t)((int)fj - 2 + 3 * lb)) * g.nz + (size_t)((int)fk - 2 + 3 * lc);
+        double f = 0.0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            double fa = 0.0;
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                const double *q = base + (size_t)a * si + (size_t)b * sj;
+                fa += (q[0] * z3[0] + q[1] * z3[1] + q[2] * z3[2]) * y3[b];
+            }
+            f += fa * x3[a];
+        }
+        return sum8(f);
+    };
+    bool oob = false;
+    int ci = -1, cj = -1, ck = -1;
+    double rec[8] = {};
+    const double ztop = g.glast[2] + 1e-9 * fabs(tmax);
+    StreamQuad q;
+    q.init(Ns, rule, 0.0);
+    double y0 = 0.0, y1 = 0.0;             // integrand at samples k-2, k-1
+    bool in0 = false, in1 = inside(u);
+    if (!in1) oob = true;
+    {       // (a sample that is skipped is still EVALUATED, at a position clamped into the grid: all lanes run the DPP sums)
+        FState uc = u;
+        if (!in1) uc.x = fmin(fmax(u.x, g.c0[0]), g.clast[0]), uc.y = fmin(fmax(u.y, g.c0[1]), g.clast[1]), uc.z = fmin(fmax(u.z, g.c0[2]), g.clast[2]);
+        const double yv = value(uc);
+        y1 = in1 ? yv : 0.0;
+    }
+    double acc = 0.0;
+    for (int k = 1; k < Ns; ++k) {
+        for (int s2 = 0; s2 < substeps; ++s2) {
+            FState kprev = {}, sum = {};
+#pragma unroll 1
+            for (int st = 0; st < 4; ++st) {
+                const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
+                kprev = fermat_rhs_lm<BEND>(g, F8, axpy(u, ca, kprev), sub, ci, cj, ck, rec, stype);
+                sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
+            }
+            u = axpy(u, h / 6.0, sum);
+        }
+        oob |= !(u.x >= g.g0[0] && u.x <= g.glast[0] && u.y >= g.g0[1] && u.y <= g.glast[1] && u.z >= g.g0[2] && u.z <= ztop);
+        const bool in2 = inside(u);
+        if (!in2) oob = true;
+        FState uc = u;
+        if (!in2) uc.x = fmin(fmax(u.x, g.c0[0]), g.clast[0]), uc.y = fmin(fmax(u.y, g.c0[1]), g.clast[1]), uc.z = fmin(fmax(u.z, g.c0[2]), g.clast[2]);
+        const double yv = value(uc);
+        const double y2 = in2 ? yv : 0.0;
+        const double wk = q.feed(k, u.s);                       // final weight of sample k-2
+        if (k >= 2 && in0) acc = fma(wk, y0, acc);
+        y0 = y1, y1 = y2, in0 = in1, in1 = in2;
+    }
+    if (Ns >= 2 && in0) acc = fma(q.w0, y0, acc);
+    if (in1) acc = fma(q.w1, y1, acc);
+    if (live && sub == 0) {
+        tec[r] = acc * ne_scale;
+        if (oob) atomicOr(oob_flag, 1);
+    }
+}
+
 }  // namespace
 
 #endif

@@ -2322,9 +2322,27 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
     if (c->nM_freq != frequency) {       // n = sqrt(1 - 8.98^2 ne / nu^2) at the nodes, rebuilt when ne or nu changed
         hipLaunchKernelGGL((k_ne_to_n<double>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double *)cur_values(c), c->d_nM, n, frequency);
         c->nM_freq = frequency;
+        c->nF8_freq = -1.0;
     }
     const GridView g = view(c);
     const dim3 grid((unsigned)((R + 63) / 64)), block(64);
+    if (!adjoint && kind_n == IONO_INTERP_TRICUBIC && g.ideal && cubic_fast_ok(c, 2) && c->variant != 17 && c->variant != 3 &&
+        R <= c->fermat_coop_max && (kind_ne == IONO_INTERP_TRILINEAR || (c->nx >= 6 && c->ny >= 6 && c->nz >= 6))) {
+        // tricubic index on an ideal-uniform grid: 8 lanes per ray, one Lekien-Marsden record of n per lane, streaming quadrature
+        // (iono_fermat_kernels.h:k_fermat_tec_lm; IONOTOMO_VARIANT=17 / 3: the lanes = rays kernel below, A/B)
+        const int rcf = ensure_n_fields(c, frequency);
+        if (rcf) return rcf;
+        const int rpw = c->fermat_coop_rpw > 0 ? c->fermat_coop_rpw : 8;
+        const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
+        if (bend)
+            hipLaunchKernelGGL((k_fermat_tec_lm<true>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps, rule,
+                               independent, kind_ne, ne_scale, tec, c->d_flags, rpw);
+        else
+            hipLaunchKernelGGL((k_fermat_tec_lm<false>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps, rule,
+                               independent, kind_ne, ne_scale, tec, c->d_flags, rpw);
+        HIP_TRY(c, hipGetLastError());
+        return IONO_OK;
+    }
     // axes (+ the wave's scatter window of the transpose: iono_fermat_kernels.h)
     const size_t lds = ((lds_bytes(c) + 15) & ~(size_t)15) + (adjoint ? sizeof(double) * FW * FW * FWZ : 0);
 #define LAUNCH_FT(K, B, A)                                                                                                              \

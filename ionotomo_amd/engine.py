@@ -58,6 +58,13 @@ class RayEngine(object):
         self.ctx.set_grid(xvec, yvec, zvec, M, storage=self.storage)
         self.shape = self.ctx.grid_shape
         self.ncells = int(np.prod(self.shape))
+        # "ideal-uniform" axes (g0 + i h to 2.5e-13 h: what np.linspace builds; the library's own rule, iono_grid_set): the tier that has
+        # the record-per-lane tricubic tracer and its fused TEC kernel
+        def ideal(a):
+            a = np.asarray(a, dtype=np.float64).ravel()
+            h = (a[-1] - a[0]) / (a.size - 1)
+            return bool(np.all(np.abs(a - (a[0] + np.arange(a.size) * h)) <= 2.5e-13 * h))
+        self.ideal_axes = all(ideal(a) for a in (xvec, yvec, zvec)) and min(self.shape) >= 6
 
     def set_values(self, M_t):
         """grid values <- float64 device tensor"""
@@ -302,12 +309,16 @@ class RayEngine(object):
     # stepper of the fused kernel (config 3: 2.3 against 31 ms): below this many bytes of rays[R,4,Ns] the two-step path serves it
     FUSED_CUBIC_ABOVE_BYTES = 8 << 30
 
-    def _two_step_fermat(self, R, Ns, kind, fused):
-        """True: trace into a TEMPORARY rays[R,4,Ns] tensor (32 R Ns bytes of device memory) and integrate along it."""
+    def _two_step_fermat(self, R, Ns, kind, fused, adjoint=False):
+        """True: trace into a TEMPORARY rays[R,4,Ns] tensor (32 R Ns bytes of device memory) and integrate along it.  Round 4: the
+        FORWARD through a tricubic index on ideal-uniform axes is fused too (k_fermat_tec_lm: 8 lanes per ray, one node record per
+        lane, streaming quadrature) -- the two-step route remains the default only for its transpose and for non-uniform axes."""
         if fused is not None:
             return not fused
         need = R * 4 * int(Ns) * 8
         if _lib.interp_kind(kind) != _lib.interp_kind("cubic") or need > self.FUSED_CUBIC_ABOVE_BYTES:
+            return False
+        if not adjoint and getattr(self, "ideal_axes", False) and self.storage in ("f64", "float64", 0):
             return False
         try:                                   # never a hidden allocation beyond half of what the device has free
             free = torch.cuda.mem_get_info(self.device)[0]
@@ -350,7 +361,7 @@ class RayEngine(object):
         ``forward_fermat``."""
         self._sync_stream()
         R = origins_t.shape[0]
-        if self._two_step_fermat(R, Ns, kind, fused):
+        if self._two_step_fermat(R, Ns, kind, fused, adjoint=True):
             if out is None:
                 out = torch.zeros(self.shape, dtype=torch.float64, device=self.device)
             rays = self.trace_fermat(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, substeps=substeps, type=type)

@@ -171,24 +171,56 @@ def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, rep, O, monk
     assert np.max(np.abs(r0 - ref)) < 1e-9
 
 
-def test_tricubic_index_takes_the_two_step_path_by_default():
-    """``fused=None``: a tricubic refractive index is traced by the 8-lanes-per-ray tracer and integrated along the stored rays
-    while rays[R,4,Ns] fits (13 x faster than the lanes = rays stepper of the fused kernel); forward and transpose equal the
-    fused kernels' to rounding, ne_scale included."""
+def test_tricubic_index_is_fused_by_default_on_ideal_axes(monkeypatch):
+    """Round 4: curved rays through a TRICUBIC refractive index no longer need rays[R,4,Ns].  ``fused=None`` on
+    ideal-uniform axes runs k_fermat_tec_lm -- the 8-lanes-per-ray stepper of the record tracer feeding the streaming quadrature --
+    and equals trace + integrate along the stored rays to 1e-11 for both integrand interpolants, both independent variables, every
+    quadrature rule and even / odd sample counts; the lanes = rays kernel (IONOTOMO_VARIANT=17) agrees too.  The TRANSPOSE keeps the
+    two-step route by default (its fused form steps lanes = rays with 216 taps)."""
+    from ionotomo_amd.engine import RayEngine
     w = syn.make_workload(antennas="example", na=6, nd=5, nt=2, n=24, margin_cells=8)
     o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
-    eng = make_engine(w)
+    yt = None
+    for interp in ("cubic", "linear"):                       # the ENGINE's interpolant = the integrand's (ne_kind default)
+        eng = make_engine(w, interp=interp)
+        eng.set_values(eng.tensor(w["ne"]))
+        ot, dt = eng.tensor(o), eng.tensor(d)
+        assert eng.ideal_axes
+        assert not eng._two_step_fermat(len(o), 21, "cubic", None) and eng._two_step_fermat(len(o), 21, "cubic", None, adjoint=True)
+        assert not eng._two_step_fermat(len(o), 21, "linear", None)
+        for typ in ("z", "s"):
+            tmax = w["tmax"] if typ == "z" else 0.8 * w["tmax"]
+            for Ns in (21, 22):
+                a = eng.forward_fermat(ot, dt, tmax, Ns, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, type=typ)              # fused (default)
+                b = eng.forward_fermat(ot, dt, tmax, Ns, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, type=typ, fused=False)  # trace + integrate
+                assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max()), (interp, typ, Ns)
+        assert not eng.check_oob()
+        if yt is None:
+            yt = eng.tensor(np.random.default_rng(4).normal(size=len(o)))
+        ga = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13)
+        gb = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
+        assert float((ga - gb).abs().max()) < 1e-12 * float(gb.abs().max())
+    # the lanes = rays kernel on the same problem
+    monkeypatch.setenv("IONOTOMO_VARIANT", "17")
+    e17 = RayEngine(0, interp="cubic")
+    e17.set_grid(w["xvec"], w["yvec"], w["zvec"])
+    e17.set_values(e17.tensor(w["ne"]))
+    c17 = e17.forward_fermat(e17.tensor(o), e17.tensor(d), w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
+    monkeypatch.delenv("IONOTOMO_VARIANT")
+    eng = RayEngine(0, interp="cubic")
+    eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
     eng.set_values(eng.tensor(w["ne"]))
-    ot, dt = eng.tensor(o), eng.tensor(d)
-    yt = eng.tensor(np.random.default_rng(4).normal(size=len(o)))
-    assert eng._two_step_fermat(len(o), 21, "cubic", None) and not eng._two_step_fermat(len(o), 21, "linear", None)
-    a = eng.forward_fermat(ot, dt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13)
-    b = eng.forward_fermat(ot, dt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
-    assert float((a - b).abs().max()) < 1e-12 * float(b.abs().max())
-    ga = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13)
-    gb = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
-    assert float((ga - gb).abs().max()) < 1e-12 * float(gb.abs().max())
-    assert not eng.check_oob()
+    a = eng.forward_fermat(eng.tensor(o), eng.tensor(d), w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13)
+    assert float((a - c17).abs().max()) < 1e-11 * float(c17.abs().max())
+    # rays that leave the tricubic domain: skipped samples + flag, as on the two-step route
+    d2 = d.copy()
+    d2[3, 0] += 0.8
+    t2 = eng.forward_fermat(eng.tensor(o), eng.tensor(d2), w["tmax"], 21, 60e6, kind="cubic", substeps=2)
+    assert eng.check_oob()
+    t3 = eng.forward_fermat(eng.tensor(o), eng.tensor(d2), w["tmax"], 21, 60e6, kind="cubic", substeps=2, fused=False)
+    assert eng.check_oob()
+    keep = np.arange(len(o)) != 3
+    assert float((t2 - t3).abs()[torch.from_numpy(keep).to(t2.device)].max()) < 1e-11 * float(t3.abs().max())
 
 
 @pytest.mark.parametrize("typ", ["z", "s"])
