@@ -102,6 +102,8 @@ out["fused_620k_bending_rays_per_s"] = o4.shape[0] / out["fused_620k_bending_ray
 y4 = torch.randn(o4.shape[0], dtype=torch.float64, device="cuda")
 g4 = torch.zeros(e4.shape, dtype=torch.float64, device="cuda")
 out["fused_620k_bending_rays_256_adjoint_ms"] = timeit(lambda: e4.adjoint_fermat(o4, d4, y4, w4["tmax"], w4["Ns"], 150e6, bend=True, kind="linear", substeps=2, out=g4), 2, 1)
+# round 4: 620 000 bending rays through a TRICUBIC index without rays[R,4,Ns] (k_fermat_tec_lm; trilinear integrand of this engine)
+out["fused_620k_bending_rays_256_cubic_index_forward_ms"] = timeit(lambda: e4.forward_fermat(o4, d4, w4["tmax"], w4["Ns"], 150e6, bend=True, kind="cubic", substeps=2, out=t4), 2, 1)
 del e4, o4, d4, t4, y4, g4, w4
 
 # ---------------------------------------------------------------- PCIe-inclusive facade call (host numpy in/out)
