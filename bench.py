@@ -632,7 +632,7 @@ def main():
             extra["tricubic_vs_trilinear_max_rel_dev"] = float((tc - tec_t).abs().div(tec_t.abs()).max().item())
             # the binned kernel is bound by LDS float-atomic throughput, the ray-stationary one by the memory-side atomic rate
             extra["adjoint_roofline"] = {"bound": "lds_atomic" if args.plan else "memory_atomic", "kernel_ms": akern * 1e3,
-                                         "kernel": "k_adjoint_binned<double, false, 0, double>" if args.plan
+                                         "kernel": "k_adjoint_binned<double, false, 0, double" if args.plan
                                          else "k_adjoint_straight_tile<double, 1, 4>"}
             if world == 1:                                  # single-rank only: the solvers at the bench shape
                 prob, x0 = solver_problem()

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 tag = sys.argv[1]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-LEG_KERNEL = {"forward": "k_forward_bundle", "adjoint": "k_adjoint_binned<double, false, 0, double>",
+LEG_KERNEL = {"forward": "k_forward_bundle", "adjoint": "k_adjoint_binned<double, false, 0, double",
               "cubic_forward": "k_forward_bundle_lm"}
 
 
