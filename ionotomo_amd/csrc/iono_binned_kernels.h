@@ -218,45 +218,94 @@ __global__ __launch_bounds__(256) void k_ray_weights(const double *__restrict__ 
 //                 (= k_rays_combine + k_ray_weights<2>: 5 -> 4)
 // + the plan's ray check of the back-projection that follows (origins non-null).  One wave per (time, direction) pair, lanes =
 // antennas; one partial per workgroup, summed in a fixed order by the consumer (no atomics: identical bits on every rank).
+#define RSTEP_WAVES 16      // waves of a workgroup of k_rays_step
+#define RSTEP_PT 16         // consecutive (time, direction) pairs per workgroup (a 128-byte run per load); 64 / RSTEP_PT antenna groups per wave
 template <int MODE>
-__global__ __launch_bounds__(256) void k_rays_step(const double *__restrict__ tq, const double *__restrict__ dobs,
-                                                   const double *__restrict__ scale, const double *__restrict__ weight, double *__restrict__ r,
-                                                   const double *an, int ann, const double *ad, int adn, int Na, int64_t NtNd, int i0,
-                                                   double *__restrict__ w, double *__restrict__ partial, const double *__restrict__ origins,
-                                                   const double *__restrict__ dirs, const uint2 *__restrict__ hash, double *__restrict__ uray,
-                                                   int *__restrict__ flags) {
-    const double alpha = MODE == 0 ? -1.0 * read_scalar(an, ann) / read_scalar(ad, adn) : 0.0;
-    const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(64 * RSTEP_WAVES) void k_rays_step(const double *__restrict__ tq, const double *__restrict__ dobs,
+                                                                const double *__restrict__ scale, const double *__restrict__ weight,
+                                                                double *__restrict__ r, const double *an, int ann, const double *ad, int adn,
+                                                                int Na, int64_t NtNd, int i0, double *__restrict__ w,
+                                                                double *__restrict__ partial, int npartial,
+                                                                const double *__restrict__ origins, const double *__restrict__ dirs,
+                                                                const uint2 *__restrict__ hash, double *__restrict__ uray,
+                                                                int *__restrict__ flags) {
+    // lanes = consecutive pairs p (ray index a NtNd + p: every load of a wave is one contiguous run), waves = groups of antennas; the
+    // sum over antennas of a pair is a sum over the waves of a workgroup, through LDS, in a fixed order
+    constexpr int AS = 64 / RSTEP_PT, NG = RSTEP_WAVES * AS;      // antenna groups per wave / per workgroup
+    __shared__ double ssum[NG][RSTEP_PT];
+    __shared__ double sacc[RSTEP_WAVES];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double alpha = 0.0;
+    if (MODE == 0) {
+        // an / ad exactly as read_scalar() forms them in the other consumers of these scalars (k_axpby_dot, k_compact_cg_update): the
+        // first 256 threads take the entries t, t + 256, ..., four wave sums, added in the same order -- the SAME bits, so x += alpha p
+        // and r -= alpha q use one alpha
+        __shared__ double red[4];
+        auto rd = [&](const double *__restrict__ pp, int n) {
+            if (!pp) return 1.0;
+            if (n == 1) return pp[0];
+            double v = 0.0;
+            if (threadIdx.x < 256)
+                for (int t = threadIdx.x; t < n; t += 256) v += pp[t];
+            const double ws = wave_sum_dpp(v);
+            __syncthreads();
+            if (wv < 4 && lane == 0) red[wv] = ws;
+            __syncthreads();
+            return ((red[0] + red[1]) + red[2]) + red[3];
+        };
+        const double va = rd(an, ann), vd = rd(ad, adn);
+        alpha = -1.0 * va / vd;
+    }
+    const int pl = lane & (RSTEP_PT - 1), gidx = wv * AS + lane / RSTEP_PT;
+    const int a_lo = Na * gidx / NG, a_hi = Na * (gidx + 1) / NG;
     double acc = 0.0;
-    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < NtNd; p += (int64_t)gridDim.x * 4) {
-        const double tref = MODE == 1 ? tq[(int64_t)i0 * NtNd + p] : 0.0;
+    for (int64_t p0 = (int64_t)blockIdx.x * RSTEP_PT; p0 < NtNd; p0 += (int64_t)gridDim.x * RSTEP_PT) {
+        const int64_t p = p0 + pl;
+        const bool on = p < NtNd;
+        const double tref = (MODE == 1 && on) ? tq[(int64_t)i0 * NtNd + p] : 0.0;
         double s = 0.0;
-        for (int a = lane; a < Na; a += 64) {
-            const int64_t i = (int64_t)a * NtNd + p;
-            if (origins) plan_verify_ray(origins, dirs, i, hash, uray, flags);
-            double v;
-            if (MODE == 0) {
-                v = fma(alpha, tq[i], 1.0 * r[i]);
-                r[i] = v;
-                acc += v * v;
-            } else {
-                v = -1.0 * (tq[i] - tref) + 1.0 * dobs[i];
-                if (r) r[i] = v;
-                acc += weight ? v * v * weight[i] : v * v;
+        if (on) {
+            for (int a = a_lo; a < a_hi; ++a) {
+                const int64_t i = (int64_t)a * NtNd + p;
+                if (origins) plan_verify_ray(origins, dirs, i, hash, uray, flags);
+                double v;
+                if (MODE == 0) {
+                    v = fma(alpha, tq[i], 1.0 * r[i]);
+                    r[i] = v;
+                    acc += v * v;
+                } else {
+                    v = -1.0 * (tq[i] - tref) + 1.0 * dobs[i];
+                    if (r) r[i] = v;
+                    acc += weight ? v * v * weight[i] : v * v;
+                }
+                const double vs = scale ? v * scale[i] : v;
+                w[i] = vs;                                   // (the reference-antenna row is corrected below)
+                s += vs;
             }
-            const double vs = scale ? v * scale[i] : v;
-            w[i] = vs;                                       // (the reference-antenna row is corrected below)
-            s += vs;
         }
-        s = wave_sum_dpp(s);
-        if (i0 % 64 == lane) {                               // the lane that wrote w[i0, p] (its own store: no fence needed)
+        ssum[gidx][pl] = s;
+        __syncthreads();
+        if (on && i0 >= a_lo && i0 < a_hi) {                 // the thread that wrote w[i0, p] (its own store)
+            double tot = 0.0;
+#pragma unroll 8
+            for (int t = 0; t < NG; ++t) tot += ssum[t][pl];
             const int64_t i = (int64_t)i0 * NtNd + p;
-            w[i] = w[i] - s;
+            w[i] = w[i] - tot;
         }
+        __syncthreads();
     }
     if (partial) {
-        const double t = block_sum_bcast(acc);
-        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+        const double t = wave_sum_dpp(acc);
+        if (lane == 0) sacc[wv] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double tot = 0.0;
+            for (int t2 = 0; t2 < RSTEP_WAVES; ++t2) tot += sacc[t2];
+            partial[blockIdx.x] = tot;
+        }
+        // entries beyond the grid of this launch read as zero by the consumers (which sum all `npartial` of them)
+        if (blockIdx.x == 0)
+            for (int t2 = (int)gridDim.x + (int)threadIdx.x; t2 < npartial; t2 += (int)blockDim.x) partial[t2] = 0.0;
     }
 }
 

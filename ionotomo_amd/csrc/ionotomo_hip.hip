@@ -1700,12 +1700,13 @@ static int rays_step_then_adjoint(iono_ctx *c, int mode, const double *o, const 
     const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax && pl.kind == kind &&
                          c->variant != 2 && c->variant != 7;
     const double *vo = planned ? o : nullptr;
+    const unsigned nblk = (unsigned)std::min<int64_t>(IONO_NPART, (NtNd + RSTEP_PT - 1) / RSTEP_PT);
     if (mode == 0)
-        hipLaunchKernelGGL((k_rays_step<0>), dim3(IONO_NPART), dim3(256), 0, c->stream, tq, dobs, scale, weight, r, an, ann, ad, adn, Na, NtNd,
-                           i0, c->d_rayw, partial, vo, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
+        hipLaunchKernelGGL((k_rays_step<0>), dim3(nblk), dim3(64 * RSTEP_WAVES), 0, c->stream, tq, dobs, scale, weight, r, an, ann, ad, adn, Na,
+                           NtNd, i0, c->d_rayw, partial, IONO_NPART, vo, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
     else
-        hipLaunchKernelGGL((k_rays_step<1>), dim3(IONO_NPART), dim3(256), 0, c->stream, tq, dobs, scale, weight, r, an, ann, ad, adn, Na, NtNd,
-                           i0, c->d_rayw, partial, vo, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
+        hipLaunchKernelGGL((k_rays_step<1>), dim3(nblk), dim3(64 * RSTEP_WAVES), 0, c->stream, tq, dobs, scale, weight, r, an, ann, ad, adn, Na,
+                           NtNd, i0, c->d_rayw, partial, IONO_NPART, vo, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
     HIP_TRY(c, hipGetLastError());
     c->plan_verified = planned;
     return adjoint_straight_launch(c, 0, o, d, order, c->d_rayw, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, kind, rule, grad, accum);
