@@ -181,6 +181,20 @@ int iono_adjoint_sirt_step_dev(iono_ctx *ctx, const double *origins_dev, const d
                                const double *tec_dev, const double *dobs_dev, const double *scale_dev, const double *weight_dev, int Na,
                                int64_t NtNd, int i0, double tmax, int Ns, int interp_kind, int quad_rule, double *r_out_dev,
                                double *partial_dev, void *grad_dev, int accum_dtype);
+/* ---- z-slabs of the back-projection plan: what lets a multi-GPU solver exchange a finished part of the update while the rest is still
+ *      being back-projected (replaces the reference's sum over per-direction gradients, inversion/gradient.py:52-54).
+ * iono_adjoint_plan_slabs(n): the NEXT iono_adjoint_plan_dev orders its work units by z-slab (n <= 8 slabs of whole box layers).
+ * iono_adjoint_plan_slab_info: nslab, unit_lo[nslab + 1] (slab s = units [unit_lo[s], unit_lo[s+1])) and z_lo[nslab + 1] (slab s owns
+ *   the node levels [z_lo[s], z_lo[s+1]): once the units of slabs 0 .. s have run, those levels are final -- provided the plan's
+ *   outside_fraction is 0, i.e. no sample bypasses its box image).
+ * iono_adjoint_unit_range(lo, hi): the next planned trilinear back-projection runs units [lo, hi) only (one-shot).
+ * iono_adjoint_cg_step_dev / _sirt_step_dev with grad_dev = NULL: the ray pass alone; iono_adjoint_planned_weights_dev then
+ *   back-projects the weights it left in the library (slab by slab with iono_adjoint_unit_range). */
+int iono_adjoint_plan_slabs(iono_ctx *ctx, int nslab);
+int iono_adjoint_plan_slab_info(iono_ctx *ctx, int *nslab_out, int *unit_lo_out, int *z_lo_out);
+int iono_adjoint_unit_range(iono_ctx *ctx, int unit_lo, int unit_hi);
+int iono_adjoint_planned_weights_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, const int *order_dev,
+                                     int64_t R, double tmax, int Ns, int interp_kind, int quad_rule, void *grad_dev, int accum_dtype);
 int iono_subtract_reference_dev(iono_ctx *ctx, double *tec_dev, int Na, int64_t NtNd, int i0);
 /* Measured load balance of the two chunked kernels.  The straight-ray forward gives every resident wave one
  * contiguous chunk of the ray walk, the LDS-tiled adjoint every resident workgroup; the cost per ray varies with where

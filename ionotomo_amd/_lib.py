@@ -78,6 +78,10 @@ _SIGNATURES = {
     "iono_adjoint_differential_straight_dev": [_V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _I, _V, _I],
     "iono_adjoint_cg_step_dev": [_V, _V, _V, _V, _V, _V, _I, _V, _I, _V, _I, _L, _I, _D, _I, _I, _I, _V, _V, _I],
     "iono_adjoint_sirt_step_dev": [_V, _V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _I, _V, _V, _V, _I],
+    "iono_adjoint_plan_slabs": [_I],
+    "iono_adjoint_plan_slab_info": [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
+    "iono_adjoint_unit_range": [_I, _I],
+    "iono_adjoint_planned_weights_dev": [_V, _V, _V, _L, _D, _I, _I, _I, _V, _I],
     "iono_subtract_reference_dev": [_V, _I, _L, _I],
     "iono_vec_axpby_dev": [_V, _V, _L, _V, _V, _D, _V, _V],
     "iono_forward_phase_straight_dev": [_V, _V, _I, _I, _I, _D, _I, _P, _I, _V, _V, _I, _I, _V, _V],

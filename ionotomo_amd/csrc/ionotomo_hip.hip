@@ -129,6 +129,9 @@ struct iono_ctx {
         double *d_partial = nullptr;                      // [R][smax] segment partial sums of the node-stationary forward
         int smax = 0;
         bool fwd_ok = false;                              // every ray has <= 255 segments
+        int nslab = 1;                                    // units are ordered by z-slab (then largest first): slab s = units [slab_unit[s], slab_unit[s + 1])
+        int slab_unit[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // ... and owns the node levels [slab_z[s], slab_z[s + 1])
+        int slab_z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
         int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
         size_t cap_uray = 0, cap_hash = 0, cap_entries = 0, cap_units = 0, cap_nseg = 0, cap_partial = 0;      // bytes (grow-only: a new geometry reuses them)
@@ -155,6 +158,8 @@ struct iono_ctx {
     size_t pinned_cap = 0;
     char *h_plan = nullptr;          // pinned staging of the plan builders' host round trips (ray summaries, walk order: 8 MB at the
     size_t plan_pinned_cap = 0;      // bench shape; from pageable memory those copies were half of the 3 ms a forward plan took)
+    int plan_slabs = 1;              // z-slabs the next back-projection plan groups its work units by (iono_adjoint_plan_slabs)
+    int unit_lo = -1, unit_hi = -1;  // work units of the NEXT planned trilinear back-projection (iono_adjoint_unit_range; -1: all)
     bool plan_verified = false;      // the ray pass in front of a planned back-projection already checked the rays (k_rays_step)
     bool lm4_attr[3] = {false, false, false};      // k_adjoint_binned_lm4<SEGL>: > 64 KB of dynamic LDS allowed (hipFuncSetAttribute, once per context)
     double *d_rayw = nullptr;        // per-ray weights of the fused modes for the binned kernel
@@ -1465,7 +1470,23 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         for (int64_t q = lo; q < hi; q += unit_segs)
             units.push_back(BinUnit{bi * BIN_SX - BIN_H, bj * BIN_SY - BIN_H, zb * BIN_SZ, (int)q, (int)std::min(hi, q + unit_segs)});
     }
-    std::stable_sort(units.begin(), units.end(), [](const BinUnit &a, const BinUnit &b) { return a.e_hi - a.e_lo > b.e_hi - b.e_lo; });
+    // z-slabs (iono_adjoint_plan_slabs; 1 by default): slab s = box layers [nbz s / nslab, nbz (s + 1) / nslab).  A unit writes the 16 node
+    // levels of its layer only, so once the units of slab s have run, the node levels below the first level of slab s + 1 are final:
+    // a multi-GPU solver exchanges them while the next slab is back-projected (ionotomo_amd/parallel.py).  Units: by slab, then largest first.
+    const int nslab = std::max(1, std::min(std::min(c->plan_slabs, 8), nbz));
+    auto slab_of = [&](const BinUnit &u) { return std::min(nslab - 1, (u.z0 / BIN_SZ) * nslab / nbz); };
+    std::stable_sort(units.begin(), units.end(), [&](const BinUnit &a, const BinUnit &b) {
+        const int sa = slab_of(a), sb = slab_of(b);
+        return sa != sb ? sa < sb : a.e_hi - a.e_lo > b.e_hi - b.e_lo;
+    });
+    pl.nslab = nslab;
+    for (int sidx = 0; sidx <= nslab; ++sidx) {
+        // first box layer of slab sidx: the smallest layer L with L * nslab / nbz >= sidx
+        int L = 0;
+        while (L < nbz && std::min(nslab - 1, L * nslab / nbz) < sidx) ++L;
+        pl.slab_z[sidx] = sidx == 0 ? 0 : (sidx == nslab ? c->nz : L * BIN_SZ);
+        pl.slab_unit[sidx] = (int)(std::lower_bound(units.begin(), units.end(), sidx, [&](const BinUnit &u, int v) { return slab_of(u) < v; }) - units.begin());
+    }
     // pass 2 on the device: the segments into their boxes (+ BIN_ENTRY_PAD zero entries: the kernel prefetches two passes ahead)
     HIP_TRY(c, plan_reserve(pl.d_entries, pl.cap_entries, ((size_t)ne + BIN_ENTRY_PAD) * sizeof(uint2)));
     HIP_TRY(c, hipMemsetAsync(pl.d_entries + ne, 0, BIN_ENTRY_PAD * sizeof(uint2), c->stream));
@@ -1575,11 +1596,16 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
     c->plan_verified = false;
     const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);      // float64 box image for either AT
     if (planned && kind == IONO_INTERP_TRILINEAR) {
-        BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds, c->stream, g,
-                                            pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, grad, -1, PhaseFreqs{}, 0));
+        int u_lo = 0, u_hi = pl.n_units;
+        if (c->unit_lo >= 0) u_lo = std::min(c->unit_lo, pl.n_units), u_hi = std::max(u_lo, std::min(c->unit_hi, pl.n_units));
+        c->unit_lo = c->unit_hi = -1;
+        if (u_hi > u_lo)
+            BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds, c->stream, g,
+                                                pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw, grad, -1, PhaseFreqs{}, 0));
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }
+    c->unit_lo = c->unit_hi = -1;
     if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
         return launch_adjoint_tile<AT, MODE, false>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, grad, -1);
     if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2) {
@@ -1709,7 +1735,35 @@ static int rays_step_then_adjoint(iono_ctx *c, int mode, const double *o, const 
                            NtNd, i0, c->d_rayw, partial, IONO_NPART, vo, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
     HIP_TRY(c, hipGetLastError());
     c->plan_verified = planned;
+    if (!grad) return IONO_OK;      // (the ray pass alone: iono_adjoint_planned_weights_dev back-projects its weights, slab by slab)
     return adjoint_straight_launch(c, 0, o, d, order, c->d_rayw, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, kind, rule, grad, accum);
+}
+int iono_adjoint_planned_weights_dev(iono_ctx *c, const double *o, const double *d, const int *order, int64_t R, double tmax, int Ns, int kind,
+                                     int rule, void *grad, int accum) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (!grad || !c->d_rayw || c->rayw_cap < R) return fail(c, IONO_ERR_ARG, "iono_adjoint_planned_weights_dev: no weights of a *_step call for these rays");
+    c->plan_verified = true;        // (checked by the step that formed the weights)
+    return adjoint_straight_launch(c, 0, o, d, order, c->d_rayw, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, kind, rule, grad, accum);
+}
+int iono_adjoint_plan_slabs(iono_ctx *c, int nslab) {
+    if (!c || nslab < 1 || nslab > 8) return fail(c, IONO_ERR_ARG, "iono_adjoint_plan_slabs: 1 <= nslab <= 8");
+    c->plan_slabs = nslab;
+    return IONO_OK;
+}
+int iono_adjoint_plan_slab_info(iono_ctx *c, int *nslab, int *unit_lo, int *z_lo) {
+    if (!c || !nslab) return fail(c, IONO_ERR_ARG, "null argument");
+    const iono_ctx::AdjPlan &pl = c->plan;
+    *nslab = pl.R >= 0 ? pl.nslab : 0;
+    for (int s = 0; s <= *nslab; ++s) {
+        if (unit_lo) unit_lo[s] = pl.slab_unit[s];
+        if (z_lo) z_lo[s] = pl.slab_z[s];
+    }
+    return IONO_OK;
+}
+int iono_adjoint_unit_range(iono_ctx *c, int lo, int hi) {
+    if (!c || lo < 0 || hi < lo) return fail(c, IONO_ERR_ARG, "iono_adjoint_unit_range: 0 <= lo <= hi");
+    c->unit_lo = lo, c->unit_hi = hi;
+    return IONO_OK;
 }
 int iono_adjoint_cg_step_dev(iono_ctx *c, const double *o, const double *d, const int *order, double *r, const double *q,
                              const double *an, int ann, const double *ad, int adn, const double *scale, int Na, int64_t NtNd, int i0,

@@ -165,18 +165,41 @@ class RayEngine(object):
                       self.kind, self.rule, _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
         return out
 
-    def plan_adjoint(self, origins_t, dirs_t, tmax, Ns):
+    def plan_adjoint(self, origins_t, dirs_t, tmax, Ns, slabs=1):
         """Bin the rays' segments by grid box ONCE (geometry only): later ``adjoint*`` calls with these same two tensors
         reduce every box in LDS and flush it once (include/ionotomo_hip.h:iono_adjoint_plan_dev).  Returns
         (segments, work units, fraction of segments not fully inside their box image) -- (0, 0, 0.0) when the grid is not
-        uniform and the ray-stationary kernels stay in charge.  Keep the tensors alive and unchanged."""
+        uniform and the ray-stationary kernels stay in charge.  A planned launch checks a checksum per ray: ``plan_stale``.
+        ``slabs`` > 1: the work units are ordered by z-slab, so that a back-projection can run slab by slab (``plan_slabs``,
+        ``adjoint_planned_weights``): what a multi-GPU solver overlaps its exchange with."""
         import ctypes
         self._sync_stream()
+        self.ctx.call("iono_adjoint_plan_slabs", int(slabs))
         self.ctx.call("iono_adjoint_plan_dev", _ptr(origins_t), _ptr(dirs_t), origins_t.shape[0], float(tmax), int(Ns), self.kind)
         self._planned = (origins_t, dirs_t)
         n, u, f = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_double(0)
         self.ctx.call("iono_adjoint_plan_info", ctypes.byref(n), ctypes.byref(u), ctypes.byref(f))
         return n.value, u.value, f.value
+
+    def plan_slabs(self):
+        """(unit_lo[nslab + 1], z_lo[nslab + 1]) of the current back-projection plan: slab s = work units [unit_lo[s], unit_lo[s+1])
+        and owns the node levels [z_lo[s], z_lo[s+1]) (final once slabs 0 .. s have run, given an outside fraction of 0)."""
+        import ctypes
+        n = ctypes.c_int(0)
+        ul, zl = (ctypes.c_int * 9)(), (ctypes.c_int * 9)()
+        self.ctx.call("iono_adjoint_plan_slab_info", ctypes.byref(n), ul, zl)
+        return list(ul[:n.value + 1]), list(zl[:n.value + 1])
+
+    def adjoint_planned_weights(self, origins_t, dirs_t, tmax, Ns, out, unit_range=None, order=None):
+        """out += G^T w for the ray weights the last ``adjoint_cg_step`` / ``adjoint_sirt_step`` (called with ``out=None``) left in the
+        library; ``unit_range`` = (lo, hi): only those work units of the plan (one z-slab)."""
+        self._sync_stream()
+        if unit_range is not None:
+            self.ctx.call("iono_adjoint_unit_range", int(unit_range[0]), int(unit_range[1]))
+        op = _lib._V(0) if order is None else _ptr(order)
+        self.ctx.call("iono_adjoint_planned_weights_dev", _ptr(origins_t), _ptr(dirs_t), op, origins_t.shape[0], float(tmax), int(Ns),
+                      self.kind, self.rule, _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+        return out
 
     def plan_segment_lanes(self):
         """Lanes per segment of the current back-projection plan (4, 8 or 16; 0: no plan)."""
@@ -233,8 +256,8 @@ class RayEngine(object):
         (anp, ann), (adp, adn) = self._sc(an), self._sc(ad)
         opt = lambda t: _lib._V(0) if t is None else _ptr(t)
         self.ctx.call("iono_adjoint_cg_step_dev", _ptr(origins_t), _ptr(dirs_t), opt(order), _ptr(r_t), _ptr(q_t), anp, ann, adp, adn,
-                      opt(scale_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.kind, self.rule, opt(part), _ptr(out),
-                      _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+                      opt(scale_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.kind, self.rule, opt(part), opt(out),
+                      _lib.F64 if out is None or out.dtype == torch.float64 else _lib.F32)
         return part
 
     def adjoint_sirt_step(self, origins_t, dirs_t, tec_t, dobs_t, scale_t, weight_t, Na, i0, tmax, Ns, out, order=None, r_out=None,
@@ -248,7 +271,7 @@ class RayEngine(object):
         opt = lambda t: _lib._V(0) if t is None else _ptr(t)
         self.ctx.call("iono_adjoint_sirt_step_dev", _ptr(origins_t), _ptr(dirs_t), opt(order), _ptr(tec_t), _ptr(dobs_t), opt(scale_t),
                       opt(weight_t), int(Na), R // Na, int(i0), float(tmax), int(Ns), self.kind, self.rule, opt(r_out), opt(part),
-                      _ptr(out), _lib.F64 if out.dtype == torch.float64 else _lib.F32)
+                      opt(out), _lib.F64 if out is None or out.dtype == torch.float64 else _lib.F32)
         return part
 
     def adjoint_residual(self, origins_t, dirs_t, tec_t, dobs_t, cdct_t, Na, i0, tmax, Ns, out=None,

@@ -54,9 +54,10 @@ class GradientExchange(object):
     then exact to ~1e-7 relative (the solvers' iterates change at that level)."""
 
     def __init__(self, mode="auto", reduce_dtype=None, dense_above=0.6):
-        assert mode in ("dense", "compact", "auto", "sharded")
+        assert mode in ("dense", "compact", "auto", "sharded", "overlap")
         self.sharded = mode == "sharded"        # fused solvers: reduce-scatter + sharded update + all-gather (below)
-        if self.sharded:
+        self.overlap = mode == "overlap"        # fused solvers: the compact sum leaves slab by slab while the back-projection still runs
+        if self.sharded or self.overlap:
             mode = "compact"
         self.mode, self.reduce_dtype, self.dense_above = mode, reduce_dtype, float(dense_above)
         self.index = None          # int64 [n_active] flat node indices, identical on every rank
@@ -130,8 +131,14 @@ class ShardedRays(object):
         # node-stationary back-projection plan (speed only, once per geometry; engine.plan_adjoint): when the grid is
         # uniform every later adjoint of THESE two tensors reduces each grid box in LDS and flushes it once
         self.plan = None
+        self.slabs = None               # exchange="overlap": (unit_lo[], z_lo[]) of the back-projection plan's z-slabs
         if plan and hasattr(engine, "plan_adjoint") and self.R_local > 0:
-            self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns)
+            if exchange == "overlap" and self.world > 1 and hasattr(engine, "plan_slabs"):
+                self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns, slabs=self.OVERLAP_SLABS)
+                if self.plan[0] and self.plan[2] == 0.0:       # every sample inside its box image: a slab's node levels are final
+                    self.slabs = engine.plan_slabs()
+            else:
+                self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns)
         # measured load balance of the ray-stationary back-projection (used when no plan could be built)
         self.partition = None
         if tune and not (self.plan and self.plan[0]) and hasattr(engine, "tune_adjoint_partition") and self.R_local > 0:
@@ -145,8 +152,18 @@ class ShardedRays(object):
             del scratch
         self.exchange = GradientExchange(exchange, reduce_dtype)
         self._active = None
+        self.slab_ranges = None
         if self.world > 1 and exchange != "dense":
             self.exchange.plan(self._touched())
+        if self.exchange.overlap and self.world > 1:
+            # every rank must have a slab plan with the same node-level boundaries (same grid -> same box layers), else nobody overlaps
+            zl = self.slabs[1] if self.slabs else []
+            flag = torch.tensor([len(zl)] + (zl + [0] * 9)[:9], dtype=torch.int64, device=dev)
+            lo_, hi_ = flag.clone(), flag.clone()
+            dist.all_reduce(lo_, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi_, op=dist.ReduceOp.MAX)
+            if not (self.slabs and bool((lo_ == hi_).all()) and len(zl) > 2):
+                self.slabs = None
 
     @property
     def order(self):
@@ -173,15 +190,55 @@ class ShardedRays(object):
         ones = torch.ones(self.R_local, dtype=torch.float64, device=self.engine.device)
         return self.engine.adjoint(self.origins, self.dirs, ones, self.tmax, self.Ns, order=self._adjoint_order())
 
+    OVERLAP_SLABS = 4
+
     def active_index(self):
-        """Sorted int32 indices of the grid nodes ANY rank's rays reach (identical on every rank; computed once per
-        geometry).  The solvers keep their grid-sized vectors compact over this set."""
+        """int32 indices of the grid nodes ANY rank's rays reach (identical on every rank; computed once per geometry), sorted --
+        with ``exchange="overlap"`` sorted by z-slab of the back-projection plan first (``slab_ranges``: the compact range of every
+        slab).  The solvers keep their grid-sized vectors compact over this set."""
         if self._active is None:
             mask = (self._touched().reshape(-1) != 0).to(torch.int32)
             if self.world > 1:
                 dist.all_reduce(mask, op=dist.ReduceOp.MAX)
-            self._active = mask.nonzero().reshape(-1).to(torch.int32).contiguous()
+            idx = mask.nonzero().reshape(-1)
+            if self.slabs is not None:
+                zl = torch.tensor(self.slabs[1][1:-1], dtype=torch.int64, device=idx.device)
+                slab = torch.bucketize(idx % self.engine.shape[2], zl, right=True)       # node level z -> slab (a boundary level: the upper one)
+                idx = idx[torch.sort(slab, stable=True)[1]]
+                cnt = torch.bincount(slab, minlength=len(self.slabs[1]) - 1).cpu().tolist()
+                lo, self.slab_ranges = 0, []
+                for c in cnt:
+                    self.slab_ranges.append((lo, lo + c))
+                    lo += c
+            self._active = idx.to(torch.int32).contiguous()
         return self._active
+
+    def overlapped(self):
+        """exchange="overlap" is in force: the plan has z-slabs every rank agrees on and the engine back-projects slab by slab."""
+        return self.world > 1 and self.slabs is not None and self.fused_steps()
+
+    def backproject_exchange_overlapped(self, ray_step, s_full, s_c, idx):
+        """The summed back-projected update in the compact vector ``s_c`` with the exchange HIDDEN behind the back-projection
+        (replaces the reference's da.sum(da.stack(...)), inversion/gradient.py:52-54): ``ray_step()`` leaves the ray weights
+        in the library; then, slab by slab, back-project the slab's work units, gather (and re-zero) its finished node levels and
+        start their all-reduce -- asynchronously, so the next slab's kernel runs while the previous slab's sum is on the links."""
+        out = ray_step()
+        ul = self.slabs[0]
+        pending = []
+        rd = self.exchange.reduce_dtype
+        for sidx, (lo, hi) in enumerate(self.slab_ranges):
+            self.engine.adjoint_planned_weights(self.origins, self.dirs, self.tmax, self.Ns, s_full, unit_range=(ul[sidx], ul[sidx + 1]))
+            if hi <= lo:
+                continue
+            view = s_c[lo:hi]
+            self.engine.compact_gather(s_full, idx[lo:hi], out=view, zero=True, want_dot=False)
+            buf = view if rd is None or rd == view.dtype else view.to(rd)
+            pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, async_op=True), buf, view))
+        for work, buf, view in pending:
+            work.wait()
+            if buf is not view:
+                view.copy_(buf)
+        return out
 
     def scalar(self, partial):
         """A device scalar from the per-workgroup partial sums of a fused pass: used as is on one rank (the consuming

@@ -262,6 +262,7 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
     # residual + objective + the back-projection's ray weights in ONE ray pass (4 launches per iteration instead of 5); with a
     # stopping rule the objective is read back BEFORE the back-projection is started, so the passes stay apart there
     fused = not small and not stop and problem.fused_steps()
+    overlap = fused and multi and not sharded and problem.overlapped()       # exchange="overlap": the sum hidden behind the back-projection
     wbuf = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device) if small else None
     defer = multi and not stop                  # objective history: ONE stacked all-reduce at the end instead of one per iteration
     held = None
@@ -292,6 +293,9 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
                 if r is None:
                     r = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device)
                 S2, _, _ = eng.small_ray_pass(1, tec, L, r, problem.Na, problem.i0, dobs=problem.dobs, weight=Wt, w=wbuf)   # r = d - A x, weights
+            elif overlap:
+                # ray pass, then back-projection, gather and all-reduce slab by slab: the exchange runs behind the next slab's kernel
+                S2 = problem.backproject_exchange_overlapped(lambda: problem.backproject_sirt_step(tec, L, Wt, None), s_full, s_c, idx)
             elif fused:
                 S2 = problem.backproject_sirt_step(tec, L, Wt, s_full)          # r = d - A x, S, s_full += A^T (L r): one ray pass
             else:
@@ -316,9 +320,11 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
                 problem.all_gather_compact(xg, x_loc)
                 eng.compact_scatter(x_full, idx, xg[:n])
                 continue
-            if multi:                            # sum the partial updates over ranks on the active nodes only
+            if multi and not overlap:            # sum the partial updates over ranks on the active nodes only
                 eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=False)
                 problem.reduce_compact_(s_c)
+                eng.compact_scatter(s_full, idx, s_c)
+            elif multi:                          # (summed slab by slab behind the back-projection, above)
                 eng.compact_scatter(s_full, idx, s_c)
             step = eng.compact_sirt_update(x_c, C_c, s_full, idx, x_full, relax, nonneg, want_max=bool(stop))
     finally:
@@ -380,6 +386,7 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
     hist, q = [rr.sum().reshape(1) if multi else rr], None
     small = _small(problem, small_pass)
     fused = not small and problem.fused_steps()      # r -= alpha q, <r, r> and the back-projection's ray weights in ONE ray pass (6 launches, not 7)
+    overlap = fused and multi and not (multi and problem.exchange.sharded) and problem.overlapped()
     wbuf = torch.empty(problem.R_local, dtype=torch.float64, device=eng.device) if small else None
     held = None
     try:
@@ -416,7 +423,9 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
             else:
                 q, qq = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, 1.0, 0.0, s1=Wh, out=q)      # W^1/2 A p
                 qq = problem.scalar(qq)
-                if fused:
+                if overlap:
+                    rr = problem.backproject_exchange_overlapped(lambda: problem.backproject_cg_step(r, q, gamma, qq, Wh, None), s_full, s_c, idx)
+                elif fused:
                     rr = problem.backproject_cg_step(r, q, gamma, qq, Wh, s_full)   # r -= alpha q, <r, r>, s_full += A^T (W^1/2 r)
                 else:
                     rr = eng.axpby_dot_(r, q, an=gamma, ad=qq, a_sign=-1.0)         # r -= alpha q
@@ -437,10 +446,13 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
                 eng.compact_scatter(p_full, idx, pg[:n])
                 gamma = gnew
                 continue
-            _, gnew = eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=not multi)
-            if multi:
-                problem.reduce_compact_(s_c)
+            if overlap:                          # (s_c was gathered and summed slab by slab behind the back-projection)
                 gnew = eng.axpby_dot_(s_c, s_c, a_sign=0.0)
+            else:
+                _, gnew = eng.compact_gather(s_full, idx, out=s_c, zero=True, want_dot=not multi)
+                if multi:
+                    problem.reduce_compact_(s_c)
+                    gnew = eng.axpby_dot_(s_c, s_c, a_sign=0.0)
             eng.compact_cg_update(x_c, p_c, s_c, idx, p_full, gamma, qq, gnew, gamma)
             gamma = gnew
         if sharded:

@@ -59,7 +59,8 @@ def _run(world, exchange="dense", engine="oracle", size=None):
     adj32 = host(p32.adjoint(p32.slice(y_full)))
     return dict(fwd=fwd, adj=adj, xc=host(xc), hc=np.array(hc), xs=host(xs), hs=np.array(hs),
                 block=(prob.lo, prob.hi), adj32=adj32, active=prob.exchange.fraction,
-                compact=prob.exchange.index is not None, P=pb["P"])
+                compact=prob.exchange.index is not None, P=pb["P"],
+                overlapped=bool(getattr(prob, "overlapped", lambda: False)()), nslab=len(prob.slab_ranges or []))
 
 
 def _worker(rank, world, port, q, exchange, engine="oracle", size=None):

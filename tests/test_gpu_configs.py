@@ -42,10 +42,12 @@ def make_engine(w, **kw):
 
 # --------------------------------------------------------------------------- two processes, one card (first: the
 # children are started before this process has touched the GPU when the file runs on its own)
-@pytest.mark.parametrize("exchange", ["dense", "auto", "sharded"])
+@pytest.mark.parametrize("exchange", ["dense", "auto", "sharded", "overlap"])
 def test_two_process_hip_engine_matches_single_rank(exchange):
     """ShardedRays over the product's RayEngine in 2 fresh processes (gloo rendezvous, both on GPU 0) against the
-    single-rank run: forward without collective, adjoint + all-reduce, CGLS / SIRT iterates, float32 links."""
+    single-rank run: forward without collective, adjoint + all-reduce, CGLS / SIRT iterates, float32 links.
+    ``overlap``: the back-projection plan in z-slabs, every slab's finished node levels all-reduced asynchronously while the next
+    slab is back-projected (parallel.ShardedRays.backproject_exchange_overlapped)."""
     import torch.multiprocessing as mp
     from test_distributed_gloo import _worker, _run, _free_port
     size = dict(na=6, nd=7, nt=6, n=40, Ns=65)
@@ -73,6 +75,8 @@ def test_two_process_hip_engine_matches_single_rank(exchange):
         assert np.max(np.abs(res[r]["adj32"] - ref["adj"])) < 3e-7 * np.abs(ref["adj"]).max()
         if exchange != "dense":
             assert 0.0 < res[r]["active"] < 1.0 and res[r]["active"] == res[0]["active"]
+        if exchange == "overlap":
+            assert res[r]["overlapped"] and res[r]["nslab"] >= 2          # the slab pipeline really ran
 
 
 # --------------------------------------------------------------------------- config 3
