@@ -377,6 +377,37 @@ def cfg4_leg(w, local, k2, torch, dist, world):
         if world > 1:
             dist.barrier()
         out["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 10 * 1e3
+    if world > 1:
+        # the same iterations with the exchange hidden behind the back-projection (exchange="overlap": the plan in z-slabs, every slab's
+        # finished node levels all-reduced asynchronously while the next slab is back-projected), float64 and float32 on the links
+        del prob
+        for tag, rd in (("overlap_f64", None), ("overlap_f32", torch.float32), ("compact_f32", torch.float32)):
+            try:
+                pr = parallel.ShardedRays(e4, c4["origins"], c4["directions"], TMAX, NS, dobs=np.zeros((NA, P)), cdct=np.full((NA, P), 1e-6),
+                                          i0=0, tune=False, exchange="overlap" if tag.startswith("overlap") else "compact", reduce_dtype=rd)
+                e4.set_values((x0 * 1.1).reshape(-1))
+                pr.dobs = pr.forward().clone()
+                sub = {"overlapped": bool(pr.overlapped()), "slabs": len(pr.slab_ranges or [])}
+                for name in ("cgls", "sirt"):
+                    fn = getattr(solvers, name)
+                    fn(pr, x0, n_iter=2)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    t0 = time.perf_counter()
+                    fn(pr, x0, n_iter=10)
+                    torch.cuda.synchronize()
+                    dist.barrier()
+                    sub["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 10 * 1e3
+                out[tag] = sub
+                del pr
+                ok = 1
+            except Exception as exc:                                # noqa: BLE001
+                out[tag] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=e4.device)      # all ranks or none enter the next variant
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if not int(flag.item()):
+                break
     return out
 
 

@@ -185,8 +185,8 @@ int iono_adjoint_sirt_step_dev(iono_ctx *ctx, const double *origins_dev, const d
  *      being back-projected (replaces the reference's sum over per-direction gradients, inversion/gradient.py:52-54).
  * iono_adjoint_plan_slabs(n): the NEXT iono_adjoint_plan_dev orders its work units by z-slab (n <= 8 slabs of whole box layers).
  * iono_adjoint_plan_slab_info: nslab, unit_lo[nslab + 1] (slab s = units [unit_lo[s], unit_lo[s+1])) and z_lo[nslab + 1] (slab s owns
- *   the node levels [z_lo[s], z_lo[s+1]): once the units of slabs 0 .. s have run, those levels are final -- provided the plan's
- *   outside_fraction is 0, i.e. no sample bypasses its box image).
+ *   the node levels [z_lo[s], z_lo[s+1]): once the units of slabs 0 .. s have run, those levels are final -- segments never leave
+ *   their z-layer of boxes, also where samples overhang the box image in x or y and go by global atomics).
  * iono_adjoint_unit_range(lo, hi): the next planned trilinear back-projection runs units [lo, hi) only (one-shot).
  * iono_adjoint_cg_step_dev / _sirt_step_dev with grad_dev = NULL: the ray pass alone; iono_adjoint_planned_weights_dev then
  *   back-projects the weights it left in the library (slab by slab with iono_adjoint_unit_range). */

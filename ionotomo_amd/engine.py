@@ -183,7 +183,7 @@ class RayEngine(object):
 
     def plan_slabs(self):
         """(unit_lo[nslab + 1], z_lo[nslab + 1]) of the current back-projection plan: slab s = work units [unit_lo[s], unit_lo[s+1])
-        and owns the node levels [z_lo[s], z_lo[s+1]) (final once slabs 0 .. s have run, given an outside fraction of 0)."""
+        and owns the node levels [z_lo[s], z_lo[s+1]) (final once slabs 0 .. s have run)."""
         import ctypes
         n = ctypes.c_int(0)
         ul, zl = (ctypes.c_int * 9)(), (ctypes.c_int * 9)()

@@ -135,7 +135,9 @@ class ShardedRays(object):
         if plan and hasattr(engine, "plan_adjoint") and self.R_local > 0:
             if exchange == "overlap" and self.world > 1 and hasattr(engine, "plan_slabs"):
                 self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns, slabs=self.OVERLAP_SLABS)
-                if self.plan[0] and self.plan[2] == 0.0:       # every sample inside its box image: a slab's node levels are final
+                # (a segment never leaves its z-layer of boxes -- the plan cuts rays at layer boundaries -- so a slab's node levels are
+                #  final once its units have run even where samples overhang their box image in x or y and go by global atomics)
+                if self.plan[0]:
                     self.slabs = engine.plan_slabs()
             else:
                 self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns)
