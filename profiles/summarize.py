@@ -25,8 +25,18 @@ def short(name):
     return name.split("(")[0]
 
 
+def newest(pattern):
+    """one file per run directory: the newest (a directory re-used by a later run of the same tag holds the older run's files too)"""
+    by_dir = {}
+    for f in glob.glob(pattern):
+        d = os.path.dirname(f)
+        if d not in by_dir or os.path.getmtime(f) > os.path.getmtime(by_dir[d]):
+            by_dir[d] = f
+    return sorted(by_dir.values())
+
+
 # kernel stats (rocprofv3 --kernel-trace --stats)
-for f in sorted(glob.glob(os.path.join(G, tag + "_stats_*", "*", "*_kernel_stats.csv"))):
+for f in newest(os.path.join(G, tag + "_stats_*", "*", "*_kernel_stats.csv")):
     rows = list(csv.DictReader(open(f)))
     out = os.path.join(P, "%s_kernel_stats.csv" % os.path.basename(os.path.dirname(os.path.dirname(f))))
     with open(out, "w") as fh:
@@ -44,7 +54,7 @@ for f in sorted(glob.glob(os.path.join(G, tag + "_stats_*.json")) + glob.glob(os
 
 # PMC passes: per leg, per kernel, per counter (mean over the launches of the pass, largest grid only)
 legs = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(list)))
-for f in glob.glob(os.path.join(G, tag + "_pmc_*", "*", "*_counter_collection.csv")):
+for f in newest(os.path.join(G, tag + "_pmc_*", "*", "*_counter_collection.csv")):
     leg = os.path.basename(os.path.dirname(os.path.dirname(f)))[len(tag) + 5:].rsplit("_", 1)[0]
     for r in csv.DictReader(open(f)):
         key = "%s|grid=%s" % (short(r["Kernel_Name"]), r.get("Grid_Size", "?"))
