@@ -79,6 +79,7 @@ _SIGNATURES = {
     "iono_adjoint_cg_step_dev": [_V, _V, _V, _V, _V, _V, _I, _V, _I, _V, _I, _L, _I, _D, _I, _I, _I, _V, _V, _I],
     "iono_adjoint_sirt_step_dev": [_V, _V, _V, _V, _V, _V, _V, _I, _L, _I, _D, _I, _I, _I, _V, _V, _V, _I],
     "iono_adjoint_plan_slabs": [_I],
+    "iono_set_deterministic": [_I],
     "iono_adjoint_plan_slab_info": [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)],
     "iono_adjoint_unit_range": [_I, _I],
     "iono_adjoint_planned_weights_dev": [_V, _V, _V, _L, _D, _I, _I, _I, _V, _I],

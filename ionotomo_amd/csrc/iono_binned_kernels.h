@@ -77,6 +77,29 @@ __global__ void k_plan_urays(GridView g, const double *__restrict__ origins, con
 __device__ __forceinline__ int plan_cell(double f0, double df, int k, int n) {
     return (int)fmin(__builtin_floor(__builtin_fabs(__builtin_fma((double)k, df, f0))), (double)(n - 2));
 }
+// The tiles (LMT_X x LMT_Y x LMT_Z nodes, iono_cubic_kernels.h) the samples of the planned rays add into, with a margin of one cell
+// either side (the corner nodes c .. c + 1 of a sample's cell c: tiles of c - 1 .. c + 2): touch[tile] = 1.  Thread per ray;
+// a store only when the tile range changed since the previous sample.
+__global__ __launch_bounds__(256) void k_plan_touch(const double *__restrict__ uray, int64_t R, int Ns, int nx, int ny, int nz, int nty,
+                                                    int ntz, unsigned char *__restrict__ touch) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const double *u = uray + r * 8;
+        if (u[7] == 0.0) continue;
+        const double fx0 = u[0], dfx = u[1], fy0 = u[2], dfy = u[3], fz0 = u[4], dfz = u[5];
+        int px = -1, py = -1, pz = -1;
+        for (int k = 0; k < Ns; ++k) {
+            const int cx = plan_cell(fx0, dfx, k, nx), cy = plan_cell(fy0, dfy, k, ny), cz = plan_cell(fz0, dfz, k, nz);
+            const int xa = max(cx - 1, 0) / LMT_X, xb = min(cx + 2, nx - 1) / LMT_X, ya = max(cy - 1, 0) / LMT_Y, yb = min(cy + 2, ny - 1) / LMT_Y;
+            const int za = max(cz - 1, 0) / LMT_Z, zb = min(cz + 2, nz - 1) / LMT_Z;
+            const int kx = xa | (xb << 16), ky = ya | (yb << 16), kz = za | (zb << 16);
+            if (kx == px && ky == py && kz == pz) continue;
+            px = kx, py = ky, pz = kz;
+            for (int a = xa; a <= xb; ++a)
+                for (int b = ya; b <= yb; ++b)
+                    for (int cc = za; cc <= zb; ++cc) touch[((int64_t)a * nty + b) * ntz + cc] = 1;
+        }
+    }
+}
 // Wave-aggregated counter update: the 64 rays of a wave are neighbours and file their k-th segments under a handful of boxes,
 // so one lane per distinct box adds the number of lanes that share it (per-segment atomics on a few hot addresses made the two
 // passes 8.6 + 9.5 ms; aggregated: see profiles/tools/time_plan.py).  Must be called by the whole wave; returns this lane's slot
@@ -309,6 +332,46 @@ __global__ __launch_bounds__(64 * RSTEP_WAVES) void k_rays_step(const double *__
     }
 }
 
+// ---- deterministic back-projection (FIX): the box image and the grid accumulate 64-bit FIXED-POINT integers ---------------------------
+// Integer addition is associative: whatever order the LDS and memory atomics are served in, the sums are the same bits run after run
+// (float atomics differ in the last bits from launch to launch, which CG amplifies once it has converged to the noise).
+// Scale = 2^e with  (largest contribution M) * 2^e <= 2^(62 - fixbits),  fixbits >= 12 bounding the contributions a node can receive
+// (the plan knows: 8 boxes' segments x lanes), so a sum never leaves int64 and a single value stays below 2^50: the conversion is ONE
+// fma against 1.5 * 2^52 (the integer sits in the mantissa) + a 64-bit subtraction.  M = max_r |w_r h_r| * 4/3 (Simpson), found by
+// k_fix_absmax for the weights of THIS launch; the grid of integers is turned into float64 and re-zeroed by k_fix_convert.
+// A NaN weight (or a ray record poisoned by plan_verify_ray) gives M = inf -> scale NaN -> NaN at every node the launch reaches.
+#define FIX_MAGIC 6755399441055744.0       // 1.5 * 2^52
+__device__ __forceinline__ double fix_scale(unsigned long long maxbits, int fixbits) {
+    const double M = __longlong_as_double((long long)maxbits) * (4.0 / 3.0) * (1.0 + 0x1p-40);
+    if (M == 0.0) return 1.0;
+    if (!(M < 1.7e308)) return __builtin_nan("");
+    return ldexp(1.0, 62 - fixbits - (ilogb(M) + 1));
+}
+__global__ __launch_bounds__(256) void k_fix_absmax(const double *__restrict__ w, const double *__restrict__ uray, int64_t R,
+                                                    unsigned long long *__restrict__ out) {
+    double m = 0.0;
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        if (uray[r * 8 + 7] == 0.0) continue;            // rays outside the grid have no segments
+        double v = __builtin_fabs(w[r] * uray[r * 8 + 6]);
+        if (!(v == v)) v = __builtin_inf();
+        m = fmax(m, v);
+    }
+    for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));      // (positive doubles order as integers)
+}
+template <typename AT>
+__global__ __launch_bounds__(256) void k_fix_convert(unsigned long long *__restrict__ F, AT *__restrict__ grad, int64_t n,
+                                                     const unsigned long long *__restrict__ fixmax, int fixbits) {
+    const double inv = 1.0 / fix_scale(*fixmax, fixbits);      // a power of two (or NaN)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const long long q = (long long)F[i];
+        if (q != 0) {
+            grad[i] = (AT)((double)grad[i] + (double)q * inv);
+            F[i] = 0ull;
+        }
+    }
+}
+
 __device__ __forceinline__ double dpp_shr1(double v) {       // value of the previous lane of the 16-lane row (0 for its first lane)
     // (bound_ctrl: the row's first lane reads 0 without an initialised destination -- eight v_mov fewer per pass)
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x111, 0xf, 0xf, true);
@@ -319,11 +382,13 @@ __device__ __forceinline__ double dpp_shr1(double v) {       // value of the pre
 // PNF > 0: transpose of the PHASE observable (inversion/iterative_newton.py:86-127) for PNF frequencies per pass: the ray weight
 // becomes a per-sample factor  sum_l wrf[r][l] / (2 n_p,l sqrt(1 - ne_k / n_p,l))  of the electron density ne_k interpolated at
 // the sample (gathered from the grid exactly as the forward kernel does), wray = wrf with row stride ldw.
-template <typename AT, bool CUBIC, int PNF = 0, typename GT = double, int SEGL = BIN_SEG>
+// FIX: deterministic fixed-point accumulation (above); G is then the grid of 64-bit integers.
+template <typename AT, bool CUBIC, int PNF = 0, typename GT = double, int SEGL = BIN_SEG, bool FIX = false>
 __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
                                                         const BinUnit *__restrict__ units, const double *__restrict__ wray,
                                                         int Ns, const double *__restrict__ unitw, AT *__restrict__ G, int field,
-                                                        PhaseFreqs pf = PhaseFreqs{}, int ldw = 0) {
+                                                        PhaseFreqs pf = PhaseFreqs{}, int ldw = 0,
+                                                        const unsigned long long *__restrict__ fixmax = nullptr, int fixbits = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     // the box image is float64 whatever the accumulation type of the result: ds_add_f32 measured FIVE times slower than
@@ -383,6 +448,27 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
         asm volatile("ds_add_f64 %0, %1 offset:8\n\tds_add_f64 %0, %2 offset:%5\n\tds_add_f64 %0, %3 offset:%6\n\tds_add_f64 %0, %4 offset:%7"
                      ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8 + 8), "n"(BIN_BY * BIN_BZP * 8 + 8), "n"((BIN_BY + 1) * BIN_BZP * 8 + 8) : "memory");
     };
+    // FIX: the same eight words as integers (the values are int64 bit patterns carried in double registers)
+    auto tile_add4_fix = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:%5\n\tds_add_u64 %0, %3 offset:%6\n\tds_add_u64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8), "n"(BIN_BY * BIN_BZP * 8), "n"((BIN_BY + 1) * BIN_BZP * 8) : "memory");
+    };
+    auto tile_add4_up_fix = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_u64 %0, %1 offset:8\n\tds_add_u64 %0, %2 offset:%5\n\tds_add_u64 %0, %3 offset:%6\n\tds_add_u64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8 + 8), "n"(BIN_BY * BIN_BZP * 8 + 8), "n"((BIN_BY + 1) * BIN_BZP * 8 + 8) : "memory");
+    };
+    const double fscale = FIX ? fix_scale(*fixmax, fixbits) : 1.0;
+    auto qf = [&](double v) {
+        const double t = fma(v, fscale, FIX_MAGIC);
+        return __longlong_as_double(__double_as_longlong(t) - __double_as_longlong(FIX_MAGIC));
+    };
+    auto global_add4_fix = [&](int i, int j, int kk, double v00, double v01, double v10, double v11) {
+        unsigned long long *p = (unsigned long long *)G + ((size_t)i * g.ny + j) * g.nz + kk;
+        atomicAdd(p, (unsigned long long)__double_as_longlong(v00));
+        atomicAdd(p + g.nz, (unsigned long long)__double_as_longlong(v01));
+        atomicAdd(p + (size_t)g.ny * g.nz, (unsigned long long)__double_as_longlong(v10));
+        atomicAdd(p + (size_t)g.ny * g.nz + g.nz, (unsigned long long)__double_as_longlong(v11));
+    };
     const unsigned tile_base = (unsigned)(size_t)tile;
     auto clampf = [](double v, double lim) {
         double o;
@@ -438,12 +524,24 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
         if (accept) l00 += p00, l01 += p01, l10 += p10, l11 += p11;
         const int taken = __builtin_amdgcn_update_dpp(0, (int)accept, 0x101, 0xf, 0xf, false);  // row_shl:1: did lane s + 1 take mine?
         const bool upper = active && !taken;
+        if (FIX) {       // (after the lane exchange: what is handed over and merged is decided by the plan, not by the launch)
+            l00 = qf(l00), l01 = qf(l01), l10 = qf(l10), l11 = qf(l11);
+            u00 = qf(u00), u01 = qf(u01), u10 = qf(u10), u11 = qf(u11);
+        }
         if (active) {
             const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
             if ((a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1))) {
                 const unsigned t = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
-                tile_add4(t, l00, l01, l10, l11);
-                if (upper) tile_add4_up(t, u00, u01, u10, u11);
+                if (FIX) {
+                    tile_add4_fix(t, l00, l01, l10, l11);
+                    if (upper) tile_add4_up_fix(t, u00, u01, u10, u11);
+                } else {
+                    tile_add4(t, l00, l01, l10, l11);
+                    if (upper) tile_add4_up(t, u00, u01, u10, u11);
+                }
+            } else if (FIX) {
+                global_add4_fix(i, j, kz, l00, l01, l10, l11);
+                if (upper) global_add4_fix(i, j, kz + 1, u00, u01, u10, u11);
             } else {
                 global_add4<AT>(G, i, j, kz, g.ny, g.nz, l00, l01, l10, l11);
                 if (upper) global_add4<AT>(G, i, j, kz + 1, g.ny, g.nz, u00, u01, u10, u11);
@@ -466,11 +564,13 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
     const int m = threadIdx.x & 15;
     for (int col = threadIdx.x >> 4; col < BIN_BX * BIN_BY; col += BIN_THREADS / 16) {
         const double v = tile[col * BIN_BZP + m];
-        if (v != 0.0) {
+        if (FIX ? __double_as_longlong(v) != 0 : v != 0.0) {
             const int a = col / BIN_BY, b = col - a * BIN_BY;
             const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + m;
-            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz)
-                atomicAdd(G + ((size_t)gi * g.ny + gj) * g.nz + gk, (AT)v);
+            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz) {
+                if (FIX) atomicAdd((unsigned long long *)G + ((size_t)gi * g.ny + gj) * g.nz + gk, (unsigned long long)__double_as_longlong(v));
+                else atomicAdd(G + ((size_t)gi * g.ny + gj) * g.nz + gk, (AT)v);
+            }
         }
     }
 }

@@ -185,6 +185,111 @@ __global__ __launch_bounds__(256) void k_lm_fold_x(const double *__restrict__ K0
     }
 }
 
+// ---- the same three passes over the TILES a back-projection plan's rays reach (round 4) ------------------------------------------------
+// A plan knows which 8 x 8 x 16-node tiles its samples add into (k_plan_touch: T).  The z pass can only give non-zero values on
+// A1 = T dilated by one tile along z, the y pass on A2 = A1 dilated along y, the x pass on A3 = A2 dilated along x: each pass runs
+// over the list of its OUTPUT tiles and reads its input only where the previous pass wrote it (flags: centre / lower / upper
+// neighbour tile of the fold axis belong to the input set; G8 is zeroed on A1 only).  Everything outside is never written and
+// never read, so the channel buffers need no full-grid memset and the folds stream the reached fraction of the grid.
+#define LMT_X 8
+#define LMT_Y 8
+#define LMT_Z 16
+#define LMT_NODES (LMT_X * LMT_Y * LMT_Z)
+struct LmTile {
+    int id;         // (ti * nty + tj) * ntz + tk
+    int flags;      // bit 0: this tile, bit 1: the tile below it along the fold axis, bit 2: the tile above it -- belong to the INPUT set
+};
+struct LmTileGeom {
+    int nx, ny, nz, nty, ntz;
+};
+// node (i, j, k) number q of tile t for thread-contiguous z runs: q = (a * LMT_Y + b) * LMT_Z + c
+__device__ __forceinline__ bool lm_tile_node(const LmTileGeom &tg, int id, int q, int &i, int &j, int &k, int &a, int &b, int &cc) {
+    const int tk = id % tg.ntz, tj = (id / tg.ntz) % tg.nty, ti = id / (tg.ntz * tg.nty);
+    cc = q % LMT_Z, b = (q / LMT_Z) % LMT_Y, a = q / (LMT_Z * LMT_Y);
+    i = ti * LMT_X + a, j = tj * LMT_Y + b, k = tk * LMT_Z + cc;
+    return i < tg.nx && j < tg.ny && k < tg.nz;
+}
+// is the neighbour at offset dd (-2..2, != 0) along an axis, local coordinate l of extent L, inside the input set?
+__device__ __forceinline__ bool lm_tile_has(int flags, int l, int dd, int L) {
+    const int m = l + dd;
+    return m < 0 ? (flags & 2) != 0 : (m >= L ? (flags & 4) != 0 : (flags & 1) != 0);
+}
+__global__ __launch_bounds__(256) void k_lm_zero_tiles(double *__restrict__ G8, const LmTile *__restrict__ tiles, LmTileGeom tg) {
+    const int64_t n = (int64_t)tg.nx * tg.ny * tg.nz;
+    const int id = tiles[blockIdx.x].id;
+    for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
+        int i, j, k, a, b, cc;
+        if (!lm_tile_node(tg, id, q, i, j, k, a, b, cc)) continue;
+        const int64_t idx = ((int64_t)i * tg.ny + j) * tg.nz + k;
+#pragma unroll
+        for (int f = 0; f < LM_NF; ++f) G8[(int64_t)f * n + idx] = 0.0;
+    }
+}
+__global__ __launch_bounds__(256) void k_lm_fold_z_tiles(const double *__restrict__ G8, double2 *__restrict__ H0, double2 *__restrict__ H1,
+                                                         const LmTile *__restrict__ tiles, LmTileGeom tg) {
+    const int64_t n = (int64_t)tg.nx * tg.ny * tg.nz;
+    const LmTile t = tiles[blockIdx.x];
+    for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
+        int i, j, k, a, b, cc;
+        if (!lm_tile_node(tg, t.id, q, i, j, k, a, b, cc)) continue;
+        const int64_t idx = ((int64_t)i * tg.ny + j) * tg.nz + k;
+        double h[4];
+#pragma unroll
+        for (int pq = 0; pq < 4; ++pq) {
+            const double *r0 = G8 + (int64_t)pq * n + idx, *r1 = G8 + (int64_t)(pq + 4) * n + idx;
+            double s = r0[0];                          // (output tiles of the z pass are its input set: G8 is zeroed on all of them)
+#pragma unroll
+            for (int dc = -2; dc <= 2; ++dc) {
+                if (dc == 0) continue;
+                const int sk = k + dc;
+                if (sk >= 2 && sk <= tg.nz - 3 && lm_tile_has(t.flags, cc, dc, LMT_Z)) s += fd_coef(-dc) * r1[dc];
+            }
+            h[pq] = s;
+        }
+        H0[idx] = make_double2(h[0], h[1]);
+        H1[idx] = make_double2(h[2], h[3]);
+    }
+}
+__global__ __launch_bounds__(256) void k_lm_fold_y_tiles(const double2 *__restrict__ H0, const double2 *__restrict__ H1, double *__restrict__ K0,
+                                                         double *__restrict__ K1, const LmTile *__restrict__ tiles, LmTileGeom tg) {
+    const LmTile t = tiles[blockIdx.x];
+    for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
+        int i, j, k, a, b, cc;
+        if (!lm_tile_node(tg, t.id, q, i, j, k, a, b, cc)) continue;
+        const int64_t idx = ((int64_t)i * tg.ny + j) * tg.nz + k;
+        double2 k2 = (t.flags & 1) ? H0[idx] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int db = -2; db <= 2; ++db) {
+            if (db == 0) continue;
+            const int sj = j + db;
+            if (sj >= 2 && sj <= tg.ny - 3 && lm_tile_has(t.flags, b, db, LMT_Y)) {
+                const double2 v = H1[idx + (int64_t)db * tg.nz];
+                k2.x += fd_coef(-db) * v.x, k2.y += fd_coef(-db) * v.y;
+            }
+        }
+        K0[idx] = k2.x, K1[idx] = k2.y;
+    }
+}
+template <typename AT>
+__global__ __launch_bounds__(256) void k_lm_fold_x_tiles(const double *__restrict__ K0, const double *__restrict__ K1, AT *__restrict__ grad,
+                                                         const LmTile *__restrict__ tiles, LmTileGeom tg) {
+    const int64_t sx = (int64_t)tg.ny * tg.nz;
+    const LmTile t = tiles[blockIdx.x];
+    for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
+        int i, j, k, a, b, cc;
+        if (!lm_tile_node(tg, t.id, q, i, j, k, a, b, cc)) continue;
+        const int64_t idx = ((int64_t)i * tg.ny + j) * tg.nz + k;
+        double acc = (t.flags & 1) ? K0[idx] : 0.0;
+#pragma unroll
+        for (int da = -2; da <= 2; ++da) {
+            if (da == 0) continue;
+            const int si = i + da;
+            if (si >= 2 && si <= tg.nx - 3 && lm_tile_has(t.flags, a, da, LMT_X)) acc += fd_coef(-da) * K1[idx + da * sx];
+        }
+        grad[idx] = (AT)((double)grad[idx] + acc);
+    }
+}
+
 struct Herm {
     double h0, h1, s0, s1;        // value weights of nodes 0 / 1, slope weights of nodes 0 / 1
 };

@@ -111,6 +111,8 @@ struct iono_ctx {
     double *d_FP = nullptr;          // the same fields PAIR-major [4][padded nodes][2] for the bundle-stationary tricubic forward (lazily built)
     bool FP_valid = false;
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
+    bool deterministic = false;      // iono_set_deterministic / env IONOTOMO_DETERMINISTIC=1: fixed-point back-projection (k_adjoint_binned<.., FIX>)
+    unsigned long long *d_fixgrid = nullptr;      // its grid of 64-bit integers [nodes] + the launch's largest |w h| behind it; all zero between launches
     double *d_LMw = nullptr;         // [nodes][6] scratch of the axis-by-axis field build / fold
     float4 *d_Q4 = nullptr;          // float32 storage: 2 x 2 (y, z) corner blocks for the 2-loads-per-sample forward (lazily built)
     bool Q4_valid = false;
@@ -133,6 +135,10 @@ struct iono_ctx {
         int slab_unit[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // ... and owns the node levels [slab_z[s], slab_z[s + 1])
         int slab_z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
+        int fix_bits = 12;                                // deterministic mode: log2 bound of the contributions one node can receive (+ 1)
+        LmTile *d_tiles = nullptr;                        // tricubic plans: output tiles of the z | y | x fold passes (k_lm_fold_*_tiles)
+        int tile_n[3] = {0, 0, 0}, tile_off[3] = {0, 0, 0};
+        size_t cap_tiles = 0;
         int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
         size_t cap_uray = 0, cap_hash = 0, cap_entries = 0, cap_units = 0, cap_nseg = 0, cap_partial = 0;      // bytes (grow-only: a new geometry reuses them)
     } plan;
@@ -177,6 +183,7 @@ void plan_free(iono_ctx *c) {
     if (c->plan.d_units) (void)hipFree(c->plan.d_units);
     if (c->plan.d_nseg) (void)hipFree(c->plan.d_nseg);
     if (c->plan.d_partial) (void)hipFree(c->plan.d_partial);
+    if (c->plan.d_tiles) (void)hipFree(c->plan.d_tiles);
     c->plan = iono_ctx::AdjPlan();
 }
 // forget the plan but keep its buffers: the next geometry (a new timestep's directions) reuses them -- hipMalloc / hipFree
@@ -187,6 +194,7 @@ void plan_reset(iono_ctx *c) {
     fresh.cap_uray = p.cap_uray, fresh.cap_entries = p.cap_entries, fresh.cap_units = p.cap_units, fresh.cap_nseg = p.cap_nseg;
     fresh.cap_partial = p.cap_partial;
     fresh.d_hash = p.d_hash, fresh.cap_hash = p.cap_hash;
+    fresh.d_tiles = p.d_tiles, fresh.cap_tiles = p.cap_tiles;
     p = fresh;
 }
 template <typename T>
@@ -489,6 +497,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 2 | 4), c->walk_mode_set = true;
     if (const char *e = getenv("IONOTOMO_FWD_PLAN")) c->fwd_plan = atoi(e);
     if (const char *e = getenv("IONOTOMO_SEG_LANES")) c->seg_lanes = atoi(e);
+    if (const char *e = getenv("IONOTOMO_DETERMINISTIC")) c->deterministic = atoi(e) != 0;
     if (const char *e = getenv("IONOTOMO_ADJ_BUNDLE")) c->adj_mode = atoi(e) & (32 | 64 | 128);
 #ifdef IONO_ABLATION
     if (const char *e = getenv("IONOTOMO_ADJ_ABLATE")) c->adj_mode |= atoi(e) & (4 | 8);     // timing only: WRONG results
@@ -516,6 +525,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_FP) (void)hipFree(c->d_FP);
     if (c->d_nF8) (void)hipFree(c->d_nF8);
     if (c->d_G8) (void)hipFree(c->d_G8);
+    if (c->d_fixgrid) (void)hipFree(c->d_fixgrid);
     if (c->d_LMw) (void)hipFree(c->d_LMw);
     if (c->d_Q4) (void)hipFree(c->d_Q4);
     if (c->d_freqs) (void)hipFree(c->d_freqs);
@@ -599,6 +609,8 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     if (c->d_FP) HIP_TRY(c, hipFree(c->d_FP));
     if (c->d_nF8) HIP_TRY(c, hipFree(c->d_nF8));
     if (c->d_G8) HIP_TRY(c, hipFree(c->d_G8));
+    if (c->d_fixgrid) HIP_TRY(c, hipFree(c->d_fixgrid));
+    c->d_fixgrid = nullptr;
     if (c->d_LMw) HIP_TRY(c, hipFree(c->d_LMw));
     if (c->d_Q4) HIP_TRY(c, hipFree(c->d_Q4));
     c->d_LMw = nullptr;
@@ -1334,6 +1346,59 @@ int iono_adjoint_plan_clear(iono_ctx *c) {
     return IONO_OK;
 }
 
+// Tricubic plans: the tiles the fold passes have to visit (iono_cubic_kernels.h: k_lm_fold_*_tiles).  T = tiles the samples reach
+// (k_plan_touch); A1 = T dilated along z, A2 = A1 along y, A3 = A2 along x; per pass the list of output tiles with the flags of its
+// input set along the fold axis.
+static int plan_fold_tiles(iono_ctx *c, int64_t R, int Ns) {
+    iono_ctx::AdjPlan &pl = c->plan;
+    pl.tile_n[0] = pl.tile_n[1] = pl.tile_n[2] = 0;
+    const int ntx = (c->nx + LMT_X - 1) / LMT_X, nty = (c->ny + LMT_Y - 1) / LMT_Y, ntz = (c->nz + LMT_Z - 1) / LMT_Z;
+    const int64_t nt = (int64_t)ntx * nty * ntz;
+    if (nt > ((int64_t)1 << 28)) return IONO_OK;
+    DevBuf tb(c);
+    HIP_TRY(c, tb.alloc((size_t)nt));
+    unsigned char *d_touch = tb.as<unsigned char>();
+    HIP_TRY(c, hipMemsetAsync(d_touch, 0, (size_t)nt, c->stream));
+    hipLaunchKernelGGL(k_plan_touch, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz, nty, ntz, d_touch);
+    HIP_TRY(c, hipGetLastError());
+    std::vector<unsigned char> in((size_t)nt), out((size_t)nt);
+    HIP_TRY(c, hipMemcpyAsync(in.data(), d_touch, (size_t)nt, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const long long reached = (long long)std::count(in.begin(), in.end(), (unsigned char)1);
+    const int64_t stride[3] = {1, ntz, (int64_t)ntz * nty};      // fold order: z, y, x
+    const int extent[3] = {ntz, nty, ntx};
+    std::vector<LmTile> lists[3];
+    auto coord = [&](int64_t t, int axis) { return axis == 0 ? (int)(t % ntz) : axis == 1 ? (int)((t / ntz) % nty) : (int)(t / ((int64_t)ntz * nty)); };
+    for (int axis = 0; axis < 3; ++axis) {
+        const int64_t st = stride[axis];
+        for (int64_t t = 0; t < nt; ++t) {
+            const int l = coord(t, axis);
+            const bool lo = l > 0 && in[(size_t)(t - st)], hi = l + 1 < extent[axis] && in[(size_t)(t + st)];
+            out[(size_t)t] = in[(size_t)t] || lo || hi;
+            if (out[(size_t)t]) lists[axis].push_back(LmTile{(int)t, (in[(size_t)t] ? 1 : 0) | (lo ? 2 : 0) | (hi ? 4 : 0)});
+        }
+        if (axis == 0)       // G8 is zeroed on A1 and the z pass reads it there: its input set is A1 itself
+            for (LmTile &e : lists[0]) {
+                const int l = coord(e.id, 0);
+                e.flags = 1 | (l > 0 && out[(size_t)(e.id - 1)] ? 2 : 0) | (l + 1 < ntz && out[(size_t)(e.id + 1)] ? 4 : 0);
+            }
+        in.swap(out);
+    }
+    const size_t total = lists[0].size() + lists[1].size() + lists[2].size();
+    if (total == 0) return IONO_OK;
+    HIP_TRY(c, plan_reserve(pl.d_tiles, pl.cap_tiles, total * sizeof(LmTile)));
+    size_t off = 0;
+    for (int axis = 0; axis < 3; ++axis) {
+        HIP_TRY(c, hipMemcpy(pl.d_tiles + off, lists[axis].data(), lists[axis].size() * sizeof(LmTile), hipMemcpyHostToDevice));
+        pl.tile_off[axis] = (int)off, pl.tile_n[axis] = (int)lists[axis].size();
+        off += lists[axis].size();
+    }
+    if (getenv("IONOTOMO_PLAN_STATS"))
+        fprintf(stderr, "[ionotomo] fold tiles: %lld of %lld reached; passes over %d / %d / %d\n",
+                reached, (long long)nt, pl.tile_n[0], pl.tile_n[1], pl.tile_n[2]);
+    return IONO_OK;
+}
+
 int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, int kind) {
     int rc = check_common(c, R, Ns, kind, 0);
     if (rc) return rc;
@@ -1501,11 +1566,21 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, plan_reserve(pl.d_nseg, pl.cap_nseg, (size_t)R));
     HIP_TRY(c, hipMemcpy(pl.d_nseg, nseg.data(), (size_t)R, hipMemcpyHostToDevice));
     pl.smax = smax, pl.fwd_ok = fwd_ok && !cubic;
+    if (cubic) {
+        rc = plan_fold_tiles(c, R, Ns);
+        if (rc) return rc;
+    }
     if (pl.fwd_ok && c->fwd_plan) HIP_TRY(c, plan_reserve(pl.d_partial, pl.cap_partial, (size_t)R * smax * sizeof(double)));
     else pl.fwd_ok = false;      // (the node-stationary FORWARD is an opt-in A/B: no 40 MB of partial sums otherwise)
     pl.o_key = o, pl.d_key = d, pl.R = R, pl.Ns = Ns, pl.tmax = tmax, pl.kind = kind;
     pl.n_entries = ne, pl.n_units = (int)units.size(), pl.n_invalid = n_invalid, pl.segl = segl;
     pl.outside_fraction = (double)outside / (double)ne;
+    {   // a node lies in the images of at most 8 boxes; a segment holds at most segl samples
+        int64_t maxcnt = 0;
+        for (int64_t b = 0; b < nbox; ++b) maxcnt = std::max<int64_t>(maxcnt, h_cnt[(size_t)b]);
+        const double bound = std::min((double)R * Ns, 8.0 * (double)maxcnt * segl);
+        pl.fix_bits = std::max(12, (int)std::ceil(std::log2(std::max(bound, 2.0))) + 1);
+    }
     return IONO_OK;
 }
 
@@ -1599,12 +1674,33 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         int u_lo = 0, u_hi = pl.n_units;
         if (c->unit_lo >= 0) u_lo = std::min(c->unit_lo, pl.n_units), u_hi = std::max(u_lo, std::min(c->unit_hi, pl.n_units));
         c->unit_lo = c->unit_hi = -1;
+        if (c->deterministic) {
+            // fixed-point accumulation: the largest |w h| of this launch -> scale; integers in the box images and in d_fixgrid; converted
+            // into `grad` (and re-zeroed) by k_fix_convert (iono_binned_kernels.h)
+            const int64_t n = ncells(c);
+            if (!c->d_fixgrid) {
+                HIP_TRY(c, hipMalloc((void **)&c->d_fixgrid, ((size_t)n + 1) * sizeof(unsigned long long)));
+                HIP_TRY(c, hipMemsetAsync(c->d_fixgrid, 0, ((size_t)n + 1) * sizeof(unsigned long long), c->stream));
+            }
+            unsigned long long *fixmax = c->d_fixgrid + n;
+            HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
+            hipLaunchKernelGGL(k_fix_absmax, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, wr, pl.d_uray, R, fixmax);
+            if (u_hi > u_lo)
+                BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, 0, double, SL, true>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds,
+                                                    c->stream, g, pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw,
+                                                    (double *)c->d_fixgrid, -1, PhaseFreqs{}, 0, fixmax, pl.fix_bits));
+            hipLaunchKernelGGL((k_fix_convert<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_fixgrid, grad, n, fixmax, pl.fix_bits);
+            HIP_TRY(c, hipGetLastError());
+            return IONO_OK;
+        }
         if (u_hi > u_lo)
             BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds, c->stream, g,
                                                 pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw, grad, -1, PhaseFreqs{}, 0));
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }
+    if (c->deterministic)
+        return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
     c->unit_lo = c->unit_hi = -1;
     if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
         return launch_adjoint_tile<AT, MODE, false>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, grad, -1);
@@ -1613,7 +1709,13 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         // difference stencils fold them into the node gradient (iono_cubic_kernels.h)
         const int64_t n = ncells(c);
         if (!c->d_G8) HIP_TRY(c, hipMalloc((void **)&c->d_G8, (size_t)n * LM_NF * sizeof(double)));
-        HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
+        // planned: only the tiles the plan's rays reach are zeroed, scattered into and folded (IONOTOMO_VARIANT=23: the whole grid, A/B)
+        const bool tiled = planned && pl.tile_n[2] > 0 && c->variant != 23;
+        const LmTileGeom tg{c->nx, c->ny, c->nz, (c->ny + LMT_Y - 1) / LMT_Y, (c->nz + LMT_Z - 1) / LMT_Z};
+        if (tiled)
+            hipLaunchKernelGGL(k_lm_zero_tiles, dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, pl.d_tiles + pl.tile_off[0], tg);
+        else
+            HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
         if (planned && c->variant != 21) {
             // four channels (one z kind) per traversal: two launches instead of eight (k_adjoint_binned_lm4; IONOTOMO_VARIANT=21: A/B)
             const size_t l4 = LM4_LDS_BYTES(Ns);
@@ -1644,6 +1746,15 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         // scratch [6 n]: H0 | H1 (double2 each) | K0 | K1
         double2 *H0 = (double2 *)c->d_LMw, *H1 = H0 + n;
         double *K0 = c->d_LMw + 4 * n, *K1 = K0 + n;
+        if (tiled) {
+            hipLaunchKernelGGL(k_lm_fold_z_tiles, dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg);
+            hipLaunchKernelGGL(k_lm_fold_y_tiles, dim3(pl.tile_n[1]), dim3(256), 0, c->stream, (const double2 *)H0, (const double2 *)H1, K0, K1,
+                               pl.d_tiles + pl.tile_off[1], tg);
+            hipLaunchKernelGGL((k_lm_fold_x_tiles<AT>), dim3(pl.tile_n[2]), dim3(256), 0, c->stream, (const double *)K0, (const double *)K1, grad,
+                               pl.d_tiles + pl.tile_off[2], tg);
+            HIP_TRY(c, hipGetLastError());
+            return IONO_OK;
+        }
         hipLaunchKernelGGL(k_lm_fold_z, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_G8, H0, H1, c->nx, c->ny, c->nz);
         hipLaunchKernelGGL(k_lm_fold_y, dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double2 *)H0, (const double2 *)H1, K0, K1, c->nx,
                            c->ny, c->nz);
@@ -1744,6 +1855,11 @@ int iono_adjoint_planned_weights_dev(iono_ctx *c, const double *o, const double 
     if (!grad || !c->d_rayw || c->rayw_cap < R) return fail(c, IONO_ERR_ARG, "iono_adjoint_planned_weights_dev: no weights of a *_step call for these rays");
     c->plan_verified = true;        // (checked by the step that formed the weights)
     return adjoint_straight_launch(c, 0, o, d, order, c->d_rayw, nullptr, nullptr, nullptr, 1, R, 0, R, tmax, Ns, kind, rule, grad, accum);
+}
+int iono_set_deterministic(iono_ctx *c, int on) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    c->deterministic = on != 0;
+    return IONO_OK;
 }
 int iono_adjoint_plan_slabs(iono_ctx *c, int nslab) {
     if (!c || nslab < 1 || nslab > 8) return fail(c, IONO_ERR_ARG, "iono_adjoint_plan_slabs: 1 <= nslab <= 8");

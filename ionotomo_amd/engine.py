@@ -42,6 +42,7 @@ class RayEngine(object):
         self.kind = _lib.interp_kind(interp)
         self.rule = _lib.quad_rule(quad)
         self.shape = None
+        self.deterministic = False
         self._bound_stream = -1
 
     def _sync_stream(self):
@@ -180,6 +181,13 @@ class RayEngine(object):
         n, u, f = ctypes.c_int64(0), ctypes.c_int(0), ctypes.c_double(0)
         self.ctx.call("iono_adjoint_plan_info", ctypes.byref(n), ctypes.byref(u), ctypes.byref(f))
         return n.value, u.value, f.value
+
+    def set_deterministic(self, on=True):
+        """Order-independent (fixed-point) accumulation in the planned trilinear back-projection: run-to-run identical bits, also
+        for every solver iterate built on it (include/ionotomo_hip.h: iono_set_deterministic).  Back-projections the fixed-point
+        kernel does not serve raise while the mode is on."""
+        self.ctx.call("iono_set_deterministic", 1 if on else 0)
+        self.deterministic = bool(on)
 
     def plan_slabs(self):
         """(unit_lo[nslab + 1], z_lo[nslab + 1]) of the current back-projection plan: slab s = work units [unit_lo[s], unit_lo[s+1])
