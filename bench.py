@@ -417,6 +417,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--extras-timeout", type=int, default=420,
+                    help="N > 1: seconds the legs after the headline may take before rank 0 prints the line without them (0: no watchdog)")
     ap.add_argument("--no-order", dest="order", action="store_false", help="walk rays in [Na][Nt][Nd] memory order")
     ap.add_argument("--no-plan", dest="plan", action="store_false",
                     help="back-project with the ray-stationary kernel (LDS tile per ray bundle) instead of the box-binned plan")
@@ -573,6 +575,39 @@ def main():
     # and only then enter code with collectives (the same on every rank); after every leg with a collective the ranks
     # agree again before the next one starts.
     extra = {"forward_plan": fwd_plan_info}
+    # N > 1: a watchdog over everything that follows.  A collective that never returns (a rank lost, a mismatch) must not cost the
+    # headline: after --extras-timeout seconds rank 0 prints the line with what it has and every rank leaves.
+    import threading
+    finish_lock, finished = threading.Lock(), [False]
+    ctx = (world, rank, dist, sha, R, kern, grid_bytes, planned, args, w, tec_gpu)
+
+    def finish(extra_, copy_gbs_, clean):
+        finish_line(line, extra_, copy_gbs_, clean, ctx)
+
+    def on_timeout():
+        print("bench.py watchdog: rank %d, %d s after the headline" % (rank, args.extras_timeout), file=sys.stderr, flush=True)
+        with finish_lock:
+            if finished[0]:
+                return
+            finished[0] = True
+        if rank == 0:
+            ex = dict(extra)
+            ex["error"] = "the legs after the headline did not finish within %d s (watchdog): line printed without them" % args.extras_timeout
+            try:
+                finish(ex, None, False)
+            finally:
+                sys.stdout.flush()
+                os._exit(0)
+        time.sleep(45)             # (rank 0's CPU baseline first)
+        os._exit(0)
+
+    watchdog = None
+    if world > 1 and args.extras_timeout > 0:
+        watchdog = threading.Timer(args.extras_timeout, on_timeout)
+        watchdog.daemon = True
+        watchdog.start()
+        if os.environ.get("IONO_BENCH_TEST_HANG"):      # rehearsal of the watchdog: the legs "hang" for that many seconds
+            time.sleep(float(os.environ["IONO_BENCH_TEST_HANG"]))
 
     def agree(ok):
         if world == 1:
@@ -706,13 +741,26 @@ def main():
             except Exception as exc:                                    # noqa: BLE001
                 extra["cfg4"] = {"error": "%s: %s" % (type(exc).__name__, exc)}
 
+    if watchdog is not None:
+        watchdog.cancel()
+    with finish_lock:
+        if finished[0]:            # (the watchdog is printing the line: let it)
+            time.sleep(3600)
+        finished[0] = True
+    finish(extra, copy_gbs, True)
+
+
+def finish_line(line, extra, copy_gbs, clean, ctx):
+    """The tail of main(): roofline + CPU baseline + the ONE stdout line.  clean=False: called by the watchdog while the main thread
+    sits in a leg that did not return -- no collective, no GPU tool."""
+    (world, rank, dist, sha, R, kern, grid_bytes, planned, args, w, tec_gpu) = ctx
     pmc, pmc_note = load_pmc(sha)
-    if world > 1:
+    if world > 1 and clean:
         # every collective is behind us: leave the group BEFORE rank 0's host-side legs (peaks tool, CPU baseline), so that no
         # rank waits in a collective while rank 0 computes on the host
         dist.barrier()
         dist.destroy_process_group()
-    peaks = measured_peaks() if rank == 0 else None
+    peaks = measured_peaks() if rank == 0 and clean else None
     rl = forward_roofline(R, kern, pmc, pmc_note, copy_gbs, grid_bytes, peaks, planned)
     ar = extra.get("adjoint_roofline")
     ca_ = (pmc or {}).get("adjoint")
