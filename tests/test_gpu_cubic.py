@@ -252,3 +252,58 @@ def test_tricubic_fast_forward_random_geometry(seed, O, monkeypatch):
         tec = eng.forward(ot, dt, z1, Ns, order=ordr).cpu().numpy()
         assert not eng.check_oob()
         assert np.max(np.abs(tec - ref) / np.abs(ref)) < 1e-11, (seed, Ns, R, slope)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_planned_tricubic_transpose_folds_only_the_tiles_the_rays_reach(seed, monkeypatch):
+    """The planned tricubic transpose zeroes, scatters into and folds only the 8 x 8 x 16-node tiles its rays reach (k_lm_*_tiles).
+    On grids whose sizes are no multiples of the tile, with pencils of rays that leave most of the grid untouched, it must equal the
+    whole-grid passes (IONOTOMO_VARIANT=23) and the unplanned transpose, also when the scratch buffers hold an EARLIER launch's
+    values outside the new plan's tiles, and leave the rest of an accumulated result alone."""
+    from ionotomo_amd.engine import RayEngine
+    rng = np.random.default_rng(100 + seed)
+    n = [int(v) for v in rng.integers(12, 75, 3)]
+    n[2] += n[2] & 1                                               # (the fast tricubic tier wants an even nz)
+    xv, yv, zv = (np.linspace(0.0, float(m - 1), m) for m in n)
+    Ns = int(rng.choice([17, 33, 65, 129]))
+
+    def pencil(R, centre, steep):
+        o = np.stack([centre[0] + rng.normal(size=R) * 0.7, centre[1] + rng.normal(size=R) * 0.7, np.full(R, zv[0] + 2.3)], 1)
+        d = np.stack([rng.normal(size=R) * steep, rng.normal(size=R) * steep, np.ones(R)], 1)
+        return o, d
+    tmax = zv[-1] - 2.3 - (zv[0] + 2.3)
+    cx = [float(rng.uniform(4, m - 5)) for m in n[:2]]
+    o1, d1 = pencil(int(rng.integers(40, 400)), cx, 0.02)
+    o2, d2 = pencil(int(rng.integers(40, 400)), [float(rng.uniform(4, m - 5)) for m in n[:2]], 0.05)
+
+    def run(o, d, y, variant, planned, eng=None, base=None):
+        if variant:
+            monkeypatch.setenv("IONOTOMO_VARIANT", variant)
+        else:
+            monkeypatch.delenv("IONOTOMO_VARIANT", raising=False)
+        if eng is None:
+            eng = RayEngine(0, interp="cubic")
+            eng.set_grid(xv, yv, zv)
+            eng.set_values(eng.tensor(np.ones(n)))
+        ot, dt = eng.tensor(o), eng.tensor(d)
+        if planned:
+            eng.plan_adjoint(ot, dt, tmax, Ns)
+        else:
+            eng.clear_adjoint_plan()
+        out = None if base is None else base.clone()
+        g = eng.adjoint(ot, dt, eng.tensor(y), tmax, Ns, out=out)
+        oob = eng.check_oob()
+        return g, eng, oob
+    y1, y2 = rng.normal(size=len(o1)), rng.normal(size=len(o2))
+    g_tiles, eng, oob1 = run(o1, d1, y1, None, True)
+    g_whole, _, _ = run(o1, d1, y1, "23", True)
+    g_free, _, _ = run(o1, d1, y1, None, False)
+    scale = float(g_free.abs().max())
+    assert scale > 0
+    assert float((g_tiles - g_whole).abs().max()) < 1e-12 * scale
+    assert float((g_tiles - g_free).abs().max()) < 1e-11 * scale
+    # the same engine, another pencil somewhere else: the first launch's channel values are still in the scratch buffers
+    base = torch.full(tuple(n), 3.0, dtype=torch.float64, device="cuda")
+    g2, _, _ = run(o2, d2, y2, None, True, eng=eng, base=base)
+    g2_free, _, _ = run(o2, d2, y2, None, False)
+    assert float((g2 - 3.0 - g2_free).abs().max()) < 1e-11 * max(float(g2_free.abs().max()), 1.0)
