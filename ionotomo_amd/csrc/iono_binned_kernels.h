@@ -357,7 +357,49 @@ __global__ __launch_bounds__(256) void k_fix_absmax(const double *__restrict__ w
         m = fmax(m, v);
     }
     for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
-    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));      // (positive doubles order as integers)
+    // one atomic per workgroup (4 000 waves on one address made this pass 50 us)
+    __shared__ double wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmax(fmax(wm[0], wm[1]), fmax(wm[2], wm[3]));
+        if (m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));      // (positive doubles order as integers)
+    }
+}
+// How many samples of the planned rays fall into the fullest cell (once per plan, when the deterministic mode first needs it): a node
+// receives contributions from the samples of its 8 cells only, so 8 x that count bounds the terms of any node's sum far below the
+// plan's segment-count bound, and the fixed-point scale can keep that many more bits (2^-46 instead of 2^-38 of the largest
+// contribution at the bench shape).  cnt: one zeroed 32-bit counter per node (= cell origin); the maximum lands in *out.
+__global__ __launch_bounds__(256) void k_fix_cellcount(const double *__restrict__ uray, int64_t R, int Ns, int nx, int ny, int nz,
+                                                       unsigned *__restrict__ cnt) {
+    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+        const double *u = uray + r * 8;
+        if (u[7] == 0.0) continue;
+        const double fx0 = u[0], dfx = u[1], fy0 = u[2], dfy = u[3], fz0 = u[4], dfz = u[5];
+        int prev = -1, run = 0;
+        for (int k = 0; k < Ns; ++k) {
+            const int lin = (plan_cell(fx0, dfx, k, nx) * ny + plan_cell(fy0, dfy, k, ny)) * nz + plan_cell(fz0, dfz, k, nz);
+            if (lin == prev) {
+                ++run;
+                continue;
+            }
+            if (run) atomicAdd(cnt + prev, (unsigned)run);
+            prev = lin, run = 1;
+        }
+        if (run) atomicAdd(cnt + prev, (unsigned)run);
+    }
+}
+__global__ __launch_bounds__(256) void k_fix_cellmax(unsigned *__restrict__ cnt, int64_t n, unsigned long long *__restrict__ out) {
+    unsigned m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        m = max(m, cnt[i]);
+        cnt[i] = 0u;                                          // (the integer grid is zero between launches)
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
+    __shared__ unsigned wm[4];
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 template <typename AT>
 __global__ __launch_bounds__(256) void k_fix_convert(unsigned long long *__restrict__ F, AT *__restrict__ grad, int64_t n,

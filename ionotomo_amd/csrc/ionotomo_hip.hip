@@ -136,6 +136,7 @@ struct iono_ctx {
         int slab_z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
         int fix_bits = 12;                                // deterministic mode: log2 bound of the contributions one node can receive (+ 1)
+        bool fix_counted = false;                         // ... tightened by a count of the samples per cell (k_fix_cellcount, first deterministic launch)
         LmTile *d_tiles = nullptr;                        // tricubic plans: output tiles of the z | y | x fold passes (k_lm_fold_*_tiles)
         int tile_n[3] = {0, 0, 0}, tile_off[3] = {0, 0, 0};
         size_t cap_tiles = 0;
@@ -1683,8 +1684,22 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                 HIP_TRY(c, hipMemsetAsync(c->d_fixgrid, 0, ((size_t)n + 1) * sizeof(unsigned long long), c->stream));
             }
             unsigned long long *fixmax = c->d_fixgrid + n;
+            if (!pl.fix_counted && (int64_t)c->nx * c->ny * c->nz < ((int64_t)1 << 31)) {
+                // the fullest cell's sample count (once per plan): at most 8 x as many terms in any node's sum
+                HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
+                hipLaunchKernelGGL(k_fix_cellcount, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz,
+                                   (unsigned *)c->d_fixgrid);
+                hipLaunchKernelGGL(k_fix_cellmax, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, c->stream,
+                                   (unsigned *)c->d_fixgrid, n, fixmax);
+                unsigned long long cellmax = 0;
+                HIP_TRY(c, hipMemcpyAsync(&cellmax, fixmax, sizeof(cellmax), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                const int bits = std::max(12, (int)std::ceil(std::log2(std::max(8.0 * (double)cellmax, 2.0))) + 1);
+                c->plan.fix_bits = std::min(pl.fix_bits, bits);
+                c->plan.fix_counted = true;
+            }
             HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
-            hipLaunchKernelGGL(k_fix_absmax, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, wr, pl.d_uray, R, fixmax);
+            hipLaunchKernelGGL(k_fix_absmax, dim3((unsigned)std::min<int64_t>(256, (R + 255) / 256)), dim3(256), 0, c->stream, wr, pl.d_uray, R, fixmax);
             if (u_hi > u_lo)
                 BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, 0, double, SL, true>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds,
                                                     c->stream, g, pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw,
