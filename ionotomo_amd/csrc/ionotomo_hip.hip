@@ -1916,6 +1916,7 @@ int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int6
     int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (accum != IONO_F64 && accum != IONO_F32) return fail(c, IONO_ERR_ARG, "bad accum_dtype");
+    if (c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
     if (R == 0) return IONO_OK;
     const GridView g = view(c);
     const dim3 grid(ray_grid_blocks(c, R)), block(256);
@@ -2012,6 +2013,7 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
     int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
     if (rc) return rc;
     if (i0 < 0 || i0 >= Na || !y || !wrf_work || !grad) return fail(c, IONO_ERR_ARG, "iono_adjoint_phase_straight_dev: bad argument");
+    if (c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
     rc = phase_freqs_dev(c, freqs, Nf);
     if (rc) return rc;
     if (R == 0) return IONO_OK;
@@ -2554,6 +2556,7 @@ int iono_forward_tec_fermat_dev(iono_ctx *c, const double *o, const double *d, i
 
 int iono_adjoint_fermat_dev(iono_ctx *c, const double *o, const double *d, const double *w, int64_t R, double tmax, int Ns, double frequency,
                             int bend, int kind_n, int substeps, int independent, int kind_ne, int rule, double ne_scale, double *grad) {
+    if (c && c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
     return fermat_tec_launch(c, true, o, d, w, R, tmax, Ns, frequency, bend, kind_n, substeps, independent, kind_ne, rule, ne_scale, nullptr, grad);
 }
 

@@ -80,6 +80,8 @@ def test_what_the_mode_does_not_serve_fails_loudly():
     eng.set_deterministic(True)
     with pytest.raises(Exception, match="deterministic"):
         eng.adjoint(ot, dt, wt, zhi, Ns)                    # no plan for these rays
+    with pytest.raises(Exception, match="deterministic"):
+        eng.adjoint_fermat(ot, dt, wt, zhi, Ns, 150e6)      # the curved-ray transpose adds with float atomics
     eng.set_deterministic(False)
     eng.adjoint(ot, dt, wt, zhi, Ns)
     eng.check_oob()
