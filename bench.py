@@ -649,6 +649,12 @@ def main():
             _, akern = time_steps(adj, k2, 1, torch, dist, 1)
             extra["adjoint_ms"] = akern * 1e3
             extra["adjoint_ray_integrals_per_s_per_gpu"] = R / akern
+            if args.plan:
+                # the same with order-independent fixed-point accumulation (RayEngine.set_deterministic: run-to-run identical bits)
+                eng.set_deterministic(True)
+                _, adk = time_steps(adj, k2, 1, torch, dist, 1)
+                eng.set_deterministic(False)
+                extra["adjoint_deterministic_ms"] = adk * 1e3
             # ---- the lanes = samples forward on the coherent walk order (what the planned kernel replaced)
             if planned:
                 eng.clear_forward_plan()
@@ -695,6 +701,11 @@ def main():
             extra["tricubic_forward_ms"] = kcf * 1e3
             extra["tricubic_forward_ray_integrals_per_s_per_gpu"] = R / kcf
             extra["tricubic_adjoint_ms"] = kca * 1e3
+            if args.plan:
+                ec.set_deterministic(True)
+                _, kcd = time_steps(ca, max(2, k2 // 4), 1, torch, dist, 1)
+                ec.set_deterministic(False)
+                extra["tricubic_adjoint_deterministic_ms"] = kcd * 1e3
             extra["tricubic_vs_trilinear_max_rel_dev"] = float((tc - tec_t).abs().div(tec_t.abs()).max().item())
             # the binned kernel is bound by LDS float-atomic throughput, the ray-stationary one by the memory-side atomic rate
             extra["adjoint_roofline"] = {"bound": "lds_atomic" if args.plan else "memory_atomic", "kernel_ms": akern * 1e3,

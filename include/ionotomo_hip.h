@@ -191,14 +191,15 @@ int iono_adjoint_sirt_step_dev(iono_ctx *ctx, const double *origins_dev, const d
  * iono_adjoint_cg_step_dev / _sirt_step_dev with grad_dev = NULL: the ray pass alone; iono_adjoint_planned_weights_dev then
  *   back-projects the weights it left in the library (slab by slab with iono_adjoint_unit_range). */
 int iono_adjoint_plan_slabs(iono_ctx *ctx, int nslab);
-/* Deterministic back-projection (also env IONOTOMO_DETERMINISTIC=1): the planned trilinear transpose accumulates 64-bit fixed-point
- * integers (box images in LDS and the grid), so the result does not depend on the order the atomics are served in: two launches on the
+/* Deterministic back-projection (also env IONOTOMO_DETERMINISTIC=1): the planned trilinear and tricubic transposes accumulate 64-bit
+ * fixed-point integers (box images in LDS and the grid / the derivative channels), so the result does not depend on the order the atomics are served in: two launches on the
  * same inputs return the same bits, and so does every solver iterate built on them.  Resolution: 2^-(62 - b) of the launch's largest
  * contribution, b = log2 bound of the contributions one node can receive (>= 12; from a count of the planned samples per cell, made at
  * the first such launch of a plan: 2^-46 at the bench shape, 4.5e-12 of the largest value from the float sum).  Costs one small
- * reduction and one grid-sized conversion pass per launch (0.32 against 0.29 ms).  A back-projection the fixed-point kernel does not
- * serve (no plan for these rays; the tricubic, explicit-sample, phase and curved-ray transposes) returns IONO_ERR_ARG while the mode is
- * on.  No counterpart in the reference (numpy sums in a fixed order). */
+ * reduction and one grid-sized conversion pass per launch (trilinear: 0.32 against 0.29 ms; the tricubic transpose, whose z fold reads the
+ * integers directly, is FASTER in this mode -- 2.21 against 2.52 ms -- because the integer LDS atomic is the cheaper instruction).  A
+ * back-projection the fixed-point kernels do not serve (no plan for these rays; the explicit-sample, phase and curved-ray transposes)
+ * returns IONO_ERR_ARG while the mode is on.  No counterpart in the reference (numpy sums in a fixed order). */
 int iono_set_deterministic(iono_ctx *ctx, int on);
 int iono_adjoint_plan_slab_info(iono_ctx *ctx, int *nslab_out, int *unit_lo_out, int *z_lo_out);
 int iono_adjoint_unit_range(iono_ctx *ctx, int unit_lo, int unit_hi);

@@ -629,11 +629,14 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
 #define LM4_THREADS 1024
 #endif
 #define LM4_LDS_BYTES(Ns) (sizeof(double) * ((((size_t)(Ns) + 1) & ~(size_t)1) + 4 * (size_t)BIN_TILE))
-template <int SEGL>
+// FIX: deterministic fixed-point accumulation (k_adjoint_binned<.., FIX>): the images and G8 hold 64-bit integers, which the z fold
+// turns into float64 as it reads them (k_lm_fold_z_tiles<FIX>).
+template <int SEGL, bool FIX = false>
 __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
                                                                     const BinUnit *__restrict__ units, const double *__restrict__ wray, int Ns,
                                                                     const double *__restrict__ unitw, double *__restrict__ G8, int64_t nstride,
-                                                                    int rbit) {
+                                                                    int rbit, const unsigned long long *__restrict__ fixmax = nullptr,
+                                                                    int fixbits = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     double *tile = wlds + ((Ns + 1) & ~1);                           // [4][BIN_BX * BIN_BY][BIN_BZP]: channel c = p + 2 q
@@ -673,6 +676,26 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
         asm volatile("ds_add_f64 %0, %1 offset:8\n\tds_add_f64 %0, %2 offset:%5\n\tds_add_f64 %0, %3 offset:%6\n\tds_add_f64 %0, %4 offset:%7"
                      ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8 + 8), "n"(BIN_BY * BIN_BZP * 8 + 8), "n"((BIN_BY + 1) * BIN_BZP * 8 + 8) : "memory");
     };
+    auto tile_add4_fix = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:%5\n\tds_add_u64 %0, %3 offset:%6\n\tds_add_u64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8), "n"(BIN_BY * BIN_BZP * 8), "n"((BIN_BY + 1) * BIN_BZP * 8) : "memory");
+    };
+    auto tile_add4_up_fix = [](unsigned a, double v00, double v01, double v10, double v11) {
+        asm volatile("ds_add_u64 %0, %1 offset:8\n\tds_add_u64 %0, %2 offset:%5\n\tds_add_u64 %0, %3 offset:%6\n\tds_add_u64 %0, %4 offset:%7"
+                     ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8 + 8), "n"(BIN_BY * BIN_BZP * 8 + 8), "n"((BIN_BY + 1) * BIN_BZP * 8 + 8) : "memory");
+    };
+    const double fscale = FIX ? fix_scale(*fixmax, fixbits) : 1.0;
+    auto qf = [&](double v) {
+        const double t = fma(v, fscale, FIX_MAGIC);
+        return __longlong_as_double(__double_as_longlong(t) - __double_as_longlong(FIX_MAGIC));
+    };
+    auto global_add4_fix = [&](double *G, int i, int j, int kk, double v00, double v01, double v10, double v11) {
+        unsigned long long *p = (unsigned long long *)G + ((size_t)i * g.ny + j) * g.nz + kk;
+        atomicAdd(p, (unsigned long long)__double_as_longlong(v00));
+        atomicAdd(p + g.nz, (unsigned long long)__double_as_longlong(v01));
+        atomicAdd(p + (size_t)g.ny * g.nz, (unsigned long long)__double_as_longlong(v10));
+        atomicAdd(p + (size_t)g.ny * g.nz + g.nz, (unsigned long long)__double_as_longlong(v11));
+    };
     const unsigned tile_base = (unsigned)(size_t)tile;
     auto pass = [&](const uint2 en0, const RayRec &r0, const int e) {
         const int cnt = e < un.e_hi ? (int)((en0.y >> 16) & 0xffu) : 0, k = min((int)(en0.y & 0xffffu) + sub, Ns - 1);
@@ -704,18 +727,32 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
             const double x0 = (ch & 1) ? xs0 : xv0, x1 = (ch & 1) ? xs1 : xv1, y0 = (ch & 2) ? ys0 : yv0, y1 = (ch & 2) ? ys1 : yv1;
             const double w00 = x0 * y0, w01 = x0 * y1, w10 = x1 * y0, w11 = x1 * y1;
             double l00 = w00 * cz0, l01 = w01 * cz0, l10 = w10 * cz0, l11 = w11 * cz0;
-            const double u00 = w00 * cz1, u01 = w01 * cz1, u10 = w10 * cz1, u11 = w11 * cz1;
+            double u00 = w00 * cz1, u01 = w01 * cz1, u10 = w10 * cz1, u11 = w11 * cz1;
             const double p00 = dpp_shr1(u00), p01 = dpp_shr1(u01), p10 = dpp_shr1(u10), p11 = dpp_shr1(u11);
             if (accept) l00 += p00, l01 += p01, l10 += p10, l11 += p11;
+            if (FIX) {
+                l00 = qf(l00), l01 = qf(l01), l10 = qf(l10), l11 = qf(l11);
+                u00 = qf(u00), u01 = qf(u01), u10 = qf(u10), u11 = qf(u11);
+            }
             if (active) {
                 if (inside) {
                     const unsigned t = t0 + (unsigned)ch * (BIN_TILE * 8u);
-                    tile_add4(t, l00, l01, l10, l11);
-                    if (upper) tile_add4_up(t, u00, u01, u10, u11);
+                    if (FIX) {
+                        tile_add4_fix(t, l00, l01, l10, l11);
+                        if (upper) tile_add4_up_fix(t, u00, u01, u10, u11);
+                    } else {
+                        tile_add4(t, l00, l01, l10, l11);
+                        if (upper) tile_add4_up(t, u00, u01, u10, u11);
+                    }
                 } else {
                     double *G = G8 + (size_t)(4 * rbit + ch) * nstride;
-                    global_add4<double>(G, i, j, kz, g.ny, g.nz, l00, l01, l10, l11);
-                    if (upper) global_add4<double>(G, i, j, kz + 1, g.ny, g.nz, u00, u01, u10, u11);
+                    if (FIX) {
+                        global_add4_fix(G, i, j, kz, l00, l01, l10, l11);
+                        if (upper) global_add4_fix(G, i, j, kz + 1, u00, u01, u10, u11);
+                    } else {
+                        global_add4<double>(G, i, j, kz, g.ny, g.nz, l00, l01, l10, l11);
+                        if (upper) global_add4<double>(G, i, j, kz + 1, g.ny, g.nz, u00, u01, u10, u11);
+                    }
                 }
             }
         }
@@ -737,12 +774,15 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
     const int mz = threadIdx.x & 15;
     for (int cc = threadIdx.x >> 4; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / 16) {
         const double v = tile[cc * BIN_BZP + mz];
-        if (v != 0.0) {
+        if (FIX ? __double_as_longlong(v) != 0 : v != 0.0) {
             const int ch = cc / (BIN_BX * BIN_BY), col = cc - ch * (BIN_BX * BIN_BY);
             const int a = col / BIN_BY, b = col - a * BIN_BY;
             const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + mz;
-            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz)
-                atomicAdd(G8 + (size_t)(4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk, v);
+            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz) {
+                double *dst = G8 + (size_t)(4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk;
+                if (FIX) atomicAdd((unsigned long long *)dst, (unsigned long long)__double_as_longlong(v));
+                else atomicAdd(dst, v);
+            }
         }
     }
 }

@@ -225,10 +225,18 @@ __global__ __launch_bounds__(256) void k_lm_zero_tiles(double *__restrict__ G8, 
         for (int f = 0; f < LM_NF; ++f) G8[(int64_t)f * n + idx] = 0.0;
     }
 }
+// FIX (deterministic mode): G8 holds the 64-bit fixed-point integers of k_adjoint_binned_lm4<.., FIX>, scale fix_scale(*fixmax, fixbits)
+// (iono_binned_kernels.h).
+__device__ __forceinline__ double fix_scale(unsigned long long maxbits, int fixbits);
+template <bool FIX>
 __global__ __launch_bounds__(256) void k_lm_fold_z_tiles(const double *__restrict__ G8, double2 *__restrict__ H0, double2 *__restrict__ H1,
-                                                         const LmTile *__restrict__ tiles, LmTileGeom tg) {
+                                                         const LmTile *__restrict__ tiles, LmTileGeom tg,
+                                                         const unsigned long long *__restrict__ fixmax, int fixbits) {
     const int64_t n = (int64_t)tg.nx * tg.ny * tg.nz;
     const LmTile t = tiles[blockIdx.x];
+    double inv = 1.0;
+    if (FIX) inv = 1.0 / fix_scale(*fixmax, fixbits);
+    auto ld = [&](const double *p) { return FIX ? (double)__double_as_longlong(*p) * inv : *p; };
     for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
         int i, j, k, a, b, cc;
         if (!lm_tile_node(tg, t.id, q, i, j, k, a, b, cc)) continue;
@@ -237,12 +245,12 @@ __global__ __launch_bounds__(256) void k_lm_fold_z_tiles(const double *__restric
 #pragma unroll
         for (int pq = 0; pq < 4; ++pq) {
             const double *r0 = G8 + (int64_t)pq * n + idx, *r1 = G8 + (int64_t)(pq + 4) * n + idx;
-            double s = r0[0];                          // (output tiles of the z pass are its input set: G8 is zeroed on all of them)
+            double s = ld(r0);                         // (output tiles of the z pass are its input set: G8 is zeroed on all of them)
 #pragma unroll
             for (int dc = -2; dc <= 2; ++dc) {
                 if (dc == 0) continue;
                 const int sk = k + dc;
-                if (sk >= 2 && sk <= tg.nz - 3 && lm_tile_has(t.flags, cc, dc, LMT_Z)) s += fd_coef(-dc) * r1[dc];
+                if (sk >= 2 && sk <= tg.nz - 3 && lm_tile_has(t.flags, cc, dc, LMT_Z)) s += fd_coef(-dc) * ld(r1 + dc);
             }
             h[pq] = s;
         }

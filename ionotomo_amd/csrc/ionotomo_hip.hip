@@ -1643,6 +1643,36 @@ static int launch_adjoint_tile(iono_ctx *c, const GridView &g, const double *o, 
     return IONO_OK;
 }
 
+// Deterministic mode, before a fixed-point launch: the integer grid (+ one word behind it for the launch's largest |w h|), the plan's
+// bound on the terms of a node's sum (a count of the planned samples per cell, once per plan), and that largest |w h| itself.
+static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
+    iono_ctx::AdjPlan &pl = c->plan;
+    const int64_t n = ncells(c);
+    if (!c->d_fixgrid) {
+        HIP_TRY(c, hipMalloc((void **)&c->d_fixgrid, ((size_t)n + 1) * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->d_fixgrid, 0, ((size_t)n + 1) * sizeof(unsigned long long), c->stream));
+    }
+    unsigned long long *fixmax = c->d_fixgrid + n;
+    if (!pl.fix_counted && n < ((int64_t)1 << 31)) {
+        // the fullest cell's sample count: at most 8 x as many terms in any node's sum
+        HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
+        hipLaunchKernelGGL(k_fix_cellcount, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz,
+                           (unsigned *)c->d_fixgrid);
+        hipLaunchKernelGGL(k_fix_cellmax, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, c->stream,
+                           (unsigned *)c->d_fixgrid, n, fixmax);
+        unsigned long long cellmax = 0;
+        HIP_TRY(c, hipMemcpyAsync(&cellmax, fixmax, sizeof(cellmax), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const int bits = std::max(12, (int)std::ceil(std::log2(std::max(8.0 * (double)cellmax, 2.0))) + 1);
+        pl.fix_bits = std::min(pl.fix_bits, bits);
+        pl.fix_counted = true;
+    }
+    HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
+    hipLaunchKernelGGL(k_fix_absmax, dim3((unsigned)std::min<int64_t>(256, (R + 255) / 256)), dim3(256), 0, c->stream, wr, pl.d_uray, R, fixmax);
+    HIP_TRY(c, hipGetLastError());
+    return IONO_OK;
+}
+
 // mode 0: weights w[R];  1: fused residual (tec, dobs, cdct);  2: differential weights of v[R] * scale[R] (tec = v,
 // cdct = scale or null).  kind: trilinear or tricubic transpose.
 template <typename AT, int MODE>
@@ -1679,27 +1709,8 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             // fixed-point accumulation: the largest |w h| of this launch -> scale; integers in the box images and in d_fixgrid; converted
             // into `grad` (and re-zeroed) by k_fix_convert (iono_binned_kernels.h)
             const int64_t n = ncells(c);
-            if (!c->d_fixgrid) {
-                HIP_TRY(c, hipMalloc((void **)&c->d_fixgrid, ((size_t)n + 1) * sizeof(unsigned long long)));
-                HIP_TRY(c, hipMemsetAsync(c->d_fixgrid, 0, ((size_t)n + 1) * sizeof(unsigned long long), c->stream));
-            }
-            unsigned long long *fixmax = c->d_fixgrid + n;
-            if (!pl.fix_counted && (int64_t)c->nx * c->ny * c->nz < ((int64_t)1 << 31)) {
-                // the fullest cell's sample count (once per plan): at most 8 x as many terms in any node's sum
-                HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
-                hipLaunchKernelGGL(k_fix_cellcount, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz,
-                                   (unsigned *)c->d_fixgrid);
-                hipLaunchKernelGGL(k_fix_cellmax, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, c->stream,
-                                   (unsigned *)c->d_fixgrid, n, fixmax);
-                unsigned long long cellmax = 0;
-                HIP_TRY(c, hipMemcpyAsync(&cellmax, fixmax, sizeof(cellmax), hipMemcpyDeviceToHost, c->stream));
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                const int bits = std::max(12, (int)std::ceil(std::log2(std::max(8.0 * (double)cellmax, 2.0))) + 1);
-                c->plan.fix_bits = std::min(pl.fix_bits, bits);
-                c->plan.fix_counted = true;
-            }
-            HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
-            hipLaunchKernelGGL(k_fix_absmax, dim3((unsigned)std::min<int64_t>(256, (R + 255) / 256)), dim3(256), 0, c->stream, wr, pl.d_uray, R, fixmax);
+            { const int rcf = fix_prepare(c, wr, R, Ns); if (rcf) return rcf; }
+            unsigned long long *fixmax = c->d_fixgrid + n;      // (allocated by fix_prepare on first use)
             if (u_hi > u_lo)
                 BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, 0, double, SL, true>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds,
                                                     c->stream, g, pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw,
@@ -1714,8 +1725,10 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }
-    if (c->deterministic)
-        return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
+    const bool fix_cubic = c->deterministic && planned && kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2 &&
+                           c->variant != 21 && c->variant != 23 && pl.tile_n[2] > 0;
+    if (c->deterministic && !fix_cubic)
+        return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear and tricubic back-projections only (iono_adjoint_plan_dev for these rays first)");
     c->unit_lo = c->unit_hi = -1;
     if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
         return launch_adjoint_tile<AT, MODE, false>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, grad, -1);
@@ -1731,17 +1744,29 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             hipLaunchKernelGGL(k_lm_zero_tiles, dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, pl.d_tiles + pl.tile_off[0], tg);
         else
             HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
+        const unsigned long long *fixmax = nullptr;
+        if (fix_cubic) {
+            const int rcf = fix_prepare(c, wr, R, Ns);
+            if (rcf) return rcf;
+            fixmax = c->d_fixgrid + n;
+        }
         if (planned && c->variant != 21) {
             // four channels (one z kind) per traversal: two launches instead of eight (k_adjoint_binned_lm4; IONOTOMO_VARIANT=21: A/B)
             const size_t l4 = LM4_LDS_BYTES(Ns);
             BY_SEGL(pl.segl, {
                 if (!c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2]) {
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_adjoint_binned_lm4<SL>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_adjoint_binned_lm4<SL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_adjoint_binned_lm4<SL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
                     c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2] = true;
                 }
-                for (int rb = 0; rb < 2; ++rb)
-                    hipLaunchKernelGGL((k_adjoint_binned_lm4<SL>), dim3(pl.n_units), dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray, pl.d_entries,
-                                       pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb);
+                for (int rb = 0; rb < 2; ++rb) {
+                    if (fix_cubic)
+                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, true>), dim3(pl.n_units), dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
+                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, fixmax, pl.fix_bits);
+                    else
+                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, false>), dim3(pl.n_units), dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
+                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb);
+                }
             });
             HIP_TRY(c, hipGetLastError());
         }
@@ -1762,7 +1787,12 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         double2 *H0 = (double2 *)c->d_LMw, *H1 = H0 + n;
         double *K0 = c->d_LMw + 4 * n, *K1 = K0 + n;
         if (tiled) {
-            hipLaunchKernelGGL(k_lm_fold_z_tiles, dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg);
+            if (fix_cubic)
+                hipLaunchKernelGGL((k_lm_fold_z_tiles<true>), dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
+                                   fixmax, pl.fix_bits);
+            else
+                hipLaunchKernelGGL((k_lm_fold_z_tiles<false>), dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
+                                   (const unsigned long long *)nullptr, 0);
             hipLaunchKernelGGL(k_lm_fold_y_tiles, dim3(pl.tile_n[1]), dim3(256), 0, c->stream, (const double2 *)H0, (const double2 *)H1, K0, K1,
                                pl.d_tiles + pl.tile_off[1], tg);
             hipLaunchKernelGGL((k_lm_fold_x_tiles<AT>), dim3(pl.tile_n[2]), dim3(256), 0, c->stream, (const double *)K0, (const double *)K1, grad,

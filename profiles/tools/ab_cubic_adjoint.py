@@ -10,7 +10,7 @@ from ionotomo_amd.engine import RayEngine
 w = bench.build_workload(0)
 R = w["origins"].shape[0]
 res, out = {}, {}
-for name, env in (("tiles", None), ("whole_grid", "23")):
+for name, env in (("tiles", None), ("whole_grid", "23"), ("tiles_deterministic", None)):
     if env:
         os.environ["IONOTOMO_VARIANT"] = env
     else:
@@ -22,6 +22,7 @@ for name, env in (("tiles", None), ("whole_grid", "23")):
     torch.manual_seed(1)
     y = torch.randn(R, dtype=torch.float64, device="cuda")
     e.plan_adjoint(o, d, bench.TMAX, bench.NS)
+    e.set_deterministic(name.endswith("deterministic"))
     g = torch.zeros(e.shape, dtype=torch.float64, device="cuda")
     for _ in range(2):
         e.adjoint(o, d, y, bench.TMAX, bench.NS, out=g)
@@ -40,6 +41,7 @@ for name, env in (("tiles", None), ("whole_grid", "23")):
     del e
 os.environ.pop("IONOTOMO_VARIANT", None)
 out["max_abs_diff"] = float((res["tiles"] - res["whole_grid"]).abs().max())
+out["max_abs_diff_deterministic_vs_float"] = float((res["tiles_deterministic"] - res["tiles"]).abs().max())
 out["max_abs"] = float(res["whole_grid"].abs().max())
 out["nonzero_fraction"] = float((res["whole_grid"] != 0).double().mean())
 print(json.dumps(out))

@@ -115,3 +115,39 @@ def test_cgls_and_sirt_iterates_are_reproducible():
         xr, hr = ref()
         assert np.allclose(np.array(h1)[:12], np.array(hr)[:12], rtol=1e-6)
         assert np.max(np.abs(np.array(h1) - np.array(hr))) < 1e-3 * hr[0]
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_tricubic_transpose_in_deterministic_mode(seed):
+    """The planned tricubic transpose with fixed-point channel images (k_adjoint_binned_lm4<.., FIX> + the z fold reading integers): the
+    same bits twice, the float transpose's numbers, accumulation into an existing result, and a clean state afterwards."""
+    rng = np.random.default_rng(40 + seed)
+    n = [int(v) for v in rng.integers(14, 60, 3)]
+    n[2] += n[2] & 1
+    xv, yv, zv = (np.linspace(0.0, float(m - 1), m) for m in n)
+    R, Ns = int(rng.integers(60, 500)), int(rng.choice([17, 33, 65, 129]))
+    steep = float(rng.choice([0.02, 0.2]))
+    o = np.stack([rng.uniform(4, n[0] - 5, R), rng.uniform(4, n[1] - 5, R), np.full(R, 2.3)], 1)
+    d = np.stack([rng.normal(size=R) * steep, rng.normal(size=R) * steep, np.ones(R)], 1)
+    tmax = zv[-1] - 4.6
+    w = rng.normal(size=R) * 10.0 ** rng.uniform(-3, 3)
+    eng = engine(xv, yv, zv, interp="cubic")
+    eng.set_values(eng.tensor(np.ones(n)))
+    ot, dt, wt = eng.tensor(o), eng.tensor(d), eng.tensor(w)
+    eng.plan_adjoint(ot, dt, tmax, Ns)
+    gf = eng.adjoint(ot, dt, wt, tmax, Ns)
+    oob = eng.check_oob()
+    eng.set_deterministic(True)
+    g1 = eng.adjoint(ot, dt, wt, tmax, Ns)
+    g2 = eng.adjoint(ot, dt, wt, tmax, Ns)
+    assert eng.check_oob() == oob
+    assert torch.equal(g1, g2)
+    scale = float(gf.abs().max())
+    assert scale > 0 and float((g1 - gf).abs().max()) < 1e-10 * scale
+    acc = torch.full(tuple(n), 2.0, dtype=torch.float64, device="cuda")
+    eng.adjoint(ot, dt, wt, tmax, Ns, out=acc)
+    assert float((acc - 2.0 - g1).abs().max()) < 1e-12 * max(scale, 1.0)
+    eng.set_deterministic(False)
+    g3 = eng.adjoint(ot, dt, wt, tmax, Ns)                      # the float path on the same scratch buffers
+    assert float((g3 - gf).abs().max()) < 1e-11 * scale
+    eng.check_oob()
