@@ -194,8 +194,8 @@ int iono_adjoint_plan_slabs(iono_ctx *ctx, int nslab);
 /* Deterministic back-projection (also env IONOTOMO_DETERMINISTIC=1): the planned trilinear and tricubic transposes accumulate 64-bit
  * fixed-point integers (box images in LDS and the grid / the derivative channels), so the result does not depend on the order the atomics are served in: two launches on the
  * same inputs return the same bits, and so does every solver iterate built on them.  Resolution: 2^-(62 - b) of the launch's largest
- * contribution, b = log2 bound of the contributions one node can receive (>= 12; from a count of the planned samples per cell, made at
- * the first such launch of a plan: 2^-46 at the bench shape, 4.5e-12 of the largest value from the float sum).  Costs one small
+ * contribution, b = log2 bound of the terms one node's sum can receive (>= 12; counted at the first such launch of a plan by running
+ * the kernel with every contribution = 1: 2^-48 at the bench shape, 9.4e-13 of the largest value from the float sum).  Costs one small
  * reduction and one grid-sized conversion pass per launch (trilinear: 0.32 against 0.29 ms; the tricubic transpose, whose z fold reads the
  * integers directly, is FASTER in this mode -- 2.21 against 2.52 ms -- because the integer LDS atomic is the cheaper instruction).  A
  * back-projection the fixed-point kernels do not serve (no plan for these rays; the explicit-sample, phase and curved-ray transposes)

@@ -366,40 +366,27 @@ __global__ __launch_bounds__(256) void k_fix_absmax(const double *__restrict__ w
         if (m > 0.0) atomicMax(out, (unsigned long long)__double_as_longlong(m));      // (positive doubles order as integers)
     }
 }
-// How many samples of the planned rays fall into the fullest cell (once per plan, when the deterministic mode first needs it): a node
-// receives contributions from the samples of its 8 cells only, so 8 x that count bounds the terms of any node's sum far below the
-// plan's segment-count bound, and the fixed-point scale can keep that many more bits (2^-46 instead of 2^-38 of the largest
-// contribution at the bench shape).  cnt: one zeroed 32-bit counter per node (= cell origin); the maximum lands in *out.
-__global__ __launch_bounds__(256) void k_fix_cellcount(const double *__restrict__ uray, int64_t R, int Ns, int nx, int ny, int nz,
-                                                       unsigned *__restrict__ cnt) {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
-        const double *u = uray + r * 8;
-        if (u[7] == 0.0) continue;
-        const double fx0 = u[0], dfx = u[1], fy0 = u[2], dfy = u[3], fz0 = u[4], dfz = u[5];
-        int prev = -1, run = 0;
-        for (int k = 0; k < Ns; ++k) {
-            const int lin = (plan_cell(fx0, dfx, k, nx) * ny + plan_cell(fy0, dfy, k, ny)) * nz + plan_cell(fz0, dfz, k, nz);
-            if (lin == prev) {
-                ++run;
-                continue;
-            }
-            if (run) atomicAdd(cnt + prev, (unsigned)run);
-            prev = lin, run = 1;
-        }
-        if (run) atomicAdd(cnt + prev, (unsigned)run);
-    }
-}
-__global__ __launch_bounds__(256) void k_fix_cellmax(unsigned *__restrict__ cnt, int64_t n, unsigned long long *__restrict__ out) {
-    unsigned m = 0;
+// The largest number of terms any node's sum receives from the planned rays (once per plan, when the deterministic mode first needs
+// it): the fixed-point kernel itself in COUNTING mode (fixbits < 0: every contribution is the integer 1) leaves that count per node in
+// the integer grid; this pass takes the maximum and re-zeroes the grid.  It bounds the sums far below the plan's segment-count bound,
+// so the scale keeps that many more bits (2^-48 instead of 2^-38 of the largest contribution at the bench shape).
+__global__ __launch_bounds__(256) void k_fix_nodemax(unsigned long long *__restrict__ F, int64_t n, unsigned long long *__restrict__ out) {
+    unsigned long long m = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        m = max(m, cnt[i]);
-        cnt[i] = 0u;                                          // (the integer grid is zero between launches)
+        const unsigned long long v = F[i];
+        if (v) {
+            m = max(m, v);
+            F[i] = 0ull;                                      // (the integer grid is zero between launches)
+        }
     }
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off));
-    __shared__ unsigned wm[4];
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)m, off), hi = (unsigned)__shfl_xor((int)(unsigned)(m >> 32), off);
+        m = max(m, ((unsigned long long)hi << 32) | lo);
+    }
+    __shared__ unsigned long long wm[4];
     if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) atomicMax(out, (unsigned long long)max(max(wm[0], wm[1]), max(wm[2], wm[3])));
+    if (threadIdx.x == 0) atomicMax(out, max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 template <typename AT>
 __global__ __launch_bounds__(256) void k_fix_convert(unsigned long long *__restrict__ F, AT *__restrict__ grad, int64_t n,
@@ -499,7 +486,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
         asm volatile("ds_add_u64 %0, %1 offset:8\n\tds_add_u64 %0, %2 offset:%5\n\tds_add_u64 %0, %3 offset:%6\n\tds_add_u64 %0, %4 offset:%7"
                      ::"v"(a), "v"(v00), "v"(v01), "v"(v10), "v"(v11), "n"(BIN_BZP * 8 + 8), "n"(BIN_BY * BIN_BZP * 8 + 8), "n"((BIN_BY + 1) * BIN_BZP * 8 + 8) : "memory");
     };
-    const double fscale = FIX ? fix_scale(*fixmax, fixbits) : 1.0;
+    const bool counting = FIX && fixbits < 0;                       // every contribution counts 1: the terms per node (k_fix_nodemax)
+    const double fscale = FIX && !counting ? fix_scale(*fixmax, fixbits) : 1.0;
     auto qf = [&](double v) {
         const double t = fma(v, fscale, FIX_MAGIC);
         return __longlong_as_double(__double_as_longlong(t) - __double_as_longlong(FIX_MAGIC));
@@ -530,7 +518,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
 #pragma unroll
             for (int l = 0; l < (PNF > 0 ? PNF : 1); ++l) wr += r0.w[l] * (0.5 * pf.inv_np[l]) * rsqrt(1.0 - ne * pf.inv_np[l]);
         }
-        const double c = sub < cnt ? wr * r0.uh * wlds[k] : 0.0;
+        const double c = sub < cnt ? (FIX && counting ? 1.0 : wr * r0.uh * wlds[k]) : 0.0;
         const bool active = c != 0.0;
         const double fi = clampf(__builtin_floor(__builtin_fabs(fx)), lim_x), fj = clampf(__builtin_floor(__builtin_fabs(fy)), lim_y),
                      fk = clampf(__builtin_floor(__builtin_fabs(fz)), lim_z);
@@ -552,6 +540,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
             u00 = w00 * tz, u01 = w01 * tz, u10 = w10 * tz, u11 = w11 * tz;
             l00 = w00 - u00, l01 = w01 - u01, l10 = w10 - u10, l11 = w11 - u11;
         }
+        if (FIX && counting) l00 = l01 = l10 = l11 = u00 = u01 = u10 = u11 = c;      // (a handed-over pair then counts 2)
         const int i = (int)fi, j = (int)fj, kz = (int)fk;
         // Consecutive samples of a ray mostly sit in consecutive z cells of the same (i, j) column: the upper-level
         // contributions of lane s then hit the very nodes of lane s + 1's lower level.  Pass them one lane up inside the

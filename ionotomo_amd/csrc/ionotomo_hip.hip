@@ -136,7 +136,7 @@ struct iono_ctx {
         int slab_z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         double outside_fraction = 0;                      // segments whose (x, y) extent exceeds the box image
         int fix_bits = 12;                                // deterministic mode: log2 bound of the contributions one node can receive (+ 1)
-        bool fix_counted = false;                         // ... tightened by a count of the samples per cell (k_fix_cellcount, first deterministic launch)
+        bool fix_counted = false;                         // ... tightened by a count of the terms per node (the kernel in counting mode + k_fix_nodemax, first deterministic launch)
         LmTile *d_tiles = nullptr;                        // tricubic plans: output tiles of the z | y | x fold passes (k_lm_fold_*_tiles)
         int tile_n[3] = {0, 0, 0}, tile_off[3] = {0, 0, 0};
         size_t cap_tiles = 0;
@@ -1644,7 +1644,7 @@ static int launch_adjoint_tile(iono_ctx *c, const GridView &g, const double *o, 
 }
 
 // Deterministic mode, before a fixed-point launch: the integer grid (+ one word behind it for the launch's largest |w h|), the plan's
-// bound on the terms of a node's sum (a count of the planned samples per cell, once per plan), and that largest |w h| itself.
+// bound on the terms of a node's sum (counted once per plan by the fixed-point kernel itself), and that largest |w h| itself.
 static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
     iono_ctx::AdjPlan &pl = c->plan;
     const int64_t n = ncells(c);
@@ -1653,17 +1653,20 @@ static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
         HIP_TRY(c, hipMemsetAsync(c->d_fixgrid, 0, ((size_t)n + 1) * sizeof(unsigned long long), c->stream));
     }
     unsigned long long *fixmax = c->d_fixgrid + n;
-    if (!pl.fix_counted && n < ((int64_t)1 << 31)) {
-        // the fullest cell's sample count: at most 8 x as many terms in any node's sum
+    if (!pl.fix_counted) {
+        // the terms of the fullest node's sum: the fixed-point kernel in counting mode over the whole plan, then the maximum
         HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
-        hipLaunchKernelGGL(k_fix_cellcount, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, pl.d_uray, R, Ns, c->nx, c->ny, c->nz,
-                           (unsigned *)c->d_fixgrid);
-        hipLaunchKernelGGL(k_fix_cellmax, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, c->stream,
-                           (unsigned *)c->d_fixgrid, n, fixmax);
-        unsigned long long cellmax = 0;
-        HIP_TRY(c, hipMemcpyAsync(&cellmax, fixmax, sizeof(cellmax), hipMemcpyDeviceToHost, c->stream));
+        const GridView g = view(c);
+        const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
+        if (pl.n_units > 0)
+            BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, 0, double, SL, true>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds,
+                                                c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, (double *)c->d_fixgrid, -1,
+                                                PhaseFreqs{}, 0, fixmax, -1));
+        hipLaunchKernelGGL(k_fix_nodemax, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, c->stream, c->d_fixgrid, n, fixmax);
+        unsigned long long nodemax = 0;
+        HIP_TRY(c, hipMemcpyAsync(&nodemax, fixmax, sizeof(nodemax), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const int bits = std::max(12, (int)std::ceil(std::log2(std::max(8.0 * (double)cellmax, 2.0))) + 1);
+        const int bits = std::max(12, (int)std::ceil(std::log2(std::max((double)nodemax, 2.0))) + 1);
         pl.fix_bits = std::min(pl.fix_bits, bits);
         pl.fix_counted = true;
     }
