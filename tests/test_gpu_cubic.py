@@ -254,7 +254,7 @@ def test_tricubic_fast_forward_random_geometry(seed, O, monkeypatch):
         assert np.max(np.abs(tec - ref) / np.abs(ref)) < 1e-11, (seed, Ns, R, slope)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(SOAK * 6))
 def test_planned_tricubic_transpose_folds_only_the_tiles_the_rays_reach(seed, monkeypatch):
     """The planned tricubic transpose zeroes, scatters into and folds only the 8 x 8 x 16-node tiles its rays reach (k_lm_*_tiles).
     On grids whose sizes are no multiples of the tile, with pencils of rays that leave most of the grid untouched, it must equal the

@@ -8,6 +8,7 @@ import torch
 from ionotomo_amd import parallel, solvers
 
 pytestmark = pytest.mark.gpu
+SOAK = int(__import__("os").environ.get("IONO_SOAK", "1"))      # IONO_SOAK=20: twenty times the seeds
 
 
 def engine(xv, yv, zv, **kw):
@@ -31,7 +32,7 @@ def geometry(seed):
     return n, xv, yv, zv, o, d, w, zhi, Ns
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(SOAK * 6))
 def test_fixed_point_back_projection_is_reproducible_and_equals_the_float_one(seed):
     from oracle import oracle_c as OC
     n, xv, yv, zv, o, d, w, zhi, Ns = geometry(seed)
@@ -117,7 +118,7 @@ def test_cgls_and_sirt_iterates_are_reproducible():
         assert np.max(np.abs(np.array(h1) - np.array(hr))) < 1e-3 * hr[0]
 
 
-@pytest.mark.parametrize("seed", range(4))
+@pytest.mark.parametrize("seed", range(SOAK * 4))
 def test_tricubic_transpose_in_deterministic_mode(seed):
     """The planned tricubic transpose with fixed-point channel images (k_adjoint_binned_lm4<.., FIX> + the z fold reading integers): the
     same bits twice, the float transpose's numbers, accumulation into an existing result, and a clean state afterwards."""
