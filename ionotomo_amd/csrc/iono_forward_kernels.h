@@ -815,6 +815,12 @@ __device__ __forceinline__ unsigned bundle_addr_magic(Corners<double> &c, double
 #ifndef B_NPF
 #define B_NPF 6
 #endif
+#ifndef B_BUFLOAD
+#define B_BUFLOAD 1     // the window's prefetch loads as buffer loads with scalar row offsets (0: global loads, A/B)
+#endif
+#ifndef B_MUL24
+#define B_MUL24 1
+#endif
 #ifdef IONO_B_STAMP      // timing-only build: in-kernel stamps (s_memtime) of every wave, summed per phase (profiles/tools/bundle_stamps.py)
 __device__ unsigned long long g_bstamp[8 * 4 * 8192];
 #define BST(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); st[i] += t_ - tlast; tlast = t_; } while (0)
@@ -879,17 +885,43 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
 #pragma unroll
     for (int n = 0; n < B_NPF; ++n) pre[n] = u32x4{0u, 0u, 0u, 0u};
     bool act = false, act_last = false;                                          // lanes of the pending copy (all loads / its last one)
+    // (24-bit multiply-adds: one full-rate instruction each where v_mul_lo_u32 runs at a quarter of the rate; the operands are a lane's
+    //  row / column slot (< 16) and the grid's z length or plane size in bytes -- the plan exists only while both are below 2^24)
+    auto mad24 = [](unsigned a, unsigned b, unsigned c) {
+        unsigned o;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(o) : "v"(a), "s"(b), "v"(c));
+        return o;
+    };
     auto issue = [&](const BWin &W) {
         int r = 0, dj = lane_q;
         if (W.rpl > 1) {                                                         // (wave-uniform)
             r = (int)(lane_qf * __uint_as_float((unsigned)W.winv));               // lane_q / wy, exact: lane_q <= 12, wy <= 12
-            dj = lane_q - r * W.wy;
+            dj = lane_q - (int)mad24((unsigned)r, (unsigned)W.wy, 0u);
         }
+#if B_BUFLOAD
+        const unsigned loff = B_MUL24 ? mad24((unsigned)r, plane8, mad24((unsigned)dj, (unsigned)g.nz, 2u * (unsigned)lane_pc) * 8u)
+                                      : (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
+#else
         const unsigned loff = (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
+#endif
         const char *rowp = (const char *)M + (size_t)W.woff * 8;
         const size_t gstep = (size_t)W.rpl * plane8;
         act = lane_q < W.rpl * W.wy;
         act_last = act && r < W.wx - (W.nl - 1) * W.rpl;
+#if B_BUFLOAD
+        // buffer loads: the window's origin in a scalar descriptor, the lane's offset in one 32-bit register for ALL loads of the window,
+        // the row-group step in the instruction's scalar offset -- no vector address arithmetic per load (global loads advanced a
+        // 64-bit vector address per load)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, (short)0, (int)0x7fffffff, (int)0x00020000);
+        const unsigned gs32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gstep);
+        if (act) {
+#pragma unroll
+            for (int n = 0; n < B_NPF; ++n)
+                if (n < W.nl - 1) pre[n] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loff, (int)((unsigned)n * gs32), 0);
+        }
+        if (act_last && W.nl - 1 <= B_NPF) pre_last = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loff, (int)((unsigned)(W.nl - 1) * gs32), 0);
+        return;
+#endif
         // (all full loads under ONE execution mask, the last -- possibly partial -- group of rows under another: per-load predicates
         //  cost four vector instructions each.  Plain loads: the compiler tracks them; the s_waitcnt builtin at the top of a chunk
         //  tells it that nothing is pending there, otherwise it cannot prove across the loop's branches that a destination's
