@@ -821,6 +821,7 @@ __device__ __forceinline__ unsigned bundle_addr_magic(Corners<double> &c, double
 #ifndef B_MUL24
 #define B_MUL24 1
 #endif
+#define B_MAX_PLANE (1u << 26)      // largest grid plane (ny nz 8 bytes) a bundle plan is made for: 32-bit offsets inside a window of <= 37 rows
 #ifdef IONO_B_STAMP      // timing-only build: in-kernel stamps (s_memtime) of every wave, summed per phase (profiles/tools/bundle_stamps.py)
 __device__ unsigned long long g_bstamp[8 * 4 * 8192];
 #define BST(i) do { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); st[i] += t_ - tlast; tlast = t_; } while (0)
@@ -886,7 +887,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
     for (int n = 0; n < B_NPF; ++n) pre[n] = u32x4{0u, 0u, 0u, 0u};
     bool act = false, act_last = false;                                          // lanes of the pending copy (all loads / its last one)
     // (24-bit multiply-adds: one full-rate instruction each where v_mul_lo_u32 runs at a quarter of the rate; the operands are a lane's
-    //  row / column slot (< 16) and the grid's z length or plane size in bytes -- the plan exists only while both are below 2^24)
+    //  row / column slot (< 16) and the grid's z length or plane size in bytes -- taken only while the plane is below 2^24 bytes)
+    const bool small24 = plane8 < (1u << 24);                                    // (wave-uniform)
     auto mad24 = [](unsigned a, unsigned b, unsigned c) {
         unsigned o;
         asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(o) : "v"(a), "s"(b), "v"(c));
@@ -896,11 +898,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
         int r = 0, dj = lane_q;
         if (W.rpl > 1) {                                                         // (wave-uniform)
             r = (int)(lane_qf * __uint_as_float((unsigned)W.winv));               // lane_q / wy, exact: lane_q <= 12, wy <= 12
-            dj = lane_q - (int)mad24((unsigned)r, (unsigned)W.wy, 0u);
+            dj = lane_q - (int)mad24((unsigned)r, (unsigned)W.wy, 0u);           // (both below 16)
         }
 #if B_BUFLOAD
-        const unsigned loff = B_MUL24 ? mad24((unsigned)r, plane8, mad24((unsigned)dj, (unsigned)g.nz, 2u * (unsigned)lane_pc) * 8u)
-                                      : (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
+        unsigned loff;
+        if (B_MUL24 && small24) loff = mad24((unsigned)r, plane8, mad24((unsigned)dj, (unsigned)g.nz, 2u * (unsigned)lane_pc) * 8u);
+        else loff = (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
 #else
         const unsigned loff = (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
 #endif
@@ -912,7 +915,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
         // buffer loads: the window's origin in a scalar descriptor, the lane's offset in one 32-bit register for ALL loads of the window,
         // the row-group step in the instruction's scalar offset -- no vector address arithmetic per load (global loads advanced a
         // 64-bit vector address per load)
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, (short)0, (int)0x7fffffff, (int)0x00020000);
+        // (offsets are 32-bit and a window spans up to 37 rows: a bundle plan exists only for planes of at most B_MAX_PLANE bytes --
+        //  iono_forward_plan_dev.  ONE load path in the kernel: with a second one the compiler can no longer tell which loads are
+        //  pending into the prefetch registers and waits in front of every one of them, +10 % measured)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)rowp, (short)0, (int)0xffffffffu, (int)0x00020000);
         const unsigned gs32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gstep);
         if (act) {
 #pragma unroll

@@ -890,7 +890,9 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     iono_ctx::FwdPlan &fp = c->fplan;
     fp.R = -1, fp.nb = 0, fp.o_key = fp.d_key = nullptr;
-    if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || c->storage != IONO_F64 || (c->nz & 1) || !o || !d) return IONO_OK;
+    if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || c->storage != IONO_F64 || (c->nz & 1) || !o || !d ||
+        (int64_t)c->ny * c->nz * 8 > (int64_t)B_MAX_PLANE)      // (the kernel's 32-bit offsets inside a window: iono_forward_kernels.h)
+        return IONO_OK;
     // keys and ray summaries on the device, device radix sort; only the sorted 32-byte summaries travel to the host for the cut
     DevBuf scratch(c);
     const size_t off_k0 = 0, off_k1 = off_k0 + (size_t)R * 8, off_i0 = off_k1 + (size_t)R * 8, off_i1 = off_i0 + (size_t)R * 4,

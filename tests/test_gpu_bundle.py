@@ -404,3 +404,31 @@ def test_planned_tensors_edited_in_place_never_give_garbage(OC, interp):
     eng.plan_adjoint(ot, dt, bench.TMAX, bench.NS)
     g2 = eng.adjoint(ot, dt, y, bench.TMAX, bench.NS).cpu().numpy()
     assert np.all(np.isfinite(g2)) and not eng.plan_stale() and np.max(np.abs(g2 - g0)) > 0.0
+
+
+def test_bundle_forward_on_a_grid_with_a_plane_above_2_to_24_bytes(OC):
+    """The window prefetch forms lane offsets with 24-bit multiply-adds while a grid plane (ny nz 8 bytes) is below 2^24 bytes; a
+    wider grid (here 12 x 8200 x 258: planes of 16.9 MB) takes the 32-bit arithmetic and must give the direct kernel's numbers."""
+    rng = np.random.default_rng(77)
+    n = (12, 8200, 258)
+    assert n[1] * n[2] * 8 > 1 << 24
+    xv, yv, zv = np.linspace(0.0, 11.0, n[0]), np.linspace(0.0, 8199.0, n[1]), np.linspace(0.0, 257.0, n[2])
+    R, Ns = 8192, 257
+    yc = rng.uniform(100, 8100, 64)                                    # 64 clusters of 128 rays: bundles fill
+    o = np.stack([rng.uniform(3, 8, R), np.repeat(yc, R // 64) + rng.normal(size=R) * 1.5, np.full(R, 1.3)], 1)
+    d = np.stack([rng.normal(size=R) * 3e-3, rng.normal(size=R) * 0.05, np.ones(R)], 1)
+    tmax = 254.0
+    eng = engine(xv, yv, zv)
+    M = rng.uniform(1, 2, size=n)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    direct = eng.forward(ot, dt, tmax, Ns).cpu().numpy()
+    assert not eng.check_oob()
+    nb, _, fit = eng.plan_forward(ot, dt, tmax, Ns)
+    assert nb > 0 and fit > 0.5
+    tec = eng.forward(ot, dt, tmax, Ns).cpu().numpy()
+    assert not eng.check_oob()
+    assert np.max(np.abs(tec - direct)) <= 2e-13 * np.max(np.abs(direct))
+    sel = rng.choice(R, 64, replace=False)
+    ref = OC.forward_tec_straight(xv, yv, zv, M, o[sel], d[sel], tmax, Ns)
+    assert np.max(np.abs(tec[sel] - ref)) <= 1e-12 * np.max(np.abs(ref))
