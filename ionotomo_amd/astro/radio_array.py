@@ -9,6 +9,7 @@ import os
 
 import numpy as np
 
+from .coords import itrs_metres
 from ..synthetic import itrs_to_enu_km, read_array_table, read_station_enu_csv
 
 _ARRAYS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "arrays")
@@ -28,6 +29,8 @@ class RadioArray(object):
             self.load_array_file(array_file)
         if antenna_pos is not None:
             self.load_pos_array(antenna_pos)
+        elif earth_locs is not None:      # (astro/radio_array.py:22-23: EarthLocation-like, ``.x .y .z``)
+            self.load_pos_array(earth_locs)
 
     def load_array_file(self, array_file):
         """Whitespace table ``X Y Z diameter label`` in ITRS metres, ``#`` comments
@@ -45,7 +48,9 @@ class RadioArray(object):
         self.calc_center()
 
     def load_pos_array(self, antenna_pos, antenna_labels=None):
-        self.locs = np.asarray(antenna_pos, dtype=np.float64)
+        """``antenna_pos``: ITRS metres [N,3], or an ITRS coordinate object as the reference holds them (read by attribute,
+        ``.cartesian.xyz``: astro/coords.py)."""
+        self.locs = np.ascontiguousarray(itrs_metres(antenna_pos), dtype=np.float64).reshape(-1, 3)
         self.Nantenna = self.locs.shape[0]
         if antenna_labels is not None:
             assert len(antenna_labels) == self.Nantenna

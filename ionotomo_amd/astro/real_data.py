@@ -24,6 +24,7 @@ import time as _time
 
 import numpy as np
 
+from . import coords
 from .radio_array import RadioArray, generate_example_radio_array
 from .frames import geodetic_from_itrs, gmst_rad, itrs_direction_to_icrs, pointing_rotation
 
@@ -58,6 +59,16 @@ class DataPack(object):
         for key in ("radio_array", "antennas", "antenna_labels", "times", "timestamps", "directions", "patch_names",
                     "freqs", "phase", "const", "clock", "prop", "variance"):
             setattr(self, key, args.get(key, None))
+        # reference-typed members (ITRS / ICRS coordinates, Time: astro/real_data.py:124-131) are read by attribute into the plain
+        # arrays this class holds (astro/coords.py; astropy is not imported)
+        if self.antennas is not None and coords.is_coordinate(self.antennas):
+            self.antennas = coords.itrs_metres(self.antennas).reshape(-1, 3)
+        if self.directions is not None and coords.is_coordinate(self.directions):
+            self.directions = coords.icrs_radec(self.directions).reshape(-1, 2)
+        if self.times is not None and coords.is_time(self.times):
+            if self.timestamps is None and hasattr(self.times, "isot"):
+                self.timestamps = np.atleast_1d(np.asarray(self.times.isot)).astype(str)
+            self.times = np.atleast_1d(coords.unix_seconds(self.times))
         self.antennas = np.asarray(self.antennas, dtype=np.float64).reshape(-1, 3)
         self.times = np.atleast_1d(np.asarray(self.times, dtype=np.float64))
         self.directions = np.asarray(self.directions, dtype=np.float64).reshape(-1, 2)

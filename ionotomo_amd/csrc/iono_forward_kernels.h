@@ -748,7 +748,8 @@ __global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__re
 
 // window of chunk c of bundle b: {imin, jmin, kz0, wx | wy << 8 | fits << 16 | rpl << 20}; one wave per bundle.  KC samples per chunk, an
 // image of LEV levels per column and MAXWY columns per row; EVEN: the window starts on an even level (8-byte values staged in 16-byte
-// pieces); rpl = whole rows of the window per staging wave-load of 64 / LEV columns (used by k_forward_bundle_lm)
+// pieces: every piece is then 16-byte aligned when nz is even; with an odd nz the columns start on 8-byte boundaries and the same
+// 16-byte loads are simply unaligned -- what the lanes = samples kernel's loads have always been); rpl = whole rows of the window per staging wave-load of 64 / LEV columns (used by k_forward_bundle_lm)
 // PACK (the trilinear kernel's record): {element offset of the window origin (imin, jmin, kz0) in the values array, byte offset of that
 // origin in an image of rows of wy columns x LEV levels, bit pattern of (float)(1 / wy), flags} with rpl = whole rows per wave-load
 // of 64 / (LEV / 2) columns: everything the staging loop needs comes out of one scalar load without 64-bit scalar arithmetic
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
             const int kmin = wave_minmax_i32<false>((int)fmax(fmin(fz, fze) - eps, 0.0)), kmax = wave_minmax_i32<true>((int)(fmax(fz, fze) + eps));
             const int kz0 = EVEN ? kmin & ~1 : kmin;
             const int wx = imax - imin + 2, wy = jmax - jmin + 2, nlev = kmax + 2 - kz0;
-            const bool fits = (!EVEN || (g.nz & 1) == 0) && wx * wy <= B_CAPCOLS && wx < 256 && wy <= MAXWY && nlev <= LEV;
+            const bool fits = wx * wy <= B_CAPCOLS && wx < 256 && wy <= MAXWY && nlev <= LEV;
             const int rpl = min(15, max(1, (PACK ? 64 / (LEV / 2) : 64 / LEV) / wy));
             unsigned flags = (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u) | ((unsigned)rpl << 20);
             if (PACK) flags |= (unsigned)min(31, (wx + rpl - 1) / rpl) << 24;      // wave-loads of the copy

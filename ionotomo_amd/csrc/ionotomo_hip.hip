@@ -848,7 +848,8 @@ static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
 // sample index, so the extent of a bundle is convex in it) + the drift of its steepest ray -- fits the LDS image of one wave;
 // (3) the exact window of every (bundle, chunk), by the device (k_bundle_windows).  Keys, sort (rocPRIM radix sort) and windows run
 // on the device; the host only cuts the sorted walk (one sequential pass over R 32-byte ray summaries).  No plan (non-uniform
-// axes, float32 storage, odd nz): the other forward kernels serve the launch.
+// axes, float32 storage): the other forward kernels serve the launch.  Any parity of nz (round 5: with an odd nz the 16-byte
+// window loads start on 8-byte boundaries, as the lanes = samples kernel's always have).
 int iono_forward_plan_clear(iono_ctx *c) {
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
     (void)hipSetDevice(c->device);
@@ -890,7 +891,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     iono_ctx::FwdPlan &fp = c->fplan;
     fp.R = -1, fp.nb = 0, fp.o_key = fp.d_key = nullptr;
-    if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || c->storage != IONO_F64 || (c->nz & 1) || !o || !d ||
+    if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || c->storage != IONO_F64 || !o || !d ||
         (int64_t)c->ny * c->nz * 8 > (int64_t)B_MAX_PLANE)      // (the kernel's 32-bit offsets inside a window: iono_forward_kernels.h)
         return IONO_OK;
     // keys and ray summaries on the device, device radix sort; only the sorted 32-byte summaries travel to the host for the cut

@@ -382,6 +382,41 @@ def test_calc_rays_from_sky_coordinates():
     assert np.allclose(tec, rays[:, 0, :, 3, -1], rtol=1e-12)
 
 
+def test_calc_rays_on_reference_typed_objects_equals_the_array_call():
+    """The reference's callers hand calc_rays astropy objects (inversion/inversion_pipeline.py:195-197,
+    astro/simulate_observables.py:50-62).  Stand-ins exposing exactly the attributes the reference touches
+    (tests/astropy_standins.py) must give the plain-array call's rays bit for bit, whatever unit the positions are held in is
+    converted, fixtime / times as Time objects, N=None -> ne_tci.nz (geometry/calc_rays.py:111-112)."""
+    import sys
+    sys.path.insert(0, __import__("os").path.dirname(__file__))
+    from astropy_standins import ICRSCoord, ITRSCoord, Time
+    import ionotomo_amd as it
+    from ionotomo_amd.astro import frames
+    ra_ = it.RadioArray(array_file=it.RadioArray.lofar_array)
+    ants, centre = ra_.get_antenna_locs()[:7], ra_.get_center()
+    lon, lat, _ = frames.geodetic_from_itrs(centre)
+    times = 1.49e9 + 8.0 * np.arange(3)
+    phase = np.array([(frames.gmst_rad(times[1]) + lon) % (2 * np.pi), lat])
+    pat = phase + np.deg2rad(np.random.default_rng(8).uniform(-2, 2, size=(5, 2)))
+    o, d = frames.model_frame_bundle_from_sky(ants, pat, times, centre, phase)
+    xv, yv, zv = frames.determine_inversion_domain(25.0, o[:, 0, 0, :], d[0].reshape(-1, 3), 1000.0, padding=3)
+    tci = it.TriCubic(xv, yv, zv, np.ones((len(xv), len(yv), len(zv))))
+    plain = it.calc_rays(ants, pat, times, centre, times[1], phase, tci, 120e6, True, 1000.0, None)
+    assert plain.shape == (7, 3, 5, 4, tci.nz)
+    typed = it.calc_rays(ITRSCoord(ants), ICRSCoord(pat[:, 0], pat[:, 1]), Time(times), ITRSCoord(centre), Time(times)[1],
+                         ICRSCoord(phase[0], phase[1]), tci, 120e6, True, 1000.0, None)
+    assert np.array_equal(plain, typed)
+    # one timestep as the pipeline's graph slices it (times[time_idx:time_idx+1], fixtime = times[time_idx]: :157-158), positions in km
+    one = it.calc_rays(ITRSCoord(ants / 1e3, "km"), ICRSCoord(pat[:, 0], pat[:, 1]), Time(times)[1:2], ITRSCoord(centre / 1e3, "km"),
+                       Time(times)[1], ICRSCoord(phase[0], phase[1]), tci, 120e6, True, 1000.0, None)
+    assert one.shape == (7, 1, 5, 4, tci.nz)
+    assert np.max(np.abs(one[:, 0] - plain[:, 1])) <= 1e-9                 # (km -> m -> km: not bit-identical, 1e-12 relative)
+    # a Time-like that only offers .gps (leap seconds handled: astro/coords.py)
+    gps = it.calc_rays(ITRSCoord(ants), ICRSCoord(pat[:, 0], pat[:, 1]), Time(times, only="gps"), ITRSCoord(centre), None,
+                       ICRSCoord(phase[0], phase[1]), tci, 120e6, True, 1000.0, None)
+    assert np.array_equal(plain, gps)
+
+
 def test_shipped_chord_gradient_from_the_product(ctx, golden, O):
     """the reference's own gradient discretisation (chord lengths, inversion/gradient.py:15-20) is
     available from the product for comparison -- pinned to the reference's ``do_gradient`` output and to the oracle's
