@@ -48,6 +48,7 @@ LDS_B64_NOMINAL_GBS = 256 * 256 * 2.4
 LDS_GUIDE_GBS = 150000.0       # the guide's LDS section: "Aggregate with every CU streaming (~2.4 GHz): ~150 TB/s for ds_read_b64/b128"
 ATOMIC_PEAK_GBS = 1300.0
 MAX_RANKS_FOR_DOMAIN = 8
+WATCHDOG_EXIT_CODE = 3      # every rank's exit code after the watchdog printed the headline without the later legs
 PMC_JSON = os.path.join(ROOT, "profiles", "pmc_counters.json")
 PEAKS_TOOL = os.path.join(ROOT, "profiles", "tools", "cache_peaks")
 
@@ -333,6 +334,26 @@ def exchange_legs(eng, fwd, adj, grad_t, o_t, d_t, order_t, R, k2, torch, dist, 
     return out
 
 
+def other_grid_leg(n, w, local, o_t, d_t, forder_t, R, kern256, k2, torch, dist):
+    """The headline rays through an n^3 grid over the same box (n odd: columns start on 8-byte boundaries), planned forward with
+    Ns = nz samples per ray, checked against the unplanned kernel of the same engine."""
+    from ionotomo_amd.engine import RayEngine
+    e = RayEngine(local, storage="f64")
+    e.set_grid(*[np.linspace(w[k][0], w[k][-1], n) for k in ("xvec", "yvec", "zvec")])
+    gen = torch.Generator(device=e.device)
+    gen.manual_seed(n)
+    e.set_values(torch.rand(n ** 3, dtype=torch.float64, device=e.device, generator=gen) + 1.0)
+    ns = n if n % 2 else n + 1
+    out = torch.empty(R, dtype=torch.float64, device=e.device)
+    direct = e.forward(o_t, d_t, TMAX, ns, order=forder_t).clone()
+    info = e.plan_forward(o_t, d_t, TMAX, ns)
+    _, k = time_steps(lambda: e.forward(o_t, d_t, TMAX, ns, out=out, order=forder_t), k2, 2, torch, dist, 1)
+    assert not e.check_oob()
+    return {"grid": [n] * 3, "Ns": ns, "bundles": info[0], "lds_chunk_fraction": info[2], "forward_ms": k * 1e3,
+            "ray_integrals_per_s": R / k, "samples_per_s": R * ns / k, "per_sample_rate_vs_256_cubed": (R * ns / k) / (R * NS / kern256),
+            "max_rel_dev_vs_unplanned_kernel": float(((out - direct).abs() / direct.abs()).max())}
+
+
 def cfg4_leg(w, local, k2, torch, dist, world):
     """BASELINE config 4 as written: 62 x 100 x 100 = 620,000 rays, 256^3 grid, rays sharded over the N ranks by (time,
     direction) block (ShardedRays / pair_block), the adjoint update summed over ranks every iteration.  Total work is fixed:
@@ -419,6 +440,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--extras-timeout", type=int, default=420,
                     help="N > 1: seconds the legs after the headline may take before rank 0 prints the line without them (0: no watchdog)")
+    ap.add_argument("--test-hang", type=float, default=0.0, help=argparse.SUPPRESS)      # test-only: the legs after the headline "hang"
     ap.add_argument("--no-order", dest="order", action="store_false", help="walk rays in [Na][Nt][Nd] memory order")
     ap.add_argument("--no-plan", dest="plan", action="store_false",
                     help="back-project with the ray-stationary kernel (LDS tile per ray bundle) instead of the box-binned plan")
@@ -590,6 +612,9 @@ def main():
             if finished[0]:
                 return
             finished[0] = True
+        # the headline line goes out FIRST, then every rank leaves with a non-zero code: a run whose collective never returned is
+        # not a success for the harness / torchrun; ranks != 0 wait long enough for rank 0's CPU baseline + print,
+        # so that torchrun's teardown cannot cut the line short
         if rank == 0:
             ex = dict(extra)
             ex["error"] = "the legs after the headline did not finish within %d s (watchdog): line printed without them" % args.extras_timeout
@@ -597,17 +622,18 @@ def main():
                 finish(ex, None, False)
             finally:
                 sys.stdout.flush()
-                os._exit(0)
-        time.sleep(45)             # (rank 0's CPU baseline first)
-        os._exit(0)
+                sys.stderr.flush()
+                os._exit(WATCHDOG_EXIT_CODE)
+        time.sleep(90)
+        os._exit(WATCHDOG_EXIT_CODE)
 
     watchdog = None
     if world > 1 and args.extras_timeout > 0:
         watchdog = threading.Timer(args.extras_timeout, on_timeout)
         watchdog.daemon = True
         watchdog.start()
-        if os.environ.get("IONO_BENCH_TEST_HANG"):      # rehearsal of the watchdog: the legs "hang" for that many seconds
-            time.sleep(float(os.environ["IONO_BENCH_TEST_HANG"]))
+        if args.test_hang > 0:                          # (--test-hang, hidden: rehearsal of the watchdog by profiles/tools)
+            time.sleep(args.test_hang)
 
     def agree(ok):
         if world == 1:
@@ -663,10 +689,21 @@ def main():
                 eng.plan_forward(o_t, d_t, TMAX, NS)
             # ---- the reference's default sampling, Ns = nz (even), with the 'avg' rule its own integrate.py spells out
             # (secondary row; tests/golden/forward_tec_even_avg.npz pins the rule)
+            # -- with a bundle plan of ITS OWN sample count (a plan is keyed on Ns; round 4 timed this row on the unplanned kernel)
             tec_even = torch.empty(R, dtype=torch.float64, device=eng.device)
+            if planned:
+                extra["even_ns_forward_plan_bundles"] = eng.plan_forward(o_t, d_t, TMAX, NS - 1)[0]
             _, kev = time_steps(lambda: eng.forward(o_t, d_t, TMAX, NS - 1, out=tec_even, order=forder_t), k2, 1, torch, dist, 1)
+            extra["even_ns_avg_rule_ms"] = kev * 1e3
             extra["even_ns_avg_rule_ray_integrals_per_s_per_gpu"] = R / kev
             extra["even_ns_avg_rule_vs_odd_max_rel_dev"] = float(((tec_even - tec_t).abs() / tec_t.abs()).max())
+            if planned:
+                eng.plan_forward(o_t, d_t, TMAX, NS)
+            # ---- grids of the other parity: N = ceil(extent / spacing) per axis comes out odd as often as even
+            # (inversion/initial_model.py:29-34), and the reference samples Ns = nz points per ray (geometry/calc_rays.py:111-112).
+            # Same box, same rays, 255^3 and 257^3 nodes, Ns = nz (odd: Simpson proper); rate per SAMPLE against the headline's
+            if planned:
+                extra["odd_grids"] = [other_grid_leg(n, w, local, o_t, d_t, forder_t, R, kern, k2, torch, dist) for n in (255, 257)]
             # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
             _, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, 1)
             extra["f32_grid_ray_integrals_per_s_per_gpu"] = R / k32

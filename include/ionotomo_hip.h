@@ -187,7 +187,8 @@ int iono_adjoint_sirt_step_dev(iono_ctx *ctx, const double *origins_dev, const d
  * iono_adjoint_plan_slab_info: nslab, unit_lo[nslab + 1] (slab s = units [unit_lo[s], unit_lo[s+1])) and z_lo[nslab + 1] (slab s owns
  *   the node levels [z_lo[s], z_lo[s+1]): once the units of slabs 0 .. s have run, those levels are final -- segments never leave
  *   their z-layer of boxes, also where samples overhang the box image in x or y and go by global atomics).
- * iono_adjoint_unit_range(lo, hi): the next planned trilinear back-projection runs units [lo, hi) only (one-shot).
+ * iono_adjoint_unit_range(lo, hi): the next planned trilinear back-projection runs units [lo, hi) only (one-shot).  Any other
+ * back-projection launched while a range is pending (no plan / a replaced plan / tricubic) returns IONO_ERR_ARG and launches nothing.
  * iono_adjoint_cg_step_dev / _sirt_step_dev with grad_dev = NULL: the ray pass alone; iono_adjoint_planned_weights_dev then
  *   back-projects the weights it left in the library (slab by slab with iono_adjoint_unit_range). */
 int iono_adjoint_plan_slabs(iono_ctx *ctx, int nslab);
@@ -363,6 +364,10 @@ int iono_forward_tec_fermat_dev(iono_ctx *ctx, const double *origins_dev, const 
 int iono_adjoint_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, const double *w_dev, int64_t R,
                             double tmax, int Ns, double frequency, int bend, int interp_kind_n, int substeps, int independent,
                             int interp_kind_ne, int quad_rule, double ne_scale, double *grad_dev);
+/* Would iono_forward_tec_fermat_dev serve (interp_kind_n, interp_kind_ne, R) with the fused tricubic-index kernel (k_fermat_tec_lm:
+ * 8 lanes per ray, 1.2 ms at config 3) -- 1 -- or with the lanes = rays kernel (31 ms there) -- 0?  The library's own dispatch
+ * predicate, so that a host layer choosing between the fused call and trace + integrate never re-implements it. */
+int iono_fermat_lm_ok(iono_ctx *ctx, int interp_kind_n, int interp_kind_ne, int64_t R, int *ok_out);
 int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
 /* Plans (iono_forward_plan_dev, iono_adjoint_plan_dev) are keyed on device pointers, but every planned launch re-hashes the rays
  * it is handed (64 bits per ray) against the hashes recorded when the plan was built.  If a planned array was edited in place:

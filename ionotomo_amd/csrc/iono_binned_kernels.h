@@ -193,11 +193,17 @@ __global__ __launch_bounds__(256) void k_plan_segments(const double *__restrict_
 // The back-projection works from the plan's OWN ray records (uray), so a planned array edited in place would silently give the
 // old rays' answer.  Every planned launch therefore re-hashes the rays it is handed (12.5 MB read at the bench shape, 3 us) against
 // the hashes the plan recorded: a ray that differs has its record poisoned (h = NaN: every node it touches comes out NaN, never a
-// plausible number) and raises flags[2] (iono_plan_stale -> the host layer turns it into IONO_ERR_ARG).
+// plausible number) and raises flags[2] (iono_plan_stale -> the host layer turns it into IONO_ERR_ARG); the poison lasts until the rays
+// are planned again (iono_adjoint_plan_dev), and so does the flag: every later launch on this plan raises it again.
 __device__ __forceinline__ void plan_verify_ray(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t r,
                                                 const uint2 *__restrict__ hash, double *__restrict__ uray, int *__restrict__ flags) {
     const uint2 want = hash[r], have = ray_hash(origins, dirs, r);
-    if ((want.x != have.x) | (want.y != have.y)) {
+    // (a record poisoned by an EARLIER launch stays poisoned even if the caller has since restored the ray in place -- the hashes
+    //  then match again -- so it raises the flag on every launch until the rays are planned anew: the flag is sticky only until it
+    //  is read once, the NaN is permanent, and the two must not come apart: ADVICE r4)
+    const double2 hv = *(const double2 *)(uray + r * 8 + 6);                     // (h, valid)
+    const bool poisoned = hv.y != 0.0 && hv.x != hv.x;
+    if ((want.x != have.x) | (want.y != have.y) | poisoned) {
         uray[r * 8 + 6] = nan("");
         atomicOr(flags + 2, 1);
     }

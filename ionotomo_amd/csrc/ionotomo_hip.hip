@@ -1670,7 +1670,9 @@ static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
         HIP_TRY(c, hipMemcpyAsync(&nodemax, fixmax, sizeof(nodemax), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         const int bits = std::max(12, (int)std::ceil(std::log2(std::max((double)nodemax, 2.0))) + 1);
-        pl.fix_bits = std::min(pl.fix_bits, bits);
+        // (the count is authoritative: it ran this very kernel, overhang samples that go by global atomics included, which the a-priori
+        //  bound of the plan -- 8 boxes x the fullest box x the segment length -- does not cover: ADVICE r4)
+        pl.fix_bits = bits;
         pl.fix_counted = true;
     }
     HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
@@ -1731,11 +1733,17 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }
+    if (c->unit_lo >= 0) {
+        // a unit range is honoured by the planned trilinear back-projection only: any other launch would add the WHOLE back-projection
+        // once per slab: refuse instead of discarding the range
+        c->unit_lo = c->unit_hi = -1;
+        return fail(c, IONO_ERR_ARG, "a work-unit range (iono_adjoint_unit_range) is pending, but this launch is not the planned trilinear "
+                                     "back-projection of these rays (no plan, a replaced plan, tricubic, or IONOTOMO_VARIANT=2/7): nothing launched");
+    }
     const bool fix_cubic = c->deterministic && planned && kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2 &&
                            c->variant != 21 && c->variant != 23 && pl.tile_n[2] > 0;
     if (c->deterministic && !fix_cubic)
         return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear and tricubic back-projections only (iono_adjoint_plan_dev for these rays first)");
-    c->unit_lo = c->unit_hi = -1;
     if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
         return launch_adjoint_tile<AT, MODE, false>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, grad, -1);
     if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2) {
@@ -1834,7 +1842,10 @@ static int adjoint_straight_launch(iono_ctx *c, int mode, const double *o, const
     int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (accum != IONO_F64 && accum != IONO_F32) return fail(c, IONO_ERR_ARG, "bad accum_dtype");
-    if (R == 0) return IONO_OK;
+    if (R == 0) {
+        c->unit_lo = c->unit_hi = -1;      // (a range never outlives the launch it was set for)
+        return IONO_OK;
+    }
     rc = ensure_unitw(c, Ns, rule);
     if (rc) return rc;
     const GridView g = view(c);
@@ -1952,7 +1963,7 @@ int iono_adjoint_rays_dev(iono_ctx *c, const double *rays, const double *w, int6
     int rc = check_common(c, R, Ns, kind, rule);
     if (rc) return rc;
     if (accum != IONO_F64 && accum != IONO_F32) return fail(c, IONO_ERR_ARG, "bad accum_dtype");
-    if (c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
+    if (c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned straight-ray back-projections (trilinear, tricubic) only: not this entry point");
     if (R == 0) return IONO_OK;
     const GridView g = view(c);
     const dim3 grid(ray_grid_blocks(c, R)), block(256);
@@ -2049,7 +2060,7 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
     int rc = check_common(c, R, Ns, IONO_INTERP_TRILINEAR, rule);
     if (rc) return rc;
     if (i0 < 0 || i0 >= Na || !y || !wrf_work || !grad) return fail(c, IONO_ERR_ARG, "iono_adjoint_phase_straight_dev: bad argument");
-    if (c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
+    if (c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned straight-ray back-projections (trilinear, tricubic) only: not this entry point");
     rc = phase_freqs_dev(c, freqs, Nf);
     if (rc) return rc;
     if (R == 0) return IONO_OK;
@@ -2529,6 +2540,17 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
 }
 
 // ---- fused curved-ray forward / transpose (iono_fermat_kernels.h): trace and integrate in one traversal ---------------------------
+// the fused forward through a tricubic index runs on k_fermat_tec_lm (ideal-uniform axes, 32-bit-safe record array, float64)
+static bool fermat_lm_ok(const iono_ctx *c, int kind_n, int kind_ne, int64_t R) {
+    return kind_n == IONO_INTERP_TRICUBIC && c->storage == IONO_F64 && view(c).ideal && cubic_fast_ok(c, 2) && c->variant != 17 &&
+           c->variant != 3 && R <= c->fermat_coop_max && (kind_ne == IONO_INTERP_TRILINEAR || (c->nx >= 6 && c->ny >= 6 && c->nz >= 6));
+}
+int iono_fermat_lm_ok(iono_ctx *c, int kind_n, int kind_ne, int64_t R, int *ok) {
+    { const int rc = need_ctx(c); if (rc) return rc; }
+    if (!ok) return fail(c, IONO_ERR_ARG, "null argument");
+    *ok = fermat_lm_ok(c, kind_n, kind_ne, R) ? 1 : 0;
+    return IONO_OK;
+}
 static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const double *dD, const double *dW, int64_t R, double tmax, int Ns,
                              double frequency, int bend, int kind_n, int substeps, int independent, int kind_ne, int rule, double ne_scale,
                              double *tec, double *grad) {
@@ -2550,8 +2572,7 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
     }
     const GridView g = view(c);
     const dim3 grid((unsigned)((R + 63) / 64)), block(64);
-    if (!adjoint && kind_n == IONO_INTERP_TRICUBIC && g.ideal && cubic_fast_ok(c, 2) && c->variant != 17 && c->variant != 3 &&
-        R <= c->fermat_coop_max && (kind_ne == IONO_INTERP_TRILINEAR || (c->nx >= 6 && c->ny >= 6 && c->nz >= 6))) {
+    if (!adjoint && fermat_lm_ok(c, kind_n, kind_ne, R)) {
         // tricubic index on an ideal-uniform grid: 8 lanes per ray, one Lekien-Marsden record of n per lane, streaming quadrature
         // (iono_fermat_kernels.h:k_fermat_tec_lm; IONOTOMO_VARIANT=17 / 3: the lanes = rays kernel below, A/B)
         const int rcf = ensure_n_fields(c, frequency);
@@ -2592,7 +2613,7 @@ int iono_forward_tec_fermat_dev(iono_ctx *c, const double *o, const double *d, i
 
 int iono_adjoint_fermat_dev(iono_ctx *c, const double *o, const double *d, const double *w, int64_t R, double tmax, int Ns, double frequency,
                             int bend, int kind_n, int substeps, int independent, int kind_ne, int rule, double ne_scale, double *grad) {
-    if (c && c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear back-projection only (iono_adjoint_plan_dev for these rays first)");
+    if (c && c->deterministic) return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned straight-ray back-projections (trilinear, tricubic) only: not this entry point");
     return fermat_tec_launch(c, true, o, d, w, R, tmax, Ns, frequency, bend, kind_n, substeps, independent, kind_ne, rule, ne_scale, nullptr, grad);
 }
 

@@ -40,6 +40,7 @@ class RayEngine(object):
         self.ctx = _lib.Context(device)
         self.storage = storage
         self.kind = _lib.interp_kind(interp)
+        self.trilinear = self.kind == _lib.interp_kind("linear")
         self.rule = _lib.quad_rule(quad)
         self.shape = None
         self.deterministic = False
@@ -59,13 +60,6 @@ class RayEngine(object):
         self.ctx.set_grid(xvec, yvec, zvec, M, storage=self.storage)
         self.shape = self.ctx.grid_shape
         self.ncells = int(np.prod(self.shape))
-        # "ideal-uniform" axes (g0 + i h to 2.5e-13 h: what np.linspace builds; the library's own rule, iono_grid_set): the tier that has
-        # the record-per-lane tricubic tracer and its fused TEC kernel
-        def ideal(a):
-            a = np.asarray(a, dtype=np.float64).ravel()
-            h = (a[-1] - a[0]) / (a.size - 1)
-            return bool(np.all(np.abs(a - (a[0] + np.arange(a.size) * h)) <= 2.5e-13 * h))
-        self.ideal_axes = all(ideal(a) for a in (xvec, yvec, zvec)) and min(self.shape) >= 6
 
     def set_values(self, M_t):
         """grid values <- float64 device tensor"""
@@ -183,7 +177,7 @@ class RayEngine(object):
         return n.value, u.value, f.value
 
     def set_deterministic(self, on=True):
-        """Order-independent (fixed-point) accumulation in the planned trilinear back-projection: run-to-run identical bits, also
+        """Order-independent (fixed-point) accumulation in the planned trilinear AND tricubic back-projections: run-to-run identical bits, also
         for every solver iterate built on it (include/ionotomo_hip.h: iono_set_deterministic).  Back-projections the fixed-point
         kernel does not serve raise while the mode is on."""
         self.ctx.call("iono_set_deterministic", 1 if on else 0)
@@ -340,7 +334,16 @@ class RayEngine(object):
     # stepper of the fused kernel (config 3: 2.3 against 31 ms): below this many bytes of rays[R,4,Ns] the two-step path serves it
     FUSED_CUBIC_ABOVE_BYTES = 8 << 30
 
-    def _two_step_fermat(self, R, Ns, kind, fused, adjoint=False):
+    def fermat_lm_ok(self, kind, ne_kind, R):
+        """Would ``forward_fermat`` run the fused tricubic-index kernel (k_fermat_tec_lm) for this launch?  Asked of the library
+        (iono_fermat_lm_ok), never re-derived here."""
+        import ctypes
+        ok = ctypes.c_int(0)
+        as_kind = lambda k: k if isinstance(k, int) else _lib.interp_kind(k)
+        self.ctx.call("iono_fermat_lm_ok", as_kind(kind), as_kind(ne_kind), int(R), ctypes.byref(ok))
+        return bool(ok.value)
+
+    def _two_step_fermat(self, R, Ns, kind, fused, adjoint=False, ne_kind=None):
         """True: trace into a TEMPORARY rays[R,4,Ns] tensor (32 R Ns bytes of device memory) and integrate along it.  Round 4: the
         FORWARD through a tricubic index on ideal-uniform axes is fused too (k_fermat_tec_lm: 8 lanes per ray, one node record per
         lane, streaming quadrature) -- the two-step route remains the default only for its transpose and for non-uniform axes."""
@@ -349,8 +352,8 @@ class RayEngine(object):
         need = R * 4 * int(Ns) * 8
         if _lib.interp_kind(kind) != _lib.interp_kind("cubic") or need > self.FUSED_CUBIC_ABOVE_BYTES:
             return False
-        if not adjoint and getattr(self, "ideal_axes", False) and self.storage in ("f64", "float64", 0):
-            return False
+        if not adjoint and self.fermat_lm_ok(kind, self.kind if ne_kind is None else ne_kind, R):
+            return False                       # the library's own dispatch predicate: its fused tricubic-index kernel serves this launch
         try:                                   # never a hidden allocation beyond half of what the device has free
             free = torch.cuda.mem_get_info(self.device)[0]
         except Exception:
@@ -367,7 +370,7 @@ class RayEngine(object):
         R = origins_t.shape[0]
         if out is None:
             out = torch.empty(R, dtype=torch.float64, device=self.device)
-        if self._two_step_fermat(R, Ns, kind, fused):
+        if self._two_step_fermat(R, Ns, kind, fused, ne_kind=ne_kind):
             rays = self.trace_fermat(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, substeps=substeps, type=type)
             self.forward_rays(rays, out=out, kind=ne_kind)
             if ne_scale != 1.0:

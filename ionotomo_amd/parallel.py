@@ -133,7 +133,9 @@ class ShardedRays(object):
         self.plan = None
         self.slabs = None               # exchange="overlap": (unit_lo[], z_lo[]) of the back-projection plan's z-slabs
         if plan and hasattr(engine, "plan_adjoint") and self.R_local > 0:
-            if exchange == "overlap" and self.world > 1 and hasattr(engine, "plan_slabs"):
+            # (slab by slab only the planned TRILINEAR back-projection can run -- a tricubic fold's stencil crosses slab boundaries:
+            #  a cubic engine keeps one slab and exchanges compactly)
+            if exchange == "overlap" and self.world > 1 and hasattr(engine, "plan_slabs") and getattr(engine, "trilinear", True):
                 self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns, slabs=self.OVERLAP_SLABS)
                 # (a segment never leaves its z-layer of boxes -- the plan cuts rays at layer boundaries -- so a slab's node levels are
                 #  final once its units have run even where samples overhang their box image in x or y and go by global atomics)
@@ -217,7 +219,12 @@ class ShardedRays(object):
 
     def overlapped(self):
         """exchange="overlap" is in force: the plan has z-slabs every rank agrees on and the engine back-projects slab by slab."""
-        return self.world > 1 and self.slabs is not None and self.fused_steps()
+        if not (self.world > 1 and self.slabs is not None and self.fused_steps()):
+            return False
+        # ... and the engine's (single) back-projection plan is still the one made here for THESE tensors: a later plan_adjoint on
+        # the same engine (another ShardedRays, say) replaces it, and a slab's unit range would mean nothing to the new plan
+        planned = getattr(self.engine, "_planned", None)
+        return planned is not None and planned[0] is self.origins and planned[1] is self.dirs
 
     def backproject_exchange_overlapped(self, ray_step, s_full, s_c, idx):
         """The summed back-projected update in the compact vector ``s_c`` with the exchange HIDDEN behind the back-projection

@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(world, exchange="dense", engine="oracle", size=None):
+def _run(world, exchange="dense", engine="oracle", size=None, interp="linear"):
     """Executed by every rank (and with world == 1 in the parent for the reference result).
     ``engine="oracle"``: the CPU stand-in (this file's tests); ``engine="hip"``: the product's RayEngine on GPU 0
     (tests/test_gpu_configs.py runs the same function in two fresh processes sharing the card)."""
@@ -38,7 +38,7 @@ def _run(world, exchange="dense", engine="oracle", size=None):
     cd = np.full((pb["na"], pb["P"]), 1e-4)
     if engine == "hip":
         from ionotomo_amd.engine import RayEngine
-        eng = RayEngine(0)
+        eng = RayEngine(0, interp=interp)
         eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
     else:
         from cpu_engine import OracleEngine
@@ -53,21 +53,26 @@ def _run(world, exchange="dense", engine="oracle", size=None):
     adj = host(prob.adjoint(prob.slice(y_full)))
     xc, hc = solvers.cgls(prob, torch.from_numpy(pb["x0"].copy()).to(dev), n_iter=4)
     xs, hs = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()).to(dev), n_iter=3)
+    overlapped = bool(getattr(prob, "overlapped", lambda: False)())      # (while the engine's plan is still prob's)
     # float32 on the links (compact plan shared with the float64 exchange above)
     p32 = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], i0=pb["i0"], exchange=exchange,
                                reduce_dtype=torch.float32)
     adj32 = host(p32.adjoint(p32.slice(y_full)))
+    # p32 has replaced the engine's single back-projection plan: prob must notice (no slab pipeline on a foreign plan: ADVICE r4)
+    # and give the same iterates through the compact exchange
+    xs2, _ = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()).to(dev), n_iter=3)
     return dict(fwd=fwd, adj=adj, xc=host(xc), hc=np.array(hc), xs=host(xs), hs=np.array(hs),
                 block=(prob.lo, prob.hi), adj32=adj32, active=prob.exchange.fraction,
                 compact=prob.exchange.index is not None, P=pb["P"],
-                overlapped=bool(getattr(prob, "overlapped", lambda: False)()), nslab=len(prob.slab_ranges or []))
+                overlapped=overlapped, overlapped_after_replan=bool(getattr(prob, "overlapped", lambda: False)()),
+                xs2=host(xs2), nslab=len(prob.slab_ranges or []))
 
 
-def _worker(rank, world, port, q, exchange, engine="oracle", size=None):
+def _worker(rank, world, port, q, exchange, engine="oracle", size=None, interp="linear"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = _run(world, exchange, engine, size)
+    out = _run(world, exchange, engine, size, interp)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()

@@ -182,6 +182,36 @@ def test_binned_tricubic_channels():
     assert not eng.check_oob()
 
 
+def test_pending_unit_range_is_refused_by_every_launch_but_the_planned_trilinear_one(monkeypatch):
+    """iono_adjoint_unit_range (one z-slab of the plan) means something to the planned trilinear back-projection only.  Any other
+    launch used to DISCARD the range and add the whole back-projection -- once per slab under exchange="overlap" (ADVICE r4): now
+    IONO_ERR_ARG, nothing launched, and the range does not linger."""
+    w = syn.make_workload(antennas="lofar", na=12, nd=5, nt=3, n=40)
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    R = len(o)
+    for interp, replan, variant in (("cubic", False, None), ("linear", True, None), ("linear", False, "2")):
+        if variant:
+            monkeypatch.setenv("IONOTOMO_VARIANT", variant)
+        eng = engine(w["xvec"], w["yvec"], w["zvec"], interp=interp)
+        monkeypatch.delenv("IONOTOMO_VARIANT", raising=False)
+        eng.set_values(eng.tensor(w["ne"] / 1e13))
+        ot, dt = eng.tensor(o), eng.tensor(d)
+        eng.plan_adjoint(ot, dt, w["tmax"], 41, slabs=4)
+        r = eng.tensor(np.random.default_rng(0).normal(size=R))
+        scale = torch.ones_like(r)
+        # a ray pass that leaves its weights in the library (out=None), as the solvers' overlapped steps do
+        eng.adjoint_sirt_step(ot, dt, r, torch.zeros_like(r), scale, scale, 12, 0, w["tmax"], 41, None, want_dot=False)
+        if replan:                                                 # the engine's single plan now belongs to other tensors
+            o2, d2 = ot.clone(), dt.clone()
+            eng.plan_adjoint(o2, d2, w["tmax"], 41)
+        out = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
+        with pytest.raises(ValueError, match="work-unit range"):
+            eng.adjoint_planned_weights(ot, dt, w["tmax"], 41, out, unit_range=(0, 1))
+        assert float(out.abs().max()) == 0.0                       # nothing launched
+        full = eng.adjoint_planned_weights(ot, dt, w["tmax"], 41, out)          # no range pending any more: the whole back-projection
+        assert float(full.abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("seed", range(SOAK * 5))
 def test_node_stationary_forward_ab_variant(seed, OC, monkeypatch):
     """IONOTOMO_FWD_PLAN=1: the forward on the ray plan (box image staged in LDS, per-segment partial sums) -- the

@@ -401,6 +401,12 @@ def test_planned_tensors_edited_in_place_never_give_garbage(OC, interp):
     dt[hit[1], 0] += 0.01                                                     # ONE ray, in place
     g1 = eng.adjoint(ot, dt, y, bench.TMAX, bench.NS).cpu().numpy()
     assert eng.plan_stale() and np.isnan(g1).any()
+    # ... and the ray restored in place: the hashes match again, but the plan's record stays poisoned -- so the flag must be raised
+    # again by every later launch until the rays are planned anew (flag and NaN never come apart)
+    dt[hit[1], 0] -= 0.01
+    g1b = eng.adjoint(ot, dt, y, bench.TMAX, bench.NS).cpu().numpy()
+    assert np.isnan(g1b).any() and eng.plan_stale()
+    dt[hit[1], 0] += 0.01
     eng.plan_adjoint(ot, dt, bench.TMAX, bench.NS)
     g2 = eng.adjoint(ot, dt, y, bench.TMAX, bench.NS).cpu().numpy()
     assert np.all(np.isfinite(g2)) and not eng.plan_stale() and np.max(np.abs(g2 - g0)) > 0.0

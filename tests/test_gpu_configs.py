@@ -42,26 +42,30 @@ def make_engine(w, **kw):
 
 # --------------------------------------------------------------------------- two processes, one card (first: the
 # children are started before this process has touched the GPU when the file runs on its own)
-@pytest.mark.parametrize("exchange", ["dense", "auto", "sharded", "overlap"])
+@pytest.mark.parametrize("exchange", ["dense", "auto", "sharded", "overlap", "overlap-cubic"])
 def test_two_process_hip_engine_matches_single_rank(exchange):
     """ShardedRays over the product's RayEngine in 2 fresh processes (gloo rendezvous, both on GPU 0) against the
     single-rank run: forward without collective, adjoint + all-reduce, CGLS / SIRT iterates, float32 links.
     ``overlap``: the back-projection plan in z-slabs, every slab's finished node levels all-reduced asynchronously while the next
-    slab is back-projected (parallel.ShardedRays.backproject_exchange_overlapped)."""
+    slab is back-projected (parallel.ShardedRays.backproject_exchange_overlapped).  ``overlap-cubic``: the same request on a tricubic
+    engine, whose transpose cannot run slab by slab (the folds' stencils cross slab boundaries): it must fall back to the compact
+    exchange and still match the single rank (it used to add the whole transpose once per slab)."""
     import torch.multiprocessing as mp
+    interp = "cubic" if exchange.endswith("-cubic") else "linear"
+    exchange = exchange.split("-")[0]
     from test_distributed_gloo import _worker, _run, _free_port
     size = dict(na=6, nd=7, nt=6, n=40, Ns=65)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, "hip", size)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, "hip", size, interp)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(2))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    ref = _run(1, exchange, "hip", size)
+    ref = _run(1, exchange, "hip", size, interp)
     P = ref["P"]
     assert res[0]["block"] == (0, P // 2) and res[1]["block"] == (P // 2, P)
     for r in range(2):
@@ -75,8 +79,12 @@ def test_two_process_hip_engine_matches_single_rank(exchange):
         assert np.max(np.abs(res[r]["adj32"] - ref["adj"])) < 3e-7 * np.abs(ref["adj"]).max()
         if exchange != "dense":
             assert 0.0 < res[r]["active"] < 1.0 and res[r]["active"] == res[0]["active"]
-        if exchange == "overlap":
+        assert np.max(np.abs(res[r]["xs2"] - ref["xs"])) < 1e-10 * np.max(np.abs(ref["xs"]))
+        assert not res[r]["overlapped_after_replan"]                      # a replaced plan is never driven slab by slab
+        if exchange == "overlap" and interp == "linear":
             assert res[r]["overlapped"] and res[r]["nslab"] >= 2          # the slab pipeline really ran
+        elif exchange == "overlap":
+            assert not res[r]["overlapped"] and res[r]["nslab"] == 0      # tricubic: compact exchange, one slab
 
 
 # --------------------------------------------------------------------------- config 3

@@ -185,7 +185,7 @@ def test_tricubic_index_is_fused_by_default_on_ideal_axes(monkeypatch):
         eng = make_engine(w, interp=interp)
         eng.set_values(eng.tensor(w["ne"]))
         ot, dt = eng.tensor(o), eng.tensor(d)
-        assert eng.ideal_axes
+        assert eng.fermat_lm_ok("cubic", interp, len(o))               # the library's own predicate (iono_fermat_lm_ok)
         assert not eng._two_step_fermat(len(o), 21, "cubic", None) and eng._two_step_fermat(len(o), 21, "cubic", None, adjoint=True)
         assert not eng._two_step_fermat(len(o), 21, "linear", None)
         for typ in ("z", "s"):
@@ -206,6 +206,8 @@ def test_tricubic_index_is_fused_by_default_on_ideal_axes(monkeypatch):
     e17.set_grid(w["xvec"], w["yvec"], w["zvec"])
     e17.set_values(e17.tensor(w["ne"]))
     c17 = e17.forward_fermat(e17.tensor(o), e17.tensor(d), w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
+    # ... which the DEFAULT route never lands on silently: where the library would not run k_fermat_tec_lm, fused=None traces + integrates
+    assert not e17.fermat_lm_ok("cubic", "cubic", len(o)) and e17._two_step_fermat(len(o), 21, "cubic", None)
     monkeypatch.delenv("IONOTOMO_VARIANT")
     eng = RayEngine(0, interp="cubic")
     eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
