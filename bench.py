@@ -398,6 +398,13 @@ def cfg4_leg(w, local, k2, torch, dist, world):
         if world > 1:
             dist.barrier()
         out["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 10 * 1e3
+        # BASELINE config 5 "as 4": the whole 50-iteration inversion, wall clock incl. the solver's set-up (normalisations, active set)
+        t0 = time.perf_counter()
+        fn(prob, x0, n_iter=50)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        out["%s_50_iterations_ms" % name] = (time.perf_counter() - t0) * 1e3
     if world > 1:
         # the same iterations with the exchange hidden behind the back-projection (exchange="overlap": the plan in z-slabs, every slab's
         # finished node levels all-reduced asynchronously while the next slab is back-projected), float64 and float32 on the links

@@ -224,12 +224,20 @@ __device__ __forceinline__ double fermat_step(double tmax, double z0, int Ns, in
     return (stype ? tmax : tmax - z0) / (double)((Ns - 1) * substeps);
 }
 // (out of line: inlined into the lanes = rays kernels -- four RK4 stages, in k_fermat_tec beside the integrand's own evaluation --
-//  the 216-tap value-and-gradient evaluation pushed them to 512 VGPRs + 1 kB of scratch per lane)
-__device__ __attribute__((noinline)) void tricubic_n_and_gradient(const GridView &g, const double *nM, double x, double y, double z,
-                                                                  double &n, double &nx, double &ny, double &nz) {
-    GridView gn = g;
-    gn.M = nM;
-    tricubic_eval<double, true>(gn, g.axes, g.axes + g.nx, g.axes + g.nx + g.ny, x, y, z, n, nx, ny, nz);
+//  the 216-tap value-and-gradient evaluation pushed them to 512 VGPRs + 1 kB of scratch per lane.  Everything crosses the call BY
+//  VALUE, in registers: with `const GridView &` in and four `double &` out -- round 4 -- the caller had to keep the 192-byte view and
+//  the four results in scratch memory, 224 bytes per lane of every k_trace_fermat<1, *> / k_fermat_tec<1, *, *>)
+struct NGrad {
+    double n, nx, ny, nz;
+};
+__device__ __attribute__((noinline)) NGrad tricubic_n_and_gradient(const double *nM, const double *axes, int nx, int ny, int nz, double ih0,
+                                                                   double ih1, double ih2, int u0, int u1, int u2, double x, double y, double z) {
+    GridView gn;
+    gn.axes = axes, gn.M = nM, gn.nx = nx, gn.ny = ny, gn.nz = nz;
+    gn.inv_h[0] = ih0, gn.inv_h[1] = ih1, gn.inv_h[2] = ih2, gn.uniform[0] = u0, gn.uniform[1] = u1, gn.uniform[2] = u2;
+    NGrad o;
+    tricubic_eval<double, true>(gn, axes, axes + nx, axes + nx + ny, x, y, z, o.n, o.nx, o.ny, o.nz);
+    return o;
 }
 template <int KIND, bool BEND>
 __device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM, const FState &u, int stype) {
@@ -238,7 +246,9 @@ __device__ __forceinline__ FState fermat_rhs(const GridView &g, const double *nM
         // ideal-uniform grid, point not on a cell face: no axis tables, no divisions (iono_device_common.h)
         if (!(g.ideal && trilinear_grad_ideal(g, nM, u.x, u.y, u.z, n, nx, ny, nz))) trilinear_grad_at(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
     } else {
-        tricubic_n_and_gradient(g, nM, u.x, u.y, u.z, n, nx, ny, nz);
+        const NGrad q = tricubic_n_and_gradient(nM, g.axes, g.nx, g.ny, g.nz, g.inv_h[0], g.inv_h[1], g.inv_h[2], g.uniform[0], g.uniform[1],
+                                                g.uniform[2], u.x, u.y, u.z);
+        n = q.n, nx = q.nx, ny = q.ny, nz = q.nz;
     }
     if (!BEND) nx = ny = nz = 0.0;
     return fermat_rates(n, nx, ny, nz, u, stype);

@@ -210,8 +210,16 @@ __device__ __forceinline__ void tricubic_eval(const GridView &g, const double *g
     const int k = cubic_axis(gz, g.nz, z, g.inv_h[2], g.uniform[2], wz, dz, GRAD);
     const GT *base = (const GT *)g.M + ((size_t)(i - 2) * g.ny + (j - 2)) * g.nz + (k - 2);
     f = fx = fy = fz = 0.0;
+    // (the x taps ROTATE through six named values instead of being indexed by the loop counter: where the compiler keeps this loop
+    //  rolled -- the Fermat kernels, which inline four of these per step -- a run-time index put wx, dx, wy, dy into scratch memory,
+    //  224 bytes per lane in the round-4 build; a select chain on the counter is turned back into an indexed load.  Where it unrolls
+    //  the loop the moves vanish.  Same operations in the same order, bit for bit)
+    double x0 = wx[0], x1 = wx[1], x2 = wx[2], x3 = wx[3], x4 = wx[4], x5 = wx[5];
+    double e0 = GRAD ? dx[0] : 0.0, e1 = GRAD ? dx[1] : 0.0, e2 = GRAD ? dx[2] : 0.0, e3 = GRAD ? dx[3] : 0.0, e4 = GRAD ? dx[4] : 0.0,
+           e5 = GRAD ? dx[5] : 0.0;
     for (int a = 0; a < 6; ++a) {
         double fa = 0.0, fya = 0.0, fza = 0.0;
+#pragma unroll
         for (int b = 0; b < 6; ++b) {
             const GT *p = base + ((size_t)a * g.ny + b) * g.nz;
             double s = 0.0, sz = 0.0;
@@ -227,12 +235,14 @@ __device__ __forceinline__ void tricubic_eval(const GridView &g, const double *g
                 fza += sz * wy[b];
             }
         }
-        f += fa * wx[a];
+        f += fa * x0;
         if (GRAD) {
-            fx += fa * dx[a];
-            fy += fya * wx[a];
-            fz += fza * wx[a];
+            fx += fa * e0;
+            fy += fya * x0;
+            fz += fza * x0;
         }
+        x0 = x1, x1 = x2, x2 = x3, x3 = x4, x4 = x5;
+        e0 = e1, e1 = e2, e2 = e3, e3 = e4, e4 = e5;
     }
 }
 

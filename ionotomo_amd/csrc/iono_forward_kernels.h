@@ -561,8 +561,9 @@ static_assert(B_LEV8 == B_LEV * 8, "B_LEV8");
 #ifndef B_UNROLL
 #define B_UNROLL 2
 #endif
-#ifndef B_WPE
-#define B_WPE 4, 5
+#ifndef B_WPE_LO
+#define B_WPE_LO 4
+#define B_WPE_HI 5
 #endif
 #define B_MAXWY (64 / B_PPC)                     // one wave-load stages one row of the window (wy columns x B_PPC pieces <= 64 lanes)
 template <bool MAX>
@@ -843,12 +844,20 @@ __device__ __forceinline__ BWin bwin_decode(uint4 w) {
 }
 typedef double dbl8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// (waves per SIMD: the TEC kernel (NF = 0, 1) is tuned for 4 -- 126 VGPRs; the phase observable's accumulators (NF = 4, 8: one per
+//  frequency, + the series / square-root temporaries) do not fit 128 VGPRs: 200 / 428 bytes of scratch per lane in the round-4
+//  build.  Their workgroups are LDS-limited to 3 / 2 per CU anyway (4 images + NF x 4 x 64 partial sums), so NF >= 4 asks for
+//  3 / 2 waves per SIMD and gets 168 / 256 VGPRs: no scratch)
+#define B_WPE_FOR(NF) ((NF) >= 8 ? 2 : (NF) >= 4 ? 3 : B_WPE_LO), ((NF) >= 8 ? 2 : (NF) >= 4 ? 3 : B_WPE_HI)
 template <int NF>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) void k_forward_bundle(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE_FOR(NF)))) void k_forward_bundle(
     GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, const BundleRec *__restrict__ brec,
     const uint2 *__restrict__ bhash, const uint4 *__restrict__ win, int nb, int nchunks, double tmax, int Ns,
     const double *__restrict__ unitw, double *__restrict__ tec, int *flags, PhaseFreqs pf, int ldf) {
     constexpr int NA = NF > 0 ? NF : 1;
+    // prefetch registers (16 bytes per lane each): 6 for TEC; the phase observable gives some to its accumulators -- 5 (one frequency,
+    // 128 VGPRs) / 4 (four, 168 VGPRs) -- so that nothing spills; taller windows finish with LDS-DMA either way
+    constexpr int NPF = NF == 0 || NF >= 8 ? B_NPF : NF >= 4 ? 4 : 5;
     extern __shared__ __attribute__((aligned(16))) char blds[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // (wave-uniform: scalar loop control)
     int b = blockIdx.x;
@@ -881,11 +890,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
     const uint4 *wb = win + (size_t)b * nchunks;
     const int c0 = nchunks * wid / B_SPLIT, c1 = nchunks * (wid + 1) / B_SPLIT;
     const unsigned plane8 = (unsigned)g.ny * (unsigned)g.nz * 8u;              // bytes between two rows (i, i + 1) of a window in memory
-    // ---- window copy, part 1: the first B_NPF wave-loads of a window into registers (lane = (row r, column dj, piece pc) of a
+    // ---- window copy, part 1: the first NPF wave-loads of a window into registers (lane = (row r, column dj, piece pc) of a
     //      load of rpl rows; the image is lane-linear: row di at byte di * wy * 80, column dj at + 80 dj) ----------------------------
-    u32x4 pre[B_NPF], pre_last = u32x4{0u, 0u, 0u, 0u};
+    u32x4 pre[NPF], pre_last = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int n = 0; n < B_NPF; ++n) pre[n] = u32x4{0u, 0u, 0u, 0u};
+    for (int n = 0; n < NPF; ++n) pre[n] = u32x4{0u, 0u, 0u, 0u};
     bool act = false, act_last = false;                                          // lanes of the pending copy (all loads / its last one)
     // (24-bit multiply-adds: one full-rate instruction each where v_mul_lo_u32 runs at a quarter of the rate; the operands are a lane's
     //  row / column slot (< 16) and the grid's z length or plane size in bytes -- taken only while the plane is below 2^24 bytes)
@@ -923,10 +932,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
         const unsigned gs32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)gstep);
         if (act) {
 #pragma unroll
-            for (int n = 0; n < B_NPF; ++n)
+            for (int n = 0; n < NPF; ++n)
                 if (n < W.nl - 1) pre[n] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loff, (int)((unsigned)n * gs32), 0);
         }
-        if (act_last && W.nl - 1 <= B_NPF) pre_last = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loff, (int)((unsigned)(W.nl - 1) * gs32), 0);
+        if (act_last && W.nl - 1 <= NPF) pre_last = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)loff, (int)((unsigned)(W.nl - 1) * gs32), 0);
         return;
 #endif
         // (all full loads under ONE execution mask, the last -- possibly partial -- group of rows under another: per-load predicates
@@ -935,12 +944,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
         //  previous load has landed and puts vmcnt(0) in front of every load of a window)
         if (act) {
 #pragma unroll
-            for (int n = 0; n < B_NPF; ++n)
+            for (int n = 0; n < NPF; ++n)
                 if (n < W.nl - 1) pre[n] = *(const u32x4 *)(rowp + (size_t)n * gstep + loff);
         }
         // (the last group in a register of its own: a slot that either block may write would make the compiler wait for the first
         //  block's loads before the second's)
-        if (act_last && W.nl - 1 <= B_NPF) pre_last = *(const u32x4 *)(rowp + (size_t)(W.nl - 1) * gstep + loff);
+        if (act_last && W.nl - 1 <= NPF) pre_last = *(const u32x4 *)(rowp + (size_t)(W.nl - 1) * gstep + loff);
     };
     double inv_np_max = 0.0;                                  // the lowest frequency of the pass has the largest ne / n_p
 #pragma unroll
@@ -997,11 +1006,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
             char *dst = img + lane * 16;
             if (act) {
 #pragma unroll
-                for (int n = 0; n < B_NPF; ++n)
+                for (int n = 0; n < NPF; ++n)
                     if (n < Wc.nl - 1) *(u32x4 *)(dst + n * lstep) = pre[n];
             }
-            if (act_last && Wc.nl - 1 <= B_NPF) *(u32x4 *)(dst + (Wc.nl - 1) * lstep) = pre_last;
-            if (Wc.nl - 1 > B_NPF) {                                              // the rest of a tall window: LDS-DMA, not prefetched
+            if (act_last && Wc.nl - 1 <= NPF) *(u32x4 *)(dst + (Wc.nl - 1) * lstep) = pre_last;
+            if (Wc.nl - 1 > NPF) {                                              // the rest of a tall window: LDS-DMA, not prefetched
                 int r = 0, dj = lane_q;
                 if (Wc.rpl > 1) {
                     r = (int)(lane_qf * __uint_as_float((unsigned)Wc.winv));
@@ -1009,10 +1018,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE))) vo
                 }
                 const unsigned loff = (unsigned)r * plane8 + ((unsigned)dj * (unsigned)g.nz + 2u * (unsigned)lane_pc) * 8u;
                 const size_t gstep = (size_t)Wc.rpl * plane8;
-                const char *rowp = (const char *)M + (size_t)Wc.woff * 8 + (size_t)B_NPF * gstep;
-                char *dd = img + B_NPF * lstep;
+                const char *rowp = (const char *)M + (size_t)Wc.woff * 8 + (size_t)NPF * gstep;
+                char *dd = img + NPF * lstep;
                 if (act) {
-                    for (int n = B_NPF; n < Wc.nl - 1; ++n) {
+                    for (int n = NPF; n < Wc.nl - 1; ++n) {
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowp + loff),
                                                          (__attribute__((address_space(3))) void *)dd, 16, 0, 0);
                         rowp += gstep, dd += lstep;

@@ -245,6 +245,143 @@ def test_config5_fifty_iterations_256_cubed():
     assert not eng.check_oob()
 
 
+class _EightEngines(object):
+    """What the solvers' dense-vector forms ask of ``problem.engine``, spread over the eight shards' engines."""
+    storage = "f64"
+
+    def __init__(self, owner):
+        self.owner = owner
+        e0 = owner.shards[0].engine
+        self.shape, self.device = e0.shape, e0.device
+
+    def set_values(self, x):
+        for s in self.owner.shards:
+            s.engine.set_values(x)
+
+    def axpby_(self, *a, **k):
+        return self.owner.shards[0].engine.axpby_(*a, **k)
+
+    def adjoint(self, origins, dirs, w, tmax, Ns, order=None):       # (parallel_adjoint_raw: G^T w without differencing)
+        g = None
+        for s, ws in zip(self.owner.shards, self.owner.split(w)):
+            part = s.engine.adjoint(s.origins, s.dirs, ws, tmax, Ns)
+            g = part if g is None else g.add_(part)
+        return g
+
+
+class EightShards(object):
+    """Config 4's 8-GPU partition on ONE card (test infrastructure): the eight ``ShardedRays`` of ``pair_block(P, 8, r)``, each on
+    an engine of its own (its own grid replica, forward plan and back-projection plan), driven in turn; the per-iteration exchange
+    is replaced by what it computes -- the SUM of the eight partial gradients.  Ray vectors are in the full problem's [Na][P]
+    order.  Offers what the solvers' dense-vector forms use, so ``solvers.sirt / cgls`` run on it unchanged."""
+    world = 1
+
+    def __init__(self, shards, Na, P, i0, tmax, Ns):
+        self.shards, self.Na, self.P_local, self.i0, self.tmax, self.Ns = shards, Na, P, i0, tmax, Ns
+        self.engine = _EightEngines(self)
+        self.origins = self.dirs = None
+        self.dobs = self.cdct = None
+
+    def _adjoint_order(self):
+        return None
+
+    def split(self, v):
+        v = v.view(self.Na, self.P_local)
+        return [v[:, s.lo:s.hi].reshape(-1).contiguous() for s in self.shards]
+
+    def _join(self, parts):
+        out = torch.empty(self.Na, self.P_local, dtype=torch.float64, device=self.engine.device)
+        for s, p_ in zip(self.shards, parts):
+            out[:, s.lo:s.hi] = p_.view(self.Na, s.hi - s.lo)
+        return out
+
+    def forward_tec(self):
+        return self._join([s.forward_tec() for s in self.shards]).reshape(-1)
+
+    def forward(self):
+        tec = self.forward_tec().view(self.Na, self.P_local)
+        return (tec - tec[self.i0:self.i0 + 1]).reshape(-1)
+
+    def adjoint(self, y):
+        g = None
+        for s, ys in zip(self.shards, self.split(y)):          # (all antennas of a pair sit in one shard: the differencing is local)
+            part = s.adjoint(ys)
+            g = part if g is None else g.add_(part)
+        return g
+
+    def dot_rays_t(self, a, b):
+        return torch.dot(a, b)
+
+    def dot_rays(self, a, b):
+        return float(torch.dot(a, b))
+
+
+def test_config5_as_written_620000_rays_and_the_sum_of_eight_shards(monkeypatch):
+    """BASELINE config 5 "as 4": 50 CGLS + 50 SIRT iterations on config 4's 620,000 rays through 256^3.  One rank (the product's
+    fused iterations): monotone objectives, the reference's stopping rule (inversion/iterative_newton.py:959-962,993).  And the
+    8-GPU path without 8 GPUs: the eight shards of ``pair_block(10000, 8, r)``, each with its own engine and plans, the exchange
+    replaced by the sum of their partial gradients (``EightShards``) -- the same SIRT iterates as one rank to 1e-8 over all 50
+    iterations and the same stopping iteration; CGLS to 1e-8 while rounding has not been amplified (the first 10 iterations), its
+    objective history to 1e-6 throughout (CG amplifies summation-order differences: profiles/r04_deterministic_cgls_agreement.json)."""
+    import bench
+    wb = bench.build_workload(0)
+    c4 = bench.build_cfg4(wb)
+    na, P = bench.NA, c4["origins"].shape[1]
+    assert na * P == 620000
+    tmax, Ns = bench.TMAX, bench.NS
+    x0 = np.exp(c4["m"]) * (c4["K_ne"] / 1e13)
+    X, Y, Z = np.meshgrid(c4["xvec"], c4["yvec"], c4["zvec"], indexing="ij")
+    x_true = x0 * (1.0 + 0.3 * np.exp(-((X - 5) ** 2 + (Y + 8) ** 2) / 15.0 ** 2 - ((Z - 300) / 80.0) ** 2))
+    del X, Y, Z
+    eng = make_engine(c4)
+    one = parallel.ShardedRays(eng, c4["origins"], c4["directions"], tmax, Ns, dobs=np.zeros((na, P)), cdct=np.full((na, P), 1e-6), i0=0,
+                               tune=False)
+    assert one.forward_plan[0] > 0 and one.plan[0] > 0
+    xt, x0t = eng.tensor(x_true), eng.tensor(x0)
+    eng.set_values(xt)
+    clean = one.forward()
+    dobs = clean + eng.tensor(np.random.default_rng(3).normal(size=na * P) * 1e-3)
+    one.dobs = dobs
+    noise_floor = 0.5 * float(((dobs - clean) ** 2).sum()) / 1e-6
+    xs1, hs1 = solvers.sirt(one, x0t, n_iter=50)
+    xc1, hc1 = solvers.cgls(one, x0t, n_iter=50)
+    hs1, hc1 = np.array(hs1), np.array(hc1)
+    assert len(hs1) == 50 and np.all(np.diff(hs1) <= 1e-9 * hs1[:-1]) and hs1[-1] < 1e-2 * hs1[0] and hs1[-1] > 0.5 * noise_floor
+    assert len(hc1) == 50 and np.all(np.diff(hc1) <= 1e-9 * hc1[:-1]) and hc1[-1] < 1e-3 * hc1[0] and hc1[-1] > 0.5 * noise_floor
+    _, hstop1 = solvers.sirt(one, x0t, n_iter=20, stop="reference")
+    _, cstop1 = solvers.cgls(one, x0t, n_iter=20, stop="reference")
+    assert 6 <= len(hstop1) <= 21 and 6 <= len(cstop1) <= 21
+    assert not eng.check_oob()
+    eng.check_plans()
+    # ---- the same through the sum of eight shards
+    shards = []
+    for r in range(8):
+        monkeypatch.setattr(parallel, "world_info", lambda r=r: (8, r))
+        shards.append(parallel.ShardedRays(make_engine(c4), c4["origins"], c4["directions"], tmax, Ns, i0=0, exchange="dense", tune=False))
+        assert shards[-1].R_local == 77500 and shards[-1].plan[0] > 0
+    monkeypatch.undo()
+    eight = EightShards(shards, na, P, 0, tmax, Ns)
+    eight.dobs, eight.cdct = dobs, one.cdct
+    xs8, hs8 = solvers.sirt(eight, x0t, n_iter=50)
+    assert np.allclose(hs8, hs1, rtol=1e-9)
+    assert float((xs8 - xs1).abs().max()) < 1e-8 * float(xs1.abs().max())
+    _, hstop8 = solvers.sirt(eight, x0t, n_iter=20, stop="reference")
+    assert len(hstop8) == len(hstop1) and np.allclose(hstop8, hstop1, rtol=1e-9)
+    xc8, hc8 = solvers.cgls(eight, x0t, n_iter=50)
+    hc8 = np.array(hc8)
+    dev = np.abs(hc8 - hc1) / hc1
+    print("cfg5 eight shards: CGLS objective history, relative deviation from one rank: first 10 %.2e, first 25 %.2e, all 50 %.2e; "
+          "of the initial objective %.2e" % (dev[:10].max(), dev[:25].max(), dev.max(), np.abs(hc8 - hc1).max() / hc1[0]))
+    assert dev[:10].max() < 1e-8 and np.abs(hc8 - hc1).max() < 1e-6 * hc1[0] and dev.max() < 5e-2
+    xc8_10, _ = solvers.cgls(eight, x0t, n_iter=10)
+    xc1_10, _ = solvers.cgls(one, x0t, n_iter=10)
+    assert float((xc8_10 - xc1_10).abs().max()) < 1e-8 * float(xc1_10.abs().max())
+    print("cfg5 eight shards: CGLS iterate after 50 iterations, max deviation / max|x| %.2e" % (float((xc8 - xc1).abs().max()) / float(xc1.abs().max())))
+    assert float((xc8 - xc1).abs().max()) < 1e-2 * float(xc1.abs().max())
+    for s in shards:
+        assert not s.engine.check_oob()
+
+
 def test_config5_fifty_iterations_match_dense_restatement():
     """All 50 iterations of SIRT and CGLS against oracle/solvers.py on a problem small enough for a dense matrix."""
     sys.path.insert(0, HERE)
