@@ -21,33 +21,20 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 #define BIN_SX 8
 #define BIN_SY 8
-#ifndef BIN_SZ
-#define BIN_SZ 14                            // cells per z-layer of boxes (round 5; 15 before: see BIN_VTOP)
-#endif
-#ifndef BIN_VTOP
-#define BIN_VTOP 1                           // the idle lane above a segment's last sample carries that sample's upper level (below)
-#endif
+#define BIN_SZ 15
 #ifndef BIN_H
 #define BIN_H 3
 #endif
 #define BIN_BX (BIN_SX + 2 * BIN_H + 1)      // nodes of the box image along x (15)
 #define BIN_BY (BIN_SY + 2 * BIN_H + 1)
-#define BIN_BZ (BIN_SZ + 1)                  // 15 z nodes (the image keeps 16 words per column: BIN_BZP)
+#define BIN_BZ (BIN_SZ + 1)                  // 16 z nodes
 #ifndef BIN_BZP
 #define BIN_BZP 16                           // z stride of the image in words.  NOT padded: ds_add_f64 is served in four groups of 16 lanes
 #endif                                       // with bank = word mod 16, a segment = one group = 16 consecutive levels, and a segment that
                                              // changes column half-way keeps distinct banks only if the column strides are multiples of 16
                                              // words (17: every such segment met a 2-way conflict: 16.2 against 8.2 cycles per instruction,
                                              // profiles/r04_lds_atomic_probe.json; nine segments in ten change column at the bench geometry)
-#define BIN_SEG 16                           // lanes per segment (a plan may use 4 or 8: `segl`); a segment holds at most segl - BIN_VTOP samples
-// BIN_VTOP (round 5).  An LDS atomic costs the same 6-8 cycles of the CU's LDS whatever its lane mask (profiles/r04_lds_atomic_probe.json),
-// and until round 4 a pass issued EIGHT per channel: four for the lower level of every sample (all lanes) and four for the upper level
-// of the samples whose upper level no neighbour takes over -- the LAST sample of every segment: one lane in sixteen, at full price.
-// Now a segment always leaves the lane above its last sample idle (<= segl - 1 samples; z-layers of 14 cells, so that a near-vertical
-// ray at one sample per cell gives runs of 14-15), and that idle lane takes the hand-over like any other: it adds the last sample's
-// upper level as ITS lower level, at the address one level up.  The sparse instructions then only remain where consecutive samples
-// change column or skip a cell.
-
+#define BIN_SEG 16                           // most samples per segment = lanes per segment (a plan may use 4 or 8: `segl`)
 #define BIN_ENTRY_PAD 1024                   // zero entries behind the list: the kernels prefetch three passes (of <= 1024 / 4 segments) ahead
 #ifndef BIN_UNIT
 #define BIN_UNIT 1024                        // segments per work unit (round 4, bench geometry, ms per back-projection: 256: 0.401, 512: 0.337, 1024: 0.322,
@@ -170,7 +157,7 @@ __global__ __launch_bounds__(256) void k_plan_segments(const double *__restrict_
             if (active) {
                 const int zb = plan_cell(fz0, dfz, k, nz) / BIN_SZ;
                 ke = k + 1;
-                while (ke < Ns && ke - k < segl - BIN_VTOP && plan_cell(fz0, dfz, ke, nz) / BIN_SZ == zb) ++ke;
+                while (ke < Ns && ke - k < segl && plan_cell(fz0, dfz, ke, nz) / BIN_SZ == zb) ++ke;
                 const int xa = plan_cell(fx0, dfx, k, nx), xb = plan_cell(fx0, dfx, ke - 1, nx);
                 const int ya = plan_cell(fy0, dfy, k, ny), yb = plan_cell(fy0, dfy, ke - 1, ny);
                 const int bi = min(nbx - 1, (xa + xb + 1) / (2 * BIN_SX)), bj = min(nby - 1, (ya + yb + 1) / (2 * BIN_SY));
@@ -570,24 +557,18 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
         const int lin = active ? (int)mad24(mad24((unsigned)i, (unsigned)g.ny, (unsigned)j), (unsigned)g.nz, (unsigned)kz) : -7;
         const int prev = __builtin_amdgcn_update_dpp(-9, lin, 0x111, 0xf, 0xf, false);          // row_shr:1 (row lane 0 keeps -9)
         const bool accept = active && prev + 1 == lin;
-        const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
-        const bool inside = (a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1));
-        unsigned t = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
-        // BIN_VTOP: an IDLE lane whose lower neighbour is a sample inside the image takes that sample's upper level as its own lower
-        // level, one word up (the image address travels with the values; level m + 1 <= BIN_BZ - 1 exists because the sample is inside)
-        const int tprev = BIN_VTOP ? __builtin_amdgcn_update_dpp(0, active && inside ? (int)t : 0, 0x111, 0xf, 0xf, false) : 0;
-        const bool vtop = BIN_VTOP && !active && tprev != 0;
         const double p00 = dpp_shr1(u00), p01 = dpp_shr1(u01), p10 = dpp_shr1(u10), p11 = dpp_shr1(u11);
-        if (accept | vtop) l00 += p00, l01 += p01, l10 += p10, l11 += p11;      // (an idle lane's own values are zeros)
-        const int taken = __builtin_amdgcn_update_dpp(0, (int)(accept | vtop), 0x101, 0xf, 0xf, false);  // row_shl:1: did lane s + 1 take mine?
+        if (accept) l00 += p00, l01 += p01, l10 += p10, l11 += p11;
+        const int taken = __builtin_amdgcn_update_dpp(0, (int)accept, 0x101, 0xf, 0xf, false);  // row_shl:1: did lane s + 1 take mine?
         const bool upper = active && !taken;
         if (FIX) {       // (after the lane exchange: what is handed over and merged is decided by the plan, not by the launch)
             l00 = qf(l00), l01 = qf(l01), l10 = qf(l10), l11 = qf(l11);
             u00 = qf(u00), u01 = qf(u01), u10 = qf(u10), u11 = qf(u11);
         }
-        if (vtop) t = (unsigned)tprev + 8u;
-        if (active | vtop) {
-            if (inside | vtop) {
+        if (active) {
+            const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
+            if ((a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1))) {
+                const unsigned t = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
                 if (FIX) {
                     tile_add4_fix(t, l00, l01, l10, l11);
                     if (upper) tile_add4_up_fix(t, u00, u01, u10, u11);
@@ -729,18 +710,12 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
         const int i = (int)fi, j = (int)fj, kz = (int)fk;
         const int lin = active ? (int)mad24(mad24((unsigned)i, (unsigned)g.ny, (unsigned)j), (unsigned)g.nz, (unsigned)kz) : -7;
         const int prev = __builtin_amdgcn_update_dpp(-9, lin, 0x111, 0xf, 0xf, false);          // row_shr:1 (row lane 0 keeps -9)
-        const bool accept0 = active && prev + 1 == lin;
-        const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
-        const bool inside0 = (a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1));
-        const unsigned t00 = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
-        // BIN_VTOP (k_adjoint_binned): the idle lane above a segment's last sample adds that sample's upper level as its own lower level
-        const int tprev = BIN_VTOP ? __builtin_amdgcn_update_dpp(0, active && inside0 ? (int)t00 : 0, 0x111, 0xf, 0xf, false) : 0;
-        const bool vtop = BIN_VTOP && !active && tprev != 0;
-        const bool accept = accept0 | vtop;
+        const bool accept = active && prev + 1 == lin;
         const int taken = __builtin_amdgcn_update_dpp(0, (int)accept, 0x101, 0xf, 0xf, false);  // row_shl:1: did lane s + 1 take mine?
         const bool upper = active && !taken;
-        const bool inside = inside0 | vtop;
-        const unsigned t0 = vtop ? (unsigned)tprev + 8u : t00;
+        const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
+        const bool inside = (a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1));
+        const unsigned t0 = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
         const double cz0 = c * z0, cz1 = c * z1;
 #pragma unroll
         for (int ch = 0; ch < 4; ++ch) {
@@ -754,7 +729,7 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
                 l00 = qf(l00), l01 = qf(l01), l10 = qf(l10), l11 = qf(l11);
                 u00 = qf(u00), u01 = qf(u01), u10 = qf(u10), u11 = qf(u11);
             }
-            if (active | vtop) {
+            if (active) {
                 if (inside) {
                     const unsigned t = t0 + (unsigned)ch * (BIN_TILE * 8u);
                     if (FIX) {
