@@ -60,15 +60,23 @@ __global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, d
 // same four (value, Dx value) pairs PAIR-major, FP[t = q + 2 r][node] (double2, node = the grid's own linear index, npad nodes per
 // pair array): the layout the bundle-stationary forward stages from (k_forward_bundle_lm).
 #define LM_XSEG 8
+// `xrange` (round 5, PAIRS only): per (j, k) line the planes [lo, hi] the current forward plan's windows hold (k_lm_touch_lines) -- only
+// those nodes are written: an inversion iteration rebuilds the fields its rays read (a third of the bench grid), not 1 GiB.
 template <bool PAIRS>
-__global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict__ Z, double *__restrict__ F8, int nx, int ny, int nz, int64_t npad) {
+__global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict__ Z, double *__restrict__ F8, int nx, int ny, int nz, int64_t npad,
+                                                      const int2 *__restrict__ xrange) {
     const int64_t sx = (int64_t)ny * nz, lines = sx * LM_XSEG;
     const int seg_len = (nx + LM_XSEG - 1) / LM_XSEG;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < lines; t += (int64_t)gridDim.x * blockDim.x) {
         const int seg = (int)(t / sx);
         const int64_t jk = t - (int64_t)seg * sx;
         const int j = (int)(jk / nz);
-        const int i0 = seg * seg_len, i1 = min(i0 + seg_len, nx);
+        int i0 = seg * seg_len, i1 = min(i0 + seg_len, nx);
+        if (xrange) {
+            const int2 xr = xrange[jk];
+            i0 = max(i0, xr.x), i1 = min(i1, xr.y + 1);
+            if (i0 >= i1) continue;
+        }
         const bool yslope = j >= 2 && j <= ny - 3;
         double2 a[5], b[5];                      // a = (f, Dy f), b = (Dz f, Dy Dz f) of planes io - 2 .. io + 2 (slot 4 = the newest)
 #pragma unroll
@@ -119,6 +127,32 @@ __global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict_
             }
         }
     }
+}
+
+// The node lines a forward plan's tricubic windows hold: xrange[j nz + k] = (first plane, last plane) over every window that contains
+// line (j, k) -- window w of chunk c holds nodes [imin, imin + wx) x [jmin, jmin + wy) x [kz0, kz0 + BL_LEV) when it fits (the plan
+// restricts a rebuild only if EVERY window fits: a chunk that does not reads nodes the record does not bound).  One thread per
+// (window, line of the window); xrange starts as (INT_MAX, -1).
+__global__ __launch_bounds__(256) void k_lm_touch_lines(const uint4 *__restrict__ win, int64_t nwin, int ny, int nz, int lev, int maxlines,
+                                                        int2 *__restrict__ xrange) {
+    const int64_t total = nwin * maxlines;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t wi = t / maxlines;
+        const int li = (int)(t - wi * maxlines);
+        const uint4 w = win[wi];
+        const int wx = (int)(w.w & 255u), wy = (int)((w.w >> 8) & 255u);
+        if (wx == 0) continue;                                   // (a bundle without a valid ray has empty records)
+        const int dj = li / lev, l = li - dj * lev;
+        if (dj >= wy) continue;
+        const int j = (int)w.y + dj, k = (int)w.z + l;
+        if (j >= ny || k >= nz) continue;
+        int *xr = (int *)(xrange + (int64_t)j * nz + k);
+        atomicMin(xr, (int)w.x);
+        atomicMax(xr + 1, (int)w.x + wx - 1);
+    }
+}
+__global__ __launch_bounds__(256) void k_lm_xrange_init(int2 *__restrict__ xrange, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) xrange[i] = make_int2(0x7fffffff, -1);
 }
 
 // grad[m] += sum_{pqr} sum_{offsets} ct_x^p ct_y^q ct_z^r G8[pqr][m + offset]: the transposed stencils, pass by pass:
@@ -740,7 +774,7 @@ __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const dou
                                                            const double *__restrict__ dirs, const int *__restrict__ order,
                                                            const int *__restrict__ bstart, const uint4 *__restrict__ win, const uint2 *__restrict__ rhash,
                                                            int nb, int nchunks, double tmax, int Ns, const double *__restrict__ unitw,
-                                                           double *__restrict__ tec, int *oob_flag, int allpairs) {
+                                                           double *__restrict__ tec, int *oob_flag, int allpairs, int restricted) {
     extern __shared__ __attribute__((aligned(16))) char blds[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int b = blockIdx.x;
@@ -749,6 +783,13 @@ __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const dou
     const BundleRays B = load_bundle<true>(g, origins, dirs, order, bstart, b, tmax, Ns, rhash);
     if (wid == 0 && __any(B.mine && !B.valid) && lane == 0) atomicOr(oob_flag, 1);
     if (wid == 0 && B.stale && lane == 0) atomicOr(oob_flag + 2, 1);
+    if (B.stale && restricted) {
+        // The rays of this bundle were edited in place since the plan was made AND the pair arrays were rebuilt only where the PLANNED
+        // rays read them: direct loads along the new rays could meet nodes that were not rebuilt.  Never a plausible number: NaN +
+        // the stale flag (iono_plan_stale / RayEngine.check_plans raise), as the planned back-projection does.
+        if (wid == 0 && B.mine) tec[B.r] = nan("");
+        return;
+    }
     if (!B.any) {
         if (wid == 0 && B.mine) tec[B.r] = nan("");
         return;

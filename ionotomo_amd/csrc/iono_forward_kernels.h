@@ -788,7 +788,10 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
         }
         if ((threadIdx.x & 63) == 0) win[(size_t)b * nchunks + c] = w;
     }
-    if (fit_count && (threadIdx.x & 63) == 0 && nfit) atomicAdd(fit_count, (unsigned long long)nfit);      // one update per bundle
+    if (fit_count && (threadIdx.x & 63) == 0) {                                                            // one update per bundle
+        if (nfit) atomicAdd(fit_count, (unsigned long long)nfit);
+        if (B.any) atomicAdd(fit_count + 1, (unsigned long long)nchunks);       // [1]: the window records that exist (bundles with a valid ray)
+    }
 }
 
 // LDS byte address of a sample's lower corner (+ its three weights) WITHOUT integer instructions: `magic` = 2^49 + (image byte

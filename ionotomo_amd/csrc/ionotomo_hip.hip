@@ -110,6 +110,8 @@ struct iono_ctx {
     bool F8_valid = false;
     double *d_FP = nullptr;          // the same fields PAIR-major [4][padded nodes][2] for the bundle-stationary tricubic forward (lazily built)
     bool FP_valid = false;
+    int64_t FP_plan_serial = -1;     // ... or valid only on the node lines forward plan number `serial` reads (FwdPlan::d_xrange)
+    int64_t fplan_counter = 0;
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
     bool deterministic = false;      // iono_set_deterministic / env IONOTOMO_DETERMINISTIC=1: fixed-point back-projection (k_adjoint_binned<.., FIX>)
     unsigned long long *d_fixgrid = nullptr;      // its grid of 64-bit integers [nodes] + the launch's largest |w h| behind it; all zero between launches
@@ -158,6 +160,10 @@ struct iono_ctx {
         size_t cap_brec = 0, cap_bhash = 0;
         uint4 *d_win_lm = nullptr;       // windows of the tricubic kernel's shorter chunks (BL_KC samples, BL_LEV levels of 16-byte nodes)
         int nchunks_lm = 0;
+        int2 *d_xrange = nullptr;        // per (j, k) node line along x: first / last plane any window of the tricubic kernel holds (lo > hi: none),
+        size_t cap_xrange = 0;           //   what a field rebuild for THIS plan needs to cover (k_lm_touch_lines; only when every window fits)
+        bool lm_all_fit = false;
+        int64_t serial = 0;              // plan number (FP_plan_serial)
         size_t cap_order = 0, cap_bstart = 0, cap_win = 0, cap_win_lm = 0;
         double fit_fraction = 0;         // chunks whose window fits the LDS image
     } fplan;
@@ -216,6 +222,7 @@ void fplan_free(iono_ctx *c) {
     if (c->fplan.d_brec) (void)hipFree(c->fplan.d_brec);
     if (c->fplan.d_bhash) (void)hipFree(c->fplan.d_bhash);
     if (c->fplan.d_win_lm) (void)hipFree(c->fplan.d_win_lm);
+    if (c->fplan.d_xrange) (void)hipFree(c->fplan.d_xrange);
     c->fplan = iono_ctx::FwdPlan();
 }
 
@@ -623,7 +630,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
     c->d_M_ext = nullptr;
     plan_free(c);
     fplan_free(c);
-    c->F8_valid = c->FP_valid = false;
+    c->F8_valid = c->FP_valid = false, c->FP_plan_serial = -1;
     c->nM_freq = c->nF8_freq = -1.0;
     c->nx = nx;
     c->ny = ny;
@@ -653,7 +660,7 @@ int iono_grid_set(iono_ctx *c, const double *xv, int nx, const double *yv, int n
 static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, double scale) {
     const int64_t n = ncells(c);
     c->nM_freq = c->nF8_freq = -1.0;
-    c->F8_valid = c->FP_valid = false;
+    c->F8_valid = c->FP_valid = false, c->FP_plan_serial = -1;
     c->Q4_valid = false;
     int rc = dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
@@ -758,8 +765,12 @@ static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks
 
 // Lekien-Marsden derivative fields of the current grid values (iono_cubic_kernels.h): rebuilt after every change.  Two layouts, each
 // built when a kernel first asks for it: node-major records F8 (k_forward_straight_lm) and pair-major arrays FP (k_forward_bundle_lm).
-static int ensure_lm_fields(iono_ctx *c, bool pairs = false) {
+// `for_plan` (pairs only): the launch that follows is the bundle kernel on the current forward plan -- rebuild only the node lines its
+// windows hold (FwdPlan::d_xrange: a third of the bench grid; the pair arrays are then valid for THAT plan only, FP_plan_serial)
+static int ensure_lm_fields(iono_ctx *c, bool pairs = false, bool for_plan = false) {
     const int64_t n = ncells(c), npad = padded_count(c);
+    const bool restricted = pairs && for_plan && c->fplan.lm_all_fit && c->fplan.d_xrange && c->variant != 25;      // (IONOTOMO_VARIANT=25: whole grid, A/B)
+    if (pairs && !c->FP_valid && restricted && c->d_FP && c->FP_plan_serial == c->fplan.serial) return IONO_OK;
     if (!pairs && !c->d_F8) {
         const size_t fb = (size_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double);
         HIP_TRY(c, hipMalloc((void **)&c->d_F8, fb));
@@ -781,12 +792,14 @@ static int ensure_lm_fields(iono_ctx *c, bool pairs = false) {
         const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
         if (pairs)
             hipLaunchKernelGGL((k_lm_fields_yx<true>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_FP,
-                               c->nx, c->ny, c->nz, npad);
+                               c->nx, c->ny, c->nz, npad, restricted ? (const int2 *)c->fplan.d_xrange : (const int2 *)nullptr);
         else
             hipLaunchKernelGGL((k_lm_fields_yx<false>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_F8,
-                               c->nx, c->ny, c->nz, npad);
+                               c->nx, c->ny, c->nz, npad, (const int2 *)nullptr);
         HIP_TRY(c, hipGetLastError());
-        (pairs ? c->FP_valid : c->F8_valid) = true;
+        if (!pairs) c->F8_valid = true;
+        else if (restricted) c->FP_plan_serial = c->fplan.serial;
+        else c->FP_valid = true;
     }
     return IONO_OK;
 }
@@ -805,7 +818,7 @@ static int ensure_n_fields(iono_ctx *c, double frequency) {
                            c->nx, c->ny, c->nz);
         const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
         hipLaunchKernelGGL((k_lm_fields_yx<false>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_nF8,
-                           c->nx, c->ny, c->nz, padded_count(c));
+                           c->nx, c->ny, c->nz, padded_count(c), (const int2 *)nullptr);
         HIP_TRY(c, hipGetLastError());
         c->nF8_freq = frequency;
     }
@@ -877,10 +890,24 @@ static int ensure_lm_windows(iono_ctx *c) {
     if (fp.R < 0 || fp.nchunks_lm > 0) return IONO_OK;
     const int nchunks_lm = (fp.Ns + BL_KC - 1) / BL_KC;
     HIP_TRY(c, plan_reserve(fp.d_win_lm, fp.cap_win_lm, (size_t)fp.nb * nchunks_lm * sizeof(uint4)));
+    // (+ the number of windows that fit and the node lines the windows hold: what a field rebuild for this plan must cover)
+    const int64_t nlines = (int64_t)c->ny * c->nz;
+    HIP_TRY(c, plan_reserve(fp.d_xrange, fp.cap_xrange, (size_t)nlines * sizeof(int2) + 16));
+    unsigned long long *d_fits = (unsigned long long *)(fp.d_xrange + nlines);
+    HIP_TRY(c, hipMemsetAsync(d_fits, 0, 2 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL((k_bundle_windows<BL_KC, BL_LEV, 2 * BL_CPL, false>), dim3(fp.nb), dim3(64), 0, c->stream, view(c),
                        (const double *)fp.o_key, (const double *)fp.d_key, fp.d_order, fp.d_bstart, fp.nb, fp.tmax, fp.Ns, nchunks_lm,
-                       fp.d_win_lm, (unsigned long long *)nullptr);
+                       fp.d_win_lm, d_fits);
+    hipLaunchKernelGGL(k_lm_xrange_init, dim3(ew_blocks(c, nlines)), dim3(256), 0, c->stream, fp.d_xrange, nlines);
+    const int64_t nwin = (int64_t)fp.nb * nchunks_lm;
+    hipLaunchKernelGGL(k_lm_touch_lines, dim3(ew_blocks(c, nwin * 2 * BL_CPL * BL_LEV)), dim3(256), 0, c->stream, (const uint4 *)fp.d_win_lm, nwin, c->ny,
+                       c->nz, BL_LEV, 2 * BL_CPL * BL_LEV, fp.d_xrange);
     HIP_TRY(c, hipGetLastError());
+    unsigned long long h_fits[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(h_fits, d_fits, sizeof(h_fits), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // every (bundle, chunk) of a bundle with a valid ray has a window record; bundles without one have none and read nothing
+    fp.lm_all_fit = h_fits[1] > 0 && h_fits[0] == h_fits[1];
     fp.nchunks_lm = nchunks_lm;
     return IONO_OK;
 }
@@ -995,7 +1022,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, plan_reserve(fp.d_win, fp.cap_win, (size_t)nb * nchunks * sizeof(uint4)));
     HIP_TRY(c, hipMemcpyAsync(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     unsigned long long *d_fits = (unsigned long long *)k0;        // (scratch: the key arrays are no longer needed)
-    HIP_TRY(c, hipMemsetAsync(d_fits, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_fits, 0, 2 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
                        nb, tmax, Ns, nchunks, fp.d_win, d_fits);
     HIP_TRY(c, plan_reserve(fp.d_brec, fp.cap_brec, (size_t)nb * 64 * sizeof(BundleRec)));
@@ -1041,6 +1068,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipStreamSynchronize(c->stream));                  // (bstart is a host vector; the walk positions sit in pinned memory)
     fp.fit_fraction = nb > 0 ? (double)*h_fits / ((double)nb * nchunks) : 0.0;
     fp.o_key = o, fp.d_key = d, fp.R = R, fp.Ns = Ns, fp.tmax = tmax, fp.nb = nb, fp.nchunks = nchunks;
+    fp.serial = ++c->fplan_counter, fp.lm_all_fit = false;
     return IONO_OK;
 }
 
@@ -1118,15 +1146,16 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                                wm, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && fplan_serves(c, o, d, R, tmax, Ns)) {
             // bundles of neighbouring rays, one field pair per wave, windows staged in LDS (iono_cubic_kernels.h:k_forward_bundle_lm)
-            int rc2 = ensure_lm_fields(c, true);
+            int rc2 = ensure_lm_windows(c);          // (first: the windows say which node lines a rebuild for this plan must cover)
             if (rc2) return rc2;
-            rc2 = ensure_lm_windows(c);
+            rc2 = ensure_lm_fields(c, true, true);
             if (rc2) return rc2;
+            const int restricted = !c->FP_valid ? 1 : 0;      // the pair arrays hold this plan's lines only
             const iono_ctx::FwdPlan &fp = c->fplan;
             static_assert(BL_LDS_BYTES <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
             hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES, c->stream, g, c->d_FP,
                                padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.d_rhash, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
-                               c->d_flags, c->variant == 16 ? 0 : 1);      // (IONOTOMO_VARIANT=16: one pair per wave for every window, A/B)
+                               c->d_flags, c->variant == 16 ? 0 : 1, restricted);      // (IONOTOMO_VARIANT=16: one pair per wave for every window, A/B)
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
@@ -1212,7 +1241,7 @@ int iono_grid_bind_values_dev(iono_ctx *c, double *values_dev) {
     if (values_dev && (((uintptr_t)values_dev) & 15)) return fail(c, IONO_ERR_ARG, "values must be 16-byte aligned");
     c->d_M_ext = values_dev;
     c->nM_freq = c->nF8_freq = -1.0;
-    c->F8_valid = c->FP_valid = false;
+    c->F8_valid = c->FP_valid = false, c->FP_plan_serial = -1;
     return IONO_OK;
 }
 
@@ -1220,7 +1249,7 @@ int iono_grid_values_changed(iono_ctx *c) {
     int rc = need_grid(c);
     if (rc) return rc;
     c->nM_freq = c->nF8_freq = -1.0;
-    c->F8_valid = c->FP_valid = false;
+    c->F8_valid = c->FP_valid = false, c->FP_plan_serial = -1;
     return IONO_OK;
 }
 
@@ -1740,8 +1769,12 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         return fail(c, IONO_ERR_ARG, "a work-unit range (iono_adjoint_unit_range) is pending, but this launch is not the planned trilinear "
                                      "back-projection of these rays (no plan, a replaced plan, tricubic, or IONOTOMO_VARIANT=2/7): nothing launched");
     }
-    const bool fix_cubic = c->deterministic && planned && kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2 &&
-                           c->variant != 21 && c->variant != 23 && pl.tile_n[2] > 0;
+    // The planned tricubic transpose accumulates 64-bit fixed point BY DEFAULT (round 5): the integer LDS atomic is the cheaper
+    // instruction (6.4 against 8.2 LDS cycles) and the z fold reads the integers directly -- 2.15 against 2.55 ms at the bench shape,
+    // run-to-run identical bits, 1.3e-12 of the largest value away from the float sum (profiles/r05_ab_binned.json).
+    // IONOTOMO_VARIANT=24: float atomics (A/B); iono_set_deterministic(1) additionally switches the TRILINEAR back-projection.
+    const bool fix_cubic = (c->deterministic || c->variant != 24) && planned && kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) &&
+                           c->variant != 2 && c->variant != 21 && c->variant != 23 && pl.tile_n[2] > 0;
     if (c->deterministic && !fix_cubic)
         return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear and tricubic back-projections only (iono_adjoint_plan_dev for these rays first)");
     if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)

@@ -308,3 +308,64 @@ def test_planned_tricubic_transpose_folds_only_the_tiles_the_rays_reach(seed, mo
     g2, _, _ = run(o2, d2, y2, None, True, eng=eng, base=base)
     g2_free, _, _ = run(o2, d2, y2, None, False)
     assert float((g2 - 3.0 - g2_free).abs().max()) < 1e-11 * max(float(g2_free.abs().max()), 1.0)
+
+
+def test_planned_forward_rebuilds_only_the_fields_its_rays_read(monkeypatch):
+    """Round 5: with new node values the planned tricubic forward rebuilds its derivative fields only on the node lines the plan's
+    windows hold (k_lm_touch_lines -> k_lm_fields_yx with an x range per line), not over the whole grid.  On a grid most of which
+    the rays never reach: every new set of values gives the unplanned kernel's numbers (whose own field array is always rebuilt in
+    full); a NEW plan for other rays on the same engine sees fields
+    for ITS lines; rays edited in place after the restricted rebuild come out NaN + stale flag, never a number from fields that
+    were not rebuilt."""
+    from ionotomo_amd.engine import RayEngine
+    rng = np.random.default_rng(42)
+    n = (52, 61, 47)
+    xv, yv, zv = (np.linspace(0.0, float(m - 1), m) for m in n)
+    tmax, Ns = 40.0, 97
+
+    def pencil(R, cx, cy, steep):
+        o = np.stack([cx + rng.normal(size=R) * 0.8, cy + rng.normal(size=R) * 0.8, np.full(R, 2.5)], 1)
+        d = np.stack([rng.normal(size=R) * steep, rng.normal(size=R) * steep, np.ones(R)], 1)
+        return o, d
+    o1, d1 = pencil(900, 14.0, 40.0, 0.03)
+    o2, d2 = pencil(700, 37.0, 17.0, 0.05)
+
+    def make(variant=None):
+        monkeypatch.setenv("IONOTOMO_VARIANT", "12" if variant is None else variant)       # 12: the bundle kernel whatever the plan's size
+        e = RayEngine(0, interp="cubic")
+        monkeypatch.delenv("IONOTOMO_VARIANT")
+        e.set_grid(xv, yv, zv)
+        return e
+    eng = make()
+    free = RayEngine(0, interp="cubic")
+    free.set_grid(xv, yv, zv)
+    ot, dt = eng.tensor(o1), eng.tensor(d1)
+    nb, _, fit = eng.plan_forward(ot, dt, tmax, Ns)
+    assert nb > 0 and fit == 1.0
+    for it in range(3):
+        M = eng.tensor(rng.uniform(1.0, 2.0, size=n))
+        eng.set_values(M), free.set_values(M)
+        a = eng.forward(ot, dt, tmax, Ns)
+        b = free.forward(ot, dt, tmax, Ns)
+        assert not eng.check_oob() and not eng.plan_stale()
+        assert float((a - b).abs().max()) < 1e-12 * float(b.abs().max()), it
+    # another plan on the same engine, same values: its own lines are rebuilt (the first plan's are not enough)
+    ot2, dt2 = eng.tensor(o2), eng.tensor(d2)
+    assert eng.plan_forward(ot2, dt2, tmax, Ns)[0] > 0
+    a2 = eng.forward(ot2, dt2, tmax, Ns)
+    b2 = free.forward(ot2, dt2, tmax, Ns)
+    assert float((a2 - b2).abs().max()) < 1e-12 * float(b2.abs().max())
+    # ... and back: plan 1 again after plan 2's restricted rebuild
+    eng.plan_forward(ot, dt, tmax, Ns)
+    a = eng.forward(ot, dt, tmax, Ns)
+    assert float((a - b).abs().max()) < 1e-12 * float(b.abs().max())
+    # rays edited in place: NaN for the bundles concerned + the stale flag (the fields exist only where the planned rays read)
+    keep = ot.clone()
+    ot[5, 0] += 20.0
+    stale = eng.forward(ot, dt, tmax, Ns)
+    assert eng.plan_stale() and bool(torch.isnan(stale).any()) and bool(torch.isnan(stale[5]))
+    ok = ~torch.isnan(stale)
+    assert float((stale[ok] - b[ok]).abs().max()) < 1e-12 * float(b.abs().max())      # untouched bundles: the right numbers
+    ot.copy_(keep)
+    again = eng.forward(ot, dt, tmax, Ns)
+    assert not eng.plan_stale() and float((again - b).abs().max()) < 1e-12 * float(b.abs().max())
