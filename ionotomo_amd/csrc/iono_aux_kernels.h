@@ -67,9 +67,6 @@ __global__ __launch_bounds__(256) void k_axpby(double *__restrict__ y, const dou
     }
     if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) y[n - 1] = fma(a, x[n - 1], b * y[n - 1]);
 }
-__global__ void k_zero(double *__restrict__ p, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.0;
-}
 
 // C_m smoothing: Covariance.smooth = scipy.ndimage.convolve(phi, c_stencil, mode='nearest')
 // (ionosphere/covariance.py:46-63,383-385).  The reference's stencil is the product of three 1-D

@@ -418,10 +418,10 @@ __device__ __forceinline__ double dpp_shr1(double v) {       // value of the pre
 // becomes a per-sample factor  sum_l wrf[r][l] / (2 n_p,l sqrt(1 - ne_k / n_p,l))  of the electron density ne_k interpolated at
 // the sample (gathered from the grid exactly as the forward kernel does), wray = wrf with row stride ldw.
 // FIX: deterministic fixed-point accumulation (above); G is then the grid of 64-bit integers.
-template <typename AT, bool CUBIC, int PNF = 0, typename GT = double, int SEGL = BIN_SEG, bool FIX = false>
+template <typename AT, int PNF = 0, typename GT = double, int SEGL = BIN_SEG, bool FIX = false>
 __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
                                                         const BinUnit *__restrict__ units, const double *__restrict__ wray,
-                                                        int Ns, const double *__restrict__ unitw, AT *__restrict__ G, int field,
+                                                        int Ns, const double *__restrict__ unitw, AT *__restrict__ G,
                                                         PhaseFreqs pf = PhaseFreqs{}, int ldw = 0,
                                                         const unsigned long long *__restrict__ fixmax = nullptr, int fixbits = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -529,17 +529,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
         const double fi = clampf(__builtin_floor(__builtin_fabs(fx)), lim_x), fj = clampf(__builtin_floor(__builtin_fabs(fy)), lim_y),
                      fk = clampf(__builtin_floor(__builtin_fabs(fz)), lim_z);
         double w00, w01, w10, w11, l00, l01, l10, l11, u00, u01, u10, u11;
-        if (CUBIC) {
-            double ax0, ax1, ay0, ay1, az0, az1;
-            axis_pair(fx - fi, field & 1, CUBIC, ax0, ax1);
-            axis_pair(fy - fj, field & 2, CUBIC, ay0, ay1);
-            axis_pair(fz - fk, field & 4, CUBIC, az0, az1);
-            const double w0 = c * ax0, w1 = c * ax1;
-            w00 = w0 * ay0, w01 = w0 * ay1, w10 = w1 * ay0, w11 = w1 * ay1;
-            l00 = w00 * az0, l01 = w01 * az0, l10 = w10 * az0, l11 = w11 * az0;      // to the 4 columns at level kz
-            u00 = w00 * az1, u01 = w01 * az1, u10 = w10 * az1, u11 = w11 * az1;      // ... at level kz + 1
-        } else {
+        {
             // trilinear: weights (1 - t, t) per axis as x (1 - t) = x - x t: one multiply and one subtraction per split
+            // (the tricubic transpose has its own kernel, four derivative channels per traversal: k_adjoint_binned_lm4)
             const double tx = fx - fi, ty = fy - fj, tz = fz - fk;
             const double w1 = c * tx, w0 = c - w1;
             w01 = w0 * ty, w00 = w0 - w01, w11 = w1 * ty, w10 = w1 - w11;
@@ -782,103 +774,8 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
     }
 }
 
-// ---- node-stationary FORWARD on the same plan -----------------------------------------------------------------------
-// north_star's "local ne voxel neighbourhood staged in LDS, coalesced reads of the grid": per ray the neighbourhood is a
-// sheared, drifting set of columns, but per grid BOX it is a block.  A workgroup loads the 15 x 15 x 16-node image of its
-// box with coalesced 128-B z-runs, then every segment (16 lanes = 16 consecutive samples of one ray) interpolates from
-// LDS -- 4 x ds_read2_b64 per sample instead of 4 global dwordx4 gathers through the texture path -- and leaves ONE
-// partial sum per segment in partial[ray][segment ordinal]; k_forward_binned_finish adds a ray's partials in order
-// (deterministic) and applies the sample spacing.  Samples outside the image read the grid directly.
-template <typename GT>
-__global__ __launch_bounds__(256) void k_forward_binned(GridView g, const double *__restrict__ uray, const uint2 *__restrict__ entries,
-                                                        const BinUnit *__restrict__ units, int Ns, const double *__restrict__ unitw,
-                                                        double *__restrict__ partial, int smax) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    double *wlds = (double *)smem;                                   // [Ns] quadrature weights
-    double *img = wlds + ((Ns + 1) & ~1);                            // [BIN_BX * BIN_BY][BIN_BZP] node values of the box
-    for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
-    const BinUnit un = units[blockIdx.x];
-    const GT *M = (const GT *)g.M;
-    {
-        const int m = threadIdx.x & 15, gk = un.z0 + m;
-        for (int col = threadIdx.x >> 4; col < BIN_BX * BIN_BY; col += 16) {
-            const int a = col / BIN_BY, b = col - a * BIN_BY;
-            const int gi = un.x0 + a, gj = un.y0 + b;
-            double v = 0.0;
-            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk < g.nz) v = (double)M[((size_t)gi * g.ny + gj) * g.nz + gk];
-            img[col * BIN_BZP + m] = v;
-        }
-    }
-    lds_barrier();
-    const GT *b00 = M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int sub = lane & (BIN_SEG - 1), grp = wid * 4 + (lane >> 4);
-    // image-local coordinates in f64: a = fi - x0 etc.; in-image <=> |a - 6.5| <= 6.5, |b - 6.5| <= 6.5, |m - 7| <= 7
-    const double cx = (double)un.x0 + 0.5 * (BIN_BX - 2), cy = (double)un.y0 + 0.5 * (BIN_BY - 2), cz = (double)un.z0 + 0.5 * (BIN_BZ - 2);
-    const double ex = (double)un.x0, ey = (double)un.y0, ez = (double)un.z0;
-    auto load_ray = [&](const uint2 en) {
-        const double2 *up = (const double2 *)(uray + (size_t)en.x * 8);
-        struct { double2 ux, uy, uz; } r;
-        r.ux = up[0], r.uy = up[1], r.uz = up[2];
-        return r;
-    };
-    int e = un.e_lo + grp;
-    uint2 en0 = entries[e], en1 = entries[e + 16];
-    auto r0 = load_ray(en0);
-    for (; e < un.e_hi; e += 16) {
-        const uint2 en2 = entries[e + 32];
-        const auto r1 = load_ray(en1);
-        const int cnt = e < un.e_hi ? (int)((en0.y >> 16) & 0xffu) : 0, k = min((int)(en0.y & 0xffffu) + sub, Ns - 1);
-        const double kd = (double)k;
-        const double fx = fma(kd, r0.ux.y, r0.ux.x), fy = fma(kd, r0.uy.y, r0.uy.x), fz = fma(kd, r0.uz.y, r0.uz.x);
-        const double fi = fmin(__builtin_floor(__builtin_fabs(fx)), (double)(g.nx - 2)),
-                     fj = fmin(__builtin_floor(__builtin_fabs(fy)), (double)(g.ny - 2)),
-                     fk = fmin(__builtin_floor(__builtin_fabs(fz)), (double)(g.nz - 2));
-        const double tx = fx - fi, ty = fy - fj, tz = fz - fk;
-        double v;
-        if ((__builtin_fabs(fi - cx) <= 0.5 * (BIN_BX - 2)) & (__builtin_fabs(fj - cy) <= 0.5 * (BIN_BY - 2)) &
-            (__builtin_fabs(fk - cz) <= 0.5 * (BIN_BZ - 2))) {
-            const int o = (int)__builtin_fma(fi - ex, (double)(BIN_BY * BIN_BZP), __builtin_fma(fj - ey, (double)BIN_BZP, fk - ez));
-            const double *q = img + o;
-            const double c000 = q[0], c001 = q[1], c010 = q[BIN_BZP], c011 = q[BIN_BZP + 1];
-            const double c100 = q[BIN_BY * BIN_BZP], c101 = q[BIN_BY * BIN_BZP + 1];
-            const double c110 = q[(BIN_BY + 1) * BIN_BZP], c111 = q[(BIN_BY + 1) * BIN_BZP + 1];
-            const double c00 = c000 + tz * (c001 - c000), c01 = c010 + tz * (c011 - c010);
-            const double c10 = c100 + tz * (c101 - c100), c11 = c110 + tz * (c111 - c110);
-            const double c0 = c00 + ty * (c01 - c00), c1 = c10 + ty * (c11 - c10);
-            v = c0 + tx * (c1 - c0);
-        } else {
-            v = trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fi + tx, fj + ty, fk + tz);      // steep segment: straight from the grid
-        }
-        double acc = sub < cnt ? wlds[k] * v : 0.0;
-        // sum of the 16 lanes of the segment (DPP row_shr ladder: lane 15 of the row ends with the total)
-        acc = dpp_add<0x111, 0xf>(acc);
-        acc = dpp_add<0x112, 0xf>(acc);
-        acc = dpp_add<0x114, 0xf>(acc);
-        acc = dpp_add<0x118, 0xf>(acc);
-        if (sub == BIN_SEG - 1 && e < un.e_hi) partial[(size_t)en0.x * smax + (en0.y >> 24)] = acc;
-        en0 = en1, en1 = en2, r0 = r1;
-    }
-}
-
-// tec[r] = h_r * (sum of the ray's segment partials, in sample order);  rays that leave the grid: NaN + flag
-__global__ __launch_bounds__(256) void k_forward_binned_finish(const double *__restrict__ uray, const unsigned char *__restrict__ nseg,
-                                                               const double *__restrict__ partial, int smax, int64_t R,
-                                                               double *__restrict__ tec, int *oob_flag) {
-    bool oob = false;
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
-        if (uray[r * 8 + 7] == 0.0) {
-            tec[r] = nan("");
-            oob = true;
-            continue;
-        }
-        const double *p = partial + (size_t)r * smax;
-        double s = 0.0;
-        for (int j = 0; j < (int)nseg[r]; ++j) s += p[j];
-        tec[r] = s * uray[r * 8 + 6];
-    }
-    if (oob) atomicOr(oob_flag, 1);
-}
+// (round 5: the node-stationary FORWARD on this plan -- k_forward_binned + k_forward_binned_finish, an A/B of north_star's wording measured
+//  at 0.42 ms against the bundle kernel's 0.11 -- profiles/r02_ab_forward_binned.json -- is no longer built)
 
 }  // namespace
 

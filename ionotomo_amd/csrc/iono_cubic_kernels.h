@@ -32,11 +32,27 @@ __device__ __forceinline__ double fd_coef(int d) {
 // F8[node][8] from the stored values, axis by axis (the stencils are separable): Z = (f, Dz f), then Dy, then Dx -- 5 loads
 // per node and pass, lanes along z in every pass, instead of the 125 loads of a direct 5 x 5 x 5 evaluation.  Nodes within 2 of a face have no slope along that axis (no valid sample
 // ever weighs them: tricubic samples live in g[2] <= x <= g[n-3]): 0.
+// `xrange` (round 5): the node lines the current forward plan's windows hold (k_lm_touch_lines) -- Z is then formed only where the
+// restricted y / x pass reads it: on the lines within two of such a line in y, two planes beyond its range in x.
 template <typename GT>
-__global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, double2 *__restrict__ Z, int nx, int ny, int nz) {
+__global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, double2 *__restrict__ Z, int nx, int ny, int nz,
+                                                     const int2 *__restrict__ xrange) {
     const int64_t n = (int64_t)nx * ny * nz;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
         const int k = (int)(idx % nz);
+        if (xrange) {
+            const int64_t ij = idx / nz;
+            const int j = (int)(ij % ny), i = (int)(ij / ny);
+            bool need = false;
+#pragma unroll
+            for (int dj = -2; dj <= 2; ++dj) {
+                const int jj = j + dj;
+                if (jj < 0 || jj >= ny) continue;
+                const int2 xr = xrange[(int64_t)jj * nz + k];
+                need |= xr.y >= 0 && i >= xr.x - 2 && i <= xr.y + 2;
+            }
+            if (!need) continue;
+        }
         const GT *row = M + idx;
         double dz = 0.0;
         if (k >= 2 && k <= nz - 3)
@@ -74,6 +90,7 @@ __global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict_
         int i0 = seg * seg_len, i1 = min(i0 + seg_len, nx);
         if (xrange) {
             const int2 xr = xrange[jk];
+            if (xr.y < 0) continue;                                // no window of the plan holds this line
             i0 = max(i0, xr.x), i1 = min(i1, xr.y + 1);
             if (i0 >= i1) continue;
         }
@@ -132,7 +149,7 @@ __global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict_
 // The node lines a forward plan's tricubic windows hold: xrange[j nz + k] = (first plane, last plane) over every window that contains
 // line (j, k) -- window w of chunk c holds nodes [imin, imin + wx) x [jmin, jmin + wy) x [kz0, kz0 + BL_LEV) when it fits (the plan
 // restricts a rebuild only if EVERY window fits: a chunk that does not reads nodes the record does not bound).  One thread per
-// (window, line of the window); xrange starts as (INT_MAX, -1).
+// (window, line of the window); xrange starts as 0xff bytes: (-1, -1) = no plane.
 __global__ __launch_bounds__(256) void k_lm_touch_lines(const uint4 *__restrict__ win, int64_t nwin, int ny, int nz, int lev, int maxlines,
                                                         int2 *__restrict__ xrange) {
     const int64_t total = nwin * maxlines;
@@ -147,12 +164,9 @@ __global__ __launch_bounds__(256) void k_lm_touch_lines(const uint4 *__restrict_
         const int j = (int)w.y + dj, k = (int)w.z + l;
         if (j >= ny || k >= nz) continue;
         int *xr = (int *)(xrange + (int64_t)j * nz + k);
-        atomicMin(xr, (int)w.x);
+        atomicMin((unsigned *)xr, w.x);                          // (all bits set = no plane yet: the array starts as 0xff bytes)
         atomicMax(xr + 1, (int)w.x + wx - 1);
     }
-}
-__global__ __launch_bounds__(256) void k_lm_xrange_init(int2 *__restrict__ xrange, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) xrange[i] = make_int2(0x7fffffff, -1);
 }
 
 // grad[m] += sum_{pqr} sum_{offsets} ct_x^p ct_y^q ct_z^r G8[pqr][m + offset]: the transposed stencils, pass by pass:
@@ -674,7 +688,7 @@ __device__ __forceinline__ double lm_pair_of(const Herm &hx, const Herm &hy, con
 template <int Q, int RZ>
 __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 *__restrict__ FP, int64_t npad, const BundleRays &B,
                                                  const uint4 *__restrict__ wb, int nchunks, int Ns, const double *__restrict__ unitw, char *img,
-                                                 int wid, int allpairs) {
+                                                 int wid) {
     const lm_d2 *FPt = FP + (size_t)wid * npad;          // this wave's pair (q, r) = (Q, RZ)
     const size_t sj = (size_t)g.nz, si = (size_t)g.ny * g.nz;
     double acc = 0.0;
@@ -683,7 +697,7 @@ __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 
         int ke = min(k0 + BL_KC, Ns);
         LmWindow W = lm_window(wb, c);
         if (B.stale) W.fits = 0;          // rays edited since the plan was made: every chunk reads its nodes from memory (exact for any bundling)
-        const bool all = allpairs && W.fits && W.wx * W.wy <= BL_ALL;
+        const bool all = W.fits && W.wx * W.wy <= BL_ALL;
         if (all && (c & (B_SPLIT - 1)) != wid) continue;          // another wave takes the whole chunk
         const double kd0 = (double)k0;
         double fx = fma(kd0, B.dfx, B.fx0), fy = fma(kd0, B.dfy, B.fy0), fz = fma(kd0, B.dfz, B.fz0);
@@ -774,7 +788,7 @@ __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const dou
                                                            const double *__restrict__ dirs, const int *__restrict__ order,
                                                            const int *__restrict__ bstart, const uint4 *__restrict__ win, const uint2 *__restrict__ rhash,
                                                            int nb, int nchunks, double tmax, int Ns, const double *__restrict__ unitw,
-                                                           double *__restrict__ tec, int *oob_flag, int allpairs, int restricted) {
+                                                           double *__restrict__ tec, int *oob_flag, int restricted) {
     extern __shared__ __attribute__((aligned(16))) char blds[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int b = blockIdx.x;
@@ -783,13 +797,6 @@ __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const dou
     const BundleRays B = load_bundle<true>(g, origins, dirs, order, bstart, b, tmax, Ns, rhash);
     if (wid == 0 && __any(B.mine && !B.valid) && lane == 0) atomicOr(oob_flag, 1);
     if (wid == 0 && B.stale && lane == 0) atomicOr(oob_flag + 2, 1);
-    if (B.stale && restricted) {
-        // The rays of this bundle were edited in place since the plan was made AND the pair arrays were rebuilt only where the PLANNED
-        // rays read them: direct loads along the new rays could meet nodes that were not rebuilt.  Never a plausible number: NaN +
-        // the stale flag (iono_plan_stale / RayEngine.check_plans raise), as the planned back-projection does.
-        if (wid == 0 && B.mine) tec[B.r] = nan("");
-        return;
-    }
     if (!B.any) {
         if (wid == 0 && B.mine) tec[B.r] = nan("");
         return;
@@ -799,10 +806,21 @@ __global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const dou
     const lm_d2 *FPd = (const lm_d2 *)FP;
     const uint4 *wb = win + (size_t)b * nchunks;
     double acc;
-    if (wid == 0) acc = bundle_lm_walk<0, 0>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 0, allpairs);
-    else if (wid == 1) acc = bundle_lm_walk<1, 0>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 1, allpairs);
-    else if (wid == 2) acc = bundle_lm_walk<0, 1>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 2, allpairs);
-    else acc = bundle_lm_walk<1, 1>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 3, allpairs);
+    if (B.stale && restricted) {
+        // The rays of this bundle were edited in place since the plan was made AND the pair arrays were rebuilt only where the PLANNED
+        // rays read them (ensure_lm_fields): direct loads along the NEW rays could meet nodes that were not rebuilt.  The node VALUES are
+        // always current: 216 taps per sample straight from them, wave w the samples k = w mod 4 -- slow, exact, and only for the
+        // bundles concerned (B holds the rays as the arrays have them now: load_bundle)
+        acc = 0.0;
+        if (B.valid)
+            for (int k = wid; k < Ns; k += B_SPLIT) {
+                const double kd = (double)k;
+                acc = fma(unitw[k], tricubic_from_nodes((const double *)g.M, g.nx, g.ny, g.nz, fma(kd, B.dfx, B.fx0), fma(kd, B.dfy, B.fy0), fma(kd, B.dfz, B.fz0)), acc);
+            }
+    } else if (wid == 0) acc = bundle_lm_walk<0, 0>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 0);
+    else if (wid == 1) acc = bundle_lm_walk<1, 0>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 1);
+    else if (wid == 2) acc = bundle_lm_walk<0, 1>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 2);
+    else acc = bundle_lm_walk<1, 1>(g, FPd, npad, B, wb, nchunks, Ns, unitw, img, 3);
     part[wid * 64 + lane] = acc;
     __syncthreads();
     if (wid == 0 && B.mine) {

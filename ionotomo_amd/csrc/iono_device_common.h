@@ -201,6 +201,40 @@ __device__ __forceinline__ int cubic_axis(const double *g, int n, double x, doub
     return i;
 }
 
+__device__ __forceinline__ void cubic_taps_ideal(double t, double (&w)[6]) {        // cubic_axis on a uniform axis: c0 = c1 = 1 / 12
+    const double t2 = t * t, t3 = t2 * t;
+    const double b0 = 2 * t3 - 3 * t2 + 1, b1 = -2 * t3 + 3 * t2, b2 = (t3 - 2 * t2 + t) * (1.0 / 12.0), b3 = (t3 - t2) * (1.0 / 12.0);
+    w[0] = b2, w[1] = -8.0 * b2 + b3, w[2] = b0 - 8.0 * b3, w[3] = b1 + 8.0 * b2, w[4] = -b2 + 8.0 * b3, w[5] = -b3;
+}
+// The interpolant at GRID coordinates (u = (x - g0) / h per axis) of an ideal-uniform grid straight from the node values: 216 taps.
+// What the planned tricubic forward falls back to for rays edited in place when its derivative fields were rebuilt only where the
+// PLANNED rays read them (k_forward_bundle_lm): slow, exact, independent of any derived array.
+__device__ __forceinline__ double tricubic_from_nodes(const double *__restrict__ M, int nx, int ny, int nz, double ux, double uy, double uz) {
+    const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(ny - 4)),
+                 fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(nz - 4));
+    double wx[6], wy[6], wz[6];
+    cubic_taps_ideal(ux - fi, wx);
+    cubic_taps_ideal(uy - fj, wy);
+    cubic_taps_ideal(uz - fk, wz);
+    const size_t sj = (size_t)nz, si = (size_t)ny * nz;
+    const double *base = M + ((size_t)((int)fi - 2) * ny + (size_t)((int)fj - 2)) * nz + (size_t)((int)fk - 2);
+    double f = 0.0;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        double fa = 0.0;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            const double *q = base + (size_t)a * si + (size_t)b * sj;
+            double s = 0.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) s += q[c] * wz[c];
+            fa += s * wy[b];
+        }
+        f += fa * wx[a];
+    }
+    return f;
+}
+
 template <typename GT, bool GRAD>
 __device__ __forceinline__ void tricubic_eval(const GridView &g, const double *gx, const double *gy, const double *gz,
                                               double x, double y, double z, double &f, double &fx, double &fy, double &fz) {

@@ -239,11 +239,6 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
 // order of operations: the samples are bit-identical to the traced ones) feeds the streaming quadrature directly.  The integrand at
 // a sample is shared by the ray's eight lanes: trilinear -- every lane one corner; tricubic -- every lane a 3 x 3 x 3 block of the
 // 6 x 6 x 6 taps (a, b, c = the lane's bits) -- summed with three DPP steps (sum8).  No ray tensor, any batch size.
-__device__ __forceinline__ void cubic_taps_ideal(double t, double (&w)[6]) {        // cubic_axis on a uniform axis: c0 = c1 = 1 / 12
-    const double t2 = t * t, t3 = t2 * t;
-    const double b0 = 2 * t3 - 3 * t2 + 1, b1 = -2 * t3 + 3 * t2, b2 = (t3 - 2 * t2 + t) * (1.0 / 12.0), b3 = (t3 - t2) * (1.0 / 12.0);
-    w[0] = b2, w[1] = -8.0 * b2 + b3, w[2] = b0 - 8.0 * b3, w[3] = b1 + 8.0 * b2, w[4] = -b2 + 8.0 * b3, w[5] = -b3;
-}
 template <bool BEND>
 __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *__restrict__ F8, const double *__restrict__ origins,
                                                       const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps, int rule,

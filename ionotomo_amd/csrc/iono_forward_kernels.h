@@ -446,73 +446,8 @@ __global__ __launch_bounds__(256, FWD_U_WG) void k_forward_straight_u(GridView g
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
-// ---- lanes = rays: 64 NEIGHBOURING rays of a walk order per wave, all at the same sample index ---------------------------------
-// k_forward_straight_u (lanes = samples) re-fetches the whole algorithmic volume from L2 every launch: a wave-load covers 64
-// samples of ONE ray (~20 lines, each used once), so nothing a wave reads is ever read again by it.  Given a walk order whose
-// neighbours are nearly the same ray (RayEngine.locality_order: 4-D Morton code of foot and end point), the transposed mapping
-// -- lane l of a wave = ray order[64 w + l], every lane at the same sample k, k = 0 .. Ns-1 in sequence -- makes the 64 lanes
-// of a wave-load read a handful of lines (the bundle is a few columns wide), and the line a lane used at sample k serves its
-// samples k+1 .. (z advances < 1 cell per sample, 16 nodes per line).  The Simpson weight is wave-uniform (a scalar load),
-// each lane owns its whole sum (no DPP reduction, no broadcasts, no tail case), and the per-sample arithmetic is unchanged.
-// Positions are re-based every T_REBASE samples (f = fma(k0, df, f0), then one add per sample) so that rounding does not
-// accumulate over the ray.  One wave-task = 64 rays; tasks are numbered XCD-major (blocks b, b + 8, ... share an XCD), so an
-// XCD's L2 sees one contiguous eighth of the walk.
-#define T_REBASE 32
-#ifndef T_UNROLL
-#define T_UNROLL 4
-#endif
-#ifndef T_WAVES
-#define T_WAVES 4
-#endif
-template <typename GT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(T_WAVES, T_WAVES))) void k_forward_straight_t(GridView g, const double *__restrict__ origins,
-                                                            const double *__restrict__ dirs, const int *__restrict__ order,
-                                                            int64_t R, double tmax, int Ns, const double *__restrict__ unitw,
-                                                            double *__restrict__ tec, int *oob_flag) {
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    int64_t bidx = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bidx = (int64_t)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const int64_t q = (bidx * wpb + wid) * 64 + lane;
-    if (q - lane >= R) return;                                  // (wave-uniform)
-    const GT *b00 = (const GT *)g.M, *b01 = b00 + g.nz, *b10 = b00 + (size_t)g.ny * g.nz, *b11 = b10 + g.nz;
-    URay u = {};
-    int64_t r = 0;
-    if (q < R) {
-        r = order ? (int64_t)order[q] : q;
-        u = load_uray(g, origins, dirs, r, tmax, Ns);
-    }
-    const bool oob = q < R && !u.valid;
-    // lanes without a valid ray walk cell (0, 0, 0) in place: same instruction stream, in-bounds loads, result discarded
-    const double fx0 = u.valid ? u.fx0 : 0.0, fy0 = u.valid ? u.fy0 : 0.0, fz0 = u.valid ? u.fz0 : 0.0;
-    const double dfx = u.valid ? u.dfx : 0.0, dfy = u.valid ? u.dfy : 0.0, dfz = u.valid ? u.dfz : 0.0;
-    double acc = 0.0;
-    for (int k0 = 0; k0 < Ns; k0 += T_REBASE) {
-        const double kd = (double)k0;
-        double fx = fma(kd, dfx, fx0), fy = fma(kd, dfy, fy0), fz = fma(kd, dfz, fz0);
-        const int ke = min(k0 + T_REBASE, Ns);
-        int k = k0;
-        for (; k + T_UNROLL <= ke; k += T_UNROLL) {
-            Corners<GT> cc[T_UNROLL];
-#pragma unroll
-            for (int b = 0; b < T_UNROLL; ++b) {
-                cc[b] = load_corners<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz);
-                fx += dfx;
-                fy += dfy;
-                fz += dfz;
-            }
-#pragma unroll
-            for (int b = 0; b < T_UNROLL; ++b) acc = fma(unitw[k + b], lerp_corners<GT>(cc[b]), acc);
-        }
-        for (; k < ke; ++k) {
-            acc = fma(unitw[k], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
-            fx += dfx;
-            fy += dfy;
-            fz += dfz;
-        }
-    }
-    if (q < R) tec[r] = u.valid ? acc * u.h : nan("");
-    if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
-}
+// (round 5: the lanes = 64-neighbouring-rays mapping k_forward_straight_t, measured slower than lanes = samples at every order, unroll and
+//  occupancy -- profiles/r03_ab_forward_lanes_rays.json -- is no longer built)
 
 // 1 - sqrt(1 - x) for the phase observable, x = ne / n_p.  A float64 square root is ~35 instruction slots
 // (quarter-rate seed + two Newton steps) and the observable needs one per sample and FREQUENCY; for x <= 0.01 -- any

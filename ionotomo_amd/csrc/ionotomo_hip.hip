@@ -90,7 +90,6 @@ struct iono_ctx {
     int walk_mode = 0;               // env IONOTOMO_WALK: forward walk A/B (see wave_chunk); never changes results
     bool walk_mode_set = false;
     int seg_lanes = 0;               // env IONOTOMO_SEG_LANES=4|8|16: lanes per segment of the back-projection plan (0: chosen per geometry)
-    int fwd_plan = 0;                // env IONOTOMO_FWD_PLAN=1: the forward uses the ray plan too (node-stationary, A/B)
     int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
                                            // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
@@ -129,10 +128,6 @@ struct iono_ctx {
         uint2 *d_hash = nullptr;                          // ray_hash of every ray as planned, by ray index (checked by every planned launch)
         uint2 *d_entries = nullptr;
         BinUnit *d_units = nullptr;
-        unsigned char *d_nseg = nullptr;                  // segments per ray (forward: partial sums per ray)
-        double *d_partial = nullptr;                      // [R][smax] segment partial sums of the node-stationary forward
-        int smax = 0;
-        bool fwd_ok = false;                              // every ray has <= 255 segments
         int nslab = 1;                                    // units are ordered by z-slab (then largest first): slab s = units [slab_unit[s], slab_unit[s + 1])
         int slab_unit[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // ... and owns the node levels [slab_z[s], slab_z[s + 1])
         int slab_z[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -143,7 +138,7 @@ struct iono_ctx {
         int tile_n[3] = {0, 0, 0}, tile_off[3] = {0, 0, 0};
         size_t cap_tiles = 0;
         int64_t n_invalid = 0;                            // rays that leave the grid (skipped; every launch raises the flag)
-        size_t cap_uray = 0, cap_hash = 0, cap_entries = 0, cap_units = 0, cap_nseg = 0, cap_partial = 0;      // bytes (grow-only: a new geometry reuses them)
+        size_t cap_uray = 0, cap_hash = 0, cap_entries = 0, cap_units = 0;      // bytes (grow-only: a new geometry reuses them)
     } plan;
     // bundle plan of the forward (iono_forward_plan_dev; k_forward_bundle): geometry only, library-owned
     struct FwdPlan {
@@ -188,8 +183,6 @@ void plan_free(iono_ctx *c) {
     if (c->plan.d_hash) (void)hipFree(c->plan.d_hash);
     if (c->plan.d_entries) (void)hipFree(c->plan.d_entries);
     if (c->plan.d_units) (void)hipFree(c->plan.d_units);
-    if (c->plan.d_nseg) (void)hipFree(c->plan.d_nseg);
-    if (c->plan.d_partial) (void)hipFree(c->plan.d_partial);
     if (c->plan.d_tiles) (void)hipFree(c->plan.d_tiles);
     c->plan = iono_ctx::AdjPlan();
 }
@@ -197,9 +190,8 @@ void plan_free(iono_ctx *c) {
 // pairs were half of the 19 ms a re-plan cost
 void plan_reset(iono_ctx *c) {
     iono_ctx::AdjPlan &p = c->plan, fresh;
-    fresh.d_uray = p.d_uray, fresh.d_entries = p.d_entries, fresh.d_units = p.d_units, fresh.d_nseg = p.d_nseg, fresh.d_partial = p.d_partial;
-    fresh.cap_uray = p.cap_uray, fresh.cap_entries = p.cap_entries, fresh.cap_units = p.cap_units, fresh.cap_nseg = p.cap_nseg;
-    fresh.cap_partial = p.cap_partial;
+    fresh.d_uray = p.d_uray, fresh.d_entries = p.d_entries, fresh.d_units = p.d_units;
+    fresh.cap_uray = p.cap_uray, fresh.cap_entries = p.cap_entries, fresh.cap_units = p.cap_units;
     fresh.d_hash = p.d_hash, fresh.cap_hash = p.cap_hash;
     fresh.d_tiles = p.d_tiles, fresh.cap_tiles = p.cap_tiles;
     p = fresh;
@@ -503,7 +495,6 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
     if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 2 | 4), c->walk_mode_set = true;
-    if (const char *e = getenv("IONOTOMO_FWD_PLAN")) c->fwd_plan = atoi(e);
     if (const char *e = getenv("IONOTOMO_SEG_LANES")) c->seg_lanes = atoi(e);
     if (const char *e = getenv("IONOTOMO_DETERMINISTIC")) c->deterministic = atoi(e) != 0;
     if (const char *e = getenv("IONOTOMO_ADJ_BUNDLE")) c->adj_mode = atoi(e) & (32 | 64 | 128);
@@ -786,7 +777,7 @@ static int ensure_lm_fields(iono_ctx *c, bool pairs = false, bool for_plan = fal
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
             hipLaunchKernelGGL((k_lm_fields_z<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c),
-                               (double2 *)c->d_LMw, c->nx, c->ny, c->nz);
+                               (double2 *)c->d_LMw, c->nx, c->ny, c->nz, restricted ? (const int2 *)c->fplan.d_xrange : (const int2 *)nullptr);
             return IONO_OK;
         });
         const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
@@ -815,7 +806,7 @@ static int ensure_n_fields(iono_ctx *c, double frequency) {
     if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
     if (c->nF8_freq != frequency) {
         hipLaunchKernelGGL((k_lm_fields_z<double>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double *)c->d_nM, (double2 *)c->d_LMw,
-                           c->nx, c->ny, c->nz);
+                           c->nx, c->ny, c->nz, (const int2 *)nullptr);
         const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
         hipLaunchKernelGGL((k_lm_fields_yx<false>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_nF8,
                            c->nx, c->ny, c->nz, padded_count(c), (const int2 *)nullptr);
@@ -834,18 +825,13 @@ static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes, const int 
     return c->walk_mode_set ? c->walk_mode : (order || array_bytes > ((uint64_t)256 << 20) ? 2 : 0);
 }
 // Forward mapping on ideal-uniform grids without a bundle plan: lanes = samples of one ray (k_forward_straight_u).
-// IONOTOMO_VARIANT=11 selects lanes = 64 neighbouring rays of the walk order (k_forward_straight_t), 10 forces lanes = samples
-// even on a planned geometry: A/B runs; results agree to rounding.
+// IONOTOMO_VARIANT=10 forces lanes = samples even on a planned geometry (A/B; results agree to rounding).
 // the bundle plan serves this launch: same ray arrays, R, tmax, Ns, and it fills the chip / is good (see the forward dispatch)
 static bool fplan_serves(const iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns) {
     const iono_ctx::FwdPlan &fp = c->fplan;
     return c->storage == IONO_F64 && fp.R == R && fp.o_key == o && fp.d_key == d && fp.Ns == Ns && fp.tmax == tmax && ideal_path_ok(c) &&
-           c->variant != 10 && c->variant != 11 &&
+           c->variant != 10 &&
            ((fp.nb >= 2 * c->num_cus && fp.fit_fraction >= 0.5 && R >= (int64_t)16 * fp.nb) || c->variant == 12);
-}
-static bool lanes_are_rays(const iono_ctx *c, int64_t R, const int *order) {
-    (void)R, (void)order;
-    return c->variant == 11;          // measured slower than lanes = samples at every order (profiles/r03_ab_forward_lanes_rays.json)
 }
 // fast tricubic tier: ideal-uniform axes, weights in LDS, 32-bit-safe field array (IONOTOMO_VARIANT=4 forces the general tier)
 static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
@@ -898,7 +884,7 @@ static int ensure_lm_windows(iono_ctx *c) {
     hipLaunchKernelGGL((k_bundle_windows<BL_KC, BL_LEV, 2 * BL_CPL, false>), dim3(fp.nb), dim3(64), 0, c->stream, view(c),
                        (const double *)fp.o_key, (const double *)fp.d_key, fp.d_order, fp.d_bstart, fp.nb, fp.tmax, fp.Ns, nchunks_lm,
                        fp.d_win_lm, d_fits);
-    hipLaunchKernelGGL(k_lm_xrange_init, dim3(ew_blocks(c, nlines)), dim3(256), 0, c->stream, fp.d_xrange, nlines);
+    HIP_TRY(c, hipMemsetAsync(fp.d_xrange, 0xff, (size_t)nlines * sizeof(int2), c->stream));
     const int64_t nwin = (int64_t)fp.nb * nchunks_lm;
     hipLaunchKernelGGL(k_lm_touch_lines, dim3(ew_blocks(c, nwin * 2 * BL_CPL * BL_LEV)), dim3(256), 0, c->stream, (const uint4 *)fp.d_win_lm, nwin, c->ny,
                        c->nz, BL_LEV, 2 * BL_CPL * BL_LEV, fp.d_xrange);
@@ -1093,16 +1079,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
     const size_t lds = lds_bytes(c);
     rc = dispatch_storage(c, [&](auto *tag) -> int {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        const iono_ctx::AdjPlan &pl = c->plan;
-        if (kind == IONO_INTERP_TRILINEAR && pl.fwd_ok && pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax &&
-            pl.kind == kind && c->variant != 8 && c->fwd_plan) {
-            // node-stationary forward on the ray plan: box images staged in LDS, one partial sum per segment, then per ray
-            const size_t bl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
-            hipLaunchKernelGGL((k_forward_binned<GT>), dim3(pl.n_units), block, bl, c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, Ns,
-                               c->d_unitw, pl.d_partial, pl.smax);
-            hipLaunchKernelGGL(k_forward_binned_finish, dim3(ew_blocks(c, R)), block, 0, c->stream, pl.d_uray, pl.d_nseg, pl.d_partial,
-                               pl.smax, R, tec, c->d_flags);
-        } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && std::is_same<GT, float>::value && c->variant != 9 &&
+        if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && std::is_same<GT, float>::value && c->variant != 9 &&
                    (uint64_t)padded_count(c) * 16 < ((uint64_t)1 << 32)) {
             // float32 storage extra: 2 x 2 corner blocks, two 16-B loads per sample (IONOTOMO_VARIANT=9: plain float32 kernel)
             const int64_t n = ncells(c), padded = padded_count(c);
@@ -1127,12 +1104,6 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             hipLaunchKernelGGL((k_forward_bundle<0>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double) + 16,
                                c->stream, g, o, d, fp.d_brec, fp.d_bhash, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec,
                                c->d_flags, PhaseFreqs{}, 0);
-        } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c) && lanes_are_rays(c, R, order)) {
-            // lanes = 64 neighbouring rays of the walk order; one wave-task per 64 rays (A/B: IONOTOMO_VARIANT=11)
-            const int64_t tasks = (R + 63) / 64;
-            const int64_t nb = ((tasks + 3) / 4 + 7) / 8 * 8;
-            hipLaunchKernelGGL((k_forward_straight_t<GT>), dim3((unsigned)nb), block, 0, c->stream, g, o, d, order, R, tmax, Ns, c->d_unitw,
-                               tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
             const size_t wl = sizeof(double) * Ns;
             const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
@@ -1155,7 +1126,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             static_assert(BL_LDS_BYTES <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
             hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES, c->stream, g, c->d_FP,
                                padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.d_rhash, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
-                               c->d_flags, c->variant == 16 ? 0 : 1, restricted);      // (IONOTOMO_VARIANT=16: one pair per wave for every window, A/B)
+                               c->d_flags, restricted);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
@@ -1207,7 +1178,7 @@ int iono_subtract_reference_dev(iono_ctx *c, double *tec, int Na, int64_t NtNd, 
     { const int rc = need_ctx(c); if (rc) return rc; }
     if (i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "reference antenna index out of range");
     hipLaunchKernelGGL(k_subtract_reference, dim3(ew_blocks(c, (int64_t)Na * NtNd)), dim3(256), 0, c->stream, tec, Na, NtNd, i0);
-    hipLaunchKernelGGL(k_zero, dim3(ew_blocks(c, NtNd)), dim3(256), 0, c->stream, tec + (int64_t)i0 * NtNd, NtNd);
+    HIP_TRY(c, hipMemsetAsync(tec + (int64_t)i0 * NtNd, 0, (size_t)NtNd * sizeof(double), c->stream));      // (row i0 - row i0, exactly)
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
 }
@@ -1484,10 +1455,7 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         return IONO_OK;
     };
     int segl = BIN_SEG;
-    if (c->fwd_plan) {                                    // the node-stationary forward (A/B) reads 16-lane segments
-        rc = count_segments(segl, nullptr);
-        if (rc) return rc;
-    } else if (c->seg_lanes == 4 || c->seg_lanes == 8 || c->seg_lanes == 16) {      // forced width (A/B, tests)
+    if (c->seg_lanes == 4 || c->seg_lanes == 8 || c->seg_lanes == 16) {      // forced width (A/B, tests)
         segl = c->seg_lanes;
         rc = count_segments(segl, nullptr);
         if (rc) return rc;
@@ -1533,19 +1501,7 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
             while (unit_segs < full && n_units(unit_segs) > slots) unit_segs += (int)pass;
         }
     }
-    std::vector<unsigned char> nseg((size_t)R, 0);
-    int smax = 1;
-    bool fwd_ok = true;
-    for (int64_t r = 0; r < R; ++r) {
-        const int j = h_nseg[(size_t)r];
-        if (j < 0) {
-            ++pl.n_invalid;
-            continue;
-        }
-        if (j > 255) fwd_ok = false;
-        nseg[(size_t)r] = (unsigned char)std::min(j, 255);
-        smax = std::max(smax, std::min(j, 255));
-    }
+    for (int64_t r = 0; r < R; ++r) pl.n_invalid += h_nseg[(size_t)r] < 0;
     // exclusive scan of the box counts; work units of <= BIN_UNIT segments, largest first
     std::vector<int> start((size_t)nbox + 1, 0);
     int64_t ne = 0;
@@ -1596,15 +1552,10 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, plan_reserve(pl.d_units, pl.cap_units, units.size() * sizeof(BinUnit)));
     HIP_TRY(c, hipMemcpyAsync(pl.d_units, units.data(), units.size() * sizeof(BinUnit), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));          // (start / units are host vectors; scratch goes back to the pool)
-    HIP_TRY(c, plan_reserve(pl.d_nseg, pl.cap_nseg, (size_t)R));
-    HIP_TRY(c, hipMemcpy(pl.d_nseg, nseg.data(), (size_t)R, hipMemcpyHostToDevice));
-    pl.smax = smax, pl.fwd_ok = fwd_ok && !cubic;
     if (cubic) {
         rc = plan_fold_tiles(c, R, Ns);
         if (rc) return rc;
     }
-    if (pl.fwd_ok && c->fwd_plan) HIP_TRY(c, plan_reserve(pl.d_partial, pl.cap_partial, (size_t)R * smax * sizeof(double)));
-    else pl.fwd_ok = false;      // (the node-stationary FORWARD is an opt-in A/B: no 40 MB of partial sums otherwise)
     pl.o_key = o, pl.d_key = d, pl.R = R, pl.Ns = Ns, pl.tmax = tmax, pl.kind = kind;
     pl.n_entries = ne, pl.n_units = (int)units.size(), pl.n_invalid = n_invalid, pl.segl = segl;
     pl.outside_fraction = (double)outside / (double)ne;
@@ -1691,8 +1642,8 @@ static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
         const GridView g = view(c);
         const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
         if (pl.n_units > 0)
-            BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, 0, double, SL, true>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds,
-                                                c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, (double *)c->d_fixgrid, -1,
+            BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, 0, double, SL, true>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds,
+                                                c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, (double *)c->d_fixgrid,
                                                 PhaseFreqs{}, 0, fixmax, -1));
         hipLaunchKernelGGL(k_fix_nodemax, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, c->stream, c->d_fixgrid, n, fixmax);
         unsigned long long nodemax = 0;
@@ -1749,16 +1700,16 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             { const int rcf = fix_prepare(c, wr, R, Ns); if (rcf) return rcf; }
             unsigned long long *fixmax = c->d_fixgrid + n;      // (allocated by fix_prepare on first use)
             if (u_hi > u_lo)
-                BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, 0, double, SL, true>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds,
+                BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, 0, double, SL, true>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds,
                                                     c->stream, g, pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw,
-                                                    (double *)c->d_fixgrid, -1, PhaseFreqs{}, 0, fixmax, pl.fix_bits));
+                                                    (double *)c->d_fixgrid, PhaseFreqs{}, 0, fixmax, pl.fix_bits));
             hipLaunchKernelGGL((k_fix_convert<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_fixgrid, grad, n, fixmax, pl.fix_bits);
             HIP_TRY(c, hipGetLastError());
             return IONO_OK;
         }
         if (u_hi > u_lo)
-            BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, false, 0, double, SL>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds, c->stream, g,
-                                                pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw, grad, -1, PhaseFreqs{}, 0));
+            BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<AT, 0, double, SL>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds, c->stream, g,
+                                                pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw, grad, PhaseFreqs{}, 0));
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }
@@ -1774,7 +1725,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
     // run-to-run identical bits, 1.3e-12 of the largest value away from the float sum (profiles/r05_ab_binned.json).
     // IONOTOMO_VARIANT=24: float atomics (A/B); iono_set_deterministic(1) additionally switches the TRILINEAR back-projection.
     const bool fix_cubic = (c->deterministic || c->variant != 24) && planned && kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) &&
-                           c->variant != 2 && c->variant != 21 && c->variant != 23 && pl.tile_n[2] > 0;
+                           c->variant != 2 && pl.tile_n[2] > 0;
     if (c->deterministic && !fix_cubic)
         return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear and tricubic back-projections only (iono_adjoint_plan_dev for these rays first)");
     if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
@@ -1784,8 +1735,8 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         // difference stencils fold them into the node gradient (iono_cubic_kernels.h)
         const int64_t n = ncells(c);
         if (!c->d_G8) HIP_TRY(c, hipMalloc((void **)&c->d_G8, (size_t)n * LM_NF * sizeof(double)));
-        // planned: only the tiles the plan's rays reach are zeroed, scattered into and folded (IONOTOMO_VARIANT=23: the whole grid, A/B)
-        const bool tiled = planned && pl.tile_n[2] > 0 && c->variant != 23;
+        // planned: only the tiles the plan's rays reach are zeroed, scattered into and folded
+        const bool tiled = planned && pl.tile_n[2] > 0;
         const LmTileGeom tg{c->nx, c->ny, c->nz, (c->ny + LMT_Y - 1) / LMT_Y, (c->nz + LMT_Z - 1) / LMT_Z};
         if (tiled)
             hipLaunchKernelGGL(k_lm_zero_tiles, dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, pl.d_tiles + pl.tile_off[0], tg);
@@ -1797,8 +1748,8 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             if (rcf) return rcf;
             fixmax = c->d_fixgrid + n;
         }
-        if (planned && c->variant != 21) {
-            // four channels (one z kind) per traversal: two launches instead of eight (k_adjoint_binned_lm4; IONOTOMO_VARIANT=21: A/B)
+        if (planned) {
+            // four channels (one z kind) per traversal: two launches instead of eight (k_adjoint_binned_lm4)
             const size_t l4 = LM4_LDS_BYTES(Ns);
             BY_SEGL(pl.segl, {
                 if (!c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2]) {
@@ -1817,14 +1768,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             });
             HIP_TRY(c, hipGetLastError());
         }
-        for (int f = 0; f < LM_NF; ++f) {
-            if (planned && c->variant != 21) break;
-            if (planned) {
-                BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, true, 0, double, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bin_lds,
-                                                    c->stream, g, pl.d_uray, pl.d_entries, pl.d_units, wr, Ns, c->d_unitw,
-                                                    c->d_G8 + (size_t)f * n, f, PhaseFreqs{}, 0));
-                continue;
-            }
+        for (int f = 0; f < LM_NF && !planned; ++f) {
             const int rc = launch_adjoint_tile<double, MODE, true>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns,
                                                                    c->d_G8 + (size_t)f * n, f);
             if (rc) return rc;
@@ -2115,8 +2059,8 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
             if (planned) {      // node-stationary: box images in LDS, ne gathered per sample (iono_binned_kernels.h)
                 const size_t bl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);
 #define PHASE_BIN(NF)                                                                                                              \
-    BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, false, NF, GT, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bl, c->stream, g, \
-                                        pl.d_uray, pl.d_entries, pl.d_units, wrf_work + f0, Ns, c->d_unitw, grad, -1, pf, Nf))
+    BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, NF, GT, SL>), dim3(pl.n_units), dim3(BIN_THREADS), bl, c->stream, g, \
+                                        pl.d_uray, pl.d_entries, pl.d_units, wrf_work + f0, Ns, c->d_unitw, grad, pf, Nf))
                 if (pf.nf == 1) PHASE_BIN(1);
                 else if (pf.nf == 2) PHASE_BIN(2);
                 else if (pf.nf <= 4) PHASE_BIN(4);

@@ -210,35 +210,3 @@ def test_pending_unit_range_is_refused_by_every_launch_but_the_planned_trilinear
         assert float(out.abs().max()) == 0.0                       # nothing launched
         full = eng.adjoint_planned_weights(ot, dt, w["tmax"], 41, out)          # no range pending any more: the whole back-projection
         assert float(full.abs().max()) > 0.0
-
-
-@pytest.mark.parametrize("seed", range(SOAK * 5))
-def test_node_stationary_forward_ab_variant(seed, OC, monkeypatch):
-    """IONOTOMO_FWD_PLAN=1: the forward on the ray plan (box image staged in LDS, per-segment partial sums) -- the
-    north-star LDS-staging design, kept as a measured A/B variant (profiles/r02_ab_forward_binned.json: slower than the
-    direct kernel) -- gives the oracle's TEC on random geometries, flags rays that leave the grid and writes NaN there."""
-    monkeypatch.setenv("IONOTOMO_FWD_PLAN", "1")
-    rng = np.random.default_rng(100 + seed)
-    n = [int(v) for v in rng.integers(8, 60, 3)]
-    xv, yv, zv = (np.linspace(0.0, float(rng.uniform(20, 200)), m) for m in n)
-    R, Ns = int(rng.integers(1, 500)), int(rng.choice([2, 16, 17, 65, 129, 257]))
-    steep = float(rng.choice([0.02, 0.5]))
-    zlo, zhi = zv[0] + rng.uniform(0, 0.3) * (zv[-1] - zv[0]), zv[-1] - rng.uniform(0, 0.2) * (zv[-1] - zv[0])
-    o = np.stack([rng.uniform(xv[0], xv[-1], R), rng.uniform(yv[0], yv[-1], R), np.full(R, zlo)], 1)
-    d = np.stack([rng.normal(size=R) * steep, rng.normal(size=R) * steep, np.ones(R)], 1)
-    end = o + d * ((zhi - zlo) / d[:, 2])[:, None]
-    inside = (end[:, 0] >= xv[0]) & (end[:, 0] <= xv[-1]) & (end[:, 1] >= yv[0]) & (end[:, 1] <= yv[-1])
-    if inside.sum() == 0:
-        d[:, :2] = 0.0
-        inside[:] = True
-    M = rng.uniform(1, 2, size=n)
-    for storage, tol in (("f64", 1e-12), ("f32", 2e-7)):
-        eng = engine(xv, yv, zv, storage=storage)
-        eng.set_values(eng.tensor(M))
-        ot, dt = eng.tensor(o), eng.tensor(d)
-        assert eng.plan_adjoint(ot, dt, zhi, Ns)[0] > 0
-        tec = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
-        assert eng.check_oob() == (not inside.all())
-        assert np.all(np.isnan(tec[~inside]))
-        ref = OC.forward_tec_straight(xv, yv, zv, M, o[inside], d[inside], zhi, Ns)
-        assert np.max(np.abs(tec[inside] - ref) / np.abs(ref)) < tol

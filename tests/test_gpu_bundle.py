@@ -322,35 +322,13 @@ def test_bundle_tricubic_bench_shape():
         print("tricubic forward %s: %.3f ms" % (name, (time.perf_counter() - t) / 20 * 1e3))
 
 
-def test_bundle_tricubic_one_pair_per_wave_variant(monkeypatch):
-    """IONOTOMO_VARIANT=16: every window through the one-pair-per-wave route (no whole-interpolant route for small windows) -- the
-    A/B of DESIGN 4.4; same TEC as the default routing and as the lanes = samples kernel."""
-    import bench
-    w = bench.build_workload(0)
-    ot = dt = None
-    res = {}
-    for variant in ("0", "16"):
-        monkeypatch.setenv("IONOTOMO_VARIANT", variant)
-        eng = engine(w["xvec"], w["yvec"], w["zvec"], force_bundle=False, interp="cubic")
-        eng.set_values(eng.tensor(np.exp(w["m"])))
-        ot, dt = eng.tensor(w["origins"].reshape(-1, 3)[:80000]), eng.tensor(w["directions"].reshape(-1, 3)[:80000])
-        direct = eng.forward(ot, dt, bench.TMAX, bench.NS)
-        nb, _, fit = eng.plan_forward(ot, dt, bench.TMAX, bench.NS)
-        assert nb >= 1024 and fit > 0.9
-        res[variant] = (eng.forward(ot, dt, bench.TMAX, bench.NS), direct)
-        assert not eng.check_oob()
-    scale = float(res["0"][1].abs().max())
-    for got, direct in res.values():
-        assert float((got - direct).abs().max()) < 1e-12 * scale
-    assert float((res["0"][0] - res["16"][0]).abs().max()) < 1e-12 * scale
-
-
 @pytest.mark.parametrize("interp", ["linear", "cubic"])
 def test_planned_tensors_edited_in_place_never_give_garbage(OC, interp):
     """a plan is keyed on device pointers -- ``o_t.copy_(new)`` into planned tensors used to make k_forward_bundle
     interpolate from LDS addresses outside the staged window.  Every planned launch now checks a 64-bit checksum per ray against the
-    plan's: the forward recomputes the bundles concerned from the arrays with direct loads (exact), the back-projection poisons
-    the edited rays (NaN, never a plausible number), both raise the flag ``plan_stale`` / ``check_plans`` report."""
+    plan's: the forward recomputes the bundles concerned from the arrays with direct loads (exact; the tricubic one, whose derivative
+    fields exist only where the PLANNED rays read them since round 5, straight from the node values: 216 taps per sample), the
+    back-projection poisons the edited rays (NaN, never a plausible number), both raise the flag ``plan_stale`` / ``check_plans`` report."""
     import bench
     from oracle import oracle as O
     w = bench.build_workload(0)
