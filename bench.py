@@ -354,6 +354,58 @@ def other_grid_leg(n, w, local, o_t, d_t, forder_t, R, kern256, k2, torch, dist)
             "max_rel_dev_vs_unplanned_kernel": float(((out - direct).abs() / direct.abs()).max())}
 
 
+def fermat_problems(w, local, torch, which=("cfg3", "cfg4")):
+    """The Fermat (refractive-bending) integrator of north_star at BASELINE config 3 -- 62 x 42 = 2,604 curved rays through 128^3 -- and
+    at config 4's ray count -- 620,000 curved rays through 256^3, traced AND integrated in one launch without a ray tensor
+    (iono_forward_tec_fermat_dev).  Grids with a 16-cell margin: this synthetic ionosphere bends 120 MHz rays by kilometres, and a ray
+    that leaves the grid raises (the reference's bounds_error=True).  Returns {name: (engine, origins, directions, tmax, Ns, frequency,
+    substeps)}; the node values are ne in m^-3 (the refractive index is derived from them)."""
+    from ionotomo_amd import synthetic as syn
+    from ionotomo_amd.engine import RayEngine
+    out = {}
+    if "cfg3" in which:
+        w3 = syn.make_workload("cfg2", margin_cells=16)
+        e3 = RayEngine(local)
+        e3.set_grid(w3["xvec"], w3["yvec"], w3["zvec"])
+        e3.set_values(e3.tensor(w3["ne"]))
+        out["cfg3"] = (e3, e3.tensor(w3["origins"].reshape(-1, 3)), e3.tensor(w3["directions"].reshape(-1, 3)), w3["tmax"], w3["Ns"], 120e6, 4)
+    if "cfg4" in which:
+        c4 = build_cfg4(w)
+        o, d = c4["origins"].reshape(-1, 3), c4["directions"].reshape(-1, 3)
+        e4 = RayEngine(local)
+        e4.set_grid(*syn.domain_for(o, d, NGRID, TMAX, margin_cells=16))
+        e4.set_values(torch.exp(e4.tensor(w["m"])).mul_(w["K_ne"]).reshape(-1))
+        out["cfg4"] = (e4, e4.tensor(o), e4.tensor(d), TMAX, NS, 150e6, 2)
+    return out
+
+
+def fermat_bytes_per_ray(ns, substeps, index_kind, integrand_corners=8):
+    """Algorithmic bytes of one curved ray, no credit for reuse (the convention of SURVEY 8d): every RK4 stage evaluates n and grad n
+    in the 8 corners of its cell -- 64-byte Lekien-Marsden records through a tricubic index, 8-byte values through a trilinear one --
+    (Ns - 1) x substeps x 4 times; every sample the integrand's 8 corner values; origin + direction in, TEC out."""
+    return (ns - 1) * substeps * 4 * 8 * (64 if index_kind == "cubic" else 8) + ns * integrand_corners * 8 + 56
+
+
+def fermat_leg(w, local, torch, dist):
+    """`extra.fermat`: config 3 and the 620,000-ray fused forward, both refractive-index interpolants, default routes; + a
+    `fermat_roofline` block for the 620,000-ray kernels (the unit that binds them comes from profiles/r05_pmc_summary.json)."""
+    out = {}
+    for name, (e, o, d, tmax, ns, freq, sub) in fermat_problems(w, local, torch).items():
+        R = int(o.shape[0])
+        t = torch.empty(R, dtype=torch.float64, device=e.device)
+        for kind in ("cubic", "linear"):
+            fn = lambda: e.forward_fermat(o, d, tmax, ns, freq, bend=True, kind=kind, substeps=sub, out=t)      # noqa: E731
+            _, k = time_steps(fn, 10 if name == "cfg3" else 3, 2 if name == "cfg3" else 1, torch, dist, 1)
+            assert not e.check_oob(), "bending rays left the grid"
+            b = fermat_bytes_per_ray(ns, sub, kind)
+            out["%s_%s_index" % (name, kind)] = {
+                "rays": R, "Ns": ns, "substeps": sub, "frequency_hz": freq, "ms": k * 1e3, "rays_per_s": R / k,
+                "kernel": ("k_fermat_tec_lm" if e.fermat_lm_ok(kind, "linear", R) else "k_fermat_tec<%d, true, false>" % (kind == "cubic")),
+                "algorithmic_bytes_per_ray": b, "algorithmic_gbs": R * b / k / 1e9}
+        del t
+    return out
+
+
 def cfg4_leg(w, local, k2, torch, dist, world):
     """BASELINE config 4 as written: 62 x 100 x 100 = 620,000 rays, 256^3 grid, rays sharded over the N ranks by (time,
     direction) block (ShardedRays / pair_block), the adjoint update summed over ranks every iteration.  Total work is fixed:
@@ -456,7 +508,8 @@ def main():
     ap.add_argument("--no-cfg4", dest="cfg4", action="store_false", help="skip the config-4 (620,000 rays, strong scaling) leg")
     ap.add_argument("--main-only", action="store_true", help="same as --only forward")
     ap.add_argument("--only", default=None,
-                    choices=["forward", "adjoint", "cubic_forward", "cubic_adjoint", "cgls", "sirt"],
+                    choices=["forward", "adjoint", "cubic_forward", "cubic_adjoint", "cgls", "sirt", "fermat_cubic", "fermat_linear",
+                             "fermat_cfg3"],
                     help="time ONE leg alone (clean rocprofv3 --stats / --pmc averages); implies --no-cpu")
     args = ap.parse_args()
     if args.main_only:
@@ -558,6 +611,13 @@ def main():
                 eng.plan_adjoint(o_t, d_t, TMAX, NS)
             elif order_t is not None:
                 eng.tune_adjoint_partition(leg, R)
+        elif args.only.startswith("fermat"):
+            name = "cfg3" if args.only == "fermat_cfg3" else "cfg4"
+            e_, o_, d_, tmax_, ns_, freq_, sub_ = fermat_problems(w, local, torch, which=(name,))[name]
+            kind_ = "linear" if args.only == "fermat_linear" else "cubic"
+            t_ = torch.empty(o_.shape[0], dtype=torch.float64, device=e_.device)
+            leg = lambda: e_.forward_fermat(o_, d_, tmax_, ns_, freq_, bend=True, kind=kind_, substeps=sub_, out=t_)      # noqa: E731
+            k = max(2, min(k, 5))
         elif args.only in ("cubic_forward", "cubic_adjoint"):
             ec, cf, ca, _ = cubic_legs()
             leg = cf if args.only == "cubic_forward" else ca
@@ -753,8 +813,10 @@ def main():
             extra["tricubic_vs_trilinear_max_rel_dev"] = float((tc - tec_t).abs().div(tec_t.abs()).max().item())
             # the binned kernel is bound by LDS float-atomic throughput, the ray-stationary one by the memory-side atomic rate
             extra["adjoint_roofline"] = {"bound": "lds_atomic" if args.plan else "memory_atomic", "kernel_ms": akern * 1e3,
-                                         "kernel": "k_adjoint_binned<double, false, 0, double" if args.plan
+                                         "kernel": "k_adjoint_binned<double, 0, double" if args.plan
                                          else "k_adjoint_straight_tile<double, 1, 4>"}
+            if world == 1:                                  # single-rank only: the Fermat integrator (config 3 + config 4's ray count)
+                extra["fermat"] = fermat_leg(w, local, torch, dist)
             if world == 1:                                  # single-rank only: the solvers at the bench shape
                 prob, x0 = solver_problem()
                 for name in ("cgls", "sirt"):

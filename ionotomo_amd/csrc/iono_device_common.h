@@ -209,7 +209,8 @@ __device__ __forceinline__ void cubic_taps_ideal(double t, double (&w)[6]) {    
 // The interpolant at GRID coordinates (u = (x - g0) / h per axis) of an ideal-uniform grid straight from the node values: 216 taps.
 // What the planned tricubic forward falls back to for rays edited in place when its derivative fields were rebuilt only where the
 // PLANNED rays read them (k_forward_bundle_lm): slow, exact, independent of any derived array.
-__device__ __forceinline__ double tricubic_from_nodes(const double *__restrict__ M, int nx, int ny, int nz, double ux, double uy, double uz) {
+// (out of line, everything by value: inlined into k_forward_bundle_lm it cost that kernel its third wave per SIMD -- 170 VGPRs)
+__device__ __attribute__((noinline)) double tricubic_from_nodes(const double *__restrict__ M, int nx, int ny, int nz, double ux, double uy, double uz) {
     const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(ny - 4)),
                  fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(nz - 4));
     double wx[6], wy[6], wz[6];

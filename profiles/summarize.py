@@ -16,8 +16,9 @@ sys.path.insert(0, ROOT)
 tag = sys.argv[1]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-LEG_KERNEL = {"forward": "k_forward_bundle", "adjoint": "k_adjoint_binned<double, false, 0, double",
-              "cubic_forward": "k_forward_bundle_lm"}
+LEG_KERNEL = {"forward": "k_forward_bundle", "adjoint": "k_adjoint_binned<double, 0, double",
+              "cubic_forward": "k_forward_bundle_lm", "fermat_cubic": "k_fermat_tec_lm", "fermat_linear": "k_fermat_tec<0",
+              "fermat_cfg3": "k_fermat_tec_lm"}
 
 
 def short(name):
@@ -77,5 +78,7 @@ if summary:
             continue
         k, v = max(cand, key=lambda kv: int(kv[0].split("grid=")[1]))
         pc[leg] = dict({c: x["mean"] for c, x in v.items()}, rays=bench.NA * bench.ND * bench.NT, Ns=bench.NS, kernel=k)
+        if leg.startswith("fermat"):
+            pc[leg]["rays"] = 2604 if leg == "fermat_cfg3" else 620000
     json.dump(pc, open(os.path.join(P, "pmc_counters.json"), "w"), indent=1, sort_keys=True)
     print("wrote profiles/pmc_counters.json for csrc", pc["csrc_sha"])
