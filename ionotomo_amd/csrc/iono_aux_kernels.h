@@ -530,13 +530,85 @@ __device__ __forceinline__ FState fermat_rhs_lm(const GridView &g, const double 
     if (!BEND) nx = ny = nz = 0.0;
     return fermat_rates(n, nx, ny, nz, u, stype);
 }
-template <bool BEND>
+// The same right-hand side with FEWER lanes per ray (round 5).  Counters of the 8-lane form at 620 000 rays (profiles/r05_pmc_summary.json,
+// leg fermat_cubic): vector issue 1.0 busy, 38.1 G wave-instructions = 62 ms of issue against 58 ms measured -- and most of them are work
+// every one of a ray's eight lanes repeats (position, cell, Hermite sets, the ray equations, the RK4 bookkeeping: ~165 of ~200 per stage;
+// only the 36 of a record's contraction differ).  With LPR lanes per ray a lane owns 8 / LPR nodes of the cell -- node (a, b, c) = the
+// bits of sub * NPL + n -- and the shared part is done LPR times instead of eight.  LPR = 8 keeps the function above (small batches:
+// 2 604 rays are 326 waves even so); large batches take LPR = 2 (four records = 64 VGPRs per lane, two waves per SIMD).
+template <int LPR>
+__device__ __forceinline__ double sum_lanes(double v) {
+    if (LPR >= 2) v = dpp_xadd<0xB1>(v);      // quad_perm:[1,0,3,2]
+    if (LPR >= 4) v = dpp_xadd<0x4E>(v);      // quad_perm:[2,3,0,1]
+    if (LPR >= 8) v = dpp_xadd<0x141>(v);     // row_half_mirror
+    return v;
+}
+template <bool BEND, int LPR>
+__device__ __forceinline__ FState fermat_rhs_lmn(const GridView &g, const double *__restrict__ F8, const FState &u, int sub, int &ci, int &cj,
+                                                 int &ck, double (&rec)[(8 / LPR) * 8], int stype) {
+    constexpr int NPL = 8 / LPR;
+    const double ux = (u.x - g.g0[0]) * g.inv_h[0], uy = (u.y - g.g0[1]) * g.inv_h[1], uz = (u.z - g.g0[2]) * g.inv_h[2];
+    const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(g.nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(g.ny - 4)),
+                 fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(g.nz - 4));
+    const int i = (int)fi, j = (int)fj, k = (int)fk;
+    if ((i != ci) | (j != cj) | (k != ck)) {          // (the lanes of a ray hold the same state: they reload together)
+#pragma unroll
+        for (int n = 0; n < NPL; ++n) {
+            const int nn = sub * NPL + n, a = nn >> 2, b = (nn >> 1) & 1, c = nn & 1;
+            const double2 *p = (const double2 *)(F8 + ((size_t)(i + a) * LM_SI(g.ny, g.nz) + (size_t)(j + b) * LM_NZP(g.nz) + (size_t)(k + c)) * LM_NF);
+            const double2 r0 = p[0], r1 = p[1], r2 = p[2], r3 = p[3];
+            double *q = rec + n * 8;
+            q[0] = r0.x, q[1] = r0.y, q[2] = r1.x, q[3] = r1.y, q[4] = r2.x, q[5] = r2.y, q[6] = r3.x, q[7] = r3.y;
+        }
+        ci = i, cj = j, ck = k;
+    }
+    // Hermite value / slope weights of BOTH nodes along each axis, and their t-derivatives: w[hi][0 = value, 1 = slope]
+    struct AxisW {
+        double w[2][2], d[2][2];
+    };
+    auto axis = [](double t) {
+        const double t2 = t * t, t3 = t2 * t;
+        AxisW A;
+        A.w[1][0] = 3.0 * t2 - 2.0 * t3, A.w[1][1] = t3 - t2, A.d[1][0] = 6.0 * t - 6.0 * t2, A.d[1][1] = 3.0 * t2 - 2.0 * t;
+        A.w[0][0] = 1.0 - (3.0 * t2 - 2.0 * t3), A.w[0][1] = t3 - 2.0 * t2 + t, A.d[0][0] = 6.0 * t2 - 6.0 * t, A.d[0][1] = 3.0 * t2 - 4.0 * t + 1.0;
+        return A;
+    };
+    const AxisW AX = axis(ux - fi), AY = axis(uy - fj), AZ = axis(uz - fk);
+    double sn = 0.0, snx = 0.0, sny = 0.0, snz = 0.0;
+#pragma unroll
+    for (int n = 0; n < NPL; ++n) {
+        const int nn = sub * NPL + n, a = nn >> 2, b = (nn >> 1) & 1, c = nn & 1;      // (b, c compile-time for LPR <= 2; a too for LPR = 1)
+        const double X0 = a ? AX.w[1][0] : AX.w[0][0], X1 = a ? AX.w[1][1] : AX.w[0][1], dX0 = a ? AX.d[1][0] : AX.d[0][0], dX1 = a ? AX.d[1][1] : AX.d[0][1];
+        const double Y0 = b ? AY.w[1][0] : AY.w[0][0], Y1 = b ? AY.w[1][1] : AY.w[0][1], dY0 = b ? AY.d[1][0] : AY.d[0][0], dY1 = b ? AY.d[1][1] : AY.d[0][1];
+        const double Z0 = c ? AZ.w[1][0] : AZ.w[0][0], Z1 = c ? AZ.w[1][1] : AZ.w[0][1], dZ0 = c ? AZ.d[1][0] : AZ.d[0][0], dZ1 = c ? AZ.d[1][1] : AZ.d[0][1];
+        const double *q = rec + n * 8;
+        // contract p (x), then q (y), then r (z): q[p + 2 q + 4 r] (fermat_rhs_lm's order)
+        const double g00 = X0 * q[0] + X1 * q[1], g10 = X0 * q[2] + X1 * q[3], g01 = X0 * q[4] + X1 * q[5], g11 = X0 * q[6] + X1 * q[7];
+        const double x00 = dX0 * q[0] + dX1 * q[1], x10 = dX0 * q[2] + dX1 * q[3], x01 = dX0 * q[4] + dX1 * q[5], x11 = dX0 * q[6] + dX1 * q[7];
+        const double h0 = Y0 * g00 + Y1 * g10, h1 = Y0 * g01 + Y1 * g11;
+        const double hx0 = Y0 * x00 + Y1 * x10, hx1 = Y0 * x01 + Y1 * x11;
+        const double hy0 = dY0 * g00 + dY1 * g10, hy1 = dY0 * g01 + dY1 * g11;
+        sn += Z0 * h0 + Z1 * h1, snx += Z0 * hx0 + Z1 * hx1, sny += Z0 * hy0 + Z1 * hy1, snz += dZ0 * h0 + dZ1 * h1;
+    }
+    const double nv = sum_lanes<LPR>(sn);
+    double nx = sum_lanes<LPR>(snx) * g.inv_h[0], ny = sum_lanes<LPR>(sny) * g.inv_h[1], nz = sum_lanes<LPR>(snz) * g.inv_h[2];
+    if (!BEND) nx = ny = nz = 0.0;
+    return fermat_rates(nv, nx, ny, nz, u, stype);
+}
+// (LPR = 8: the function the round-4 kernels were validated with, instruction for instruction)
+template <bool BEND, int LPR>
+__device__ __forceinline__ FState fermat_rhs_lm_any(const GridView &g, const double *__restrict__ F8, const FState &u, int sub, int &ci, int &cj,
+                                                    int &ck, double (&rec)[(8 / LPR) * 8], int stype) {
+    if constexpr (LPR == 8) return fermat_rhs_lm<BEND>(g, F8, u, sub, ci, cj, ck, rec, stype);
+    else return fermat_rhs_lmn<BEND, LPR>(g, F8, u, sub, ci, cj, ck, rec, stype);
+}
+template <bool BEND, int LPR = 8>
 __global__ __launch_bounds__(64) void k_trace_fermat_lm(GridView g, const double *__restrict__ F8, const double *__restrict__ origins,
                                                         const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps,
                                                         double *__restrict__ rays, int *oob_flag, int rays_per_wave, int stype) {
-    if ((int)(threadIdx.x >> 3) >= rays_per_wave) return;
-    const int sub = threadIdx.x & 7;
-    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x >> 3);
+    if ((int)(threadIdx.x / LPR) >= rays_per_wave) return;
+    const int sub = threadIdx.x & (LPR - 1);
+    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x / LPR);
     const bool live = r < R;
     if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
     const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
@@ -551,7 +623,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat_lm(GridView g, const double
     if (writer) o[0] = u.x, o[Ns] = u.y, o[2 * Ns] = u.z, o[3 * Ns] = u.s;
     bool oob = false;
     int ci = -1, cj = -1, ck = -1;
-    double rec[8] = {};
+    double rec[(8 / LPR) * 8] = {};
     const double ztop = g.glast[2] + 1e-9 * fabs(tmax);
     for (int k = 1; k < Ns; ++k) {
         for (int s2 = 0; s2 < substeps; ++s2) {
@@ -559,7 +631,7 @@ __global__ __launch_bounds__(64) void k_trace_fermat_lm(GridView g, const double
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs_lm<BEND>(g, F8, axpy(u, ca, kprev), sub, ci, cj, ck, rec, stype);
+                kprev = fermat_rhs_lm_any<BEND, LPR>(g, F8, axpy(u, ca, kprev), sub, ci, cj, ck, rec, stype);
                 sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
             }
             u = axpy(u, h / 6.0, sum);

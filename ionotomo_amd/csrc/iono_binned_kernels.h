@@ -21,7 +21,9 @@ namespace {
 // ------------------------------------------------------------------------------------------------
 #define BIN_SX 8
 #define BIN_SY 8
-#define BIN_SZ 15
+#ifndef BIN_SZ
+#define BIN_SZ 15                            // cells per z-layer of boxes (A/B builds: -DBIN_SZ=7 -DBIN_BZP=8, profiles/r05_backprojection_occupancy.json)
+#endif
 #ifndef BIN_H
 #define BIN_H 3
 #endif
@@ -590,8 +592,9 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
     }
     lds_barrier();
     // ---- flush the box once: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
-    const int m = threadIdx.x & 15;
-    for (int col = threadIdx.x >> 4; col < BIN_BX * BIN_BY; col += BIN_THREADS / 16) {
+    static_assert((BIN_BZP & (BIN_BZP - 1)) == 0 && BIN_BZP >= BIN_BZ, "the image keeps a power-of-two number of words per column");
+    const int m = threadIdx.x & (BIN_BZP - 1);
+    for (int col = threadIdx.x / BIN_BZP; col < BIN_BX * BIN_BY; col += BIN_THREADS / BIN_BZP) {
         const double v = tile[col * BIN_BZP + m];
         if (FIX ? __double_as_longlong(v) != 0 : v != 0.0) {
             const int a = col / BIN_BY, b = col - a * BIN_BY;
@@ -758,8 +761,8 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
     }
     lds_barrier();
     // ---- flush the four images: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
-    const int mz = threadIdx.x & 15;
-    for (int cc = threadIdx.x >> 4; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / 16) {
+    const int mz = threadIdx.x & (BIN_BZP - 1);
+    for (int cc = threadIdx.x / BIN_BZP; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / BIN_BZP) {
         const double v = tile[cc * BIN_BZP + mz];
         if (FIX ? __double_as_longlong(v) != 0 : v != 0.0) {
             const int ch = cc / (BIN_BX * BIN_BY), col = cc - ch * (BIN_BX * BIN_BY);

@@ -239,15 +239,17 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
 // order of operations: the samples are bit-identical to the traced ones) feeds the streaming quadrature directly.  The integrand at
 // a sample is shared by the ray's eight lanes: trilinear -- every lane one corner; tricubic -- every lane a 3 x 3 x 3 block of the
 // 6 x 6 x 6 taps (a, b, c = the lane's bits) -- summed with three DPP steps (sum8).  No ray tensor, any batch size.
-template <bool BEND>
+// LPR (round 5): lanes per ray -- 8 as above, or fewer lanes that own 8 / LPR nodes of the cell each (fermat_rhs_lmn, iono_aux_kernels.h):
+// the launch is bound by vector-instruction issue, and most of what the eight lanes of a ray issue is the same work eight times.
+template <bool BEND, int LPR = 8>
 __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *__restrict__ F8, const double *__restrict__ origins,
                                                       const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps, int rule,
                                                       int stype, int kne, double ne_scale, double *__restrict__ tec, int *oob_flag,
                                                       int rays_per_wave) {
-    if ((int)(threadIdx.x >> 3) >= rays_per_wave) return;
-    const int sub = threadIdx.x & 7;
-    const int la = sub >> 2, lb = (sub >> 1) & 1, lc = sub & 1;
-    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x >> 3);
+    if ((int)(threadIdx.x / LPR) >= rays_per_wave) return;
+    constexpr int NPL = 8 / LPR;                // nodes of a cell per lane: node (a, b, c) = the bits of sub * NPL + n
+    const int sub = threadIdx.x & (LPR - 1);
+    int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x / LPR);
     const bool live = r < R;
     if (!live) r = R - 1;                      // idle groups shadow the last ray (DPP needs all lanes running)
     const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
@@ -266,14 +268,20 @@ __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *
         if (cubic) return p.x >= g.c0[0] && p.x <= g.clast[0] && p.y >= g.c0[1] && p.y <= g.clast[1] && p.z >= g.c0[2] && p.z <= g.clast[2];
         return p.x >= g.g0[0] && p.x <= g.glast[0] && p.y >= g.g0[1] && p.y <= g.glast[1] && p.z >= g.g0[2] && p.z <= g.glast[2];
     };
-    auto value = [&](const FState &p) {          // called by all eight lanes of a ray with the same p
+    auto value = [&](const FState &p) {          // called by all the lanes of a ray with the same p
         const double ux = (p.x - g.g0[0]) * g.inv_h[0], uy = (p.y - g.g0[1]) * g.inv_h[1], uz = (p.z - g.g0[2]) * g.inv_h[2];
         if (!cubic) {
             const double fi = fmin(__builtin_floor(__builtin_fabs(ux)), (double)(g.nx - 2)), fj = fmin(__builtin_floor(__builtin_fabs(uy)), (double)(g.ny - 2)),
                          fk = fmin(__builtin_floor(__builtin_fabs(uz)), (double)(g.nz - 2));
             const double tx = ux - fi, ty = uy - fj, tz = uz - fk;
-            const double v = M[((size_t)((int)fi + la) * g.ny + (size_t)((int)fj + lb)) * g.nz + (size_t)((int)fk + lc)];
-            return sum8(v * (la ? tx : 1.0 - tx) * (lb ? ty : 1.0 - ty) * (lc ? tz : 1.0 - tz));
+            double f = 0.0;
+#pragma unroll
+            for (int n = 0; n < NPL; ++n) {
+                const int nn = sub * NPL + n, la = nn >> 2, lb = (nn >> 1) & 1, lc = nn & 1;
+                const double v = M[((size_t)((int)fi + la) * g.ny + (size_t)((int)fj + lb)) * g.nz + (size_t)((int)fk + lc)];
+                f += v * (la ? tx : 1.0 - tx) * (lb ? ty : 1.0 - ty) * (lc ? tz : 1.0 - tz);
+            }
+            return sum_lanes<LPR>(f);
         }
         const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(g.nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(g.ny - 4)),
                      fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(g.nz - 4));
@@ -281,27 +289,33 @@ __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *
         cubic_taps_ideal(ux - fi, wx);
         cubic_taps_ideal(uy - fj, wy);
         cubic_taps_ideal(uz - fk, wz);
-        // this lane's half of each axis' six taps (selects, not indexed arrays: no scratch)
-        const double x3[3] = {la ? wx[3] : wx[0], la ? wx[4] : wx[1], la ? wx[5] : wx[2]};
-        const double y3[3] = {lb ? wy[3] : wy[0], lb ? wy[4] : wy[1], lb ? wy[5] : wy[2]};
-        const double z3[3] = {lc ? wz[3] : wz[0], lc ? wz[4] : wz[1], lc ? wz[5] : wz[2]};
-        const double *base = M + ((size_t)((int)fi - 2 + 3 * la) * g.ny + (size_t)((int)fj - 2 + 3 * lb)) * g.nz + (size_t)((int)fk - 2 + 3 * lc);
         double f = 0.0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            double fa = 0.0;
+        for (int n = 0; n < NPL; ++n) {
+            const int nn = sub * NPL + n, la = nn >> 2, lb = (nn >> 1) & 1, lc = nn & 1;
+            // this node's half of each axis' six taps: a 3 x 3 x 3 block of the 6 x 6 x 6 (selects, not indexed arrays: no scratch)
+            const double x3[3] = {la ? wx[3] : wx[0], la ? wx[4] : wx[1], la ? wx[5] : wx[2]};
+            const double y3[3] = {lb ? wy[3] : wy[0], lb ? wy[4] : wy[1], lb ? wy[5] : wy[2]};
+            const double z3[3] = {lc ? wz[3] : wz[0], lc ? wz[4] : wz[1], lc ? wz[5] : wz[2]};
+            const double *base = M + ((size_t)((int)fi - 2 + 3 * la) * g.ny + (size_t)((int)fj - 2 + 3 * lb)) * g.nz + (size_t)((int)fk - 2 + 3 * lc);
+            double fn = 0.0;
 #pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const double *q = base + (size_t)a * si + (size_t)b * sj;
-                fa += (q[0] * z3[0] + q[1] * z3[1] + q[2] * z3[2]) * y3[b];
+            for (int a = 0; a < 3; ++a) {
+                double fa = 0.0;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    const double *q = base + (size_t)a * si + (size_t)b * sj;
+                    fa += (q[0] * z3[0] + q[1] * z3[1] + q[2] * z3[2]) * y3[b];
+                }
+                fn += fa * x3[a];
             }
-            f += fa * x3[a];
+            f += fn;
         }
-        return sum8(f);
+        return sum_lanes<LPR>(f);
     };
     bool oob = false;
     int ci = -1, cj = -1, ck = -1;
-    double rec[8] = {};
+    double rec[NPL * 8] = {};
     const double ztop = g.glast[2] + 1e-9 * fabs(tmax);
     StreamQuad q;
     q.init(Ns, rule, 0.0);
@@ -321,7 +335,7 @@ __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *
 #pragma unroll 1
             for (int st = 0; st < 4; ++st) {
                 const double ca = st == 0 ? 0.0 : (st == 3 ? h : 0.5 * h);
-                kprev = fermat_rhs_lm<BEND>(g, F8, axpy(u, ca, kprev), sub, ci, cj, ck, rec, stype);
+                kprev = fermat_rhs_lm_any<BEND, LPR>(g, F8, axpy(u, ca, kprev), sub, ci, cj, ck, rec, stype);
                 sum = axpy(sum, (st == 1 || st == 2) ? 2.0 : 1.0, kprev);
             }
             u = axpy(u, h / 6.0, sum);

@@ -91,6 +91,9 @@ struct iono_ctx {
     bool walk_mode_set = false;
     int seg_lanes = 0;               // env IONOTOMO_SEG_LANES=4|8|16: lanes per segment of the back-projection plan (0: chosen per geometry)
     int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
+    int fermat_lm_lanes = 0;            // record tracer / fused TEC through a tricubic index: lanes per ray (8 or 2); 0 = by batch size
+                                        // (env IONOTOMO_FERMAT_LM_LANES): 8 below fermat_lm_few_min rays, 2 from there on
+    int64_t fermat_lm_few_min = 32768;  // (env IONOTOMO_FERMAT_LM_FEW_MIN)
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
                                            // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
     int fermat_coop_rpw = 0;               // rays per wave of that kernel, 1..8: 0 = default (env IONOTOMO_FERMAT_COOP_RPW)
@@ -502,6 +505,8 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_ADJ_ABLATE")) c->adj_mode |= atoi(e) & (4 | 8);     // timing only: WRONG results
 #endif
     if (const char *e = getenv("IONOTOMO_FERMAT_COOP_MAX")) c->fermat_coop_max = atoll(e);
+    if (const char *e = getenv("IONOTOMO_FERMAT_LM_LANES")) c->fermat_lm_lanes = atoi(e);
+    if (const char *e = getenv("IONOTOMO_FERMAT_LM_FEW_MIN")) c->fermat_lm_few_min = atoll(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_COOP_RPW")) c->fermat_coop_rpw = std::min(8, std::max(1, atoi(e)));
     if (const char *e = getenv("IONOTOMO_FERMAT_LIN4_MAX")) c->fermat_lin4_max = atoll(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_POLY_MAX")) c->fermat_poly_max = atoll(e);
@@ -838,6 +843,13 @@ static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
     // (field records of 64 B per node, addressed with 32-bit byte offsets from the column bases)
     return ideal_path_ok(c, Ns) && c->variant != 4 && c->nx >= 6 && c->ny >= 6 && c->nz >= 6 &&
            (uint64_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double) < ((uint64_t)1 << 32);
+}
+
+// lanes per ray of the record tracer / fused TEC kernel (iono_aux_kernels.h: fermat_rhs_lmn): few lanes once the batch fills the chip
+static int fermat_lm_lanes(const iono_ctx *c, int64_t R) {
+    const int f = c->fermat_lm_lanes;
+    if (f == 8 || f == 2) return f;      // (4 and 1 lanes were measured too: profiles/r05_ab_fermat_lanes.json)
+    return R >= c->fermat_lm_few_min ? 2 : 8;
 }
 
 // ---- bundle plan of the forward (k_forward_bundle) ---------------------------------------------------------------------------
@@ -2492,14 +2504,15 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
         // IONOTOMO_VARIANT=17 keeps the 216-tap kernel below for A/B)
         const int rcf = ensure_n_fields(c, frequency);
         if (rcf) return rcf;
-        const int rpw = c->fermat_coop_rpw > 0 ? c->fermat_coop_rpw : 8;
+        const int lpr = fermat_lm_lanes(c, R);
+        const int rpw = lpr == 8 && c->fermat_coop_rpw > 0 ? std::min(c->fermat_coop_rpw, 8) : 64 / lpr;
         const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
-        if (bend)
-            hipLaunchKernelGGL((k_trace_fermat_lm<true>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps,
-                               dR, c->d_flags, rpw, stype);
-        else
-            hipLaunchKernelGGL((k_trace_fermat_lm<false>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps,
-                               dR, c->d_flags, rpw, stype);
+#define LAUNCH_TLM(B, L)                                                                                                                     \
+    hipLaunchKernelGGL((k_trace_fermat_lm<B, L>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps, dR, \
+                       c->d_flags, rpw, stype)
+        if (bend) { if (lpr == 8) LAUNCH_TLM(true, 8); else LAUNCH_TLM(true, 2); }
+        else { if (lpr == 8) LAUNCH_TLM(false, 8); else LAUNCH_TLM(false, 2); }
+#undef LAUNCH_TLM
     } else {                                // 8 lanes per ray: the 6x6x6 stencil of one ray spread over 8 lanes
         const int rpw = c->fermat_coop_rpw > 0 ? c->fermat_coop_rpw : 8;
         const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
@@ -2554,14 +2567,15 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
         // (iono_fermat_kernels.h:k_fermat_tec_lm; IONOTOMO_VARIANT=17 / 3: the lanes = rays kernel below, A/B)
         const int rcf = ensure_n_fields(c, frequency);
         if (rcf) return rcf;
-        const int rpw = c->fermat_coop_rpw > 0 ? c->fermat_coop_rpw : 8;
+        const int lpr = fermat_lm_lanes(c, R);
+        const int rpw = lpr == 8 && c->fermat_coop_rpw > 0 ? std::min(c->fermat_coop_rpw, 8) : 64 / lpr;
         const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
-        if (bend)
-            hipLaunchKernelGGL((k_fermat_tec_lm<true>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps, rule,
-                               independent, kind_ne, ne_scale, tec, c->d_flags, rpw);
-        else
-            hipLaunchKernelGGL((k_fermat_tec_lm<false>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps, rule,
-                               independent, kind_ne, ne_scale, tec, c->d_flags, rpw);
+#define LAUNCH_FLM(B, L)                                                                                                                       \
+    hipLaunchKernelGGL((k_fermat_tec_lm<B, L>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps, rule,   \
+                       independent, kind_ne, ne_scale, tec, c->d_flags, rpw)
+        if (bend) { if (lpr == 8) LAUNCH_FLM(true, 8); else LAUNCH_FLM(true, 2); }
+        else { if (lpr == 8) LAUNCH_FLM(false, 8); else LAUNCH_FLM(false, 2); }
+#undef LAUNCH_FLM
         HIP_TRY(c, hipGetLastError());
         return IONO_OK;
     }

@@ -254,3 +254,56 @@ def test_tricubic_tracer_on_node_records_equals_the_216_tap_kernel(typ, O, monke
     field = O.n_field_tricubic(xv, yv, zv, O.ne_to_n(w["ne"], 100e6))
     ref = O.fermat_trace(o, d, tmax, Ns, field, bend=True, substeps=2, type=typ)
     assert np.max(np.abs(res["0"][0] - ref)) < 1e-9
+
+
+@pytest.mark.parametrize("how", ["forced", "by_batch_size"])
+def test_two_lanes_per_ray_of_the_record_tracer(how, O, monkeypatch):
+    """Round 5: from 32 768 rays on the record tracer and the fused curved-ray TEC kernel give a ray TWO lanes (four nodes of the cell
+    each: fermat_rhs_lmn) instead of eight -- the launch is bound by vector-instruction issue and most of what eight lanes issue is the
+    same work eight times (620 000 rays: 58 -> 24 ms, profiles/r05_ab_fermat_lanes.json).  Same right-hand side to rounding: traced
+    rays against the 8-lane form and the oracle's RK4, fused TEC (both integrands, both independent variables, even / odd sample
+    counts, shipped behaviour bend=False too) against trace + integrate, rays that leave the tricubic domain flagged alike."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="example", na=7, nd=5, nt=3, n=33, margin_cells=10)
+    xv, yv, zv = w["xvec"], w["yvec"], w["zvec"]
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)          # 105 rays: not a multiple of 32 (idle groups shadow the last ray)
+
+    def make(lanes, interp):
+        monkeypatch.delenv("IONOTOMO_FERMAT_LM_LANES", raising=False)
+        monkeypatch.delenv("IONOTOMO_FERMAT_LM_FEW_MIN", raising=False)
+        if lanes == 2 and how == "forced":
+            monkeypatch.setenv("IONOTOMO_FERMAT_LM_LANES", "2")
+        elif lanes == 2:
+            monkeypatch.setenv("IONOTOMO_FERMAT_LM_FEW_MIN", "64")              # "a batch that fills the chip" starts at 64 rays here
+        else:
+            monkeypatch.setenv("IONOTOMO_FERMAT_LM_LANES", "8")
+        e = RayEngine(0, interp=interp)
+        e.set_grid(xv, yv, zv)
+        e.set_values(e.tensor(w["ne"]))
+        return e
+    for interp in ("linear", "cubic"):
+        e8, e2 = make(8, interp), make(2, interp)
+        o8, d8, o2, d2 = e8.tensor(o), e8.tensor(d), e2.tensor(o), e2.tensor(d)
+        for typ in ("z", "s"):
+            tmax = float(zv[24]) if typ == "z" else 0.7 * float(zv[24])
+            for bend in (True, False):
+                r8 = e8.trace_fermat(o8, d8, tmax, 21, 100e6, bend=bend, kind="cubic", substeps=2, type=typ)
+                r2 = e2.trace_fermat(o2, d2, tmax, 21, 100e6, bend=bend, kind="cubic", substeps=2, type=typ)
+                assert float((r8 - r2).abs().max()) < 1e-10
+                for Ns in (21, 22):
+                    a = e2.forward_fermat(o2, d2, tmax, Ns, 100e6, bend=bend, kind="cubic", substeps=2, type=typ, ne_scale=1e-13, fused=True)
+                    b = e8.forward_fermat(o8, d8, tmax, Ns, 100e6, bend=bend, kind="cubic", substeps=2, type=typ, ne_scale=1e-13, fused=False)
+                    assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max()), (interp, typ, bend, Ns)
+            assert not e8.check_oob() and not e2.check_oob()
+        if interp == "cubic":
+            field = O.n_field_tricubic(xv, yv, zv, O.ne_to_n(w["ne"], 100e6))
+            ref = O.fermat_trace(o, d, float(zv[24]), 21, field, bend=True, substeps=2, type="z")
+            got = e2.trace_fermat(o2, d2, float(zv[24]), 21, 100e6, bend=True, kind="cubic", substeps=2, type="z").cpu().numpy()
+            assert np.max(np.abs(got - ref)) < 1e-9
+        # rays that leave the domain: skipped samples + flag, the same numbers either way
+        far = o.copy()
+        far[::7, 0] = xv[-1] - 0.5 * (xv[1] - xv[0])
+        a = e2.forward_fermat(e2.tensor(far), d2, float(zv[24]), 21, 100e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
+        b = e8.forward_fermat(e8.tensor(far), d8, float(zv[24]), 21, 100e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
+        assert e2.check_oob() and e8.check_oob()
+        assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max())
