@@ -3,6 +3,7 @@
 #   part 1: bench line + rocprofv3 --kernel-trace --stats of every leg           (~5 min)
 #   part 2: PMC passes of the forward kernel, one counter set per run            (~5 min)
 #   part 3: PMC passes of the adjoint and the tricubic forward                   (~5 min)
+#   part 5: PMC passes of the Fermat kernels                                     (~2 min)
 # Produces gpurun_out/<tag>_*; `python profiles/summarize.py <tag>` condenses them into profiles/.
 # (--pmc runs carry --kernel-trace only: gpurun refuses PMC combined with other trace domains.)
 TAG=${1:-r02}
@@ -56,5 +57,10 @@ if [ "$PART" = "4" ]; then      # selected sets for one leg:  run_profiles.sh <t
 fi
 if [ "$PART" = "3" ]; then
   i=0; for C in "${SETS[@]}"; do i=$((i+1)); [ $i -ge $FIRST ] && pmc adjoint $i "$C"; done
-  for i in 1 3 4 5 8; do pmc cubic_forward $i "${SETS[$((i-1))]}"; done
+  for i in 1 3 4 5 6 7 8 10; do pmc cubic_forward $i "${SETS[$((i-1))]}"; done
+fi
+if [ "$PART" = "5" ]; then      # the Fermat integrator: 620 000 curved rays (both indices) and config 3
+  for i in 5 6 7 8; do pmc fermat_cubic $i "${SETS[$((i-1))]}"; done
+  for i in 5 6 7 8; do pmc fermat_linear $i "${SETS[$((i-1))]}"; done
+  for i in 7 8; do pmc fermat_cfg3 $i "${SETS[$((i-1))]}"; done
 fi
