@@ -175,7 +175,10 @@ def cpu_baseline(w, tec_gpu):
         cpu_model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
     except Exception:
         cpu_model = "unknown"
-    return dict(value=R / dt, unit="ray-integrals/s", cores=threads, kind="port", host_cpus=os.cpu_count(), cpu_model=cpu_model,
+    return dict(value=R / dt, unit="ray-integrals/s", cores=threads, kind="port", optimised=False,
+                note="context only: a straightforward port of the reference's arithmetic (binary search + three divisions per sample, "
+                     "weights recomputed per ray), NOT a tuned CPU implementation -- the GPU / CPU ratio says nothing about kernel quality",
+                host_cpus=os.cpu_count(), cpu_model=cpu_model,
                 sample="full per-GPU batch (%d rays x %d samples, 256^3 f64 grid) x %d repetitions, unoptimised C/OpenMP "
                        "port oracle/oracle_c.c on %d threads; numpy per-ray-loop port (1 thread, %d rays): %.3g "
                        "ray-integrals/s; numpy vectorised phase port (1 process, %d rays x 2 frequencies): %.3g ray-integrals/s"
@@ -400,7 +403,8 @@ def fermat_leg(w, local, torch, dist):
             b = fermat_bytes_per_ray(ns, sub, kind)
             out["%s_%s_index" % (name, kind)] = {
                 "rays": R, "Ns": ns, "substeps": sub, "frequency_hz": freq, "ms": k * 1e3, "rays_per_s": R / k,
-                "kernel": ("k_fermat_tec_lm" if e.fermat_lm_ok(kind, "linear", R) else "k_fermat_tec<%d, true, false>" % (kind == "cubic")),
+                "kernel": ("k_fermat_tec_lm<true, %d>" % (2 if R >= 32768 else 8) if e.fermat_lm_ok(kind, "linear", R)
+                           else "k_fermat_tec<%d, true, false>" % (kind == "cubic")),      # (lanes per ray: the library's default rule)
                 "algorithmic_bytes_per_ray": b, "algorithmic_gbs": R * b / k / 1e9}
         del t
     return out
@@ -892,6 +896,25 @@ def finish_line(line, extra, copy_gbs, clean, ctx):
                          "bank_conflict_frac": ca_.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(ca_["SQ_LDS_IDX_ACTIVE"], 1.0),
                          "atomic_wave_instructions": ca_.get("SQ_INSTS_LDS_ATOMIC")}
         ar["frac"] = ar["lds"]["busy_frac"] if ar["bound"] == "lds_atomic" and "lds" in ar else ar["memory_atomics"]["frac"]
+    # the Fermat integrator's dominant kernel (620,000 curved rays through a tricubic index): what binds it is vector-instruction issue,
+    # not bytes -- the corner records of a cell stay in registers while the ray stays in the cell
+    fz = (extra.get("fermat") or {}).get("cfg4_cubic_index")
+    if fz:
+        fr = {"kernel": fz["kernel"], "bound": "valu_issue", "rays": fz["rays"], "kernel_ms": fz["ms"],
+              "algorithmic_bytes_per_ray": fz["algorithmic_bytes_per_ray"], "achieved": fz["algorithmic_gbs"], "unit": "GB/s",
+              "note": "algorithmic bytes = (Ns - 1) x substeps x 4 RK4 stages x 8 corner records x 64 B + the integrand's 8 x 8 B per sample + 56; "
+                      "`issue_*` from the committed PMC pass of this build (profiles/pmc_counters.json, leg fermat_cubic) when it matches"}
+        cf = (pmc or {}).get("fermat_cubic")
+        if cf and cf.get("rays") == fz["rays"] and "SQ_INSTS_VALU" in cf and "GRBM_GUI_ACTIVE" in cf:
+            cyc = cf["GRBM_GUI_ACTIVE"] / 8.0
+            fr["issue_vector_wave_instructions"] = cf["SQ_INSTS_VALU"]
+            fr["issue_floor_ms_at_4_cycles"] = cf["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (cyc / (fz["ms"] * 1e-3)) * 1e3
+            if "SQ_ACTIVE_INST_VALU" in cf:
+                fr["valu_busy"] = fr["frac"] = min(1.0, 4.0 * cf["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc))
+            if "TA_TA_BUSY_sum" in cf:
+                fr["ta_busy"] = cf["TA_TA_BUSY_sum"] / (256.0 * cyc)
+            fr["kernel_pmc"] = cf.get("kernel")
+        extra["fermat_roofline"] = fr
     line["roofline"] = rl
     line["extra"] = extra
     if rank == 0 and not args.no_cpu:

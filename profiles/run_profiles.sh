@@ -25,6 +25,11 @@ pmc() {     # pmc <leg> <set index> "<counters>"
   # (a counter set the hardware cannot schedule aborts the profiled process, which can then hang in finalisation:
   #  bound every run)
   timeout -k 5 150 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT/${TAG}_pmc_${LEG}_$I -- python3 $REPO/bench.py --only $LEG --steps 5 --warmup 1 > /dev/null 2> $OUT/${TAG}_pmc_${LEG}_$I.err || note "pmc $LEG set $I ($C) FAILED"
+  # keep only this library's kernels (the torch helper kernels of the workload set-up are most of the rows; gpurun copies back <= 64 MiB)
+  for f in $OUT/${TAG}_pmc_${LEG}_$I/*/*_counter_collection.csv; do
+    [ -f "$f" ] && { head -1 "$f" > "$f.tmp"; grep "::k_" "$f" >> "$f.tmp"; mv "$f.tmp" "$f"; }
+  done
+  rm -f $OUT/${TAG}_pmc_${LEG}_$I/*/*_kernel_trace.csv
   note "pmc $LEG $I done"
 }
 
