@@ -1078,9 +1078,6 @@ int iono_forward_plan_info(iono_ctx *c, int64_t *n_bundles, int *n_chunks, doubl
     return IONO_OK;
 }
 
-#ifndef BL_EXTRA_LDS
-#define BL_EXTRA_LDS 0      // (timing-only A/B builds: unused LDS per workgroup, to lower the occupancy -- profiles/r05_cubic_forward_occupancy.json)
-#endif
 // ---- forward (device pointers) ---------------------------------------------------------------
 int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d, const int *order, int64_t R, double tmax,
                                   int Ns, int kind, int rule, double *tec) {
@@ -1138,8 +1135,8 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             if (rc2) return rc2;
             const int restricted = !c->FP_valid ? 1 : 0;      // the pair arrays hold this plan's lines only
             const iono_ctx::FwdPlan &fp = c->fplan;
-            static_assert(BL_LDS_BYTES + BL_EXTRA_LDS <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
-            hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES + BL_EXTRA_LDS, c->stream, g, c->d_FP,
+            static_assert(BL_LDS_BYTES <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
+            hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES, c->stream, g, c->d_FP,
                                padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.d_rhash, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
                                c->d_flags, restricted);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
