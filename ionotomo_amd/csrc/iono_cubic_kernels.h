@@ -578,15 +578,18 @@ __global__ __launch_bounds__(256, LM_WG) void k_forward_straight_lm(GridView g, 
 // per node, contiguous along z), stage ITS window with LDS-DMA (one node per lane, BL_CPL columns per wave-load) and walk ALL the
 // samples; the four partial integrals are added in a fixed order.  Per ray the arithmetic never depends on the bundling, and a
 // chunk whose window does not fit reads the same 16-B nodes from memory: results do not depend on the plan.
-// Chunks are BL_KC = 4 samples here (their own windows in the plan: BL_LEV = 6 levels >= 3 dfz + 2 + the spread of the lanes): an
-// image of 11.5 KB per wave, three workgroups = twelve waves per CU -- while one wave waits for its window the others compute.
+// Chunks are BL_KC = 4 samples here (their own windows in the plan: BL_LEV = 6 levels >= 3 dfz + 2 + the spread of the lanes).
+// Round 5: the kernel lives on the waves that hide its L1 fills (two workgroups per CU instead of three: 0.94 against 0.76 ms,
+// profiles/r05_cubic_forward_occupancy.json), so it is built for FOUR workgroups = sixteen waves per CU: an image of BL_CAPCOLS = 100
+// columns = 9.6 KB per wave (4 x 40.4 KB of a CU's 160 KB; 120 columns = 11.5 KB gave three) and at most 128 VGPRs (the sample loops keep
+// ONE set of eight nodes in flight instead of two: 166 before) -- 0.80 -> 0.735 ms on the box that measured both.
 typedef double lm_d2 __attribute__((ext_vector_type(2)));
 #define BL_NODE 16
 #define BL_KC 4                                   // samples per chunk
 #define BL_LEV 6                                  // levels per staged column
 #define BL_COL (BL_LEV * BL_NODE)                 // 96 B per staged column
 #define BL_CPL (64 / BL_LEV)                      // columns per staging wave-load (10: 60 lanes, one node each)
-#define BL_WAVE_LDS (B_CAPCOLS * BL_COL)          // 11 520 B per wave
+#define BL_WAVE_LDS (BL_CAPCOLS * BL_COL)         // 9 600 B per wave
 #define BL_LDS_BYTES (B_SPLIT * BL_WAVE_LDS + B_SPLIT * 64 * (int)sizeof(double))
 
 struct LmPairW {          // weights of one sample for the wave's pair (q, r): x needs both kinds, y and z one kind each
@@ -608,13 +611,13 @@ __device__ __forceinline__ double lm_pair_value(const LmPairW &w, const lm_d2 (&
 }
 
 // Two ways through a chunk, chosen by the size of its window (wave-uniform, from the plan):
-//  * at most BL_ALL = 30 columns (the median window has 20): ONE wave -- wave c mod 4 -- copies the windows of all four pairs into
+//  * at most BL_ALL = 25 columns (the median window has 20): ONE wave -- wave c mod 4 -- copies the windows of all four pairs into
 //    the four quarters of its image and evaluates the whole interpolant for its lanes: position, floor and the three Hermite
 //    sets are then computed once per sample instead of once per sample and wave (31 of the 67 vector instructions);
 //  * larger: every wave copies the window of ITS pair and adds its quarter of the interpolant, as above.
 // One wave-load moves 60 nodes = BL_CPL columns x BL_LEV levels: floor(BL_CPL / wy) whole rows of a window wy <= BL_CPL wide, or one
 // of the two column groups of a wider row.
-#define BL_ALL (B_CAPCOLS / 4)
+#define BL_ALL (BL_CAPCOLS / 4)
 struct LmWindow {
     int imin, jmin, kz0, wx, wy, rpl, fits;      // rpl: rows per staging wave-load (bits 20..23 of the plan's window word)
 };
@@ -722,15 +725,15 @@ __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 
                 const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
                 const Herm hx = hermite(fx - fi), hy = hermite(fy - fj), hz = hermite(fz - fk);
                 const unsigned a = (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * BL_NODE + ibase;
-                lm_d2 na[8], nb[8];
+                lm_d2 na[8];
                 lm_read8(na, a, row2);
-                lm_read8(nb, a + PS, row2);
                 double v = lm_pair_of<0, 0>(hx, hy, hz, na);
+                lm_read8(na, a + PS, row2);
+                v += lm_pair_of<1, 0>(hx, hy, hz, na);
                 lm_read8(na, a + 2 * PS, row2);
-                v += lm_pair_of<1, 0>(hx, hy, hz, nb);
-                lm_read8(nb, a + 3 * PS, row2);
                 v += lm_pair_of<0, 1>(hx, hy, hz, na);
-                v += lm_pair_of<1, 1>(hx, hy, hz, nb);
+                lm_read8(na, a + 3 * PS, row2);
+                v += lm_pair_of<1, 1>(hx, hy, hz, na);
                 const int dk = k - k0;
                 acc = fma(dk == 0 ? w0 : dk == 1 ? w1 : dk == 2 ? w2 : w3, v, acc);
                 fx += B.dfx, fy += B.dfy, fz += B.dfz;
@@ -747,26 +750,16 @@ __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 
                 lm_read8(n, (unsigned)__builtin_fma(fi, cw, __builtin_fma(fj, cj, fk)) * BL_NODE + ibase, row2);
                 fx += B.dfx, fy += B.dfy, fz += B.dfz;
             };
-            LmPairW pa, pb;
-            lm_d2 na[8], nb[8];
-            fetch(pa, na);
+            LmPairW pa;
+            lm_d2 na[8];
 #if defined(IONO_BL_ABL) && IONO_BL_ABL == 2      // timing-only build (WRONG results): staging only
+            fetch(pa, na);
             acc = fma(w0, lm_pair_value(pa, na), acc);
 #else
-            if (ke - k0 == BL_KC) {                // (wave-uniform; a ray's last chunk may be shorter)
-                fetch(pb, nb);
-                acc = fma(w0, lm_pair_value(pa, na), acc);
+            for (int k = k0; k < ke; ++k) {
                 fetch(pa, na);
-                acc = fma(w1, lm_pair_value(pb, nb), acc);
-                fetch(pb, nb);
-                acc = fma(w2, lm_pair_value(pa, na), acc);
-                acc = fma(w3, lm_pair_value(pb, nb), acc);
-            } else {
-                acc = fma(w0, lm_pair_value(pa, na), acc);
-                for (int k = k0 + 1; k < ke; ++k) {
-                    fetch(pa, na);
-                    acc = fma(unitw[k], lm_pair_value(pa, na), acc);
-                }
+                const int dk = k - k0;
+                acc = fma(dk == 0 ? w0 : dk == 1 ? w1 : dk == 2 ? w2 : w3, lm_pair_value(pa, na), acc);
             }
 #endif
         } else {
@@ -784,7 +777,7 @@ __device__ __forceinline__ double bundle_lm_walk(const GridView &g, const lm_d2 
     return acc;
 }
 
-__global__ __launch_bounds__(256) void k_forward_bundle_lm(GridView g, const double *__restrict__ FP, int64_t npad, const double *__restrict__ origins,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_forward_bundle_lm(GridView g, const double *__restrict__ FP, int64_t npad, const double *__restrict__ origins,
                                                            const double *__restrict__ dirs, const int *__restrict__ order,
                                                            const int *__restrict__ bstart, const uint4 *__restrict__ win, const uint2 *__restrict__ rhash,
                                                            int nb, int nchunks, double tmax, int Ns, const double *__restrict__ unitw,

@@ -489,6 +489,9 @@ static_assert(B_LEV8 == B_LEV * 8, "B_LEV8");
 #define B_CAPCOLS 120                            // columns per wave image
 #endif
 #define B_WAVE_LDS (B_CAPCOLS * B_PPC * 16)      // 9 600 B per wave, 4 waves per workgroup
+#ifndef BL_CAPCOLS
+#define BL_CAPCOLS 100                           // columns per wave image of the TRICUBIC bundle kernel (96-B columns: 9 600 B per wave, so that
+#endif                                           // four workgroups fit a CU's LDS: k_forward_bundle_lm, iono_cubic_kernels.h)
 #define B_SPLIT 4                                // z-parts of a ray = waves of a workgroup
 #ifndef B_LOOKAHEAD
 #define B_LOOKAHEAD 48                           // rejected rays a bundle looks past before it closes (plan, host side)
@@ -697,7 +700,7 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
     if (b >= nb) return;
     const BundleRays B = load_bundle(g, origins, dirs, order, bstart, b, tmax, Ns);
     const double eps = 1e-9;       // the samples of a chunk are reached by accumulation from its first one: margin of the window
-    int nfit = 0;
+    int nfit = 0, nbounded = 0;
     for (int c = 0; c < nchunks; ++c) {
         uint4 w = make_uint4(0, 0, 0, 0);
         if (B.any) {
@@ -710,7 +713,7 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
             const int kmin = wave_minmax_i32<false>((int)fmax(fmin(fz, fze) - eps, 0.0)), kmax = wave_minmax_i32<true>((int)(fmax(fz, fze) + eps));
             const int kz0 = EVEN ? kmin & ~1 : kmin;
             const int wx = imax - imin + 2, wy = jmax - jmin + 2, nlev = kmax + 2 - kz0;
-            const bool fits = wx * wy <= B_CAPCOLS && wx < 256 && wy <= MAXWY && nlev <= LEV;
+            const bool fits = wx * wy <= (PACK ? B_CAPCOLS : BL_CAPCOLS) && wx < 256 && wy <= MAXWY && nlev <= LEV;
             const int rpl = min(15, max(1, (PACK ? 64 / (LEV / 2) : 64 / LEV) / wy));
             unsigned flags = (unsigned)wx | ((unsigned)wy << 8) | (fits ? 1u << 16 : 0u) | ((unsigned)rpl << 20);
             if (PACK) flags |= (unsigned)min(31, (wx + rpl - 1) / rpl) << 24;      // wave-loads of the copy
@@ -720,12 +723,14 @@ __global__ __launch_bounds__(64) void k_bundle_windows(GridView g, const double 
             else
                 w = make_uint4((unsigned)imin, (unsigned)jmin, (unsigned)kz0, flags);
             nfit += fits;
+            nbounded += wx < 256 && wy <= MAXWY && nlev <= LEV;      // the record bounds every node the chunk reads, whether or not the window fits the image
         }
         if ((threadIdx.x & 63) == 0) win[(size_t)b * nchunks + c] = w;
     }
     if (fit_count && (threadIdx.x & 63) == 0) {                                                            // one update per bundle
         if (nfit) atomicAdd(fit_count, (unsigned long long)nfit);
         if (B.any) atomicAdd(fit_count + 1, (unsigned long long)nchunks);       // [1]: the window records that exist (bundles with a valid ray)
+        if (nbounded) atomicAdd(fit_count + 2, (unsigned long long)nbounded);   // [2]: ... whose extents bound what the chunk reads
     }
 }
 

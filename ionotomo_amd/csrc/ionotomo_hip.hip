@@ -890,9 +890,9 @@ static int ensure_lm_windows(iono_ctx *c) {
     HIP_TRY(c, plan_reserve(fp.d_win_lm, fp.cap_win_lm, (size_t)fp.nb * nchunks_lm * sizeof(uint4)));
     // (+ the number of windows that fit and the node lines the windows hold: what a field rebuild for this plan must cover)
     const int64_t nlines = (int64_t)c->ny * c->nz;
-    HIP_TRY(c, plan_reserve(fp.d_xrange, fp.cap_xrange, (size_t)nlines * sizeof(int2) + 16));
+    HIP_TRY(c, plan_reserve(fp.d_xrange, fp.cap_xrange, (size_t)nlines * sizeof(int2) + 32));
     unsigned long long *d_fits = (unsigned long long *)(fp.d_xrange + nlines);
-    HIP_TRY(c, hipMemsetAsync(d_fits, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_fits, 0, 3 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL((k_bundle_windows<BL_KC, BL_LEV, 2 * BL_CPL, false>), dim3(fp.nb), dim3(64), 0, c->stream, view(c),
                        (const double *)fp.o_key, (const double *)fp.d_key, fp.d_order, fp.d_bstart, fp.nb, fp.tmax, fp.Ns, nchunks_lm,
                        fp.d_win_lm, d_fits);
@@ -901,11 +901,13 @@ static int ensure_lm_windows(iono_ctx *c) {
     hipLaunchKernelGGL(k_lm_touch_lines, dim3(ew_blocks(c, nwin * 2 * BL_CPL * BL_LEV)), dim3(256), 0, c->stream, (const uint4 *)fp.d_win_lm, nwin, c->ny,
                        c->nz, BL_LEV, 2 * BL_CPL * BL_LEV, fp.d_xrange);
     HIP_TRY(c, hipGetLastError());
-    unsigned long long h_fits[2] = {0, 0};
+    unsigned long long h_fits[3] = {0, 0, 0};
     HIP_TRY(c, hipMemcpyAsync(h_fits, d_fits, sizeof(h_fits), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // every (bundle, chunk) of a bundle with a valid ray has a window record; bundles without one have none and read nothing
-    fp.lm_all_fit = h_fits[1] > 0 && h_fits[0] == h_fits[1];
+    // every (bundle, chunk) of a bundle with a valid ray has a window record; bundles without one have none and read nothing.  A rebuild
+    // may be restricted to the recorded lines when every record BOUNDS its chunk's reads (a window too wide for the image still does:
+    // its chunk then reads the same nodes from memory; one that needs more levels than the record can say does not)
+    fp.lm_all_fit = h_fits[1] > 0 && h_fits[2] == h_fits[1];
     fp.nchunks_lm = nchunks_lm;
     return IONO_OK;
 }
@@ -1020,7 +1022,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, plan_reserve(fp.d_win, fp.cap_win, (size_t)nb * nchunks * sizeof(uint4)));
     HIP_TRY(c, hipMemcpyAsync(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     unsigned long long *d_fits = (unsigned long long *)k0;        // (scratch: the key arrays are no longer needed)
-    HIP_TRY(c, hipMemsetAsync(d_fits, 0, 2 * sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(d_fits, 0, 3 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
                        nb, tmax, Ns, nchunks, fp.d_win, d_fits);
     HIP_TRY(c, plan_reserve(fp.d_brec, fp.cap_brec, (size_t)nb * 64 * sizeof(BundleRec)));
