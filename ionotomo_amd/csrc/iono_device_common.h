@@ -209,8 +209,9 @@ __device__ __forceinline__ void cubic_taps_ideal(double t, double (&w)[6]) {    
 // The interpolant at GRID coordinates (u = (x - g0) / h per axis) of an ideal-uniform grid straight from the node values: 216 taps.
 // What the planned tricubic forward falls back to for rays edited in place when its derivative fields were rebuilt only where the
 // PLANNED rays read them (k_forward_bundle_lm): slow, exact, independent of any derived array.
-// (out of line, everything by value: inlined into k_forward_bundle_lm it cost that kernel its third wave per SIMD -- 170 VGPRs)
-__device__ __attribute__((noinline)) double tricubic_from_nodes(const double *__restrict__ M, int nx, int ny, int nz, double ux, double uy, double uz) {
+// (inlined with the x loop ROLLED -- its taps rotate through named values, as in tricubic_eval below -- so that it needs ~60 VGPRs and
+//  no call: fully unrolled it cost k_forward_bundle_lm a wave per SIMD, out of line it left that kernel with a scratch frame)
+__device__ __forceinline__ double tricubic_from_nodes(const double *__restrict__ M, int nx, int ny, int nz, double ux, double uy, double uz) {
     const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(ny - 4)),
                  fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(nz - 4));
     double wx[6], wy[6], wz[6];
@@ -219,19 +220,22 @@ __device__ __attribute__((noinline)) double tricubic_from_nodes(const double *__
     cubic_taps_ideal(uz - fk, wz);
     const size_t sj = (size_t)nz, si = (size_t)ny * nz;
     const double *base = M + ((size_t)((int)fi - 2) * ny + (size_t)((int)fj - 2)) * nz + (size_t)((int)fk - 2);
+    double x0 = wx[0], x1 = wx[1], x2 = wx[2], x3 = wx[3], x4 = wx[4], x5 = wx[5];
     double f = 0.0;
-#pragma unroll
+#pragma unroll 1
     for (int a = 0; a < 6; ++a) {
         double fa = 0.0;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
-            const double *q = base + (size_t)a * si + (size_t)b * sj;
+            const double *q = base + (size_t)b * sj;
             double s = 0.0;
 #pragma unroll
             for (int c = 0; c < 6; ++c) s += q[c] * wz[c];
             fa += s * wy[b];
         }
-        f += fa * wx[a];
+        f += fa * x0;
+        x0 = x1, x1 = x2, x2 = x3, x3 = x4, x4 = x5;
+        base += si;
     }
     return f;
 }
