@@ -153,3 +153,27 @@ def test_phase_inversion_descends():
     # (the reference rule stops after its 5 mandatory updates here: steps fall below pgtol = 1e-2)
     assert len(hist) >= 6 and all(b <= a * (1 + 1e-12) for a, b in zip(hist, hist[1:])) and hist[-1] < 0.5 * hist[0]
     assert not eng.check_oob()
+
+
+def test_simulate_phase_on_a_datapack_built_from_reference_typed_members(tmp_path, monkeypatch):
+    """The reference builds a DataPack from astropy objects (astro/real_data.py:124-131: ITRS antennas, ICRS directions, Time) and
+    hands it to simulate_phase (astro/simulate_observables.py:22-66).  A DataPack made from stand-ins with exactly those attributes
+    (tests/astropy_standins.py) must simulate the same phases, bit for bit, as the one made from plain arrays."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    from astropy_standins import ICRSCoord, ITRSCoord, Time
+    import ionotomo_amd as it
+    from ionotomo_amd.astro.real_data import DataPack
+    monkeypatch.chdir(tmp_path)
+    dp = small_datapack()
+    d = dp.get_data_dict()
+    typed = DataPack(dict(d, antennas=ITRSCoord(dp.antennas), directions=ICRSCoord(dp.directions[:, 0], dp.directions[:, 1]),
+                          times=Time(dp.times), timestamps=None))
+    assert list(typed.timestamps) == list(dp.timestamps)
+    tci = it.create_turbulent_model(dp, factor=2., corr=20., seed=5, spacing=10., padding=8)
+    tci2 = it.create_turbulent_model(typed, factor=2., corr=20., seed=5, spacing=10., padding=8)
+    assert np.array_equal(tci.M, tci2.M) and np.array_equal(tci.xvec, tci2.xvec)
+    a = it.simulate_phase(dp.clone(), ne_tci=tci.copy(), seed=7)
+    b = it.simulate_phase(typed, ne_tci=tci2.copy(), seed=7)
+    assert np.array_equal(a.phase, b.phase) and a.ref_ant == b.ref_ant
