@@ -79,6 +79,8 @@ def itrs_metres(obj):
     * a plain array [N,3] / [3] already in metres."""
     if obj is None:
         return None
+    if isinstance(obj, np.ndarray):                  # (incl. this package's own ITRSArray: already metres)
+        return np.asarray(obj, dtype=np.float64)
     if hasattr(obj, "earth_location"):
         obj = obj.earth_location
     if hasattr(obj, "cartesian"):
@@ -104,6 +106,8 @@ def icrs_radec(obj):
     ``.deg``, or a Quantity) or a plain array already in radians."""
     if obj is None:
         return None
+    if isinstance(obj, np.ndarray):                  # (incl. this package's own ICRSArray: already radians)
+        return np.asarray(obj, dtype=np.float64)
     if hasattr(obj, "ra") and hasattr(obj, "dec"):
         return np.stack([_angle_rad(obj.ra), _angle_rad(obj.dec)], axis=-1)
     return np.asarray(obj, dtype=np.float64)
@@ -119,3 +123,106 @@ def unix_seconds(obj):
         if hasattr(obj, "gps"):
             return unix_from_gps(obj.gps)
     return np.asarray(obj, dtype=np.float64)
+
+
+# ---- the other direction: what this package hands BACK -----------------------------------------------------------------------------
+# The reference's getters return astropy objects (RadioArray.get_antenna_locs / get_center, DataPack.get_antennas / get_directions /
+# get_times: astro/radio_array.py:96-124, astro/real_data.py:145-170), and reference-side code reads attributes off them
+# (``antennas.cartesian.xyz.to(au.km).value.transpose()``, ``directions.ra.deg``, ``times.gps``: geometry/calc_rays.py:129,
+# astro/real_data.py:55-60).  The arrays this package returns are ndarray SUBCLASSES that answer those same attribute chains -- plain
+# float64 arrays for everything numpy does (slicing, ufuncs, np.asarray), so nothing inside the package changes -- without astropy.
+class QuantityLike(object):
+    """Numbers with a unit name; ``to`` / ``to_value`` take a unit object or its name (``str(unit)``: astropy units print as 'km')."""
+    __slots__ = ("value", "unit", "_table")
+
+    def __init__(self, value, unit, table):
+        self.value, self.unit, self._table = np.asarray(value, dtype=np.float64), str(unit), table
+
+    def to_value(self, unit):
+        name = str(unit).strip()
+        if name not in self._table:
+            raise ValueError("unknown unit '%s'" % name)
+        return self.value * (self._table[self.unit] / self._table[name])
+
+    def to(self, unit):
+        return QuantityLike(self.to_value(unit), str(unit).strip(), self._table)
+
+    def transpose(self):
+        return QuantityLike(self.value.transpose(), self.unit, self._table)
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.value, dtype=dtype)
+
+
+class AngleLike(object):
+    __slots__ = ("rad",)
+
+    def __init__(self, rad):
+        self.rad = np.asarray(rad, dtype=np.float64)
+
+    radian = property(lambda self: self.rad)
+    deg = property(lambda self: self.rad / _DEG)
+    degree = deg
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.rad, dtype=dtype)
+
+
+class _CartesianLike(object):
+    __slots__ = ("xyz",)
+
+    def __init__(self, xyz):
+        self.xyz = xyz
+
+
+class _EarthLocationLike(object):
+    __slots__ = ("x", "y", "z")
+
+    def __init__(self, xyz_m):
+        m = np.moveaxis(np.asarray(xyz_m, dtype=np.float64), -1, 0)
+        self.x, self.y, self.z = (QuantityLike(m[a], "m", _LENGTH_IN_M) for a in range(3))
+
+
+def _no_transform(self, *args, **kwargs):
+    raise NotImplementedError("frame transformations are astropy's; this package rotates ITRS / ICRS numbers into the model frame "
+                              "itself (ionotomo_amd.astro.frames, calc_rays)")
+
+
+class ITRSArray(np.ndarray):
+    """ITRS positions in metres, [N,3] or [3]: a float64 array that also answers ``.cartesian.xyz`` ([3,N] Quantity-like, as
+    astropy orders it) and ``.earth_location`` (``.x .y .z``)."""
+    def __new__(cls, xyz_m):
+        return np.ascontiguousarray(xyz_m, dtype=np.float64).view(cls)
+
+    cartesian = property(lambda self: _CartesianLike(QuantityLike(np.moveaxis(np.asarray(self), -1, 0), "m", _LENGTH_IN_M)))
+    earth_location = property(lambda self: _EarthLocationLike(np.asarray(self)))
+    transform_to = _no_transform
+
+
+class ICRSArray(np.ndarray):
+    """(ra, dec) in radians, [N,2] or [2]: a float64 array that also answers ``.ra`` / ``.dec`` (``.rad``, ``.deg``)."""
+    def __new__(cls, radec_rad):
+        return np.ascontiguousarray(radec_rad, dtype=np.float64).view(cls)
+
+    ra = property(lambda self: AngleLike(np.asarray(self)[..., 0]))
+    dec = property(lambda self: AngleLike(np.asarray(self)[..., 1]))
+    transform_to = _no_transform
+
+
+class TimeArray(np.ndarray):
+    """UTC unix seconds: a float64 array that also answers ``.unix``, ``.gps`` and ``.isot``."""
+    def __new__(cls, unix):
+        return np.ascontiguousarray(unix, dtype=np.float64).view(cls)
+
+    unix = property(lambda self: np.asarray(self))
+    gps = property(lambda self: gps_from_unix(np.asarray(self)))
+
+    @property
+    def isot(self):
+        import time as _t
+
+        def one(t):
+            t = float(t)
+            return _t.strftime("%Y-%m-%dT%H:%M:%S", _t.gmtime(int(np.floor(t)))) + ".{:03d}".format(int(round((t - np.floor(t)) * 1000)) % 1000)
+        a = np.asarray(self)
+        return one(a) if a.ndim == 0 else np.array([one(t) for t in a.ravel()]).reshape(a.shape)

@@ -2,14 +2,15 @@
 that the ray-integral path consumes, without astropy: positions are plain ITRS metres.
 
 ``get_antenna_locs()`` returns an ndarray [N,3] (ITRS m) where the reference returns an astropy
-SkyCoord; ``get_center()`` the centroid [3]; ``enu_km()`` gives the model-frame antenna positions
+SkyCoord -- an ndarray SUBCLASS that also answers the attribute chains reference-side code reads off that
+SkyCoord (``.cartesian.xyz.to(unit).value``, ``.earth_location``: astro/coords.py); ``get_center()`` the centroid [3], likewise; ``enu_km()`` gives the model-frame antenna positions
 (local East/North/Up km about the centroid) that ``calc_rays`` takes.
 """
 import os
 
 import numpy as np
 
-from .coords import itrs_metres
+from .coords import ITRSArray, itrs_metres
 from ..synthetic import itrs_to_enu_km, read_array_table, read_station_enu_csv
 
 _ARRAYS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "arrays")
@@ -39,7 +40,7 @@ class RadioArray(object):
             xyz, diam, labels = read_station_enu_csv(array_file)     # ENU-offset station table shipped here
         else:
             xyz, diam, labels = read_array_table(array_file)         # the reference's X Y Z diam label format
-        self.locs = xyz
+        self.locs = ITRSArray(xyz)
         if diam is not None and np.all(np.asarray(diam) < 0):
             diam = None                                # table without dish diameters (GMRT)
         self.diameters = diam
@@ -50,7 +51,7 @@ class RadioArray(object):
     def load_pos_array(self, antenna_pos, antenna_labels=None):
         """``antenna_pos``: ITRS metres [N,3], or an ITRS coordinate object as the reference holds them (read by attribute,
         ``.cartesian.xyz``: astro/coords.py)."""
-        self.locs = np.ascontiguousarray(itrs_metres(antenna_pos), dtype=np.float64).reshape(-1, 3)
+        self.locs = ITRSArray(np.ascontiguousarray(itrs_metres(antenna_pos), dtype=np.float64).reshape(-1, 3))
         self.Nantenna = self.locs.shape[0]
         if antenna_labels is not None:
             assert len(antenna_labels) == self.Nantenna

@@ -69,9 +69,11 @@ class DataPack(object):
             if self.timestamps is None and hasattr(self.times, "isot"):
                 self.timestamps = np.atleast_1d(np.asarray(self.times.isot)).astype(str)
             self.times = np.atleast_1d(coords.unix_seconds(self.times))
-        self.antennas = np.asarray(self.antennas, dtype=np.float64).reshape(-1, 3)
-        self.times = np.atleast_1d(np.asarray(self.times, dtype=np.float64))
-        self.directions = np.asarray(self.directions, dtype=np.float64).reshape(-1, 2)
+        # (plain float64 arrays that ALSO answer the attribute chains reference-side code reads off the astropy objects the reference
+        #  holds here -- .cartesian.xyz, .ra / .dec, .unix / .gps / .isot: astro/coords.py)
+        self.antennas = coords.ITRSArray(np.asarray(self.antennas, dtype=np.float64).reshape(-1, 3))
+        self.times = coords.TimeArray(np.atleast_1d(np.asarray(self.times, dtype=np.float64)))
+        self.directions = coords.ICRSArray(np.asarray(self.directions, dtype=np.float64).reshape(-1, 2))
         self.freqs = np.atleast_1d(np.asarray(self.freqs, dtype=np.float64))
         self.Na, self.Nt, self.Nd, self.Nf = len(self.antennas), len(self.times), len(self.directions), len(self.freqs)
         if self.timestamps is None:
@@ -191,8 +193,9 @@ class DataPack(object):
         the circle, so a field straddling ra = 0 gets its true centre (the reference's plain ``np.mean`` of the
         wrapped angles does not)."""
         ra = self.directions[:, 0]
-        return np.array([np.arctan2(np.mean(np.sin(ra)), np.mean(np.cos(ra))) % (2 * np.pi),
-                         np.mean(self.directions[:, 1])])
+        ra = np.asarray(ra)
+        return coords.ICRSArray([np.arctan2(np.mean(np.sin(ra)), np.mean(np.cos(ra))) % (2 * np.pi),
+                                 float(np.mean(np.asarray(self.directions)[:, 1]))])
 
     # -- reference antenna (astro/real_data.py:366-378) -----------------------------------------------
     def set_reference_antenna(self, ref_ant):

@@ -125,3 +125,44 @@ def test_sky_coordinates_without_a_frame_are_refused():
     ants, pat, times, centre, phase = _sky_case()
     with pytest.raises(ValueError):
         calc_rays(ITRSCoord(ants), ICRSCoord(pat[:, 0], pat[:, 1]), Time(times), None, None, None, None, 120e6, True, 1000.0, 9)
+
+
+def test_what_the_package_hands_back_answers_the_reference_side_attribute_chains():
+    """RadioArray / DataPack getters return float64 arrays that ALSO answer what reference-side code reads off the astropy objects the
+    reference returns there (astro/coords.py: ITRSArray, ICRSArray, TimeArray) -- and feed straight back into calc_rays."""
+    import ionotomo_amd as it
+    from ionotomo_amd.astro.real_data import DataPack, isot_from_unix
+    ants, pat, times, centre, phase = _sky_case()
+    ra_ = it.RadioArray(antenna_pos=ants)
+    locs, cen = ra_.get_antenna_locs(), ra_.get_center()
+    assert isinstance(locs, np.ndarray) and locs.dtype == np.float64 and np.array_equal(locs, ants)
+    # geometry/calc_rays.py:129: antennas.transform_to(...).cartesian.xyz.to(au.km).value.transpose()
+    assert np.allclose(locs.cartesian.xyz.to("km").value.transpose(), ants / 1e3, rtol=1e-15, atol=0)
+    assert locs.cartesian.xyz.value.shape == (3, len(ants)) and locs.cartesian.xyz.unit == "m"
+    assert np.array_equal(locs[2].cartesian.xyz.value, ants[2]) and np.array_equal(locs[1:3].cartesian.xyz.value, ants[1:3].T)
+    # geometry/calc_rays.py:124: array_center.earth_location
+    el = cen.earth_location
+    assert np.allclose([el.x.to_value("m"), el.y.to_value("m"), el.z.to_value("m")], np.mean(ants, 0), rtol=1e-15, atol=0)
+    with pytest.raises(NotImplementedError):
+        locs.transform_to("itrs")
+    shape = (len(ants), len(times), len(pat), 1)
+    dp = DataPack(dict(radio_array=ra_, antennas=ants, antenna_labels=["a%d" % i for i in range(len(ants))], directions=pat,
+                       patch_names=["p%d" % i for i in range(len(pat))], times=times, freqs=[150e6], phase=np.zeros(shape),
+                       variance=np.ones(shape), clock=np.zeros(shape[:2]), const=np.zeros(shape[0])))
+    a, _ = dp.get_antennas(ant_idx=-1)
+    d, _ = dp.get_directions(dir_idx=[0, 2])
+    t, stamps = dp.get_times(time_idx=-1)
+    # astro/real_data.py:55-60: directions.ra.deg / .dec.deg, times.gps
+    assert np.allclose(d.ra.deg, np.rad2deg(pat[[0, 2], 0])) and np.array_equal(d.dec.rad, pat[[0, 2], 1])
+    assert np.array_equal(t.unix, times) and np.array_equal(t.gps, coords.gps_from_unix(times))
+    assert list(t.isot) == [isot_from_unix(x) for x in times] == list(stamps)
+    c = dp.get_center_direction()
+    assert c.shape == (2,) and float(c.ra.rad) == float(c[0]) and float(c.dec.deg) == np.rad2deg(float(c[1]))
+    # numpy sees plain arrays; the readers take them back unchanged
+    assert np.array_equal(np.asarray(a), ants) and type(np.asarray(a)) is np.ndarray
+    assert np.array_equal(coords.itrs_metres(a), ants) and np.array_equal(coords.icrs_radec(d), pat[[0, 2]])
+    assert np.array_equal(coords.unix_seconds(t), times)
+    o0, d0 = frames.model_frame_bundle_from_sky(ants, pat, times, centre, phase)
+    o1, d1 = frames.model_frame_bundle_from_sky(coords.itrs_metres(a), coords.icrs_radec(dp.get_directions(dir_idx=-1)[0]),
+                                                coords.unix_seconds(t), coords.itrs_metres(coords.ITRSArray(centre)), coords.icrs_radec(coords.ICRSArray(phase)))
+    assert np.array_equal(o0, o1) and np.array_equal(d0, d1)
