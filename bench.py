@@ -403,10 +403,23 @@ def fermat_leg(w, local, torch, dist):
             b = fermat_bytes_per_ray(ns, sub, kind)
             out["%s_%s_index" % (name, kind)] = {
                 "rays": R, "Ns": ns, "substeps": sub, "frequency_hz": freq, "ms": k * 1e3, "rays_per_s": R / k,
-                "kernel": ("k_fermat_tec_lm<true, %d>" % (2 if R >= 32768 else 8) if e.fermat_lm_ok(kind, "linear", R)
+                "kernel": ("k_fermat_tec_lm<true, %d, false>" % (2 if R >= 32768 else 8) if e.fermat_lm_ok(kind, "linear", R)
                            else "k_fermat_tec<%d, true, false>" % (kind == "cubic")),      # (lanes per ray: the library's default rule)
                 "algorithmic_bytes_per_ray": b, "algorithmic_gbs": R * b / k / 1e9}
         del t
+        if name == "cfg4":          # the TRANSPOSE of the same launch (re-trace + back-project, no ray tensor): default routes
+            y = torch.ones(R, dtype=torch.float64, device=e.device)
+            g = torch.zeros(e.shape, dtype=torch.float64, device=e.device)
+            for kind in ("cubic", "linear"):
+                fn = lambda: e.adjoint_fermat(o, d, y, tmax, ns, freq, bend=True, kind=kind, substeps=sub, out=g)      # noqa: E731
+                _, k = time_steps(fn, 3, 1, torch, dist, 1)
+                e.check_oob()
+                out["%s_%s_index" % (name, kind)]["transpose_ms"] = k * 1e3
+                out["%s_%s_index" % (name, kind)]["transpose_kernel"] = (
+                    "k_fermat_tec_lm<true, 2, true>" if e.fermat_lm_ok(kind, "linear", R, transpose=True)
+                    else "k_trace_fermat_lm + k_adjoint_rays (ray tensor)" if e._two_step_fermat(R, ns, kind, None, adjoint=True)
+                    else "k_fermat_tec<%d, true, true>" % (kind == "cubic"))
+            del y, g
     return out
 
 

@@ -364,10 +364,12 @@ int iono_forward_tec_fermat_dev(iono_ctx *ctx, const double *origins_dev, const 
 int iono_adjoint_fermat_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, const double *w_dev, int64_t R,
                             double tmax, int Ns, double frequency, int bend, int interp_kind_n, int substeps, int independent,
                             int interp_kind_ne, int quad_rule, double ne_scale, double *grad_dev);
-/* Would iono_forward_tec_fermat_dev serve (interp_kind_n, interp_kind_ne, R) with the fused tricubic-index kernel (k_fermat_tec_lm:
- * 8 lanes per ray, 1.2 ms at config 3) -- 1 -- or with the lanes = rays kernel (31 ms there) -- 0?  The library's own dispatch
- * predicate, so that a host layer choosing between the fused call and trace + integrate never re-implements it. */
-int iono_fermat_lm_ok(iono_ctx *ctx, int interp_kind_n, int interp_kind_ne, int64_t R, int *ok_out);
+/* Would iono_forward_tec_fermat_dev (transpose = 0) / iono_adjoint_fermat_dev (transpose = 1) serve (interp_kind_n, interp_kind_ne, R,
+ * bend) with the fused tricubic-index kernel (k_fermat_tec_lm: a few lanes per ray on node records, 1.2 ms at config 3) -- 1 -- or with
+ * the lanes = rays kernel (31 ms there) -- 0?  The library's own dispatch predicate, so that a host layer choosing between the fused
+ * call and trace + integrate never re-implements it.  (The transpose runs on it for bending rays in batches large enough for two
+ * lanes per ray: where the alternative is a ray tensor of 32 R Ns bytes.) */
+int iono_fermat_lm_ok(iono_ctx *ctx, int interp_kind_n, int interp_kind_ne, int64_t R, int transpose, int bend, int *ok_out);
 int iono_check_oob(iono_ctx *ctx, int *oob_out);          /* synchronises; reads and clears the flag */
 /* Plans (iono_forward_plan_dev, iono_adjoint_plan_dev) are keyed on device pointers, but every planned launch re-hashes the rays
  * it is handed (64 bits per ray) against the hashes recorded when the plan was built.  If a planned array was edited in place:

@@ -116,7 +116,7 @@ _SIGNATURES = {
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _V],
     "iono_forward_tec_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],
     "iono_adjoint_fermat_dev": [_V, _V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],
-    "iono_fermat_lm_ok": [_I, _I, _L, ctypes.POINTER(ctypes.c_int)],
+    "iono_fermat_lm_ok": [_I, _I, _L, _I, _I, ctypes.POINTER(ctypes.c_int)],
     "iono_check_oob": [ctypes.POINTER(ctypes.c_int)],
     "iono_plan_stale": [ctypes.POINTER(ctypes.c_int)],
     "iono_smooth_separable": [_P, _P, _P, _P, _P, _I],

@@ -241,12 +241,16 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
 // 6 x 6 x 6 taps (a, b, c = the lane's bits) -- summed with three DPP steps (sum8).  No ray tensor, any batch size.
 // LPR (round 5): lanes per ray -- 8 as above, or fewer lanes that own 8 / LPR nodes of the cell each (fermat_rhs_lmn, iono_aux_kernels.h):
 // the launch is bound by vector-instruction issue, and most of what the eight lanes of a ray issue is the same work eight times.
-template <bool BEND, int LPR = 8>
+// ADJ (round 5): the transpose on the same stepper -- G += ne_scale * w[r] * c_k * (interpolation weights at x_k), the samples
+// bit-identical to the forward's.  Trilinear integrand: the first lane of a ray adds its eight corners into the wave's ScatterWindow
+// (all lanes make the call); tricubic integrand: every lane adds its 3 x 3 x 3 blocks of the 6 x 6 x 6 taps with global atomics.
+// Launched with every lane group live (rays_per_wave = 64 / LPR): the window is a wave operation.
+template <bool BEND, int LPR = 8, bool ADJ = false>
 __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *__restrict__ F8, const double *__restrict__ origins,
                                                       const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps, int rule,
                                                       int stype, int kne, double ne_scale, double *__restrict__ tec, int *oob_flag,
-                                                      int rays_per_wave) {
-    if ((int)(threadIdx.x / LPR) >= rays_per_wave) return;
+                                                      int rays_per_wave, const double *__restrict__ wray, double *__restrict__ G) {
+    if (!ADJ && (int)(threadIdx.x / LPR) >= rays_per_wave) return;
     constexpr int NPL = 8 / LPR;                // nodes of a cell per lane: node (a, b, c) = the bits of sub * NPL + n
     const int sub = threadIdx.x & (LPR - 1);
     int64_t r = (int64_t)blockIdx.x * rays_per_wave + (threadIdx.x / LPR);
@@ -319,17 +323,12 @@ __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *
     const double ztop = g.glast[2] + 1e-9 * fabs(tmax);
     StreamQuad q;
     q.init(Ns, rule, 0.0);
-    double y0 = 0.0, y1 = 0.0;             // integrand at samples k-2, k-1
-    bool in0 = false, in1 = inside(u);
-    if (!in1) oob = true;
-    {       // (a sample that is skipped is still EVALUATED, at a position clamped into the grid: all lanes run the DPP sums)
-        FState uc = u;
-        if (!in1) uc.x = fmin(fmax(u.x, g.c0[0]), g.clast[0]), uc.y = fmin(fmax(u.y, g.c0[1]), g.clast[1]), uc.z = fmin(fmax(u.z, g.c0[2]), g.clast[2]);
-        const double yv = value(uc);
-        y1 = in1 ? yv : 0.0;
-    }
-    double acc = 0.0;
-    for (int k = 1; k < Ns; ++k) {
+    auto clamped = [&](const FState &p, bool in) {       // (a sample that is skipped is still EVALUATED, at a position clamped into the grid)
+        FState uc = p;
+        if (!in) uc.x = fmin(fmax(p.x, g.c0[0]), g.clast[0]), uc.y = fmin(fmax(p.y, g.c0[1]), g.clast[1]), uc.z = fmin(fmax(p.z, g.c0[2]), g.clast[2]);
+        return uc;
+    };
+    auto step = [&]() {
         for (int s2 = 0; s2 < substeps; ++s2) {
             FState kprev = {}, sum = {};
 #pragma unroll 1
@@ -341,21 +340,95 @@ __global__ __launch_bounds__(64) void k_fermat_tec_lm(GridView g, const double *
             u = axpy(u, h / 6.0, sum);
         }
         oob |= !(u.x >= g.g0[0] && u.x <= g.glast[0] && u.y >= g.g0[1] && u.y <= g.glast[1] && u.z >= g.g0[2] && u.z <= ztop);
-        const bool in2 = inside(u);
-        if (!in2) oob = true;
-        FState uc = u;
-        if (!in2) uc.x = fmin(fmax(u.x, g.c0[0]), g.clast[0]), uc.y = fmin(fmax(u.y, g.c0[1]), g.clast[1]), uc.z = fmin(fmax(u.z, g.c0[2]), g.clast[2]);
-        const double yv = value(uc);
-        const double y2 = in2 ? yv : 0.0;
-        const double wk = q.feed(k, u.s);                       // final weight of sample k-2
-        if (k >= 2 && in0) acc = fma(wk, y0, acc);
-        y0 = y1, y1 = y2, in0 = in1, in1 = in2;
-    }
-    if (Ns >= 2 && in0) acc = fma(q.w0, y0, acc);
-    if (in1) acc = fma(q.w1, y1, acc);
-    if (live && sub == 0) {
-        tec[r] = acc * ne_scale;
-        if (oob) atomicOr(oob_flag, 1);
+    };
+    bool in0 = false, in1 = inside(u);
+    if (!in1) oob = true;
+    if constexpr (ADJ) {
+        __shared__ __attribute__((aligned(16))) double window[FW * FW * FWZ];
+        const bool windowed = !cubic && g.nx >= FW && g.ny >= FW && g.nz >= FWZ;             // (wave-uniform)
+        ScatterWindow sw;
+        if (windowed) sw.init(window);
+        const double wr = wray[r] * ne_scale;
+        const bool ray_on = live && wr != 0.0;
+        auto scatter = [&](const FState &p, double wgt, bool on) {         // every lane of the wave makes the call
+            const double ux = (p.x - g.g0[0]) * g.inv_h[0], uy = (p.y - g.g0[1]) * g.inv_h[1], uz = (p.z - g.g0[2]) * g.inv_h[2];
+            if (!cubic) {                // cell and weights as value() forms them; the ray's first lane adds the eight corners
+                const double fi = fmin(__builtin_floor(__builtin_fabs(ux)), (double)(g.nx - 2)), fj = fmin(__builtin_floor(__builtin_fabs(uy)), (double)(g.ny - 2)),
+                             fk = fmin(__builtin_floor(__builtin_fabs(uz)), (double)(g.nz - 2));
+                const bool mine = on && sub == 0;
+                if (windowed) {
+                    sw.add(g, G, mine, (int)fi, (int)fj, (int)fk, ux - fi, uy - fj, uz - fk, wgt);
+                } else if (mine) {
+                    const double tx = ux - fi, ty = uy - fj, tz = uz - fk;
+                    double *pp = G + ((size_t)(int)fi * g.ny + (size_t)(int)fj) * g.nz + (size_t)(int)fk;
+#pragma unroll
+                    for (int nn = 0; nn < 8; ++nn) {
+                        const int la = nn >> 2, lb = (nn >> 1) & 1, lc = nn & 1;
+                        atomicAdd(pp + la * si + lb * sj + lc, wgt * (la ? tx : 1.0 - tx) * (lb ? ty : 1.0 - ty) * (lc ? tz : 1.0 - tz));
+                    }
+                }
+                return;
+            }
+            if (!on) return;
+            const double fi = fmin(fmax(__builtin_floor(ux), 2.0), (double)(g.nx - 4)), fj = fmin(fmax(__builtin_floor(uy), 2.0), (double)(g.ny - 4)),
+                         fk = fmin(fmax(__builtin_floor(uz), 2.0), (double)(g.nz - 4));
+            double wx[6], wy[6], wz[6];
+            cubic_taps_ideal(ux - fi, wx);
+            cubic_taps_ideal(uy - fj, wy);
+            cubic_taps_ideal(uz - fk, wz);
+#pragma unroll
+            for (int n = 0; n < NPL; ++n) {
+                const int nn = sub * NPL + n, la = nn >> 2, lb = (nn >> 1) & 1, lc = nn & 1;
+                const double x3[3] = {la ? wx[3] : wx[0], la ? wx[4] : wx[1], la ? wx[5] : wx[2]};
+                const double y3[3] = {lb ? wy[3] : wy[0], lb ? wy[4] : wy[1], lb ? wy[5] : wy[2]};
+                const double z3[3] = {lc ? wz[3] : wz[0], lc ? wz[4] : wz[1], lc ? wz[5] : wz[2]};
+                double *base = G + ((size_t)((int)fi - 2 + 3 * la) * g.ny + (size_t)((int)fj - 2 + 3 * lb)) * g.nz + (size_t)((int)fk - 2 + 3 * lc);
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) {
+                        double *qq = base + (size_t)a * si + (size_t)b * sj;
+                        const double wab = wgt * x3[a] * y3[b];
+                        atomicAdd(qq, wab * z3[0]), atomicAdd(qq + 1, wab * z3[1]), atomicAdd(qq + 2, wab * z3[2]);
+                    }
+            }
+        };
+        FState p0 = u, p1 = u;                 // positions of samples k-2, k-1
+        for (int k = 1; k < Ns; ++k) {
+            step();
+            const bool in2 = inside(u);
+            if (!in2) oob = true;
+            const double wk = q.feed(k, u.s);                       // final weight of sample k-2
+            if (k >= 2) scatter(p0, wr * wk, in0 && ray_on);
+            p0 = p1, p1 = u, in0 = in1, in1 = in2;
+        }
+        if (Ns >= 2) scatter(p0, wr * q.w0, in0 && ray_on);
+        scatter(p1, wr * q.w1, in1 && ray_on);
+        if (windowed) sw.flush(g, G);
+        if (live && sub == 0 && oob) atomicOr(oob_flag, 1);
+    } else {
+        double y0 = 0.0, y1 = 0.0;             // integrand at samples k-2, k-1
+        {       // (all lanes run the DPP sums)
+            const double yv = value(clamped(u, in1));
+            y1 = in1 ? yv : 0.0;
+        }
+        double acc = 0.0;
+        for (int k = 1; k < Ns; ++k) {
+            step();
+            const bool in2 = inside(u);
+            if (!in2) oob = true;
+            const double yv = value(clamped(u, in2));
+            const double y2 = in2 ? yv : 0.0;
+            const double wk = q.feed(k, u.s);                       // final weight of sample k-2
+            if (k >= 2 && in0) acc = fma(wk, y0, acc);
+            y0 = y1, y1 = y2, in0 = in1, in1 = in2;
+        }
+        if (Ns >= 2 && in0) acc = fma(q.w0, y0, acc);
+        if (in1) acc = fma(q.w1, y1, acc);
+        if (live && sub == 0) {
+            tec[r] = acc * ne_scale;
+            if (oob) atomicOr(oob_flag, 1);
+        }
     }
 }
 

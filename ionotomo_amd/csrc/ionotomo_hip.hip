@@ -2533,14 +2533,17 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
 
 // ---- fused curved-ray forward / transpose (iono_fermat_kernels.h): trace and integrate in one traversal ---------------------------
 // the fused forward through a tricubic index runs on k_fermat_tec_lm (ideal-uniform axes, 32-bit-safe record array, float64)
-static bool fermat_lm_ok(const iono_ctx *c, int kind_n, int kind_ne, int64_t R) {
+// (its transpose: bending rays at two lanes per ray -- the large batches, where the alternative is a ray tensor of 32 R Ns bytes and
+//  a back-projection with one hardware atomic per corner; small batches keep k_trace_fermat_lm + k_adjoint_rays)
+static bool fermat_lm_ok(const iono_ctx *c, int kind_n, int kind_ne, int64_t R, bool transpose = false, int bend = 1) {
+    if (transpose && !(bend && fermat_lm_lanes(c, R) == 2)) return false;
     return kind_n == IONO_INTERP_TRICUBIC && c->storage == IONO_F64 && view(c).ideal && cubic_fast_ok(c, 2) && c->variant != 17 &&
            c->variant != 3 && R <= c->fermat_coop_max && (kind_ne == IONO_INTERP_TRILINEAR || (c->nx >= 6 && c->ny >= 6 && c->nz >= 6));
 }
-int iono_fermat_lm_ok(iono_ctx *c, int kind_n, int kind_ne, int64_t R, int *ok) {
+int iono_fermat_lm_ok(iono_ctx *c, int kind_n, int kind_ne, int64_t R, int transpose, int bend, int *ok) {
     { const int rc = need_ctx(c); if (rc) return rc; }
     if (!ok) return fail(c, IONO_ERR_ARG, "null argument");
-    *ok = fermat_lm_ok(c, kind_n, kind_ne, R) ? 1 : 0;
+    *ok = fermat_lm_ok(c, kind_n, kind_ne, R, transpose != 0, bend) ? 1 : 0;
     return IONO_OK;
 }
 static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const double *dD, const double *dW, int64_t R, double tmax, int Ns,
@@ -2564,7 +2567,7 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
     }
     const GridView g = view(c);
     const dim3 grid((unsigned)((R + 63) / 64)), block(64);
-    if (!adjoint && fermat_lm_ok(c, kind_n, kind_ne, R)) {
+    if (fermat_lm_ok(c, kind_n, kind_ne, R, adjoint, bend)) {
         // tricubic index on an ideal-uniform grid: 8 lanes per ray, one Lekien-Marsden record of n per lane, streaming quadrature
         // (iono_fermat_kernels.h:k_fermat_tec_lm; IONOTOMO_VARIANT=17 / 3: the lanes = rays kernel below, A/B)
         const int rcf = ensure_n_fields(c, frequency);
@@ -2574,8 +2577,11 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
         const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
 #define LAUNCH_FLM(B, L)                                                                                                                       \
     hipLaunchKernelGGL((k_fermat_tec_lm<B, L>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps, rule,   \
-                       independent, kind_ne, ne_scale, tec, c->d_flags, rpw)
-        if (bend) { if (lpr == 8) LAUNCH_FLM(true, 8); else LAUNCH_FLM(true, 2); }
+                       independent, kind_ne, ne_scale, tec, c->d_flags, rpw, (const double *)nullptr, (double *)nullptr)
+        if (adjoint)      // (fermat_lm_ok: bending rays, two lanes per ray)
+            hipLaunchKernelGGL((k_fermat_tec_lm<true, 2, true>), cgrid, block, 0, c->stream, g, (const double *)c->d_nF8, dO, dD, R, tmax, Ns, substeps,
+                               rule, independent, kind_ne, ne_scale, (double *)nullptr, c->d_flags, rpw, dW, grad);
+        else if (bend) { if (lpr == 8) LAUNCH_FLM(true, 8); else LAUNCH_FLM(true, 2); }
         else { if (lpr == 8) LAUNCH_FLM(false, 8); else LAUNCH_FLM(false, 2); }
 #undef LAUNCH_FLM
         HIP_TRY(c, hipGetLastError());

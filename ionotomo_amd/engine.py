@@ -334,25 +334,26 @@ class RayEngine(object):
     # stepper of the fused kernel (config 3: 2.3 against 31 ms): below this many bytes of rays[R,4,Ns] the two-step path serves it
     FUSED_CUBIC_ABOVE_BYTES = 8 << 30
 
-    def fermat_lm_ok(self, kind, ne_kind, R):
-        """Would ``forward_fermat`` run the fused tricubic-index kernel (k_fermat_tec_lm) for this launch?  Asked of the library
-        (iono_fermat_lm_ok), never re-derived here."""
+    def fermat_lm_ok(self, kind, ne_kind, R, transpose=False, bend=True):
+        """Would ``forward_fermat`` (``transpose``: ``adjoint_fermat``) run the fused tricubic-index kernel (k_fermat_tec_lm) for this
+        launch?  Asked of the library (iono_fermat_lm_ok), never re-derived here."""
         import ctypes
         ok = ctypes.c_int(0)
         as_kind = lambda k: k if isinstance(k, int) else _lib.interp_kind(k)
-        self.ctx.call("iono_fermat_lm_ok", as_kind(kind), as_kind(ne_kind), int(R), ctypes.byref(ok))
+        self.ctx.call("iono_fermat_lm_ok", as_kind(kind), as_kind(ne_kind), int(R), int(bool(transpose)), int(bool(bend)), ctypes.byref(ok))
         return bool(ok.value)
 
-    def _two_step_fermat(self, R, Ns, kind, fused, adjoint=False, ne_kind=None):
+    def _two_step_fermat(self, R, Ns, kind, fused, adjoint=False, ne_kind=None, bend=True):
         """True: trace into a TEMPORARY rays[R,4,Ns] tensor (32 R Ns bytes of device memory) and integrate along it.  Round 4: the
-        FORWARD through a tricubic index on ideal-uniform axes is fused too (k_fermat_tec_lm: 8 lanes per ray, one node record per
-        lane, streaming quadrature) -- the two-step route remains the default only for its transpose and for non-uniform axes."""
+        FORWARD through a tricubic index on ideal-uniform axes is fused too (k_fermat_tec_lm: a few lanes per ray on node records,
+        streaming quadrature); round 5: so is its TRANSPOSE for large batches of bending rays -- the two-step route remains the
+        default for small transposes and for non-uniform axes."""
         if fused is not None:
             return not fused
         need = R * 4 * int(Ns) * 8
         if _lib.interp_kind(kind) != _lib.interp_kind("cubic") or need > self.FUSED_CUBIC_ABOVE_BYTES:
             return False
-        if not adjoint and self.fermat_lm_ok(kind, self.kind if ne_kind is None else ne_kind, R):
+        if self.fermat_lm_ok(kind, self.kind if ne_kind is None else ne_kind, R, transpose=adjoint, bend=bend):
             return False                       # the library's own dispatch predicate: its fused tricubic-index kernel serves this launch
         try:                                   # never a hidden allocation beyond half of what the device has free
             free = torch.cuda.mem_get_info(self.device)[0]
@@ -370,7 +371,7 @@ class RayEngine(object):
         R = origins_t.shape[0]
         if out is None:
             out = torch.empty(R, dtype=torch.float64, device=self.device)
-        if self._two_step_fermat(R, Ns, kind, fused, ne_kind=ne_kind):
+        if self._two_step_fermat(R, Ns, kind, fused, ne_kind=ne_kind, bend=bend):
             rays = self.trace_fermat(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, substeps=substeps, type=type)
             self.forward_rays(rays, out=out, kind=ne_kind)
             if ne_scale != 1.0:
@@ -395,7 +396,7 @@ class RayEngine(object):
         ``forward_fermat``."""
         self._sync_stream()
         R = origins_t.shape[0]
-        if self._two_step_fermat(R, Ns, kind, fused, adjoint=True):
+        if self._two_step_fermat(R, Ns, kind, fused, adjoint=True, ne_kind=ne_kind, bend=bend):
             if out is None:
                 out = torch.zeros(self.shape, dtype=torch.float64, device=self.device)
             rays = self.trace_fermat(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, substeps=substeps, type=type)

@@ -307,3 +307,67 @@ def test_two_lanes_per_ray_of_the_record_tracer(how, O, monkeypatch):
         b = e8.forward_fermat(e8.tensor(far), d8, float(zv[24]), 21, 100e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
         assert e2.check_oob() and e8.check_oob()
         assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+def test_transpose_on_the_record_stepper(interp, monkeypatch):
+    """Round 5: large batches of bending rays through a tricubic index are BACK-PROJECTED on the record stepper too (k_fermat_tec_lm<ADJ>:
+    two lanes per ray, the wave's LDS scatter window for a trilinear integrand, per-lane 3 x 3 x 3 blocks for a tricubic one) instead of
+    through a ray tensor of 32 R Ns bytes.  Same numbers as trace + explicit-sample transpose, <A x, w> = <x, A^T w> against its own
+    forward, zero weights and rays leaving the domain contribute nothing, and small batches keep the two-step default."""
+    from ionotomo_amd.engine import RayEngine
+    w = syn.make_workload(antennas="example", na=7, nd=5, nt=3, n=33, margin_cells=10)
+    xv, yv, zv = w["xvec"], w["yvec"], w["zvec"]
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)          # 105 rays: the last wave has idle lane groups
+    small = RayEngine(0, interp=interp)
+    small.set_grid(xv, yv, zv)
+    assert small.fermat_lm_ok("cubic", interp, len(o)) and not small.fermat_lm_ok("cubic", interp, len(o), transpose=True)
+    assert small.fermat_lm_ok("cubic", interp, 40000, transpose=True) and not small.fermat_lm_ok("cubic", interp, 40000, transpose=True, bend=False)
+    assert small._two_step_fermat(len(o), 21, "cubic", None, adjoint=True) and not small._two_step_fermat(40000, 21, "cubic", None, adjoint=True)
+    monkeypatch.setenv("IONOTOMO_FERMAT_LM_FEW_MIN", "64")
+    eng = RayEngine(0, interp=interp)
+    eng.set_grid(xv, yv, zv)
+    eng.set_values(eng.tensor(w["ne"]))
+    assert eng.fermat_lm_ok("cubic", interp, len(o), transpose=True) and not eng._two_step_fermat(len(o), 21, "cubic", None, adjoint=True)
+    rng = np.random.default_rng(11)
+    y = rng.normal(size=len(o))
+    y[::9] = 0.0
+    ot, dt, yt = eng.tensor(o), eng.tensor(d), eng.tensor(y)
+    for typ in ("z", "s"):
+        tmax = float(zv[24]) if typ == "z" else 0.7 * float(zv[24])
+        for Ns in (21, 22):
+            ga = eng.adjoint_fermat(ot, dt, yt, tmax, Ns, 100e6, kind="cubic", substeps=2, type=typ, ne_scale=1e-13)                # the record stepper
+            gb = eng.adjoint_fermat(ot, dt, yt, tmax, Ns, 100e6, kind="cubic", substeps=2, type=typ, ne_scale=1e-13, fused=False)   # trace + scatter
+            assert float((ga - gb).abs().max()) < 1e-11 * float(gb.abs().max()), (typ, Ns)
+            # <A x, w> = <x, A^T w> with the fused forward on the same stepper
+            x = eng.tensor(rng.uniform(0.5, 1.5, size=w["ne"].shape) * 1e11)
+            eng.set_values(x)
+            ax = eng.forward_fermat(ot, dt, tmax, Ns, 100e6, kind="cubic", substeps=2, type=typ, ne_scale=1e-13)
+            atw = eng.adjoint_fermat(ot, dt, yt, tmax, Ns, 100e6, kind="cubic", substeps=2, type=typ, ne_scale=1e-13)
+            lhs, rhs = float((ax * yt).sum()), float((atw * x).sum())
+            assert abs(lhs - rhs) < 1e-10 * max(abs(lhs), float((ax.abs() * yt.abs()).sum())), (typ, Ns)
+            eng.set_values(eng.tensor(w["ne"]))
+    assert not eng.check_oob()
+    # accumulates into `out`; a ray that leaves the (tricubic) domain is flagged and its outside samples add nothing, like the two-step route
+    far = o.copy()
+    far[::7, 0] = xv[-1] - 0.5 * (xv[1] - xv[0])
+    ft = eng.tensor(far)
+    base = eng.tensor(rng.normal(size=w["ne"].shape))
+    ga = eng.adjoint_fermat(ft, dt, yt, float(zv[24]), 21, 100e6, kind="cubic", substeps=2, out=base.clone())
+    assert eng.check_oob()
+    gb = eng.adjoint_fermat(ft, dt, yt, float(zv[24]), 21, 100e6, kind="cubic", substeps=2, fused=False, out=base.clone())
+    assert eng.check_oob()
+    assert float((gb - base).abs().max()) > 1.0 and float((ga - gb).abs().max()) < 1e-11 * float((gb - base).abs().max())
+    # a grid too small for the scatter window (fewer than 12 x 12 x 16 nodes): plain atomics, same numbers
+    ws = syn.make_workload(antennas="example", na=5, nd=4, nt=2, n=11, margin_cells=3)
+    monkeypatch.setenv("IONOTOMO_FERMAT_LM_FEW_MIN", "16")
+    es = RayEngine(0, interp=interp)
+    es.set_grid(ws["xvec"], ws["yvec"], ws["zvec"])
+    es.set_values(es.tensor(ws["ne"]))
+    os_, ds_ = es.tensor(ws["origins"].reshape(-1, 3)), es.tensor(ws["directions"].reshape(-1, 3))
+    ys = es.tensor(rng.normal(size=os_.shape[0]))
+    tm = float(ws["zvec"][7])
+    assert es.fermat_lm_ok("cubic", interp, os_.shape[0], transpose=True)
+    ga = es.adjoint_fermat(os_, ds_, ys, tm, 15, 100e6, kind="cubic", substeps=2, ne_scale=1e-13)
+    gb = es.adjoint_fermat(os_, ds_, ys, tm, 15, 100e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=False)
+    assert float((ga - gb).abs().max()) < 1e-11 * float(gb.abs().max())
