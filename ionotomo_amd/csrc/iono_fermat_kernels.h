@@ -57,8 +57,16 @@ struct StreamQuad {
 // are skipped) and flushes it at the end.  A sample that does not fit even the re-centred window (rays of the wave far apart)
 // goes straight to global atomics: exactness never depends on the rays being neighbours.  Plain hardware atomics per corner
 // (64 lanes in 64 different rows) measured 131 ms at 620 000 rays x 257 samples; see profiles/ for the windowed number.
-#define FW 12
-#define FWZ 16
+// Window size (round 5, 620 000 rays x 257 samples through a trilinear index, ms per transpose; FW x FW x FWZ): 12 x 12 x 16 (rounds
+// 3-4) 13.5 | 12 x 12 x 8: 10.5 | 12 x 12 x 4: 10.0 | 16 x 16 x 4: 9.0 | 14 x 14 x 4: 8.3 | 16 x 16 x 3: 8.8 | 18 x 18 x 4: 9.5 | 8 x 8 x 8: 12.4.  The rays
+// of a wave are at (nearly) the same height at the same step, so a few levels suffice, and every KB of window costs resident waves
+// (18 KB: six waves per CU where the registers allow twelve).
+#ifndef FW
+#define FW 14
+#endif
+#ifndef FWZ
+#define FWZ 4
+#endif
 struct ScatterWindow {
     double *win;            // [FW][FW][FWZ] in LDS, this wave's
     int i0, j0, k0;         // first node of the window

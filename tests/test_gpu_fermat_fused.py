@@ -358,7 +358,7 @@ def test_transpose_on_the_record_stepper(interp, monkeypatch):
     gb = eng.adjoint_fermat(ft, dt, yt, float(zv[24]), 21, 100e6, kind="cubic", substeps=2, fused=False, out=base.clone())
     assert eng.check_oob()
     assert float((gb - base).abs().max()) > 1.0 and float((ga - gb).abs().max()) < 1e-11 * float((gb - base).abs().max())
-    # a grid too small for the scatter window (fewer than 12 x 12 x 16 nodes): plain atomics, same numbers
+    # a grid too small for the scatter window (fewer than 14 x 14 x 4 nodes): plain atomics, same numbers
     ws = syn.make_workload(antennas="example", na=5, nd=4, nt=2, n=11, margin_cells=3)
     monkeypatch.setenv("IONOTOMO_FERMAT_LM_FEW_MIN", "16")
     es = RayEngine(0, interp=interp)
