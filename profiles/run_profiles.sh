@@ -36,12 +36,14 @@ pmc() {     # pmc <leg> <set index> "<counters>"
 if [ "$PART" = "1" ]; then
   python3 $REPO/bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err || exit 1
   note "bench done"
-  stats forward --only forward --steps 20 --warmup 3          # the average IS the per-launch duration of the timed launches
-  stats adjoint --only adjoint --steps 10 --warmup 2
-  stats cubic_forward --only cubic_forward --steps 10 --warmup 2
-  stats cubic_adjoint --only cubic_adjoint --steps 4 --warmup 1
-  stats cgls --only cgls --steps 30 --warmup 1
-  stats sirt --only sirt --steps 30 --warmup 1
+  # (--settle-ms 150 as in the default bench run: ~1 000 untimed launches of the leg first, so the average is the SUSTAINED per-launch
+  #  duration the bench line times -- bench.py:settle, profiles/r05_clock_ramp.json)
+  stats forward --only forward --steps 20 --warmup 3 --settle-ms 600
+  stats adjoint --only adjoint --steps 10 --warmup 2 --settle-ms 150
+  stats cubic_forward --only cubic_forward --steps 10 --warmup 2 --settle-ms 150
+  stats cubic_adjoint --only cubic_adjoint --steps 10 --warmup 2 --settle-ms 150
+  stats cgls --only cgls --steps 30 --warmup 1 --settle-ms 150
+  stats sirt --only sirt --steps 30 --warmup 1 --settle-ms 150
   stats all --no-cpu --steps 20 --warmup 3
 fi
 SETS=("FETCH_SIZE" "WRITE_SIZE"
