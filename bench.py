@@ -833,7 +833,9 @@ def main():
             sel = torch.arange(R, device=eng.device).reshape(NA, NT, ND)[:, 0, :].reshape(-1)
             o1, d1 = o_t[sel].contiguous(), d_t[sel].contiguous()
             t1 = torch.empty(o1.shape[0], dtype=torch.float64, device=eng.device)
-            _, k1 = time_steps(lambda: eng.forward(o1, d1, TMAX, NS, out=t1), 50, 5, torch, dist, 1)
+            # (a latency figure, 50 launches of a few microseconds each: no settle phase -- a stream of launch-bound launches leaves the
+            #  device between power states and reads 10-13 us)
+            _, k1 = time_steps(lambda: eng.forward(o1, d1, TMAX, NS, out=t1), 50, 5, torch, dist, 1, settle_ms=0.0)
             extra["single_timestep_rays"] = int(o1.shape[0])
             extra["single_timestep_us"] = k1 * 1e6
             # ---- measured device-to-device copy (1 GiB read + 1 GiB written): the achievable HBM rate on this box
