@@ -8,46 +8,52 @@ namespace {
 // small elementwise / geometry kernels
 // ------------------------------------------------------------------------------------------------
 template <typename GT>
-__global__ void k_set_values(const double *__restrict__ src, GT *__restrict__ dst, int64_t n, int do_exp, double scale,
-                             int *nonfinite) {
-    bool bad = false;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+struct SetValues {                 // dst = (GT)src, or (GT)(exp(src) * scale); flags NaN / Inf
+    const double *__restrict__ src;
+    GT *__restrict__ dst;
+    int do_exp;
+    double scale;
+    int *nonfinite;
+    __device__ __forceinline__ void operator()(int64_t i) const {
         double v = src[i];
         if (do_exp) v = exp(v) * scale;
-        if (!isfinite(v)) bad = true;
+        if (!isfinite(v)) atomicOr(nonfinite, 1);
         dst[i] = (GT)v;
     }
-    if (bad) atomicOr(nonfinite, 1);
-}
+};
 
 template <typename GT>
-__global__ void k_get_values(const GT *__restrict__ src, double *__restrict__ dst, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        dst[i] = (double)src[i];
-}
+struct GetValues {
+    const GT *__restrict__ src;
+    double *__restrict__ dst;
+    __device__ __forceinline__ void operator()(int64_t i) const { dst[i] = (double)src[i]; }
+};
 
 // n = sqrt(1 - 8.980^2 ne / nu^2) at the nodes (inversion/fermat.py:36-46)
 template <typename GT>
-__global__ void k_ne_to_n(const GT *__restrict__ ne, double *__restrict__ nM, int64_t n, double freq) {
-    const double A = -PLASMA_A / (freq * freq);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        nM[i] = sqrt(1.0 + (double)ne[i] * A);
-}
+struct NeToN {
+    const GT *__restrict__ ne;
+    double *__restrict__ nM;
+    double freq;
+    __device__ __forceinline__ void operator()(int64_t i) const { nM[i] = sqrt(1.0 + (double)ne[i] * (-PLASMA_A / (freq * freq))); }
+};
 
 template <typename AT, typename GT>
-__global__ void k_scale_by_grid(AT *__restrict__ G, const GT *__restrict__ M, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        G[i] = (AT)((double)G[i] * (double)M[i]);
-}
+struct ScaleByGrid {
+    AT *__restrict__ G;
+    const GT *__restrict__ M;
+    __device__ __forceinline__ void operator()(int64_t i) const { G[i] = (AT)((double)G[i] * (double)M[i]); }
+};
 
-__global__ void k_subtract_reference(double *__restrict__ tec, int Na, int64_t NtNd, int i0) {
-    // rows other than i0 first (they read row i0), row i0 is zeroed by a second launch
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (int64_t)Na * NtNd;
-         idx += (int64_t)gridDim.x * blockDim.x) {
+struct SubtractReference {         // over Na * NtNd: rows other than i0 (they read row i0); row i0 is zeroed by a memset afterwards
+    double *__restrict__ tec;
+    int64_t NtNd;
+    int i0;
+    __device__ __forceinline__ void operator()(int64_t idx) const {
         const int a = idx / NtNd;
         if (a != i0) tec[idx] -= tec[(int64_t)i0 * NtNd + idx % NtNd];
     }
-}
+};
 // y = a x + b y with a = sa * a_num / a_den, b = b_num / b_den read from DEVICE scalars (null pointer = 1): the
 // solvers' step lengths are ratios of all-reduced dot products that never visit the host.  One pass, 16 B per lane.
 __global__ __launch_bounds__(256) void k_axpby(double *__restrict__ y, const double *__restrict__ x, int64_t n,
@@ -166,34 +172,36 @@ __global__ void k_interp_points(GridView g, const double *__restrict__ x, const 
 
 // stype = 1: arc length is the independent variable (Fermat type='s', inversion/fermat.py:74-82,165-166):
 // s = linspace(0, tmax, Ns), position = origin + p s
-__global__ void k_trace_straight(const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
-                                 int Ns, int stype, double *__restrict__ rays) {
-    const int64_t n = R * Ns;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+struct TraceStraight {             // over R * Ns samples
+    const double *__restrict__ origins;
+    const double *__restrict__ dirs;
+    double tmax;
+    int Ns, stype;
+    double *__restrict__ rays;
+    __device__ __forceinline__ void operator()(int64_t idx) const {
         const int64_t r = idx / Ns;
         const int k = idx % Ns;
+        double *o = rays + (size_t)r * 4 * Ns;
         if (stype) {
             const double dx = dirs[3 * r], dy = dirs[3 * r + 1], dz = dirs[3 * r + 2];
             const double nrm = sqrt(dx * dx + dy * dy + dz * dz);
             const double sv = (k == Ns - 1) ? tmax : tmax * ((double)k * (1.0 / (double)(Ns - 1)));
-            double *o = rays + (size_t)r * 4 * Ns;
             o[k] = origins[3 * r] + dx / nrm * sv;
             o[Ns + k] = origins[3 * r + 1] + dy / nrm * sv;
             o[2 * Ns + k] = origins[3 * r + 2] + dz / nrm * sv;
             o[3 * Ns + k] = sv;
-            continue;
+            return;
         }
         const StraightRay q = load_straight(origins, dirs, r, tmax, Ns);
         double x, y, z;
         straight_point(q, k, Ns, x, y, z);
-        double *o = rays + (size_t)r * 4 * Ns;
         o[k] = x;
         o[Ns + k] = y;
         o[2 * Ns + k] = z;
         const double frac = (k == Ns - 1) ? 1.0 : (double)k * q.step;
         o[3 * Ns + k] = q.L * frac / q.pz;     // s = (z - z0)/pz
     }
-}
+};
 
 // Fermat ray ODE in z (inversion/fermat.py:64-72; notebooks/FermatClass.ipynb c0:76-84):
 //   s' = n/pz, p' = grad(n) n/pz, x' = px/pz, y' = py/pz, z' = 1.   Lanes = rays, RK4.

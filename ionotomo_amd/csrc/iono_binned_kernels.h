@@ -55,15 +55,21 @@ struct BinUnit {
 // ray parameters in ideal grid coordinates, computed ONCE with the kernels' own arithmetic (load_uray / load_uray_cubic)
 // so that validity and sample positions are those of the forward kernels: uray[r] = fx0, dfx, fy0, dfy, fz0, dfz, h, valid
 template <bool CUBIC>
-__global__ void k_plan_urays(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, int64_t R, double tmax,
-                             int Ns, double *__restrict__ uray, uint2 *__restrict__ hash) {
-    for (int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; r < R; r += (int64_t)gridDim.x * blockDim.x) {
+struct PlanUrays {                 // over the R rays
+    GridView g;
+    const double *__restrict__ origins;
+    const double *__restrict__ dirs;
+    double tmax;
+    int Ns;
+    double *__restrict__ uray;
+    uint2 *__restrict__ hash;
+    __device__ __forceinline__ void operator()(int64_t r) const {
         const URay u = CUBIC ? load_uray_cubic(g, origins, dirs, r, tmax, Ns) : load_uray(g, origins, dirs, r, tmax, Ns);
         hash[r] = ray_hash(origins, dirs, r);
         double *o = uray + r * 8;
         o[0] = u.fx0, o[1] = u.dfx, o[2] = u.fy0, o[3] = u.dfy, o[4] = u.fz0, o[5] = u.dfz, o[6] = u.h, o[7] = u.valid ? 1.0 : 0.0;
     }
-}
+};
 
 // The plan itself, on the device (one thread per ray; a host loop over R x Ns samples took 0.26 s at the bench shape, eight
 // times a 50-iteration inversion).  Segments: <= segl consecutive samples of a ray inside one z-layer of boxes, filed under
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(64 * RSTEP_WAVES) void k_rays_step(const double *__
 // Scale = 2^e with  (largest contribution M) * 2^e <= 2^(62 - fixbits),  fixbits >= 12 bounding the contributions a node can receive
 // (the plan knows: 8 boxes' segments x lanes), so a sum never leaves int64 and a single value stays below 2^50: the conversion is ONE
 // fma against 1.5 * 2^52 (the integer sits in the mantissa) + a 64-bit subtraction.  M = max_r |w_r h_r| * 4/3 (Simpson), found by
-// k_fix_absmax for the weights of THIS launch; the grid of integers is turned into float64 and re-zeroed by k_fix_convert.
+// k_fix_absmax for the weights of THIS launch; the grid of integers is turned into float64 and re-zeroed by FixConvert (k_map).
 // A NaN weight (or a ray record poisoned by plan_verify_ray) gives M = inf -> scale NaN -> NaN at every node the launch reaches.
 #define FIX_MAGIC 6755399441055744.0       // 1.5 * 2^52
 __device__ __forceinline__ double fix_scale(unsigned long long maxbits, int fixbits) {
@@ -397,17 +403,21 @@ __global__ __launch_bounds__(256) void k_fix_nodemax(unsigned long long *__restr
     if (threadIdx.x == 0) atomicMax(out, max(max(wm[0], wm[1]), max(wm[2], wm[3])));
 }
 template <typename AT>
-__global__ __launch_bounds__(256) void k_fix_convert(unsigned long long *__restrict__ F, AT *__restrict__ grad, int64_t n,
-                                                     const unsigned long long *__restrict__ fixmax, int fixbits) {
-    const double inv = 1.0 / fix_scale(*fixmax, fixbits);      // a power of two (or NaN)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+struct FixConvert {                // grad += F / scale; F = 0 (the integer grid is zero between launches)
+    unsigned long long *__restrict__ F;
+    AT *__restrict__ grad;
+    const unsigned long long *__restrict__ fixmax;
+    int fixbits;
+    double inv;
+    __device__ __forceinline__ void begin() { inv = 1.0 / fix_scale(*fixmax, fixbits); }      // a power of two (or NaN)
+    __device__ __forceinline__ void operator()(int64_t i) const {
         const long long q = (long long)F[i];
         if (q != 0) {
             grad[i] = (AT)((double)grad[i] + (double)q * inv);
             F[i] = 0ull;
         }
     }
-}
+};
 
 __device__ __forceinline__ double dpp_shr1(double v) {       // value of the previous lane of the 16-lane row (0 for its first lane)
     // (bound_ctrl: the row's first lane reads 0 without an initialised destination -- eight v_mov fewer per pass)

@@ -410,6 +410,20 @@ __device__ __forceinline__ void straight_point(const StraightRay &q, int k, int 
     z = q.oz + dz;
 }
 
+// ---- one kernel for every element-wise helper: f(i) for i in [0, n), grid-stride.  F is a small struct of the operands with
+// `__device__ void operator()(int64_t i) const` and, where a per-thread set-up pays (device scalars), `__device__ void begin()`.
+template <class F>
+__device__ __forceinline__ auto map_begin(F &f, int) -> decltype(f.begin(), void()) {
+    f.begin();
+}
+template <class F>
+__device__ __forceinline__ void map_begin(F &, long) {}
+template <class F>
+__global__ __launch_bounds__(256) void k_map(int64_t n, F f) {
+    map_begin(f, 0);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) f(i);
+}
+
 }  // namespace
 
 #endif

@@ -672,18 +672,24 @@ __global__ __launch_bounds__(256) void k_bundle_keys(GridView g, const double *_
         keys[r] = code, idx[r] = (int)r, rec[r] = h;
     }
 }
-__global__ __launch_bounds__(256) void k_bundle_permute(const int *__restrict__ sorted_idx, const int *__restrict__ perm, int64_t R,
-                                                        int *__restrict__ order, const uint2 *__restrict__ hash_by_ray, uint2 *__restrict__ rhash) {
-    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < R; q += (int64_t)gridDim.x * blockDim.x) {
+struct BundlePermute {             // over the R walk positions
+    const int *__restrict__ sorted_idx;
+    const int *__restrict__ perm;
+    int *__restrict__ order;
+    const uint2 *__restrict__ hash_by_ray;
+    uint2 *__restrict__ rhash;
+    __device__ __forceinline__ void operator()(int64_t q) const {
         const int r = sorted_idx[perm[q]];
         order[q] = r;
         if (rhash) rhash[q] = hash_by_ray[r];           // in walk order: a bundle's hashes are one contiguous run
     }
-}
-__global__ __launch_bounds__(256) void k_bundle_gather(const BundleSummary *__restrict__ rec, const int *__restrict__ order, int64_t R,
-                                                       BundleSummary *__restrict__ sorted) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < R; i += (int64_t)gridDim.x * blockDim.x) sorted[i] = rec[order[i]];
-}
+};
+struct BundleGather {
+    const BundleSummary *__restrict__ rec;
+    const int *__restrict__ order;
+    BundleSummary *__restrict__ sorted;
+    __device__ __forceinline__ void operator()(int64_t i) const { sorted[i] = rec[order[i]]; }
+};
 
 // window of chunk c of bundle b: {imin, jmin, kz0, wx | wy << 8 | fits << 16 | rpl << 20}; one wave per bundle.  KC samples per chunk, an
 // image of LEV levels per column and MAXWY columns per row; EVEN: the window starts on an even level (8-byte values staged in 16-byte
@@ -1087,14 +1093,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(B_WPE_FOR(N
 // The headline kernel is bound by the NUMBER of vector-memory instructions (4 per 64 samples: a lane moves at most 16 B
 // per instruction and float64 trilinear needs four (i, j) corner columns x one 16-B z-pair).  With float32 storage the
 // four (j, k) corners of one x-plane fit ONE 16-B load if they are stored contiguously: Q4[i][j][k] = (M[i,j,k],
-// M[i,j,k+1], M[i,j+1,k], M[i,j+1,k+1]) -- 4 x the float32 memory, built by k_block_pairs whenever the values change --
+// M[i,j,k+1], M[i,j+1,k], M[i,j+1,k+1]) -- 4 x the float32 memory, built by BlockPairs (k_map) whenever the values change --
 // and a sample needs TWO loads (planes i and i + 1).  A storage-mode extra (values rounded to float32 once: 1e-7 relative),
 // never the float64 headline; arithmetic stays float64.
-__global__ __launch_bounds__(256) void k_block_pairs(const float *__restrict__ M, float4 *__restrict__ Q, int64_t n, int nz) {
+struct BlockPairs {
     // M is the padded float32 array (one plane + one row + 2 zeros beyond n): the far corners of the last nodes read zeros
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        Q[i] = make_float4(M[i], M[i + 1], M[i + nz], M[i + nz + 1]);
-}
+    const float *__restrict__ M;
+    float4 *__restrict__ Q;
+    int nz;
+    __device__ __forceinline__ void operator()(int64_t i) const { Q[i] = make_float4(M[i], M[i + 1], M[i + nz], M[i + nz + 1]); }
+};
 __device__ __forceinline__ double trilinear_q4(const float4 *__restrict__ q0p, const float4 *__restrict__ q1p, int ny, int nz, double fx,
                                                double fy, double fz) {
     const double fi = __builtin_floor(__builtin_fabs(fx)), fj = __builtin_floor(__builtin_fabs(fy)), fk = __builtin_floor(__builtin_fabs(fz));
@@ -1367,12 +1375,16 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
 }
 
-// transpose of k_phase_finish w.r.t. phi: per-ray, per-frequency weights of the phase adjoint
+// transpose of PhaseFinish w.r.t. phi: per-ray, per-frequency weights of the phase adjoint
 //   wrf[r][l] = -(2 pi nu_l / c) (y[r][l] - [a == i0] sum_a' y[a', p][l]),   y = dS/dg
-__global__ void k_phase_weights(const double *__restrict__ y, const double *__restrict__ freqs, int Na, int64_t NtNd, int Nf, int i0,
-                                double *__restrict__ wrf) {
-    const int64_t n = (int64_t)Na * NtNd * Nf;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+struct PhaseWeights {              // over Na * NtNd * Nf
+    const double *__restrict__ y;
+    const double *__restrict__ freqs;
+    int Na;
+    int64_t NtNd;
+    int Nf, i0;
+    double *__restrict__ wrf;
+    __device__ __forceinline__ void operator()(int64_t idx) const {
         const int l = idx % Nf;
         const int64_t r = idx / Nf;
         const int64_t p = r % NtNd;
@@ -1385,14 +1397,17 @@ __global__ void k_phase_weights(const double *__restrict__ y, const double *__re
         }
         wrf[idx] = -(2.0 * M_PI * freqs[l] / SPEED_OF_LIGHT) * v;
     }
-}
+};
 
 // g = const_i + 2 pi nu clock_ij - (phi - phi[i0]) 2 pi nu / c   (inversion/iterative_newton.py:107-123)
-__global__ void k_phase_finish(const double *__restrict__ phi, const double *__restrict__ freqs,
-                               const double *__restrict__ clock, const double *__restrict__ cst, int Na, int Nt, int Nd,
-                               int Nf, int i0, double *__restrict__ gout) {
-    const int64_t n = (int64_t)Na * Nt * Nd * Nf;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
+struct PhaseFinish {               // over Na * Nt * Nd * Nf
+    const double *__restrict__ phi;
+    const double *__restrict__ freqs;
+    const double *__restrict__ clock;
+    const double *__restrict__ cst;
+    int Nt, Nd, Nf, i0;
+    double *__restrict__ gout;
+    __device__ __forceinline__ void operator()(int64_t idx) const {
         const int l = idx % Nf;
         const int64_t r = idx / Nf;
         const int64_t td = r % ((int64_t)Nt * Nd);
@@ -1402,7 +1417,7 @@ __global__ void k_phase_finish(const double *__restrict__ phi, const double *__r
         const double ph = (phi[r * Nf + l] - phi[((int64_t)i0 * Nt * Nd + td) * Nf + l]) * (a_ / SPEED_OF_LIGHT);
         gout[idx] = cst[a] + a_ * clock[(int64_t)a * Nt + t] - ph;
     }
-}
+};
 
 }  // namespace
 

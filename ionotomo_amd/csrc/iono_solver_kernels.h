@@ -173,11 +173,12 @@ __global__ __launch_bounds__(256) void k_compact_gather(double *__restrict__ ful
     }
 }
 
-__global__ __launch_bounds__(256) void k_compact_scatter(double *__restrict__ full, const int *__restrict__ idx, int64_t n,
-                                                         const double *__restrict__ src) {
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (int64_t)gridDim.x * blockDim.x)
-        full[idx[t]] = src[t];
-}
+struct CompactScatter {
+    double *__restrict__ full;
+    const int *__restrict__ idx;
+    const double *__restrict__ src;
+    __device__ __forceinline__ void operator()(int64_t t) const { full[idx[t]] = src[t]; }
+};
 
 // CGLS tail in one pass:  x += alpha p;  p = s + beta p;  full_p[idx] = p      (alpha = an / ad, beta = bn / bd)
 __global__ __launch_bounds__(256) void k_compact_cg_update(double *__restrict__ x, double *__restrict__ p,

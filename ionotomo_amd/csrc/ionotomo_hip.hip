@@ -352,6 +352,12 @@ int ew_blocks(const iono_ctx *c, int64_t n) {
     return (int)(b > cap ? cap : (b < 1 ? 1 : b));
 }
 
+// the element-wise helpers are functors of ONE kernel (iono_device_common.h:k_map): F{operands...} by value, 256 threads per workgroup
+template <class F, class... A>
+void launch_map(iono_ctx *c, int blocks, int64_t n, A... a) {
+    hipLaunchKernelGGL((k_map<F>), dim3((unsigned)blocks), dim3(256), 0, c->stream, n, F{a...});
+}
+
 // unit-spacing quadrature weights (h = 1): straight rays sample s uniformly, so the integral is
 // h * sum(unitw * y).  Same formulas as quad_weight() above, evaluated once on the host.
 void host_unit_weights(int N, int rule, std::vector<double> &w) {
@@ -660,8 +666,7 @@ static int set_values_dev_impl(iono_ctx *c, const double *src_dev, int do_exp, d
     c->Q4_valid = false;
     int rc = dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL((k_set_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, src_dev, (GT *)cur_values(c), n,
-                           do_exp, scale, c->d_flags + 1);
+        launch_map<SetValues<GT>>(c, ew_blocks(c, n), n, src_dev, (GT *)cur_values(c), do_exp, scale, c->d_flags + 1);
         return IONO_OK;
     });
     HIP_TRY(c, hipGetLastError());
@@ -704,8 +709,7 @@ int iono_grid_get_values(iono_ctx *c, double *out) {
     HIP_TRY(c, tmp.alloc((size_t)n * 8));
     dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL((k_get_values<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c),
-                           tmp.as<double>(), n);
+        launch_map<GetValues<GT>>(c, ew_blocks(c, n), n, (const GT *)cur_values(c), tmp.as<double>());
         return IONO_OK;
     });
     HIP_TRY(c, hipGetLastError());
@@ -937,7 +941,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     uint2 *hash_by_ray = (uint2 *)(sb + off_h);
     hipLaunchKernelGGL(k_bundle_keys, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, view(c), o, d, R, tmax, Ns, k0, i0, r0, hash_by_ray);
     HIP_TRY(c, rocprim::radix_sort_pairs(sb + off_tmp, tmp_bytes, k0, k1, i0, i1, (size_t)R, 0, 64, c->stream));
-    hipLaunchKernelGGL(k_bundle_gather, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, r0, i1, R, r1);
+    launch_map<BundleGather>(c, ew_blocks(c, R), R, r0, i1, r1);
     HIP_TRY(c, hipGetLastError());
     // (pinned: [R summaries | R walk positions])
     char *hp = nullptr;
@@ -1013,7 +1017,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     {
         int *d_perm = i0;                                         // (scratch: the unsorted index array is no longer needed)
         HIP_TRY(c, hipMemcpyAsync(d_perm, perm, (size_t)R * sizeof(int), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_bundle_permute, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, i1, d_perm, R, fp.d_order, hash_by_ray, fp.d_rhash);
+        launch_map<BundlePermute>(c, ew_blocks(c, R), R, i1, d_perm, fp.d_order, hash_by_ray, fp.d_rhash);
         HIP_TRY(c, hipGetLastError());
     }
     bstart.push_back((int)R);
@@ -1102,7 +1106,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                 HIP_TRY(c, hipMemsetAsync(c->d_Q4, 0, (size_t)padded * sizeof(float4), c->stream));
             }
             if (!c->Q4_valid) {
-                hipLaunchKernelGGL(k_block_pairs, dim3(ew_blocks(c, n)), block, 0, c->stream, (const float *)cur_values(c), c->d_Q4, n, c->nz);
+                launch_map<BlockPairs>(c, ew_blocks(c, n), n, (const float *)cur_values(c), c->d_Q4, c->nz);
                 c->Q4_valid = true;
             }
             const size_t wl = sizeof(double) * Ns;
@@ -1191,7 +1195,7 @@ int iono_forward_tec_rays_dev(iono_ctx *c, const double *rays, int64_t R, int Ns
 int iono_subtract_reference_dev(iono_ctx *c, double *tec, int Na, int64_t NtNd, int i0) {
     { const int rc = need_ctx(c); if (rc) return rc; }
     if (i0 < 0 || i0 >= Na) return fail(c, IONO_ERR_ARG, "reference antenna index out of range");
-    hipLaunchKernelGGL(k_subtract_reference, dim3(ew_blocks(c, (int64_t)Na * NtNd)), dim3(256), 0, c->stream, tec, Na, NtNd, i0);
+    launch_map<SubtractReference>(c, ew_blocks(c, (int64_t)Na * NtNd), (int64_t)Na * NtNd, tec, NtNd, i0);
     HIP_TRY(c, hipMemsetAsync(tec + (int64_t)i0 * NtNd, 0, (size_t)NtNd * sizeof(double), c->stream));      // (row i0 - row i0, exactly)
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
@@ -1295,7 +1299,7 @@ int iono_compact_gather_dev(iono_ctx *c, double *full, const int *idx, int64_t n
 int iono_compact_scatter_dev(iono_ctx *c, double *full, const int *idx, int64_t n, const double *src) {
     { const int rc = need_ctx(c); if (rc) return rc; }
     { const int rc = compact_args_ok(c, idx, n); if (rc) return rc; }
-    hipLaunchKernelGGL(k_compact_scatter, dim3(IONO_NPART), dim3(256), 0, c->stream, full, idx, n, src);
+    launch_map<CompactScatter>(c, IONO_NPART, n, full, idx, src);
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
 }
@@ -1431,9 +1435,9 @@ int iono_adjoint_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, plan_reserve(pl.d_hash, pl.cap_hash, (size_t)R * sizeof(uint2)));
     const GridView g = view(c);
     if (cubic)
-        hipLaunchKernelGGL((k_plan_urays<true>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray, pl.d_hash);
+        launch_map<PlanUrays<true>>(c, ew_blocks(c, R), R, g, o, d, tmax, Ns, pl.d_uray, pl.d_hash);
     else
-        hipLaunchKernelGGL((k_plan_urays<false>), dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, g, o, d, R, tmax, Ns, pl.d_uray, pl.d_hash);
+        launch_map<PlanUrays<false>>(c, ew_blocks(c, R), R, g, o, d, tmax, Ns, pl.d_uray, pl.d_hash);
     HIP_TRY(c, hipGetLastError());
     const int nbx = (c->nx - 1 + BIN_SX - 1) / BIN_SX, nby = (c->ny - 1 + BIN_SY - 1) / BIN_SY, nbz = (c->nz - 1 + BIN_SZ - 1) / BIN_SZ;
     const int64_t nbox = (int64_t)nbx * nby * nbz;
@@ -1709,7 +1713,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         c->unit_lo = c->unit_hi = -1;
         if (c->deterministic) {
             // fixed-point accumulation: the largest |w h| of this launch -> scale; integers in the box images and in d_fixgrid; converted
-            // into `grad` (and re-zeroed) by k_fix_convert (iono_binned_kernels.h)
+            // into `grad` (and re-zeroed) by FixConvert (iono_binned_kernels.h)
             const int64_t n = ncells(c);
             { const int rcf = fix_prepare(c, wr, R, Ns); if (rcf) return rcf; }
             unsigned long long *fixmax = c->d_fixgrid + n;      // (allocated by fix_prepare on first use)
@@ -1717,7 +1721,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                 BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, 0, double, SL, true>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds,
                                                     c->stream, g, pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw,
                                                     (double *)c->d_fixgrid, PhaseFreqs{}, 0, fixmax, pl.fix_bits));
-            hipLaunchKernelGGL((k_fix_convert<AT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, c->d_fixgrid, grad, n, fixmax, pl.fix_bits);
+            launch_map<FixConvert<AT>>(c, ew_blocks(c, n), n, c->d_fixgrid, grad, fixmax, pl.fix_bits, 0.0);
             HIP_TRY(c, hipGetLastError());
             return IONO_OK;
         }
@@ -2038,8 +2042,7 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
             return IONO_OK;
         });
     }
-    hipLaunchKernelGGL(k_phase_finish, dim3(ew_blocks(c, R * Nf)), dim3(256), 0, c->stream, phi_work, c->d_freqs, clock, cst, Na, Nt,
-                       Nd, Nf, i0, gout);
+    launch_map<PhaseFinish>(c, ew_blocks(c, R * Nf), (int64_t)Na * Nt * Nd * Nf, phi_work, c->d_freqs, clock, cst, Nt, Nd, Nf, i0, gout);
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
 }
@@ -2058,7 +2061,7 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
     rc = ensure_unitw(c, Ns, rule);
     if (rc) return rc;
     const GridView g = view(c);
-    hipLaunchKernelGGL(k_phase_weights, dim3(ew_blocks(c, R * Nf)), dim3(256), 0, c->stream, y, c->d_freqs, Na, NtNd, Nf, i0, wrf_work);
+    launch_map<PhaseWeights>(c, ew_blocks(c, R * Nf), (int64_t)Na * NtNd * Nf, y, c->d_freqs, Na, NtNd, Nf, i0, wrf_work);
     const bool tiled = ideal_path_ok(c, Ns) && c->variant != 2;
     const iono_ctx::AdjPlan &pl = c->plan;
     const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax &&
@@ -2095,8 +2098,7 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
         const int64_t n = ncells(c);
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_scale_by_grid<double, GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, grad,
-                               (const GT *)cur_values(c), n);
+            launch_map<ScaleByGrid<double, GT>>(c, ew_blocks(c, n), n, grad, (const GT *)cur_values(c));
             return IONO_OK;
         });
     }
@@ -2233,8 +2235,7 @@ int iono_forward_phase_rays(iono_ctx *c, const double *rays, int Na, int Nt, int
             return IONO_OK;
         });
     }
-    hipLaunchKernelGGL(k_phase_finish, dim3(ew_blocks(c, (int64_t)nphi)), dim3(256), 0, c->stream, dPhi, dF, dClock, dConst, Na,
-                       Nt, Nd, Nf, i0, dG);
+    launch_map<PhaseFinish>(c, ew_blocks(c, (int64_t)nphi), (int64_t)Na * Nt * Nd * Nf, dPhi, dF, dClock, dConst, Nt, Nd, Nf, i0, dG);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(gout, dG, nphi * 8, hipMemcpyDeviceToHost, c->stream));
     return finish_host_call(c, "iono_forward_phase_rays");
@@ -2245,8 +2246,7 @@ static int adjoint_host_finish(iono_ctx *c, double *dG, int scale_by_grid, doubl
     if (scale_by_grid)
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_scale_by_grid<double, GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, dG,
-                               (const GT *)cur_values(c), n);
+            launch_map<ScaleByGrid<double, GT>>(c, ew_blocks(c, n), n, dG, (const GT *)cur_values(c));
             return IONO_OK;
         });
     HIP_TRY(c, hipGetLastError());
@@ -2317,7 +2317,7 @@ int iono_scale_by_grid_dev(iono_ctx *c, double *grad_dev) {
     const int64_t n = ncells(c);
     dispatch_storage(c, [&](auto *tag) {
         using GT = std::remove_pointer_t<decltype(tag)>;
-        hipLaunchKernelGGL((k_scale_by_grid<double, GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, grad_dev, (const GT *)cur_values(c), n);
+        launch_map<ScaleByGrid<double, GT>>(c, ew_blocks(c, n), n, grad_dev, (const GT *)cur_values(c));
         return IONO_OK;
     });
     HIP_TRY(c, hipGetLastError());
@@ -2440,7 +2440,7 @@ int iono_trace_straight(iono_ctx *c, const double *o, const double *d, int64_t R
     double *dR = b.as<double>(), *dO = dR + nr, *dD = dO + 3 * R;
     HIP_TRY(c, hipMemcpyAsync(dO, o, R * 24, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(dD, d, R * 24, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_trace_straight, dim3(ew_blocks(c, R * Ns)), dim3(256), 0, c->stream, dO, dD, R, tmax, Ns, independent, dR);
+    launch_map<TraceStraight>(c, ew_blocks(c, R * Ns), R * Ns, dO, dD, tmax, Ns, independent, dR);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(rays_out, dR, nr * 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -2460,8 +2460,7 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
     if (c->nM_freq != frequency) {       // n = sqrt(1 - 8.98^2 ne / nu^2) at the nodes, rebuilt when ne or nu changed
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_ne_to_n<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c), c->d_nM, n,
-                               frequency);
+            launch_map<NeToN<GT>>(c, ew_blocks(c, n), n, (const GT *)cur_values(c), c->d_nM, frequency);
             return IONO_OK;
         });
         c->nM_freq = frequency;
@@ -2561,7 +2560,7 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
     const int64_t n = ncells(c);
     if (!c->d_nM) HIP_TRY(c, hipMalloc((void **)&c->d_nM, (size_t)n * 8));
     if (c->nM_freq != frequency) {       // n = sqrt(1 - 8.98^2 ne / nu^2) at the nodes, rebuilt when ne or nu changed
-        hipLaunchKernelGGL((k_ne_to_n<double>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double *)cur_values(c), c->d_nM, n, frequency);
+        launch_map<NeToN<double>>(c, ew_blocks(c, n), n, (const double *)cur_values(c), c->d_nM, frequency);
         c->nM_freq = frequency;
         c->nF8_freq = -1.0;
     }
