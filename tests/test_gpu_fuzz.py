@@ -165,3 +165,47 @@ def test_library_then_torch_in_a_fresh_process():
             "print('ok')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", range(SOAK * 6))
+def test_random_curved_ray_launches_fused_against_traced(seed, monkeypatch):
+    """Random grids (ideal-uniform, any parity, some too small for the scatter window), ray sets, sample counts, rules and independent
+    variables: the fused curved-ray forward and transpose -- every route the library picks: lanes = rays, the record stepper with 8 and
+    with 2 lanes per ray, the windowed and the plain scatter -- against trace + explicit-sample kernels, and <A x, w> = <x, A^T w>."""
+    import torch
+    from ionotomo_amd.engine import RayEngine
+    rng = np.random.default_rng(900 + seed)
+    nx, ny, nz = (int(v) for v in rng.integers(9, 34, 3))
+    xv, yv, zv = np.linspace(-30.0, 25.0, nx), np.linspace(-18.0, 33.0, ny), np.linspace(0.0, 120.0, nz)
+    # a smooth ionosphere (bending stays a fraction of a cell) + roughness; values in m^-3
+    X, Y, Z = np.meshgrid(xv, yv, zv, indexing="ij")
+    ne = 1e11 * (1.0 + 0.5 * np.exp(-((Z - 60.0) / 25.0) ** 2) * (1.0 + 0.2 * np.sin(X / 9.0) * np.cos(Y / 7.0))) * rng.uniform(0.97, 1.03, size=X.shape)
+    R = int(rng.integers(3, 150))
+    Ns = int(rng.choice([5, 8, 9, 16, 21, 30]))
+    typ = "zs"[seed % 2]
+    rule = ["avg", "scipy", "trapz"][seed % 3]
+    kind = ["cubic", "linear"][(seed // 2) % 2]
+    interp = ["linear", "cubic"][(seed // 3) % 2]
+    lanes = [None, "2", "8"][seed % 3]
+    if lanes:
+        monkeypatch.setenv("IONOTOMO_FERMAT_LM_LANES", lanes)
+    eng = RayEngine(0, interp=interp, quad=rule)
+    eng.set_grid(xv, yv, zv)
+    eng.set_values(eng.tensor(ne))
+    hx, hy = xv[1] - xv[0], yv[1] - yv[0]
+    o = np.stack([rng.uniform(xv[0] + 4 * hx, xv[-1] - 4 * hx, R), rng.uniform(yv[0] + 4 * hy, yv[-1] - 4 * hy, R), rng.uniform(zv[2], zv[3], R)], -1)
+    d = np.stack([rng.uniform(-0.02, 0.02, R), rng.uniform(-0.02, 0.02, R), rng.uniform(0.8, 1.2, R)], -1)
+    tmax = float(zv[-3] - rng.uniform(0.0, 5.0)) if typ == "z" else float(0.8 * (zv[-3] - zv[3]))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    y = eng.tensor(rng.normal(size=R))
+    kw = dict(bend=True, kind=kind, substeps=int(rng.integers(1, 4)), type=typ, ne_scale=1e-13)
+    a = eng.forward_fermat(ot, dt, tmax, Ns, 80e6, fused=True, **kw)
+    b = eng.forward_fermat(ot, dt, tmax, Ns, 80e6, fused=False, **kw)
+    assert not eng.check_oob(), "test geometry: rays must stay inside"
+    assert float((a - b).abs().max()) < 1e-11 * float(b.abs().max()), (seed, "forward")
+    ga = eng.adjoint_fermat(ot, dt, y, tmax, Ns, 80e6, fused=True, **kw)
+    gb = eng.adjoint_fermat(ot, dt, y, tmax, Ns, 80e6, fused=False, **kw)
+    assert float((ga - gb).abs().max()) < 1e-11 * float(gb.abs().max()), (seed, "transpose")
+    lhs, rhs = float((a * y).sum()), float((ga * eng.tensor(ne)).sum()) * 1.0
+    assert abs(lhs - rhs) < 1e-10 * float((a.abs() * y.abs()).sum()), (seed, "dot")
+    del torch
