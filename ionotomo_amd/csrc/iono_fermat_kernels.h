@@ -122,11 +122,14 @@ struct ScatterWindow {
 // KN: interpolant of the refractive index (the tracer's right-hand side); kne (run-time): interpolant of the integrand.
 // ADJ = false: tec[r] = ne_scale * sum_k c_k ne(x_k);  ADJ = true: G += ne_scale * w[r] * c_k * (interpolation weights at x_k).
 // Lanes = rays; samples that leave the grid are skipped and flagged, as in k_forward_rays / k_adjoint_rays.
+// (the trilinear-index FORWARD is built for four waves per SIMD -- 127 VGPRs, 0 B of scratch: 620 000 rays 6.1 -> 5.6 ms, half of its
+//  wave cycles wait on memory; the same cap costs the transpose 44 B of scratch in its scatter: 8.2 -> 10.0 ms, left alone)
+#define FT_WPE_FOR(KN, ADJ) ((KN) == 0 && !(ADJ) ? 4 : 1), ((KN) == 0 && !(ADJ) ? 4 : 8)
 template <int KN, bool BEND, bool ADJ>
-__global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__restrict__ nM, const double *__restrict__ origins,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FT_WPE_FOR(KN, ADJ)))) void k_fermat_tec(GridView g, const double *__restrict__ nM, const double *__restrict__ origins,
                                                    const double *__restrict__ dirs, int64_t R, double tmax, int Ns, int substeps, int rule,
                                                    int stype, int kne, double ne_scale, const double *__restrict__ wray,
-                                                   double *__restrict__ tec, double *__restrict__ G, int *oob_flag) {
+                                                   double *__restrict__ tec, double *__restrict__ G, int *oob_flag, double ztop) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const Axes ax = stage_axes(g, lds);
     const bool windowed = ADJ && kne == IONO_INTERP_TRILINEAR && g.nx >= FW && g.ny >= FW && g.nz >= FWZ;     // (wave-uniform)
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
     u.x = origins[3 * r], u.y = origins[3 * r + 1], u.z = origins[3 * r + 2];
     u.s = 0.0;
     const double h = fermat_step(tmax, u.z, Ns, substeps, stype);
-    const double ztop = ax.z[ax.nz - 1] + 1e-9 * fabs(tmax);
+    // (ztop = last level + 1e-9 |tmax|, from the host: a kernel argument stays in scalar registers; computed here it was a vector
+    //  register pair the four-waves build spilled)
     bool oob = false;
     // value of the integrand (forward) or "inside" marker (adjoint) of the samples in the window
     const bool ideal_lin = g.ideal && kne == IONO_INTERP_TRILINEAR;       // (wave-uniform) no axis tables for the integrand either
@@ -235,7 +239,8 @@ __global__ __launch_bounds__(64) void k_fermat_tec(GridView g, const double *__r
     } else {
         if (Ns >= 2 && in0) acc = fma(q.w0, y0, acc);
         if (in1) acc = fma(q.w1, y1, acc);
-        tec[r] = acc * ne_scale;
+        // (the ray index again from the lane id -- one wave per workgroup -- instead of a register pair held, or spilled, for the whole walk)
+        tec[(int64_t)blockIdx.x * 64 + __lane_id()] = acc * ne_scale;
     }
     if (oob && lane_on) atomicOr(oob_flag, 1);
 }

@@ -2590,7 +2590,7 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
     const size_t lds = ((lds_bytes(c) + 15) & ~(size_t)15) + (adjoint ? sizeof(double) * FW * FW * FWZ : 0);
 #define LAUNCH_FT(K, B, A)                                                                                                              \
     hipLaunchKernelGGL((k_fermat_tec<K, B, A>), grid, block, lds, c->stream, g, c->d_nM, dO, dD, R, tmax, Ns, substeps, rule, independent,   \
-                       kind_ne, ne_scale, dW, tec, grad, c->d_flags)
+                       kind_ne, ne_scale, dW, tec, grad, c->d_flags, g.glast[2] + 1e-9 * std::fabs(tmax))
     if (kind_n == IONO_INTERP_TRILINEAR) {
         if (adjoint) { if (bend) LAUNCH_FT(IONO_INTERP_TRILINEAR, true, true); else LAUNCH_FT(IONO_INTERP_TRILINEAR, false, true); }
         else { if (bend) LAUNCH_FT(IONO_INTERP_TRILINEAR, true, false); else LAUNCH_FT(IONO_INTERP_TRILINEAR, false, false); }
