@@ -636,13 +636,18 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
                                                                     const BinUnit *__restrict__ units, const double *__restrict__ wray, int Ns,
                                                                     const double *__restrict__ unitw, double *__restrict__ G8, int64_t nstride,
                                                                     int rbit, const unsigned long long *__restrict__ fixmax = nullptr,
-                                                                    int fixbits = 0) {
+                                                                    int fixbits = 0, int n_units = 0, int *__restrict__ next_unit = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     double *tile = wlds + ((Ns + 1) & ~1);                           // [4][BIN_BX * BIN_BY][BIN_BZP]: channel c = p + 2 q
     for (int t = threadIdx.x; t < Ns; t += LM4_THREADS) wlds[t] = unitw[t];
     for (int t = threadIdx.x; t < 4 * BIN_TILE; t += LM4_THREADS) tile[t] = 0.0;
-    const BinUnit un = units[blockIdx.x];
+    // PERSISTENT workgroups (the four images leave room for one per CU): a workgroup starts on unit blockIdx.x and then takes the next
+    // unit nobody has (`next_unit`, zeroed by the host: the list is sorted largest first, so this is longest-processing-time-first);
+    // the images are re-zeroed word by word as they are flushed, the weights are staged once -- a unit no longer pays a workgroup
+    // launch, a 115-KB zeroing pass and a weights load, and the tail of the launch is one small unit per CU.
+    __shared__ int ui_next;
+    BinUnit un = units[blockIdx.x];
     lds_barrier();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     constexpr int PASS = LM4_THREADS / SEGL;
@@ -757,33 +762,40 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
             }
         }
     };
-    int e = un.e_lo + grp;
-    uint2 en0 = entries[e], en1 = entries[e + PASS];
-    RayRec r0 = load_ray(en0);
-    for (; e < un.e_hi; e += 2 * PASS) {
-        const uint2 en2 = entries[e + 2 * PASS];
-        const RayRec r1 = load_ray(en1);
-        pass(en0, r0, e);
-        const uint2 en3 = entries[e + 3 * PASS];
-        r0 = load_ray(en2);
-        pass(en1, r1, e + PASS);
-        en0 = en2, en1 = en3;
-    }
-    lds_barrier();
-    // ---- flush the four images: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
     const int mz = threadIdx.x & (BIN_BZP - 1);
-    for (int cc = threadIdx.x / BIN_BZP; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / BIN_BZP) {
-        const double v = tile[cc * BIN_BZP + mz];
-        if (FIX ? __double_as_longlong(v) != 0 : v != 0.0) {
-            const int ch = cc / (BIN_BX * BIN_BY), col = cc - ch * (BIN_BX * BIN_BY);
-            const int a = col / BIN_BY, b = col - a * BIN_BY;
-            const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + mz;
-            if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz) {
-                double *dst = G8 + (size_t)(4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk;
-                if (FIX) atomicAdd((unsigned long long *)dst, (unsigned long long)__double_as_longlong(v));
-                else atomicAdd(dst, v);
+    for (int ui = blockIdx.x; ui < n_units;) {
+        if (ui != (int)blockIdx.x) un = units[ui];
+        if (threadIdx.x == 0) ui_next = (int)gridDim.x + atomicAdd(next_unit, 1);
+        int e = un.e_lo + grp;
+        uint2 en0 = entries[e], en1 = entries[e + PASS];
+        RayRec r0 = load_ray(en0);
+        for (; e < un.e_hi; e += 2 * PASS) {
+            const uint2 en2 = entries[e + 2 * PASS];
+            const RayRec r1 = load_ray(en1);
+            pass(en0, r0, e);
+            const uint2 en3 = entries[e + 3 * PASS];
+            r0 = load_ray(en2);
+            pass(en1, r1, e + PASS);
+            en0 = en2, en1 = en3;
+        }
+        lds_barrier();
+        // ---- flush the four images: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
+        for (int cc = threadIdx.x / BIN_BZP; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / BIN_BZP) {
+            const double v = tile[cc * BIN_BZP + mz];
+            if (FIX ? __double_as_longlong(v) != 0 : v != 0.0) {
+                tile[cc * BIN_BZP + mz] = 0.0;                       // (the next unit of this workgroup starts from a clean image)
+                const int ch = cc / (BIN_BX * BIN_BY), col = cc - ch * (BIN_BX * BIN_BY);
+                const int a = col / BIN_BY, b = col - a * BIN_BY;
+                const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + mz;
+                if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz) {
+                    double *dst = G8 + (size_t)(4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk;
+                    if (FIX) atomicAdd((unsigned long long *)dst, (unsigned long long)__double_as_longlong(v));
+                    else atomicAdd(dst, v);
+                }
             }
         }
+        lds_barrier();
+        ui = ui_next;
     }
 }
 

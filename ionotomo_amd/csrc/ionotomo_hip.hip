@@ -92,6 +92,8 @@ struct iono_ctx {
     int seg_lanes = 0;               // env IONOTOMO_SEG_LANES=4|8|16: lanes per segment of the back-projection plan (0: chosen per geometry)
     int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
     int fermat_lm_lanes = 0;            // record tracer / fused TEC through a tricubic index: lanes per ray (8 or 2); 0 = by batch size
+    int *d_lm4_next = nullptr;          // [2] unit counters of the two persistent k_adjoint_binned_lm4 launches of a tricubic transpose
+    int lm4_groups = 0;                 // env IONOTOMO_LM4_GROUPS: persistent workgroups of the planned tricubic transpose (A/B; default: one per CU)
                                         // (env IONOTOMO_FERMAT_LM_LANES): 8 below fermat_lm_few_min rays, 2 from there on
     int64_t fermat_lm_few_min = 32768;  // (env IONOTOMO_FERMAT_LM_FEW_MIN)
     int64_t fermat_coop_max = INT64_MAX;   // tricubic tracer: 8 lanes per ray (faster than lanes = rays at every batch size
@@ -512,6 +514,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
 #endif
     if (const char *e = getenv("IONOTOMO_FERMAT_COOP_MAX")) c->fermat_coop_max = atoll(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_LM_LANES")) c->fermat_lm_lanes = atoi(e);
+    if (const char *e = getenv("IONOTOMO_LM4_GROUPS")) c->lm4_groups = atoi(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_LM_FEW_MIN")) c->fermat_lm_few_min = atoll(e);
     if (const char *e = getenv("IONOTOMO_FERMAT_COOP_RPW")) c->fermat_coop_rpw = std::min(8, std::max(1, atoi(e)));
     if (const char *e = getenv("IONOTOMO_FERMAT_LIN4_MAX")) c->fermat_lin4_max = atoll(e);
@@ -535,6 +538,7 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_FP) (void)hipFree(c->d_FP);
     if (c->d_nF8) (void)hipFree(c->d_nF8);
     if (c->d_G8) (void)hipFree(c->d_G8);
+    if (c->d_lm4_next) (void)hipFree(c->d_lm4_next);
     if (c->d_fixgrid) (void)hipFree(c->d_fixgrid);
     if (c->d_LMw) (void)hipFree(c->d_LMw);
     if (c->d_Q4) (void)hipFree(c->d_Q4);
@@ -1775,13 +1779,19 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_adjoint_binned_lm4<SL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
                     c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2] = true;
                 }
+                // (persistent workgroups, one per CU -- the four images are all the LDS a CU has -- pulling units off a counter)
+                const dim3 pgrid((unsigned)std::min(pl.n_units, c->lm4_groups > 0 ? c->lm4_groups : c->num_cus));
+                if (!c->d_lm4_next) HIP_TRY(c, hipMalloc((void **)&c->d_lm4_next, 2 * sizeof(int)));
+                HIP_TRY(c, hipMemsetAsync(c->d_lm4_next, 0, 2 * sizeof(int), c->stream));
                 for (int rb = 0; rb < 2; ++rb) {
                     if (fix_cubic)
-                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, true>), dim3(pl.n_units), dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
-                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, fixmax, pl.fix_bits);
+                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, true>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
+                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, fixmax, pl.fix_bits, pl.n_units,
+                                           c->d_lm4_next + rb);
                     else
-                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, false>), dim3(pl.n_units), dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
-                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb);
+                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, false>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
+                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, (const unsigned long long *)nullptr, 0,
+                                           pl.n_units, c->d_lm4_next + rb);
                 }
             });
             HIP_TRY(c, hipGetLastError());
