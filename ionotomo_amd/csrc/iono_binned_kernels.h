@@ -763,12 +763,11 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
         }
     };
     const int mz = threadIdx.x & (BIN_BZP - 1);
+    int e = un.e_lo + grp;
+    uint2 en0 = entries[e], en1 = entries[e + PASS];
+    RayRec r0 = load_ray(en0);
     for (int ui = blockIdx.x; ui < n_units;) {
-        if (ui != (int)blockIdx.x) un = units[ui];
         if (threadIdx.x == 0) ui_next = (int)gridDim.x + atomicAdd(next_unit, 1);
-        int e = un.e_lo + grp;
-        uint2 en0 = entries[e], en1 = entries[e + PASS];
-        RayRec r0 = load_ray(en0);
         for (; e < un.e_hi; e += 2 * PASS) {
             const uint2 en2 = entries[e + 2 * PASS];
             const RayRec r1 = load_ray(en1);
@@ -779,6 +778,15 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
             en0 = en2, en1 = en3;
         }
         lds_barrier();
+        // the next unit's record, first entries and first ray records are in flight while this unit's images are flushed
+        const int x0 = un.x0, y0 = un.y0, z0 = un.z0;
+        ui = ui_next;
+        if (ui < n_units) {
+            un = units[ui];
+            e = un.e_lo + grp;
+            en0 = entries[e], en1 = entries[e + PASS];
+            r0 = load_ray(en0);
+        }
         // ---- flush the four images: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
         for (int cc = threadIdx.x / BIN_BZP; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / BIN_BZP) {
             const double v = tile[cc * BIN_BZP + mz];
@@ -786,7 +794,7 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
                 tile[cc * BIN_BZP + mz] = 0.0;                       // (the next unit of this workgroup starts from a clean image)
                 const int ch = cc / (BIN_BX * BIN_BY), col = cc - ch * (BIN_BX * BIN_BY);
                 const int a = col / BIN_BY, b = col - a * BIN_BY;
-                const int gi = un.x0 + a, gj = un.y0 + b, gk = un.z0 + mz;
+                const int gi = x0 + a, gj = y0 + b, gk = z0 + mz;
                 if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz) {
                     double *dst = G8 + (size_t)(4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk;
                     if (FIX) atomicAdd((unsigned long long *)dst, (unsigned long long)__double_as_longlong(v));
@@ -795,7 +803,6 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
             }
         }
         lds_barrier();
-        ui = ui_next;
     }
 }
 

@@ -265,6 +265,7 @@ __device__ __forceinline__ bool lm_tile_has(int flags, int l, int dd, int L) {
 __global__ __launch_bounds__(256) void k_lm_zero_tiles(double *__restrict__ G8, const LmTile *__restrict__ tiles, LmTileGeom tg) {
     const int64_t n = (int64_t)tg.nx * tg.ny * tg.nz;
     const int id = tiles[blockIdx.x].id;
+#pragma unroll
     for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
         int i, j, k, a, b, cc;
         if (!lm_tile_node(tg, id, q, i, j, k, a, b, cc)) continue;
@@ -309,6 +310,7 @@ __global__ __launch_bounds__(256) void k_lm_fold_z_tiles(const double *__restric
 __global__ __launch_bounds__(256) void k_lm_fold_y_tiles(const double2 *__restrict__ H0, const double2 *__restrict__ H1, double *__restrict__ K0,
                                                          double *__restrict__ K1, const LmTile *__restrict__ tiles, LmTileGeom tg) {
     const LmTile t = tiles[blockIdx.x];
+#pragma unroll
     for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
         int i, j, k, a, b, cc;
         if (!lm_tile_node(tg, t.id, q, i, j, k, a, b, cc)) continue;
@@ -331,6 +333,7 @@ __global__ __launch_bounds__(256) void k_lm_fold_x_tiles(const double *__restric
                                                          const LmTile *__restrict__ tiles, LmTileGeom tg) {
     const int64_t sx = (int64_t)tg.ny * tg.nz;
     const LmTile t = tiles[blockIdx.x];
+#pragma unroll
     for (int q = threadIdx.x; q < LMT_NODES; q += 256) {
         int i, j, k, a, b, cc;
         if (!lm_tile_node(tg, t.id, q, i, j, k, a, b, cc)) continue;

@@ -1654,8 +1654,9 @@ static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
     iono_ctx::AdjPlan &pl = c->plan;
     const int64_t n = ncells(c);
     if (!c->d_fixgrid) {
-        HIP_TRY(c, hipMalloc((void **)&c->d_fixgrid, ((size_t)n + 1) * sizeof(unsigned long long)));
-        HIP_TRY(c, hipMemsetAsync(c->d_fixgrid, 0, ((size_t)n + 1) * sizeof(unsigned long long), c->stream));
+        // [n] integer grid | the launch's largest |w h| | the two unit counters of a tricubic transpose (one memset clears both words)
+        HIP_TRY(c, hipMalloc((void **)&c->d_fixgrid, ((size_t)n + 2) * sizeof(unsigned long long)));
+        HIP_TRY(c, hipMemsetAsync(c->d_fixgrid, 0, ((size_t)n + 2) * sizeof(unsigned long long), c->stream));
     }
     unsigned long long *fixmax = c->d_fixgrid + n;
     if (!pl.fix_counted) {
@@ -1677,7 +1678,7 @@ static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
         pl.fix_bits = bits;
         pl.fix_counted = true;
     }
-    HIP_TRY(c, hipMemsetAsync(fixmax, 0, sizeof(unsigned long long), c->stream));
+    HIP_TRY(c, hipMemsetAsync(fixmax, 0, 2 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_fix_absmax, dim3((unsigned)std::min<int64_t>(256, (R + 255) / 256)), dim3(256), 0, c->stream, wr, pl.d_uray, R, fixmax);
     HIP_TRY(c, hipGetLastError());
     return IONO_OK;
@@ -1781,13 +1782,15 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                 }
                 // (persistent workgroups, one per CU -- the four images are all the LDS a CU has -- pulling units off a counter)
                 const dim3 pgrid((unsigned)std::min(pl.n_units, c->lm4_groups > 0 ? c->lm4_groups : c->num_cus));
-                if (!c->d_lm4_next) HIP_TRY(c, hipMalloc((void **)&c->d_lm4_next, 2 * sizeof(int)));
-                HIP_TRY(c, hipMemsetAsync(c->d_lm4_next, 0, 2 * sizeof(int), c->stream));
+                if (!fix_cubic) {          // (fixed point: fix_prepare has just cleared the counters behind its scale word)
+                    if (!c->d_lm4_next) HIP_TRY(c, hipMalloc((void **)&c->d_lm4_next, 2 * sizeof(int)));
+                    HIP_TRY(c, hipMemsetAsync(c->d_lm4_next, 0, 2 * sizeof(int), c->stream));
+                }
                 for (int rb = 0; rb < 2; ++rb) {
                     if (fix_cubic)
                         hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, true>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
                                            pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, fixmax, pl.fix_bits, pl.n_units,
-                                           c->d_lm4_next + rb);
+                                           (int *)(c->d_fixgrid + n + 1) + rb);
                     else
                         hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, false>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
                                            pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, (const unsigned long long *)nullptr, 0,
