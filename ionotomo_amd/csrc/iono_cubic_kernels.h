@@ -34,30 +34,48 @@ __device__ __forceinline__ double fd_coef(int d) {
 // ever weighs them: tricubic samples live in g[2] <= x <= g[n-3]): 0.
 // `xrange` (round 5): the node lines the current forward plan's windows hold (k_lm_touch_lines) -- Z is then formed only where the
 // restricted y / x pass reads it: on the lines within two of such a line in y, two planes beyond its range in x.
+#define LM_XSEG 8
 template <typename GT>
 __global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, double2 *__restrict__ Z, int nx, int ny, int nz,
                                                      const int2 *__restrict__ xrange) {
     const int64_t n = (int64_t)nx * ny * nz;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int k = (int)(idx % nz);
-        if (xrange) {
-            const int64_t ij = idx / nz;
-            const int j = (int)(ij % ny), i = (int)(ij / ny);
-            bool need = false;
-#pragma unroll
-            for (int dj = -2; dj <= 2; ++dj) {
-                const int jj = j + dj;
-                if (jj < 0 || jj >= ny) continue;
-                const int2 xr = xrange[(int64_t)jj * nz + k];
-                need |= xr.y >= 0 && i >= xr.x - 2 && i <= xr.y + 2;
-            }
-            if (!need) continue;
-        }
+    auto one = [&](int64_t idx, int k) {
         const GT *row = M + idx;
         double dz = 0.0;
         if (k >= 2 && k <= nz - 3)
             dz = fd_coef(-2) * (double)row[-2] + fd_coef(-1) * (double)row[-1] + fd_coef(1) * (double)row[1] + fd_coef(2) * (double)row[2];
         Z[idx] = make_double2((double)row[0], dz);
+    };
+    if (!xrange) {
+        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) one(idx, (int)(idx % nz));
+        return;
+    }
+    // restricted: a thread owns a (j, k) line (lanes along k) and one of LM_XSEG stretches of it, reads the five x-ranges that decide
+    // which of its nodes the y / x pass will read ONCE, and visits only those (an element-wise pass looked the ranges up for every
+    // node of the grid: 126 us for a third of the bench grid)
+    const int64_t sx = (int64_t)ny * nz, lines = sx * LM_XSEG;
+    const int seg_len = (nx + LM_XSEG - 1) / LM_XSEG;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < lines; t += (int64_t)gridDim.x * blockDim.x) {
+        const int seg = (int)(t / sx);
+        const int64_t jk = t - (int64_t)seg * sx;
+        const int j = (int)(jk / nz), k = (int)(jk - (int64_t)j * nz);
+        int lo[5], hi[5], i0 = nx, i1 = -1;
+#pragma unroll
+        for (int dj = -2; dj <= 2; ++dj) {
+            const int jj = j + dj;
+            int2 xr = make_int2(0, -1);
+            if (jj >= 0 && jj < ny) xr = xrange[(int64_t)jj * nz + k];
+            const bool any = xr.y >= 0;
+            lo[dj + 2] = any ? xr.x - 2 : nx, hi[dj + 2] = any ? xr.y + 2 : -1;
+            i0 = min(i0, lo[dj + 2]), i1 = max(i1, hi[dj + 2]);
+        }
+        i0 = max(max(i0, 0), seg * seg_len), i1 = min(min(i1, nx - 1), seg * seg_len + seg_len - 1);
+        for (int i = i0; i <= i1; ++i) {
+            bool need = false;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) need |= i >= lo[q] && i <= hi[q];
+            if (need) one((int64_t)i * sx + jk, k);
+        }
     }
 }
 // z stride of F8 in nodes.  (Padding it to nz + 1 -- at 256^3 the column and plane strides, 16 KB and 4 MB, are powers of
@@ -75,7 +93,6 @@ __global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, d
 // store of a wave is one contiguous run.  Output: F8[node][p + 2 (q + 2 r)] node-major (k_forward_straight_lm), or -- PAIRS -- the
 // same four (value, Dx value) pairs PAIR-major, FP[t = q + 2 r][node] (double2, node = the grid's own linear index, npad nodes per
 // pair array): the layout the bundle-stationary forward stages from (k_forward_bundle_lm).
-#define LM_XSEG 8
 // `xrange` (round 5, PAIRS only): per (j, k) line the planes [lo, hi] the current forward plan's windows hold (k_lm_touch_lines) -- only
 // those nodes are written: an inversion iteration rebuilds the fields its rays read (a third of the bench grid), not 1 GiB.
 template <bool PAIRS>

@@ -789,8 +789,9 @@ static int ensure_lm_fields(iono_ctx *c, bool pairs = false, bool for_plan = fal
     if (!(pairs ? c->FP_valid : c->F8_valid)) {
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_lm_fields_z<GT>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const GT *)cur_values(c),
-                               (double2 *)c->d_LMw, c->nx, c->ny, c->nz, restricted ? (const int2 *)c->fplan.d_xrange : (const int2 *)nullptr);
+            hipLaunchKernelGGL((k_lm_fields_z<GT>), dim3(ew_blocks(c, restricted ? (int64_t)c->ny * c->nz * LM_XSEG : n)), dim3(256), 0, c->stream,
+                               (const GT *)cur_values(c), (double2 *)c->d_LMw, c->nx, c->ny, c->nz,
+                               restricted ? (const int2 *)c->fplan.d_xrange : (const int2 *)nullptr);
             return IONO_OK;
         });
         const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
