@@ -223,28 +223,49 @@ __global__ __launch_bounds__(256) void k_plan_verify(const double *__restrict__ 
 }
 
 // per-ray weights of the fused modes (residual / differential), one value per ray: the binned kernel visits a ray once
-// per segment, so the reference-antenna sums are formed here, once.  One wave per (time, direction) pair p, lanes =
-// antennas: the column sum over antennas is a wave reduction instead of a 62-step loop in the i0 threads.
+// per segment, so the reference-antenna sums are formed here, once.  Lanes = RSTEP_PT consecutive (time, direction) pairs p (ray
+// index a NtNd + p: every load of a wave is a few contiguous 128-byte runs), the 64 / RSTEP_PT x RSTEP_WAVES lane groups of a workgroup
+// = groups of antennas; the column sum over antennas goes through LDS in a fixed order.  (Round 5: lanes = antennas -- every lane of
+// a load in a different row of the arrays, the ray check included -- took 21 us of a 0.28 ms back-projection.)
 // (+ the plan's ray check of the launch that follows, in the same pass over the rays: `origins` non-null)
+#define RSTEP_WAVES 16      // waves of a workgroup of k_ray_weights / k_rays_step
+#define RSTEP_PT 16         // consecutive (time, direction) pairs per workgroup (a 128-byte run per load); 64 / RSTEP_PT antenna groups per wave
 template <int MODE>
-__global__ __launch_bounds__(256) void k_ray_weights(const double *__restrict__ tec, const double *__restrict__ dobs,
-                                                     const double *__restrict__ cdct, int Na, int64_t NtNd, int i0,
-                                                     double *__restrict__ w, const double *__restrict__ origins = nullptr,
-                                                     const double *__restrict__ dirs = nullptr, const uint2 *__restrict__ hash = nullptr,
-                                                     double *__restrict__ uray = nullptr, int *__restrict__ flags = nullptr) {
-    const int lane = threadIdx.x & 63;
-    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < NtNd; p += (int64_t)gridDim.x * 4) {
-        if (origins)
-            for (int a = lane; a < Na; a += 64) plan_verify_ray(origins, dirs, (int64_t)a * NtNd + p, hash, uray, flags);
-        const double tref = MODE == 2 ? 0.0 : tec[(int64_t)i0 * NtNd + p];
+__global__ __launch_bounds__(64 * RSTEP_WAVES) void k_ray_weights(const double *__restrict__ tec, const double *__restrict__ dobs,
+                                                                  const double *__restrict__ cdct, int Na, int64_t NtNd, int i0,
+                                                                  double *__restrict__ w, const double *__restrict__ origins = nullptr,
+                                                                  const double *__restrict__ dirs = nullptr,
+                                                                  const uint2 *__restrict__ hash = nullptr, double *__restrict__ uray = nullptr,
+                                                                  int *__restrict__ flags = nullptr) {
+    constexpr int AS = 64 / RSTEP_PT, NG = RSTEP_WAVES * AS;      // antenna groups per wave / per workgroup
+    __shared__ double ssum[NG][RSTEP_PT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pl = lane & (RSTEP_PT - 1), gidx = wv * AS + lane / RSTEP_PT;
+    const int a_lo = Na * gidx / NG, a_hi = Na * (gidx + 1) / NG;
+    for (int64_t p0 = (int64_t)blockIdx.x * RSTEP_PT; p0 < NtNd; p0 += (int64_t)gridDim.x * RSTEP_PT) {
+        const int64_t p = p0 + pl;
+        const bool on = p < NtNd;
+        const double tref = (MODE != 2 && on) ? tec[(int64_t)i0 * NtNd + p] : 0.0;
         double s = 0.0;
-        for (int a = lane; a < Na; a += 64) s += dd_of<MODE>(tec, dobs, cdct, tref, (int64_t)a * NtNd + p);
-        s = wave_sum_dpp(s);
-        for (int a = lane; a < Na; a += 64) {
-            const int64_t r = (int64_t)a * NtNd + p;
-            const double v = dd_of<MODE>(tec, dobs, cdct, tref, r);
-            w[r] = a == i0 ? v - s : v;
+        if (on) {
+            for (int a = a_lo; a < a_hi; ++a) {
+                const int64_t r = (int64_t)a * NtNd + p;
+                if (origins) plan_verify_ray(origins, dirs, r, hash, uray, flags);
+                const double v = dd_of<MODE>(tec, dobs, cdct, tref, r);
+                w[r] = v;                                    // (the reference-antenna row is corrected below)
+                s += v;
+            }
         }
+        ssum[gidx][pl] = s;
+        __syncthreads();
+        if (on && i0 >= a_lo && i0 < a_hi) {                 // the thread that wrote w[i0, p] (its own store)
+            double tot = 0.0;
+#pragma unroll 8
+            for (int t = 0; t < NG; ++t) tot += ssum[t][pl];
+            const int64_t r = (int64_t)i0 * NtNd + p;
+            w[r] = w[r] - tot;
+        }
+        __syncthreads();
     }
 }
 
@@ -255,8 +276,6 @@ __global__ __launch_bounds__(256) void k_ray_weights(const double *__restrict__ 
 //                 (= k_rays_combine + k_ray_weights<2>: 5 -> 4)
 // + the plan's ray check of the back-projection that follows (origins non-null).  One wave per (time, direction) pair, lanes =
 // antennas; one partial per workgroup, summed in a fixed order by the consumer (no atomics: identical bits on every rank).
-#define RSTEP_WAVES 16      // waves of a workgroup of k_rays_step
-#define RSTEP_PT 16         // consecutive (time, direction) pairs per workgroup (a 128-byte run per load); 64 / RSTEP_PT antenna groups per wave
 template <int MODE>
 __global__ __launch_bounds__(64 * RSTEP_WAVES) void k_rays_step(const double *__restrict__ tq, const double *__restrict__ dobs,
                                                                 const double *__restrict__ scale, const double *__restrict__ weight,

@@ -1705,7 +1705,8 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             c->rayw_cap = R;
         }
         // (+ the check that the rays are still the planned ones, in the same pass: plan_verify_ray)
-        hipLaunchKernelGGL((k_ray_weights<MODE == 0 ? 1 : MODE>), dim3(ew_blocks(c, NtNd * 64)), dim3(256), 0, c->stream, tec, dobs,
+        hipLaunchKernelGGL((k_ray_weights<MODE == 0 ? 1 : MODE>), dim3((unsigned)std::min<int64_t>(IONO_NPART, (NtNd + RSTEP_PT - 1) / RSTEP_PT)),
+                           dim3(64 * RSTEP_WAVES), 0, c->stream, tec, dobs,
                            cdct, Na, NtNd, i0, c->d_rayw, o, d, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
         wr = c->d_rayw;
     } else if (planned && !c->plan_verified) {
