@@ -486,22 +486,13 @@ def cfg4_leg(w, local, k2, torch, dist, world):
     for name in ("cgls", "sirt"):
         fn = getattr(solvers, name)
         fn(prob, x0, n_iter=2)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        fn(prob, x0, n_iter=10)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        out["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 10 * 1e3
-        # BASELINE config 5 "as 4": the whole 50-iteration inversion, wall clock incl. the solver's set-up (normalisations, active set)
-        t0 = time.perf_counter()
-        fn(prob, x0, n_iter=50)
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        out["%s_50_iterations_ms" % name] = (time.perf_counter() - t0) * 1e3
+        # (whole solves, set-up included -- normalisations, active set, buffers -- timed like every other leg: settled, wall clock, MAX over ranks)
+        w10, _ = time_steps(lambda: fn(prob, x0, n_iter=10), 3, 1, torch, dist, world)
+        out["%s_ms_per_iteration" % name] = w10 / 3 / 10 * 1e3
+        # BASELINE config 5 "as 4": the whole 50-iteration inversion
+        w50, _ = time_steps(lambda: fn(prob, x0, n_iter=50), 2, 0, torch, dist, world)
+        out["%s_50_iterations_ms" % name] = w50 / 2 * 1e3
+        out["%s_ms_per_iteration_marginal" % name] = (w50 / 2 - w10 / 3) / 40 * 1e3        # an iteration without the solve's set-up
     if world > 1:
         # the same iterations with the exchange hidden behind the back-projection (exchange="overlap": the plan in z-slabs, every slab's
         # finished node levels all-reduced asynchronously while the next slab is back-projected), float64 and float32 on the links
@@ -879,11 +870,11 @@ def main():
                 for name in ("cgls", "sirt"):
                     fn = getattr(solvers, name)
                     fn(prob, x0, n_iter=2)
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    fn(prob, x0, n_iter=30)
-                    torch.cuda.synchronize()
-                    extra["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 30 * 1e3
+                    # (whole solves, set-up included, settled like every other leg; `_marginal`: an iteration without the set-up)
+                    w30, _ = time_steps(lambda: fn(prob, x0, n_iter=30), 3, 1, torch, dist, 1)
+                    w10, _ = time_steps(lambda: fn(prob, x0, n_iter=10), 3, 1, torch, dist, 1)
+                    extra["%s_ms_per_iteration" % name] = w30 / 3 / 30 * 1e3
+                    extra["%s_ms_per_iteration_marginal" % name] = (w30 - w10) / 3 / 20 * 1e3
                 del prob
                 if planned:                                 # (the solver problem planned its own tensors: back to the bench's)
                     eng.plan_forward(o_t, d_t, TMAX, NS)
