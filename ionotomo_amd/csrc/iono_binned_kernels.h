@@ -16,8 +16,9 @@ namespace {
 //   * segments are sorted by box; a workgroup takes a unit (a box and up to BIN_UNIT of its segments), accumulates them
 //     in an LDS image of the box (16 lanes per segment, lanes = consecutive samples = consecutive z words: conflict-free
 //     LDS atomics) and flushes the box ONCE.
-// Contributions that fall outside the box image (steep segments) go straight to global atomics, and every sample of
-// every ray is in exactly one segment by construction, so the result never depends on the quality of the binning.
+// Every sample of every ray is in exactly one segment by construction, and a segment is cut where its (x, y) extent would leave
+// the halo (round 5: a steep ray gets shorter segments, `outside` is 0 for every geometry); the kernels still send a contribution
+// that falls outside the box image straight to global atomics, so the result never depends on the quality of the binning.
 // ------------------------------------------------------------------------------------------------
 #define BIN_SX 8
 #define BIN_SY 8
@@ -164,10 +165,16 @@ __global__ __launch_bounds__(256) void k_plan_segments(const double *__restrict_
             int box = 0, ke = k;
             if (active) {
                 const int zb = plan_cell(fz0, dfz, k, nz) / BIN_SZ;
+                const int xa = plan_cell(fx0, dfx, k, nx), ya = plan_cell(fy0, dfy, k, ny);
                 ke = k + 1;
-                while (ke < Ns && ke - k < segl && plan_cell(fz0, dfz, ke, nz) / BIN_SZ == zb) ++ke;
-                const int xa = plan_cell(fx0, dfx, k, nx), xb = plan_cell(fx0, dfx, ke - 1, nx);
-                const int ya = plan_cell(fy0, dfy, k, ny), yb = plan_cell(fy0, dfy, ke - 1, ny);
+                // (... and whose (x, y) extent fits the halo whatever its middle box: a steep ray is cut into shorter segments instead of
+                //  sending samples past the image to global atomics -- `outside` stays 0 for every geometry)
+                int xb = xa, yb = ya;
+                while (ke < Ns && ke - k < segl && plan_cell(fz0, dfz, ke, nz) / BIN_SZ == zb) {
+                    const int xn = plan_cell(fx0, dfx, ke, nx), yn = plan_cell(fy0, dfy, ke, ny);
+                    if (abs(xn - xa) > 2 * BIN_H - 1 || abs(yn - ya) > 2 * BIN_H - 1) break;
+                    xb = xn, yb = yn, ++ke;
+                }
                 const int bi = min(nbx - 1, (xa + xb + 1) / (2 * BIN_SX)), bj = min(nby - 1, (ya + yb + 1) / (2 * BIN_SY));
                 box = (bi * nby + bj) * nbz + zb;
                 if (!EMIT) {

@@ -50,7 +50,7 @@ def test_binned_adjoint_random_geometries(seed, OC):
     ot, dt = eng.tensor(o), eng.tensor(d)
     w = rng.normal(size=R)
     segs, units, outside = eng.plan_adjoint(ot, dt, zhi, Ns)
-    assert segs > 0 and units > 0 and 0.0 <= outside <= 1.0
+    assert segs > 0 and units > 0 and outside == 0.0      # (round 5: a steep ray is cut into segments that fit their box image: nothing goes past it)
     g = eng.adjoint(ot, dt, eng.tensor(w), zhi, Ns).cpu().numpy()
     assert eng.check_oob() == (not inside.all())                               # rays leaving the grid are skipped and flagged
     gref = OC.adjoint_straight(xv, yv, zv, o[inside], d[inside], w[inside], zhi, Ns)
