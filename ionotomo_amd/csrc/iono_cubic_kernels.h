@@ -251,14 +251,19 @@ __global__ __launch_bounds__(256) void k_lm_fold_x(const double *__restrict__ K0
 }
 
 // ---- the same three passes over the TILES a back-projection plan's rays reach (round 4) ------------------------------------------------
-// A plan knows which 8 x 8 x 16-node tiles its samples add into (k_plan_touch: T).  The z pass can only give non-zero values on
+// A plan knows which LMT_X x LMT_Y x LMT_Z-node tiles its samples add into (k_plan_touch: T).  The z pass can only give non-zero values on
 // A1 = T dilated by one tile along z, the y pass on A2 = A1 dilated along y, the x pass on A3 = A2 dilated along x: each pass runs
 // over the list of its OUTPUT tiles and reads its input only where the previous pass wrote it (flags: centre / lower / upper
 // neighbour tile of the fold axis belong to the input set; G8 is zeroed on A1 only).  Everything outside is never written and
 // never read, so the channel buffers need no full-grid memset and the folds stream the reached fraction of the grid.
-#define LMT_X 8
-#define LMT_Y 8
+// (tile shape, ms per planned tricubic back-projection at the bench shape, same box: 8 x 8 x 16 (round 4) 2.010 | 4 x 4 x 16 1.973 | 8 x 4 x 16 1.979 |
+//  4 x 2 x 16 1.992 | 2 x 4 x 16 1.999 | 4 x 4 x 32 2.002 | 4 x 4 x 8 2.002 | 4 x 8 x 32 2.049 | 4 x 4 x 64 2.088 | 2 x 2 x 16 2.090: the finer the tiles
+//  across the rays, the tighter the set the zeroing and the three folds stream; longer z runs bought nothing)
+#ifndef LMT_X
+#define LMT_X 4
+#define LMT_Y 4
 #define LMT_Z 16
+#endif
 #define LMT_NODES (LMT_X * LMT_Y * LMT_Z)
 struct LmTile {
     int id;         // (ti * nty + tj) * ntz + tk
