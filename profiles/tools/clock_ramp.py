@@ -5,12 +5,13 @@
 import csv, glob, json, statistics, sys
 
 f = glob.glob(sys.argv[1] + "/*/*_kernel_trace.csv")[0]
-rows = [r for r in csv.DictReader(open(f)) if "k_forward_bundle" in r["Kernel_Name"]]
+NAME = sys.argv[2] if len(sys.argv) > 2 else "k_forward_bundle"
+rows = [r for r in csv.DictReader(open(f)) if NAME in r["Kernel_Name"]]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 d = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in rows]
 s = [int(r["Start_Timestamp"]) for r in rows]
 windows = [(0, 10), (10, 20), (20, 30), (30, 50), (50, 100), (100, 200), (200, 400), (400, 800), (800, 1600), (1600, 3200), (3200, len(d))]
-out = {"what": "k_forward_bundle<0>, bench shape (260 400 rays x 257 samples, 256^3): device duration of each of %d back-to-back launches "
+out = {"what": ("k_forward_bundle<0>, bench shape (260 400 rays x 257 samples, 256^3)" if NAME == "k_forward_bundle" else NAME) + ": device duration of each of %d back-to-back launches "
                "after idle (rocprofv3 --kernel-trace of `bench.py --only forward --steps %d`), mean per window of launch indices" % (len(d), len(d) - 3),
        "mean_us_by_launch_index": {"%d-%d" % (a, min(b, len(d))): round(statistics.mean(d[a:b]), 2) for a, b in windows if a < len(d)},
        "elapsed_ms_at_index": {str(i): round((s[i] - s[0]) / 1e6, 2) for i in (10, 50, 100, 200, 400, 800, 1600, 3200) if i < len(d)},
