@@ -29,55 +29,13 @@ __device__ __forceinline__ double fd_coef(int d) {
     return d == -2 ? 1.0 / 12.0 : d == -1 ? -8.0 / 12.0 : d == 1 ? 8.0 / 12.0 : d == 2 ? -1.0 / 12.0 : 0.0;
 }
 
-// F8[node][8] from the stored values, axis by axis (the stencils are separable): Z = (f, Dz f), then Dy, then Dx -- 5 loads
-// per node and pass, lanes along z in every pass, instead of the 125 loads of a direct 5 x 5 x 5 evaluation.  Nodes within 2 of a face have no slope along that axis (no valid sample
+// F8[node][8] from the stored values, axis by axis (the stencils are separable): Z = (f, Dz f), then Dy, then Dx, lanes along z,
+// instead of the 125 loads of a direct 5 x 5 x 5 evaluation.  (Round 5: Z is formed on the fly inside the y / x kernel -- its five z
+// taps are the neighbouring lanes' own loads, L1 hits -- instead of by a pass of its own through a 16-byte-per-node array.)  Nodes within 2 of a face have no slope along that axis (no valid sample
 // ever weighs them: tricubic samples live in g[2] <= x <= g[n-3]): 0.
 // `xrange` (round 5): the node lines the current forward plan's windows hold (k_lm_touch_lines) -- Z is then formed only where the
 // restricted y / x pass reads it: on the lines within two of such a line in y, two planes beyond its range in x.
 #define LM_XSEG 8
-template <typename GT>
-__global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, double2 *__restrict__ Z, int nx, int ny, int nz,
-                                                     const int2 *__restrict__ xrange) {
-    const int64_t n = (int64_t)nx * ny * nz;
-    auto one = [&](int64_t idx, int k) {
-        const GT *row = M + idx;
-        double dz = 0.0;
-        if (k >= 2 && k <= nz - 3)
-            dz = fd_coef(-2) * (double)row[-2] + fd_coef(-1) * (double)row[-1] + fd_coef(1) * (double)row[1] + fd_coef(2) * (double)row[2];
-        Z[idx] = make_double2((double)row[0], dz);
-    };
-    if (!xrange) {
-        for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (int64_t)gridDim.x * blockDim.x) one(idx, (int)(idx % nz));
-        return;
-    }
-    // restricted: a thread owns a (j, k) line (lanes along k) and one of LM_XSEG stretches of it, reads the five x-ranges that decide
-    // which of its nodes the y / x pass will read ONCE, and visits only those (an element-wise pass looked the ranges up for every
-    // node of the grid: 126 us for a third of the bench grid)
-    const int64_t sx = (int64_t)ny * nz, lines = sx * LM_XSEG;
-    const int seg_len = (nx + LM_XSEG - 1) / LM_XSEG;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < lines; t += (int64_t)gridDim.x * blockDim.x) {
-        const int seg = (int)(t / sx);
-        const int64_t jk = t - (int64_t)seg * sx;
-        const int j = (int)(jk / nz), k = (int)(jk - (int64_t)j * nz);
-        int lo[5], hi[5], i0 = nx, i1 = -1;
-#pragma unroll
-        for (int dj = -2; dj <= 2; ++dj) {
-            const int jj = j + dj;
-            int2 xr = make_int2(0, -1);
-            if (jj >= 0 && jj < ny) xr = xrange[(int64_t)jj * nz + k];
-            const bool any = xr.y >= 0;
-            lo[dj + 2] = any ? xr.x - 2 : nx, hi[dj + 2] = any ? xr.y + 2 : -1;
-            i0 = min(i0, lo[dj + 2]), i1 = max(i1, hi[dj + 2]);
-        }
-        i0 = max(max(i0, 0), seg * seg_len), i1 = min(min(i1, nx - 1), seg * seg_len + seg_len - 1);
-        for (int i = i0; i <= i1; ++i) {
-            bool need = false;
-#pragma unroll
-            for (int q = 0; q < 5; ++q) need |= i >= lo[q] && i <= hi[q];
-            if (need) one((int64_t)i * sx + jk, k);
-        }
-    }
-}
 // z stride of F8 in nodes.  (Padding it to nz + 1 -- at 256^3 the column and plane strides, 16 KB and 4 MB, are powers of
 // two and TCP_READ_TAGCONFLICT_STALL is 15 % of the forward's cycles -- measured 8 % SLOWER: 2.07 vs 1.92 ms.)
 #ifndef LM_PAD_J
@@ -95,8 +53,8 @@ __global__ __launch_bounds__(256) void k_lm_fields_z(const GT *__restrict__ M, d
 // pair array): the layout the bundle-stationary forward stages from (k_forward_bundle_lm).
 // `xrange` (round 5, PAIRS only): per (j, k) line the planes [lo, hi] the current forward plan's windows hold (k_lm_touch_lines) -- only
 // those nodes are written: an inversion iteration rebuilds the fields its rays read (a third of the bench grid), not 1 GiB.
-template <bool PAIRS>
-__global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict__ Z, double *__restrict__ F8, int nx, int ny, int nz, int64_t npad,
+template <bool PAIRS, typename GT>
+__global__ __launch_bounds__(256) void k_lm_fields_yx(const GT *__restrict__ M, double *__restrict__ F8, int nx, int ny, int nz, int64_t npad,
                                                       const int2 *__restrict__ xrange) {
     const int64_t sx = (int64_t)ny * nz, lines = sx * LM_XSEG;
     const int seg_len = (nx + LM_XSEG - 1) / LM_XSEG;
@@ -112,6 +70,14 @@ __global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict_
             if (i0 >= i1) continue;
         }
         const bool yslope = j >= 2 && j <= ny - 3;
+        const int kk = (int)(jk - (int64_t)j * nz);
+        const bool zslope = kk >= 2 && kk <= nz - 3;
+        auto zpair = [&](int64_t node) {                 // Z = (f, Dz f) of a node: 0 slope within two of a z face
+            const GT *row = M + node;
+            double dz = 0.0;
+            if (zslope) dz = fd_coef(-2) * (double)row[-2] + fd_coef(-1) * (double)row[-1] + fd_coef(1) * (double)row[1] + fd_coef(2) * (double)row[2];
+            return make_double2((double)row[0], dz);
+        };
         double2 a[5], b[5];                      // a = (f, Dy f), b = (Dz f, Dy Dz f) of planes io - 2 .. io + 2 (slot 4 = the newest)
 #pragma unroll
         for (int q = 0; q < 5; ++q) a[q] = b[q] = make_double2(0.0, 0.0);
@@ -120,14 +86,14 @@ __global__ __launch_bounds__(256) void k_lm_fields_yx(const double2 *__restrict_
             for (int q = 0; q < 4; ++q) a[q] = a[q + 1], b[q] = b[q + 1];
             a[4] = b[4] = make_double2(0.0, 0.0);
             if (ii >= 0 && ii < nx) {
-                const double2 *zp = Z + (int64_t)ii * sx + jk;
-                const double2 z0 = zp[0];
+                const int64_t node = (int64_t)ii * sx + jk;
+                const double2 z0 = zpair(node);
                 double dy0 = 0.0, dy1 = 0.0;
                 if (yslope) {
 #pragma unroll
                     for (int db = -2; db <= 2; ++db) {
                         if (db == 0) continue;
-                        const double2 z = zp[(int64_t)db * nz];
+                        const double2 z = zpair(node + (int64_t)db * nz);
                         dy0 += fd_coef(db) * z.x, dy1 += fd_coef(db) * z.y;
                     }
                 }

@@ -119,7 +119,7 @@ struct iono_ctx {
     double *d_G8 = nullptr;          // channel buffers [8][nodes] of the tricubic transpose (lazily allocated)
     bool deterministic = false;      // iono_set_deterministic / env IONOTOMO_DETERMINISTIC=1: fixed-point back-projection (k_adjoint_binned<.., FIX>)
     unsigned long long *d_fixgrid = nullptr;      // its grid of 64-bit integers [nodes] + the launch's largest |w h| behind it; all zero between launches
-    double *d_LMw = nullptr;         // [nodes][6] scratch of the axis-by-axis field build / fold
+    double *d_LMw = nullptr;         // [nodes][6] scratch of the tricubic transpose's folds (H0 | H1 | K0 | K1)
     float4 *d_Q4 = nullptr;          // float32 storage: 2 x 2 (y, z) corner blocks for the 2-loads-per-sample forward (lazily built)
     bool Q4_valid = false;
     // node-stationary back-projection plan (iono_adjoint_plan_dev; iono_binned_kernels.h): geometry only, library-owned
@@ -785,22 +785,18 @@ static int ensure_lm_fields(iono_ctx *c, bool pairs = false, bool for_plan = fal
         HIP_TRY(c, hipMalloc((void **)&c->d_FP, fb));
         HIP_TRY(c, hipMemsetAsync(c->d_FP, 0, fb, c->stream));      // (pad nodes: staged with a window's last levels, never weighed)
     }
-    if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
     if (!(pairs ? c->FP_valid : c->F8_valid)) {
+        const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            hipLaunchKernelGGL((k_lm_fields_z<GT>), dim3(ew_blocks(c, restricted ? (int64_t)c->ny * c->nz * LM_XSEG : n)), dim3(256), 0, c->stream,
-                               (const GT *)cur_values(c), (double2 *)c->d_LMw, c->nx, c->ny, c->nz,
-                               restricted ? (const int2 *)c->fplan.d_xrange : (const int2 *)nullptr);
+            if (pairs)
+                hipLaunchKernelGGL((k_lm_fields_yx<true, GT>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const GT *)cur_values(c), c->d_FP,
+                                   c->nx, c->ny, c->nz, npad, restricted ? (const int2 *)c->fplan.d_xrange : (const int2 *)nullptr);
+            else
+                hipLaunchKernelGGL((k_lm_fields_yx<false, GT>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const GT *)cur_values(c), c->d_F8,
+                                   c->nx, c->ny, c->nz, npad, (const int2 *)nullptr);
             return IONO_OK;
         });
-        const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
-        if (pairs)
-            hipLaunchKernelGGL((k_lm_fields_yx<true>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_FP,
-                               c->nx, c->ny, c->nz, npad, restricted ? (const int2 *)c->fplan.d_xrange : (const int2 *)nullptr);
-        else
-            hipLaunchKernelGGL((k_lm_fields_yx<false>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_F8,
-                               c->nx, c->ny, c->nz, npad, (const int2 *)nullptr);
         HIP_TRY(c, hipGetLastError());
         if (!pairs) c->F8_valid = true;
         else if (restricted) c->FP_plan_serial = c->fplan.serial;
@@ -817,12 +813,9 @@ static int ensure_n_fields(iono_ctx *c, double frequency) {
         HIP_TRY(c, hipMemsetAsync(c->d_nF8, 0, fb, c->stream));
         c->nF8_freq = -1.0;
     }
-    if (!c->d_LMw) HIP_TRY(c, hipMalloc((void **)&c->d_LMw, (size_t)n * 6 * sizeof(double)));
     if (c->nF8_freq != frequency) {
-        hipLaunchKernelGGL((k_lm_fields_z<double>), dim3(ew_blocks(c, n)), dim3(256), 0, c->stream, (const double *)c->d_nM, (double2 *)c->d_LMw,
-                           c->nx, c->ny, c->nz, (const int2 *)nullptr);
         const int64_t lines = (int64_t)c->ny * c->nz * LM_XSEG;
-        hipLaunchKernelGGL((k_lm_fields_yx<false>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double2 *)c->d_LMw, c->d_nF8,
+        hipLaunchKernelGGL((k_lm_fields_yx<false, double>), dim3(ew_blocks(c, lines)), dim3(256), 0, c->stream, (const double *)c->d_nM, c->d_nF8,
                            c->nx, c->ny, c->nz, padded_count(c), (const int2 *)nullptr);
         HIP_TRY(c, hipGetLastError());
         c->nF8_freq = frequency;
