@@ -1757,7 +1757,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         const bool tiled = planned && pl.tile_n[2] > 0;
         const LmTileGeom tg{c->nx, c->ny, c->nz, (c->ny + LMT_Y - 1) / LMT_Y, (c->nz + LMT_Z - 1) / LMT_Z};
         if (tiled)
-            hipLaunchKernelGGL(k_lm_zero_tiles, dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, pl.d_tiles + pl.tile_off[0], tg);
+            hipLaunchKernelGGL(k_lm_zero_tiles, dim3(pl.tile_n[0]), dim3(LMT_NODES / 2), 0, c->stream, c->d_G8, pl.d_tiles + pl.tile_off[0], tg);
         else
             HIP_TRY(c, hipMemsetAsync(c->d_G8, 0, (size_t)n * LM_NF * sizeof(double), c->stream));
         const unsigned long long *fixmax = nullptr;
@@ -1805,14 +1805,14 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         double *K0 = c->d_LMw + 4 * n, *K1 = K0 + n;
         if (tiled) {
             if (fix_cubic)
-                hipLaunchKernelGGL((k_lm_fold_z_tiles<true>), dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
+                hipLaunchKernelGGL((k_lm_fold_z_tiles<true>), dim3(pl.tile_n[0]), dim3(LMT_NODES / 2), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
                                    fixmax, pl.fix_bits);
             else
-                hipLaunchKernelGGL((k_lm_fold_z_tiles<false>), dim3(pl.tile_n[0]), dim3(256), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
+                hipLaunchKernelGGL((k_lm_fold_z_tiles<false>), dim3(pl.tile_n[0]), dim3(LMT_NODES / 2), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
                                    (const unsigned long long *)nullptr, 0);
             hipLaunchKernelGGL(k_lm_fold_y_tiles, dim3(pl.tile_n[1]), dim3(256), 0, c->stream, (const double2 *)H0, (const double2 *)H1, K0, K1,
                                pl.d_tiles + pl.tile_off[1], tg);
-            hipLaunchKernelGGL((k_lm_fold_x_tiles<AT>), dim3(pl.tile_n[2]), dim3(256), 0, c->stream, (const double *)K0, (const double *)K1, grad,
+            hipLaunchKernelGGL((k_lm_fold_x_tiles<AT>), dim3(pl.tile_n[2]), dim3(LMT_NODES / 2), 0, c->stream, (const double *)K0, (const double *)K1, grad,
                                pl.d_tiles + pl.tile_off[2], tg);
             HIP_TRY(c, hipGetLastError());
             return IONO_OK;
