@@ -444,6 +444,29 @@ struct FixConvert {                // grad += F / scale; F = 0 (the integer grid
         }
     }
 };
+// the same over the tiles the planned rays reach (iono_cubic_kernels.h: LmTile; i = tile ordinal * LMT_NODES + node of the tile): a third
+// of the bench grid instead of all of it
+template <typename AT>
+struct FixConvertTiles {
+    unsigned long long *__restrict__ F;
+    AT *__restrict__ grad;
+    const unsigned long long *__restrict__ fixmax;
+    int fixbits;
+    const LmTile *__restrict__ tiles;
+    LmTileGeom tg;
+    double inv;
+    __device__ __forceinline__ void begin() { inv = 1.0 / fix_scale(*fixmax, fixbits); }
+    __device__ __forceinline__ void operator()(int64_t it) const {
+        int i, j, k, a, b, cc;
+        if (!lm_tile_node(tg, tiles[it / LMT_NODES].id, (int)(it % LMT_NODES), i, j, k, a, b, cc)) return;
+        const int64_t idx = ((int64_t)i * tg.ny + j) * tg.nz + k;
+        const long long q = (long long)F[idx];
+        if (q != 0) {
+            grad[idx] = (AT)((double)grad[idx] + (double)q * inv);
+            F[idx] = 0ull;
+        }
+    }
+};
 
 __device__ __forceinline__ double dpp_shr1(double v) {       // value of the previous lane of the 16-lane row (0 for its first lane)
     // (bound_ctrl: the row's first lane reads 0 without an initialised destination -- eight v_mov fewer per pass)

@@ -1671,6 +1671,11 @@ static int fix_prepare(iono_ctx *c, const double *wr, int64_t R, int Ns) {
         //  bound of the plan -- 8 boxes x the fullest box x the segment length -- does not cover: ADVICE r4)
         pl.fix_bits = bits;
         pl.fix_counted = true;
+        // a trilinear plan: list the tiles its rays reach, so that the integer grid is converted (and re-zeroed) only there
+        if (pl.kind == IONO_INTERP_TRILINEAR && pl.tile_n[0] == 0) {
+            const int rct = plan_fold_tiles(c, R, Ns);
+            if (rct) return rct;
+        }
     }
     HIP_TRY(c, hipMemsetAsync(fixmax, 0, 2 * sizeof(unsigned long long), c->stream));
     hipLaunchKernelGGL(k_fix_absmax, dim3((unsigned)std::min<int64_t>(256, (R + 255) / 256)), dim3(256), 0, c->stream, wr, pl.d_uray, R, fixmax);
@@ -1721,7 +1726,14 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                 BY_SEGL(pl.segl, hipLaunchKernelGGL((k_adjoint_binned<double, 0, double, SL, true>), dim3(u_hi - u_lo), dim3(BIN_THREADS), bin_lds,
                                                     c->stream, g, pl.d_uray, pl.d_entries, pl.d_units + u_lo, wr, Ns, c->d_unitw,
                                                     (double *)c->d_fixgrid, PhaseFreqs{}, 0, fixmax, pl.fix_bits));
-            launch_map<FixConvert<AT>>(c, ew_blocks(c, n), n, c->d_fixgrid, grad, fixmax, pl.fix_bits, 0.0);
+            if (pl.tile_n[0] > 0) {          // (the tiles the planned rays reach, listed when the mode was first used: fix_prepare)
+                const LmTileGeom tg{c->nx, c->ny, c->nz, (c->ny + LMT_Y - 1) / LMT_Y, (c->nz + LMT_Z - 1) / LMT_Z};
+                const int64_t nn = (int64_t)pl.tile_n[0] * LMT_NODES;
+                launch_map<FixConvertTiles<AT>>(c, ew_blocks(c, nn), nn, c->d_fixgrid, grad, fixmax, pl.fix_bits,
+                                                (const LmTile *)(pl.d_tiles + pl.tile_off[0]), tg, 0.0);
+            } else {
+                launch_map<FixConvert<AT>>(c, ew_blocks(c, n), n, c->d_fixgrid, grad, fixmax, pl.fix_bits, 0.0);
+            }
             HIP_TRY(c, hipGetLastError());
             return IONO_OK;
         }
