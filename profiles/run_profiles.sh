@@ -65,6 +65,7 @@ fi
 if [ "$PART" = "3" ]; then
   i=0; for C in "${SETS[@]}"; do i=$((i+1)); [ $i -ge $FIRST ] && pmc adjoint $i "$C"; done
   for i in 1 3 4 5 6 7 8 10; do pmc cubic_forward $i "${SETS[$((i-1))]}"; done
+  for i in 4 5 7 8 10; do pmc cubic_adjoint $i "${SETS[$((i-1))]}"; done
 fi
 if [ "$PART" = "5" ]; then      # the Fermat integrator: 620 000 curved rays (both indices) and config 3
   for i in 5 6 7 8; do pmc fermat_cubic $i "${SETS[$((i-1))]}"; done
