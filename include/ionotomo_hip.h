@@ -272,6 +272,18 @@ int iono_scale_by_grid_dev(iono_ctx *ctx, double *grad_dev);
 int iono_forward_plan_dev(iono_ctx *ctx, const double *origins_dev, const double *directions_dev, int64_t R, double tmax, int Ns);
 int iono_forward_plan_clear(iono_ctx *ctx);
 int iono_forward_plan_info(iono_ctx *ctx, int64_t *n_bundles, int *n_chunks, double *fit_fraction);
+/* Hybrid dispatch (round 6): which bundles are worth a workgroup is decided per BUNDLE when the plan is made, not per launch.  A
+ * bundle costs its workgroup the same whether it holds 64 rays or 3, the lanes = samples kernel costs per ray, and a second launch
+ * costs ~5 us: the plan picks the threshold T (serve bundles of >= T rays; 1 = all, 65 = none) with the smallest modelled time
+ * (env IONOTOMO_HYBRID_MIN=1..65 forces T).  The rays of unserved bundles form the tail of the plan's walk and every planned launch
+ * (TEC, tricubic TEC, phase) hands that tail to the lanes = samples kernel of the same interpolant in the same call.  Reports: bundles
+ * the cut produced, bundles served, rays in served bundles, rays in the tail, T, (hist65, optional, 65 entries) the number of bundles
+ * by ray count as cut, (model_us3, optional) the model's microseconds for: all bundles served | the chosen split | lanes = samples only.
+ * iono_forward_plan_info's n_bundles counts the SERVED bundles (0: the plan only orders the walk).  A batch that mixes well-filled
+ * bundles with thousands of singletons -- a few timesteps of a sparse array, cf. the coherence windows of
+ * inversion/inversion_pipeline.py:41-50 -- keeps its bundles this way instead of losing the plan.  Results never depend on T. */
+int iono_forward_plan_split(iono_ctx *ctx, int64_t *bundles_cut, int64_t *bundles_served, int64_t *rays_served, int64_t *rays_rest,
+                            int *min_rays, int64_t *hist65, double *model_us3);
 /* Solver vector update  y = a x + b y  on device vectors (16-byte aligned), one pass.  The coefficients are ratios
  * of DEVICE scalars, a = a_sign * a_num[0] / a_den[0], b = b_num[0] / b_den[0] (a null pointer stands for 1), so the
  * step lengths of the iteration -- eps = sum(Gdm dd/Cd) / sum(Gdm^2/Cd), inversion/iterative_newton.py:542-554; the

@@ -112,6 +112,8 @@ _SIGNATURES = {
     "iono_forward_plan_dev": [_V, _V, _L, _D, _I],
     "iono_forward_plan_clear": [],
     "iono_forward_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
+    "iono_forward_plan_split": [ctypes.POINTER(ctypes.c_int64)] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
+                                ctypes.POINTER(ctypes.c_double)],
     "iono_walk_order": [_P, _P, _L, _D, ctypes.POINTER(ctypes.c_int)],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _V],
     "iono_forward_tec_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],

@@ -354,15 +354,10 @@ __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode, const int64_t *
     return c;
 }
 
-#if defined(IONO_FWD_ABL) && IONO_FWD_ABL == 6
-#define FWD_U_WG 3
-#define FWD_U_BATCH 4
-#elif defined(IONO_FWD_ABL) && IONO_FWD_ABL == 7
-#define FWD_U_WG 4
-#define FWD_U_BATCH 2
-#else
 #define FWD_U_WG 6
-#endif
+// (round 6: a variant with the loads of all four 64-sample slabs of a ray in flight before the first interpolation -- 164 VGPRs, for
+//  launches of a ray or two per wave -- measured no faster: 2 604 rays 7.4 against 7.5 us, 10 416 rays 12.2 against 12.5 us.  Such
+//  launches are bound by the ~6 us interval between dependent dispatches, not by a wave's chain of loads; not built.)
 template <typename GT>
 __global__ __launch_bounds__(256, FWD_U_WG) void k_forward_straight_u(GridView g, const double *__restrict__ origins,
                                                             const double *__restrict__ dirs, const int *__restrict__ order,
@@ -402,7 +397,9 @@ __global__ __launch_bounds__(256, FWD_U_WG) void k_forward_straight_u(GridView g
             if (!u.valid) oob = true;
         }
         // ---- one ray at a time, lanes = samples ----------------------------------------------------
-        double res = 0.0;
+        // (lane l collects ray l's total on top of its tail samples: one register pair for both, and the 12 bytes of scratch the
+        //  kernel carried at 80 VGPRs are gone)
+        double res = tail;
         for (int gi = 0; gi < cnt; ++gi) {
             const int ok = __builtin_amdgcn_readlane((int)u.valid, gi);
             if (!ok) continue;
@@ -415,20 +412,6 @@ __global__ __launch_bounds__(256, FWD_U_WG) void k_forward_straight_u(GridView g
             // (a software-pipelined version of this loop -- next iteration's loads in flight during the
             //  interpolation -- measured 15 % SLOWER: +26 VGPRs cost more occupancy than the overlap won)
             int it = 0;
-#ifdef FWD_U_BATCH     // timing study: the loads of FWD_U_BATCH slabs in flight before the first interpolation
-            for (; it + FWD_U_BATCH <= nfull; it += FWD_U_BATCH) {
-                Corners<GT> cc[FWD_U_BATCH];
-#pragma unroll
-                for (int b = 0; b < FWD_U_BATCH; ++b) {
-                    cc[b] = load_corners<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz);
-                    fx += sx64;
-                    fy += sy64;
-                    fz += sz64;
-                }
-#pragma unroll
-                for (int b = 0; b < FWD_U_BATCH; ++b) acc = fma(wp[(it + b) << 6], lerp_corners<GT>(cc[b]), acc);
-            }
-#endif
             for (; it < nfull; ++it) {
                 acc = fma(wp[it << 6], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
                 fx += sx64;
@@ -438,9 +421,9 @@ __global__ __launch_bounds__(256, FWD_U_WG) void k_forward_straight_u(GridView g
             if (!tail_by_lane && lane + ntail0 < Ns)
                 acc = fma(wp[ntail0], trilinear_u<GT>(b00, b01, b10, b11, g.ny, g.nz, fx, fy, fz), acc);
             const double total = wave_sum_dpp(acc);
-            if (lane == gi) res = total;
+            if (lane == gi) res = total + res;
         }
-        if (lane < cnt) tec[r] = u.valid ? (res + tail) * u.h : nan("");
+        if (lane < cnt) tec[r] = u.valid ? res * u.h : nan("");
     }
     if (wave_cycles && lane == 0) wave_cycles[ch.widx] = __builtin_readcyclecounter() - t_dbg0;    // per chunk, walk order
     if (__any(oob) && lane == 0) atomicOr(oob_flag, 1);
@@ -1299,7 +1282,7 @@ __global__ __launch_bounds__(256) void k_forward_phase_straight(GridView g, cons
 // for ONE frequency against 0.24 ms for the TEC kernel).
 template <typename GT, int NF>
 __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const double *__restrict__ origins, const double *__restrict__ dirs,
-                                                         int64_t R, double tmax, int Ns, const double *__restrict__ unitw, PhaseFreqs pf,
+                                                         const int *__restrict__ order, int64_t R, double tmax, int Ns, const double *__restrict__ unitw, PhaseFreqs pf,
                                                          int ldf, double *__restrict__ phi, int *oob_flag) {
     extern __shared__ __attribute__((aligned(16))) double wlds[];
     for (int t = threadIdx.x; t < Ns; t += blockDim.x) wlds[t] = unitw[t];
@@ -1321,8 +1304,10 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
         double tail[NF];
 #pragma unroll
         for (int l = 0; l < NF; ++l) tail[l] = 0.0;
+        int rmine = 0;                     // (`order`: the rays of a hybrid launch's tail, int32 indices)
         if (lane < cnt) {
-            u = load_uray(g, origins, dirs, q0 + lane, tmax, Ns);
+            rmine = order ? order[q0 + lane] : (int)(q0 + lane);
+            u = load_uray(g, origins, dirs, (int64_t)rmine, tmax, Ns);
             if (u.valid && tail_by_lane) {
                 for (int k = ntail0; k < Ns; ++k) {
                     const double kd = (double)k;
@@ -1335,7 +1320,7 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
             if (!u.valid) {
                 oob = true;
                 for (int l = 0; l < NF; ++l)
-                    if (l < pf.nf) phi[(size_t)(q0 + lane) * ldf + l] = nan("");
+                    if (l < pf.nf) phi[(size_t)rmine * ldf + l] = nan("");
             }
         }
         for (int gi = 0; gi < cnt; ++gi) {
@@ -1365,10 +1350,11 @@ __global__ __launch_bounds__(256) void k_forward_phase_u(GridView g, const doubl
                 for (int l = 0; l < NF; ++l) acc[l] = fma(c, phase_one_minus_sqrt(ne * pf.inv_np[l], false), acc[l]);
             }
             const double hh = bcast_lane(u.h, gi);
+            const size_t rg = (size_t)__builtin_amdgcn_readlane(rmine, gi);
 #pragma unroll
             for (int l = 0; l < NF; ++l) {
                 const double total = wave_sum_dpp(acc[l]) + bcast_lane(tail[l], gi);
-                if (lane == 0 && l < pf.nf) phi[(size_t)(q0 + gi) * ldf + l] = total * hh;
+                if (lane == 0 && l < pf.nf) phi[rg * ldf + l] = total * hh;
             }
         }
     }

@@ -84,6 +84,9 @@ struct iono_ctx {
     double *d_nF8 = nullptr;         // Lekien-Marsden records of the refractive index (tricubic tracer on ideal grids), lazily built
     double nF8_freq = -1.0;          // frequency they were built for; < 0 = stale
     int variant = 0;                 // kernel variant for A/B runs (env IONOTOMO_VARIANT)
+    int hybrid_min = 0;              // forward plan: bundles of fewer rays are left to the lanes = samples kernel.  0 (default): chosen per
+                                     //   plan by the cost model in iono_forward_plan_dev; env IONOTOMO_HYBRID_MIN=1..65 forces it (1: every
+                                     //   bundle to the bundle kernels; 65: none -- the plan then only orders the walk)
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     ncclComm_t comm = nullptr;       // iono_comm_init
     int comm_ranks = 0;
@@ -149,7 +152,13 @@ struct iono_ctx {
     struct FwdPlan {
         const void *o_key = nullptr, *d_key = nullptr;
         int64_t R = -1;
-        int Ns = 0, nb = 0, nchunks = 0;
+        int Ns = 0, nb = 0, nchunks = 0;      // nb: the bundles the bundle kernels serve (those of >= hybrid_min rays, first in the walk)
+        int nb_all = 0, split_min = 0;         // bundles the cut produced; the threshold this plan was split at
+        int64_t n_planned = 0, n_rest = 0;     // rays in the nb served bundles | the rest: walk positions [n_planned, R), served by the
+                                               //   lanes = samples kernels in the SAME call (hybrid dispatch, round 6)
+        int64_t hist[65] = {0};                // bundles by ray count, as cut (before the split)
+        double model_us[3] = {0, 0, 0};        // the cost model's estimates: every bundle served | the chosen split | lanes = samples only
+        bool forced = false;                   // the threshold was forced (env), not chosen
         double tmax = 0;
         int *d_order = nullptr, *d_bstart = nullptr;
         uint4 *d_win = nullptr;
@@ -505,6 +514,7 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_FORCE_GENERAL")) c->force_general = atoi(e);
     if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
+    if (const char *e = getenv("IONOTOMO_HYBRID_MIN")) c->hybrid_min = std::min(65, std::max(0, atoi(e)));
     if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 2 | 4), c->walk_mode_set = true;
     if (const char *e = getenv("IONOTOMO_SEG_LANES")) c->seg_lanes = atoi(e);
     if (const char *e = getenv("IONOTOMO_DETERMINISTIC")) c->deterministic = atoi(e) != 0;
@@ -836,9 +846,10 @@ static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes, const int 
 // the bundle plan serves this launch: same ray arrays, R, tmax, Ns, and it fills the chip / is good (see the forward dispatch)
 static bool fplan_serves(const iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns) {
     const iono_ctx::FwdPlan &fp = c->fplan;
+    // (WHICH bundles are worth a workgroup -- all, those of >= T rays, none -- was decided when the plan was made: iono_forward_plan_dev;
+    //  IONOTOMO_VARIANT=10: never, A/B)
     return c->storage == IONO_F64 && fp.R == R && fp.o_key == o && fp.d_key == d && fp.Ns == Ns && fp.tmax == tmax && ideal_path_ok(c) &&
-           c->variant != 10 &&
-           ((fp.nb >= 2 * c->num_cus && fp.fit_fraction >= 0.5 && R >= (int64_t)16 * fp.nb) || c->variant == 12);
+           c->variant != 10 && fp.nb > 0 && (fp.fit_fraction >= 0.5 || fp.forced);
 }
 // fast tricubic tier: ideal-uniform axes, weights in LDS, 32-bit-safe field array (IONOTOMO_VARIANT=4 forces the general tier)
 static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
@@ -943,7 +954,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipGetLastError());
     // (pinned: [R summaries | R walk positions])
     char *hp = nullptr;
-    rc = plan_pinned(c, (size_t)R * (sizeof(BundleSummary) + sizeof(int)) + 64, &hp);
+    rc = plan_pinned(c, (size_t)R * (sizeof(BundleSummary) + 2 * sizeof(int)) + 64, &hp);
     if (rc) return rc;
     const BundleSummary *hr = (const BundleSummary *)hp;
     int *perm = (int *)(hp + (size_t)R * sizeof(BundleSummary));
@@ -1011,6 +1022,69 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     }
     std::vector<int> bstart;
     for (const std::vector<int> &bs : starts) bstart.insert(bstart.end(), bs.begin(), bs.end());
+    bstart.push_back((int)R);
+    // Hybrid dispatch (round 6): a bundle costs its workgroup the same whether it holds 64 rays or 3 (a lane per ray), while the
+    // lanes = samples kernel costs per RAY -- the two meet at ~25 rays per bundle (21 ns per bundle against 0.8 ns per ray at the bench
+    // shape).  So the choice is made per BUNDLE, not per launch: bundles of >= hybrid_min rays move to the front of the walk and are
+    // what the bundle kernels serve; the rays of the others follow, still in Morton order, and every planned launch hands them to the
+    // lanes = samples kernel of the same interpolant (its `order` argument = that tail of the walk).  A batch of a few timesteps --
+    // what the reference's pipeline forms per coherence window -- thus keeps its well-filled bundles instead of losing the plan.
+    const int nb_all = (int)bstart.size() - 1;
+    for (int64_t &h : fp.hist) h = 0;
+    for (int b = 0; b < nb_all; ++b) ++fp.hist[std::min(bstart[(size_t)b + 1] - bstart[(size_t)b], 64)];
+    // The threshold T (serve bundles of >= T rays; 1: all, 65: none): forced (IONOTOMO_HYBRID_MIN, IONOTOMO_VARIANT=12 = 1), else the T
+    // with the smallest modelled time.  Model, fitted to the round-6 sweeps on MI355X (profiles/r06_coherence_sweep.json; 256^3 float64,
+    // Ns = 257, scaled by Ns): a bundle launch of n workgroups takes max(20, 8 + 0.019 n) us (one workgroup lives ~20 us; 4 597 bundles:
+    // 95 us), a lanes = samples launch of r rays 5.5 + 0.00078 r us (2 604 rays: 7.7 us; 260 400: 208 us).  Checked against the
+    // measurements: 42 directions x 1 / 4 / 16 / 100 timesteps of 62 stations -> none / none / all / all, as measured fastest.
+    fp.forced = c->variant == 12 || c->hybrid_min > 0;
+    int hmin = c->variant == 12 ? 1 : c->hybrid_min;
+    {
+        const double su = (double)Ns / 257.0;
+        auto t_bundles = [&](int64_t n) { return n ? std::max(20.0 * (0.25 + 0.75 * su), 8.0 + 0.019 * su * (double)n) : 0.0; };
+        auto t_rays = [&](int64_t r) { return r ? 5.5 + 0.00078 * su * (double)r : 0.0; };
+        const int cand[10] = {1, 2, 4, 8, 12, 16, 24, 32, 48, 65};
+        double best = -1.0;
+        for (int T : cand) {
+            int64_t nbT = 0, restT = 0;
+            for (int n = 1; n <= 64; ++n) {
+                if (n >= T) nbT += fp.hist[n];
+                else restT += (int64_t)n * fp.hist[n];
+            }
+            const double t = t_bundles(nbT) + t_rays(restT);
+            if (T == 1) fp.model_us[0] = t;
+            if (T == 65) fp.model_us[2] = t;
+            if (best < 0 || t < best) {
+                best = t;
+                if (!fp.forced) hmin = T;
+            }
+            if (T == hmin) fp.model_us[1] = t;
+        }
+    }
+    int nb = 0;
+    int64_t n_planned = 0;
+    for (int b = 0; b < nb_all; ++b) {
+        const int cnt = bstart[(size_t)b + 1] - bstart[(size_t)b];
+        if (cnt >= hmin) ++nb, n_planned += cnt;
+    }
+    if (nb != nb_all) {
+        int *perm2 = perm + R;
+        std::vector<int> bs2;
+        bs2.reserve((size_t)nb + 1);
+        int64_t np = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int b = 0; b < nb_all; ++b) {
+                const int lo = bstart[(size_t)b], cnt = bstart[(size_t)b + 1] - lo;
+                if ((cnt >= hmin) != (pass == 0)) continue;
+                if (pass == 0) bs2.push_back((int)np);
+                std::copy(perm + lo, perm + lo + cnt, perm2 + np);
+                np += cnt;
+            }
+            if (pass == 0) bs2.push_back((int)np);
+        }
+        perm = perm2;
+        bstart.swap(bs2);
+    }
     // order[q] = sorted index at walk position perm[q]
     {
         int *d_perm = i0;                                         // (scratch: the unsorted index array is no longer needed)
@@ -1018,8 +1092,14 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
         launch_map<BundlePermute>(c, ew_blocks(c, R), R, i1, d_perm, fp.d_order, hash_by_ray, fp.d_rhash);
         HIP_TRY(c, hipGetLastError());
     }
-    bstart.push_back((int)R);
-    const int nb = (int)bstart.size() - 1, nchunks = (Ns + B_KC - 1) / B_KC;
+    const int nchunks = (Ns + B_KC - 1) / B_KC;
+    fp.nb_all = nb_all, fp.split_min = hmin, fp.n_planned = n_planned, fp.n_rest = R - n_planned;
+    if (nb == 0) {      // no bundle worth a workgroup: the walk order alone is kept (the back-projection plan walks the rays in it)
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        fp.o_key = o, fp.d_key = d, fp.R = R, fp.Ns = Ns, fp.tmax = tmax, fp.nb = 0, fp.nchunks = nchunks, fp.nchunks_lm = 0;
+        fp.fit_fraction = 0.0, fp.serial = ++c->fplan_counter, fp.lm_all_fit = false;
+        return IONO_OK;
+    }
     HIP_TRY(c, plan_reserve(fp.d_bstart, fp.cap_bstart, bstart.size() * sizeof(int)));
     HIP_TRY(c, plan_reserve(fp.d_win, fp.cap_win, (size_t)nb * nchunks * sizeof(uint4)));
     HIP_TRY(c, hipMemcpyAsync(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
@@ -1074,6 +1154,23 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     return IONO_OK;
 }
 
+int iono_forward_plan_split(iono_ctx *c, int64_t *bundles_cut, int64_t *bundles_served, int64_t *rays_served, int64_t *rays_rest, int *min_rays,
+                            int64_t *hist65, double *model_us3) {
+    if (!c) return fail(c, IONO_ERR_ARG, "null context");
+    const iono_ctx::FwdPlan &fp = c->fplan;
+    const bool have = fp.R >= 0;
+    if (bundles_cut) *bundles_cut = have ? fp.nb_all : 0;
+    if (bundles_served) *bundles_served = have ? fp.nb : 0;
+    if (rays_served) *rays_served = have ? fp.n_planned : 0;
+    if (rays_rest) *rays_rest = have ? fp.n_rest : 0;
+    if (min_rays) *min_rays = have ? fp.split_min : 0;
+    if (hist65)
+        for (int i = 0; i < 65; ++i) hist65[i] = have ? fp.hist[i] : 0;
+    if (model_us3)
+        for (int i = 0; i < 3; ++i) model_us3[i] = have ? fp.model_us[i] : 0.0;
+    return IONO_OK;
+}
+
 int iono_forward_plan_info(iono_ctx *c, int64_t *n_bundles, int *n_chunks, double *fit_fraction) {
     if (!c) return fail(c, IONO_ERR_ARG, "null context");
     if (n_bundles) *n_bundles = c->fplan.R >= 0 ? c->fplan.nb : 0;
@@ -1095,6 +1192,31 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
     const size_t lds = lds_bytes(c);
     rc = dispatch_storage(c, [&](auto *tag) -> int {
         using GT = std::remove_pointer_t<decltype(tag)>;
+        // lanes = samples on ideal-uniform grids (k_forward_straight_u) for the rays ord[0 .. Rn) (ord null: all, in memory order)
+        auto launch_u = [&](const int *ord, int64_t Rn, hipStream_t st) -> int {
+            const size_t wl = sizeof(double) * Ns;
+            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), Rn);
+            iono_ctx::WalkPart &wp = c->walk[0];
+            const int nw = nb * 4;                              // one chunk per wave
+            const int wm = forward_walk_mode(c, (uint64_t)ncells(c) * sizeof(GT), ord);
+            const bool use_part = wp.n == nw && wp.R == Rn && !(wm & 3) && ord == nullptr;
+            const int rc2 = walk_cycles_reserve(c, wp, nw, nw);
+            if (rc2) return rc2;
+            hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, st, g, o, d, ord, Rn, tmax, Ns,
+                               wm, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
+            return IONO_OK;
+        };
+        // the tricubic counterpart on the node-major Lekien-Marsden records (k_forward_straight_lm; ensure_lm_fields first)
+        auto launch_lm = [&](const int *ord, int64_t Rn, hipStream_t st) {
+            const size_t wl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + 4 * U_MAXG * LM_RS);      // weights + ray state of 4 waves
+            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_lm, wl), Rn);
+            // default walk for this kernel: all the waves of an XCD interleaved in that XCD's eighth of the walk (what is in
+            // flight on an XCD is then one short stretch of neighbouring rays whose field records stay in its L2):
+            // 1.49 ms against 1.60 with one contiguous chunk per wave
+            const int wm = c->walk_mode_set ? c->walk_mode : 2;
+            hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, st, g, c->d_F8, o, d, ord, Rn, tmax, Ns, wm,
+                               c->d_unitw, tec, c->d_flags);
+        };
         if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && std::is_same<GT, float>::value && c->variant != 9 &&
                    (uint64_t)padded_count(c) * 16 < ((uint64_t)1 << 32)) {
             // float32 storage extra: 2 x 2 corner blocks, two 16-B loads per sample (IONOTOMO_VARIANT=9: plain float32 kernel)
@@ -1113,24 +1235,22 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                                forward_walk_mode(c, (uint64_t)padded * sizeof(float4), order), c->d_unitw, tec, c->d_flags);
         } else if (kind == IONO_INTERP_TRILINEAR && std::is_same<GT, double>::value && fplan_serves(c, o, d, R, tmax, Ns)) {
             // (a workgroup per bundle: below two bundles per CU -- a single timestep is 214 -- the lanes = samples kernel, one wave
-            //  per ray, fills the chip better: 7.5 against 11 us at config 2; likewise when the plan is poor: windows that mostly do
-            //  not fit the LDS image, or bundles of a few rays.  IONOTOMO_VARIANT=12 forces the bundle kernel)
-            // bundle-stationary: one workgroup per planned bundle of <= 64 rays, windows staged in LDS (iono_forward_plan_dev)
+            //  per ray, fills the chip better: 7.5 against 11 us at config 2; likewise when the windows mostly do not fit the LDS
+            //  image.  IONOTOMO_VARIANT=12 forces the bundle kernel for every bundle)
+            // bundle-stationary: one workgroup per SERVED bundle, windows staged in LDS (iono_forward_plan_dev); the rays of the other
+            // bundles, if the plan left any: lanes = samples, right behind it on the same stream (a second stream between fork / join
+            // events measured SLOWER at every batch size: 0.106 against 0.103 ms at the bench shape, 0.040 against 0.032 at 41 664 rays)
             const iono_ctx::FwdPlan &fp = c->fplan;
             hipLaunchKernelGGL((k_forward_bundle<0>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * B_WAVE_LDS + B_SPLIT * 64 * sizeof(double) + 16,
                                c->stream, g, o, d, fp.d_brec, fp.d_bhash, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw, tec,
                                c->d_flags, PhaseFreqs{}, 0);
+            if (fp.n_rest > 0) {
+                const int rc2 = launch_u(fp.d_order + fp.n_planned, fp.n_rest, c->stream);
+                if (rc2) return rc2;
+            }
         } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
-            const size_t wl = sizeof(double) * Ns;
-            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_u<GT>, wl), R);
-            iono_ctx::WalkPart &wp = c->walk[0];
-            const int nw = nb * 4;                              // one chunk per wave
-            const int wm = forward_walk_mode(c, (uint64_t)ncells(c) * sizeof(GT), order);
-            const bool use_part = wp.n == nw && wp.R == R && !(wm & 3) && order == nullptr;
-            const int rc2 = walk_cycles_reserve(c, wp, nw, nw);
+            const int rc2 = launch_u(order, R, c->stream);
             if (rc2) return rc2;
-            hipLaunchKernelGGL((k_forward_straight_u<GT>), dim3(nb), block, wl, c->stream, g, o, d, order, R, tmax, Ns,
-                               wm, c->d_unitw, tec, c->d_flags, use_part ? wp.d_starts : nullptr, wp.d_cyc);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && fplan_serves(c, o, d, R, tmax, Ns)) {
             // bundles of neighbouring rays, one field pair per wave, windows staged in LDS (iono_cubic_kernels.h:k_forward_bundle_lm)
             int rc2 = ensure_lm_windows(c);          // (first: the windows say which node lines a rebuild for this plan must cover)
@@ -1139,21 +1259,19 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             if (rc2) return rc2;
             const int restricted = !c->FP_valid ? 1 : 0;      // the pair arrays hold this plan's lines only
             const iono_ctx::FwdPlan &fp = c->fplan;
+            if (fp.n_rest > 0) {      // hybrid: the rays outside the served bundles on the node-major records, lanes = samples
+                rc2 = ensure_lm_fields(c);
+                if (rc2) return rc2;
+            }
             static_assert(BL_LDS_BYTES <= 64 * 1024, "dynamic LDS beyond 64 KB would need hipFuncSetAttribute per device");
             hipLaunchKernelGGL(k_forward_bundle_lm, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, BL_LDS_BYTES, c->stream, g, c->d_FP,
                                padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.d_rhash, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
                                c->d_flags, restricted);
+            if (fp.n_rest > 0) launch_lm(fp.d_order + fp.n_planned, fp.n_rest, c->stream);
         } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
-            const size_t wl = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + 4 * U_MAXG * LM_RS);      // weights + ray state of 4 waves
-            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_lm, wl), R);
-            // default walk for this kernel: all the waves of an XCD interleaved in that XCD's eighth of the walk (what is in
-            // flight on an XCD is then one short stretch of neighbouring rays whose field records stay in its L2):
-            // 1.49 ms against 1.60 with one contiguous chunk per wave
-            const int wm = c->walk_mode_set ? c->walk_mode : 2;
-            hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, c->stream, g, c->d_F8, o, d, order, R, tmax, Ns, wm,
-                               c->d_unitw, tec, c->d_flags);
+            launch_lm(order, R, c->stream);
         } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))      // (`order` is a speed hint: ignored here)
             hipLaunchKernelGGL((k_forward_straight_fast<GT>), grid, block, 2 * lds, c->stream, g, o, d, R, tmax, Ns,
                                c->d_unitw, tec, c->d_flags);
@@ -2033,6 +2151,21 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
     const bool ideal = ideal_path_ok(c, Ns);
     for (int f0 = 0; f0 < Nf; f0 += 8) {
         const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
+        // lanes = samples on ideal-uniform grids for the rays ord[0 .. Rn) (null: all of them)
+        auto phase_u = [&](const int *ord, int64_t Rn, hipStream_t st) {
+            dispatch_storage(c, [&](auto *tag) {
+                using GT = std::remove_pointer_t<decltype(tag)>;
+                const size_t wl = sizeof(double) * Ns;
+#define PHASE_U(NF)                                                                                                                  \
+    hipLaunchKernelGGL((k_forward_phase_u<GT, NF>), dim3(chunk_grid_blocks(resident_blocks(c, k_forward_phase_u<GT, NF>, wl), Rn)), block, \
+                       wl, st, g, o, d, ord, Rn, tmax, Ns, c->d_unitw, pf, Nf, phi_work + f0, c->d_flags)
+                if (pf.nf == 1) PHASE_U(1);
+                else if (pf.nf <= 4) PHASE_U(4);          // (two frequencies: the 4-slot series kernel beats two plain roots)
+                else PHASE_U(8);
+#undef PHASE_U
+                return IONO_OK;
+            });
+        };
         if (fplan_serves(c, o, d, R, tmax, Ns)) {      // bundle-stationary (k_forward_bundle<NF>: windows in LDS), as the TEC forward
             const iono_ctx::FwdPlan &fp = c->fplan;
 #define PHASE_B(NF)                                                                                                                        \
@@ -2043,22 +2176,17 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
             else if (pf.nf <= 4) PHASE_B(4);
             else PHASE_B(8);
 #undef PHASE_B
+            if (fp.n_rest > 0) phase_u(fp.d_order + fp.n_planned, fp.n_rest, c->stream);      // (hybrid: the rays outside the served bundles)
+            continue;
+        }
+        if (ideal) {
+            phase_u(nullptr, R, c->stream);
             continue;
         }
         dispatch_storage(c, [&](auto *tag) {
             using GT = std::remove_pointer_t<decltype(tag)>;
-            if (ideal) {
-                const size_t wl = sizeof(double) * Ns;
-#define PHASE_U(NF)                                                                                                                 \
-    hipLaunchKernelGGL((k_forward_phase_u<GT, NF>), dim3(chunk_grid_blocks(resident_blocks(c, k_forward_phase_u<GT, NF>, wl), R)), block, \
-                       wl, c->stream, g, o, d, R, tmax, Ns, c->d_unitw, pf, Nf, phi_work + f0, c->d_flags)
-                if (pf.nf == 1) PHASE_U(1);
-                else if (pf.nf <= 4) PHASE_U(4);          // (two frequencies: the 4-slot series kernel beats two plain roots)
-                else PHASE_U(8);
-#undef PHASE_U
-            } else
-                hipLaunchKernelGGL((k_forward_phase_straight<GT, false>), grid, block, lds_bytes(c), c->stream, g, o, d, R, tmax, Ns,
-                                   c->d_unitw, pf, Nf, phi_work + f0, c->d_flags);
+            hipLaunchKernelGGL((k_forward_phase_straight<GT, false>), grid, block, lds_bytes(c), c->stream, g, o, d, R, tmax, Ns,
+                               c->d_unitw, pf, Nf, phi_work + f0, c->d_flags);
             return IONO_OK;
         });
     }

@@ -45,6 +45,8 @@ class RayEngine(object):
         self.shape = None
         self.deterministic = False
         self._bound_stream = -1
+        self._values_serial = 0        # bumped whenever the node values may have changed: invalidates the cached Fermat step choice
+        self._fermat_steps = {}
 
     def _sync_stream(self):
         s = torch.cuda.current_stream(self.device).cuda_stream
@@ -58,6 +60,7 @@ class RayEngine(object):
     # -- grid ------------------------------------------------------------------------------------
     def set_grid(self, xvec, yvec, zvec, M=None):
         self.ctx.set_grid(xvec, yvec, zvec, M, storage=self.storage)
+        self._values_serial += 1
         self.shape = self.ctx.grid_shape
         self.ncells = int(np.prod(self.shape))
 
@@ -66,12 +69,14 @@ class RayEngine(object):
         self._sync_stream()
         assert M_t.is_cuda and M_t.dtype == torch.float64 and M_t.numel() == self.ncells and M_t.is_contiguous()
         self.ctx.call("iono_grid_set_values_dev", _ptr(M_t))
+        self._values_serial += 1
 
     def set_log_model(self, m_t, scale):
         """grid values <- scale * exp(m) at the nodes (inversion/forward_equation.py:41-43)"""
         self._sync_stream()
         assert m_t.is_cuda and m_t.dtype == torch.float64 and m_t.numel() == self.ncells and m_t.is_contiguous()
         self.ctx.call("iono_grid_set_exp_dev", _ptr(m_t), float(scale))
+        self._values_serial += 1
 
     # -- hot path ----------------------------------------------------------------------------------
     def forward(self, origins_t, dirs_t, tmax, Ns, out=None, order=None):
@@ -224,6 +229,23 @@ class RayEngine(object):
         self.ctx.call("iono_forward_plan_info", ctypes.byref(n), ctypes.byref(k), ctypes.byref(f))
         return n.value, k.value, f.value
 
+    def forward_plan_split(self, histogram=False):
+        """How the current forward plan divides its rays (hybrid dispatch, include/ionotomo_hip.h:iono_forward_plan_split): bundles as
+        cut / served by the bundle kernels, rays in served bundles / in the lanes = samples tail, the rays-per-bundle threshold the
+        plan chose (1: every bundle served, 65: none) and its cost model's estimates."""
+        import ctypes
+        v = [ctypes.c_int64(0) for _ in range(4)]
+        m = ctypes.c_int(0)
+        h = (ctypes.c_int64 * 65)()
+        us = (ctypes.c_double * 3)()
+        self.ctx.call("iono_forward_plan_split", *[ctypes.byref(x) for x in v], ctypes.byref(m), h, us)
+        out = {"bundles_cut": v[0].value, "bundles_served": v[1].value, "rays_served": v[2].value, "rays_tail": v[3].value,
+               "min_rays_per_served_bundle": m.value,
+               "model_us": {"all_bundles": us[0], "chosen": us[1], "lanes_samples_only": us[2]}}
+        if histogram:
+            out["bundles_by_ray_count"] = list(h)
+        return out
+
     def clear_forward_plan(self):
         self.ctx.call("iono_forward_plan_clear")
         self._fplanned = None
@@ -321,8 +343,10 @@ class RayEngine(object):
         return out
 
     def trace_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=False, kind="linear", substeps=4, out=None, type="z"):
-        """rays[R,4,Ns] (x,y,z,s) of the Fermat ray ODE, on the device; the grid must hold ne [m^-3]."""
+        """rays[R,4,Ns] (x,y,z,s) of the Fermat ray ODE, on the device; the grid must hold ne [m^-3].  ``substeps``: RK4 steps per
+        output sample, or "auto" / ("auto", rtol): chosen by step doubling (``choose_fermat_substeps``)."""
         self._sync_stream()
+        substeps = self._fermat_substeps(substeps, origins_t, dirs_t, tmax, Ns, frequency, bend, kind, type)
         R = origins_t.shape[0]
         if out is None:
             out = torch.empty((R, 4, int(Ns)), dtype=torch.float64, device=self.device)
@@ -361,6 +385,40 @@ class RayEngine(object):
             free = 0
         return need <= free // 2
 
+    def choose_fermat_substeps(self, origins_t, dirs_t, tmax, Ns, frequency, bend=True, kind="linear", type="z", rtol=None, atol=None,
+                               max_substeps=32, fraction=0.01):
+        """Error control for the fixed-step RK4 tracer (the reference integrates with adaptive LSODA, ``odeint`` default
+        rtol = atol = 1.49e-8: inversion/fermat.py:163-167): a strided sample of <= 1 % of the rays (>= 208) is traced at s and 2 s
+        steps per output sample, s = 1, 2, 4, ...; returns (the smallest s whose step-doubling difference on x, y, s meets
+        rtol |y| + atol, report).  One small launch per level; call again when the node values have changed enough to matter."""
+        from .inversion import fermat as F
+        rtol = F.ODEINT_RTOL if rtol is None else float(rtol)
+        idx = torch.as_tensor(F.sample_indices(origins_t.shape[0], fraction), device=self.device)
+        o_s, d_s = origins_t.index_select(0, idx).contiguous(), dirs_t.index_select(0, idx).contiguous()
+
+        def trace(sub):
+            return self.trace_fermat(o_s, d_s, tmax, Ns, frequency, bend=bend, kind=kind, substeps=sub, type=type).cpu().numpy()
+        return F.choose_substeps(trace, rtol, atol, max_substeps=max_substeps)
+
+    def _fermat_substeps(self, substeps, origins_t, dirs_t, tmax, Ns, frequency, bend, kind, type):
+        """``substeps``: an int, "auto" (step doubling at the reference's odeint tolerance) or ("auto", rtol[, atol]).  The choice is
+        remembered per (ray tensors, sampling, frequency, interpolant, tolerance) until the node values change; ``fermat_step_report``
+        keeps what it was based on."""
+        if not (substeps == "auto" or (isinstance(substeps, tuple) and substeps and substeps[0] == "auto")):
+            return int(substeps)
+        if not bend:
+            return 1 if type == "z" else 4
+        tol = tuple(substeps[1:]) if isinstance(substeps, tuple) else ()
+        key = (origins_t.data_ptr(), dirs_t.data_ptr(), tuple(origins_t.shape), float(tmax), int(Ns), float(frequency), str(kind), str(type), tol)
+        hit = self._fermat_steps.get(key)
+        if hit is None or hit[0] != self._values_serial:
+            sub, rep = self.choose_fermat_substeps(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, type=type,
+                                                   rtol=tol[0] if len(tol) > 0 else None, atol=tol[1] if len(tol) > 1 else None)
+            self._fermat_steps = {key: (self._values_serial, sub, rep)}
+            hit = self._fermat_steps[key]
+        self.fermat_step_report = hit[2]
+        return hit[1]
+
     def forward_fermat(self, origins_t, dirs_t, tmax, Ns, frequency, bend=True, kind="linear", substeps=4, type="z", ne_kind=None,
                        ne_scale=1.0, out=None, fused=None):
         """tec[R] along the Fermat rays WITHOUT materialising them: RK4 stepper + streaming non-uniform Simpson in one kernel
@@ -371,6 +429,7 @@ class RayEngine(object):
         R = origins_t.shape[0]
         if out is None:
             out = torch.empty(R, dtype=torch.float64, device=self.device)
+        substeps = self._fermat_substeps(substeps, origins_t, dirs_t, tmax, Ns, frequency, bend, kind, type)
         if self._two_step_fermat(R, Ns, kind, fused, ne_kind=ne_kind, bend=bend):
             rays = self.trace_fermat(origins_t, dirs_t, tmax, Ns, frequency, bend=bend, kind=kind, substeps=substeps, type=type)
             self.forward_rays(rays, out=out, kind=ne_kind)
@@ -396,6 +455,7 @@ class RayEngine(object):
         ``forward_fermat``."""
         self._sync_stream()
         R = origins_t.shape[0]
+        substeps = self._fermat_substeps(substeps, origins_t, dirs_t, tmax, Ns, frequency, bend, kind, type)
         if self._two_step_fermat(R, Ns, kind, fused, adjoint=True, ne_kind=ne_kind, bend=bend):
             if out is None:
                 out = torch.zeros(self.shape, dtype=torch.float64, device=self.device)
@@ -557,9 +617,11 @@ class RayEngine(object):
         self._sync_stream()
         self.ctx.call("iono_grid_bind_values_dev", _lib._V(0) if padded is None else _ptr(padded))
         self._bound = padded                                  # keep it alive
+        self._values_serial += 1
 
     def values_changed(self):
         self.ctx.call("iono_grid_values_changed")
+        self._values_serial += 1
 
     def _partial(self, want):
         return torch.empty(_lib.NPART, dtype=torch.float64, device=self.device) if want else None

@@ -15,16 +15,59 @@ z from z0 to ``tmax`` (``type='z'``, what every reference call site uses) or arc
   (notebooks/FermatClass.ipynb c0:60-96) with grad n from the ``kind`` interpolant ('linear' or
   'cubic'; default 'cubic' when bending).
 The ODE is integrated on the GPU with fixed-step RK4 (``substeps`` steps per output sample)
-instead of per-ray LSODA calls.
+instead of per-ray LSODA calls.  The reference's integrator is adaptive (``odeint``, LSODA, default
+``rtol = atol = 1.49e-8``: inversion/fermat.py:163-167); ``rtol=...`` restores that contract for the
+batch: ``choose_substeps`` traces a strided sample of the rays at ``substeps`` and ``2 substeps``
+and takes the smallest step count whose step-doubling difference meets the tolerance.
 """
 import numpy as np
 
 from .. import _lib
 
+ODEINT_RTOL = 1.49012e-8          # scipy.integrate.odeint's default rtol and atol (what inversion/fermat.py:167 runs with)
+
+
+def sample_indices(R, fraction=0.01, at_least=208):
+    """A strided sample of the batch for the step-doubling estimate: ``fraction`` of the rays, at least ``at_least``."""
+    R = int(R)
+    n = min(R, max(int(at_least), int(np.ceil(R * fraction))))
+    return np.unique(np.linspace(0, R - 1, n).round().astype(np.int64)) if R > 0 else np.zeros(0, dtype=np.int64)
+
+
+def doubling_error(coarse, fine, rtol, atol):
+    """max over rays, samples and components (x, y, z, s) of |coarse - fine| / (rtol |fine| + atol): the
+    mixed test LSODA applies per step, here on the whole trajectory.  <= 1: the coarse solution meets the tolerance (its own global
+    error is 16/15 of the difference for a 4th-order scheme; on a piecewise-trilinear index, whose gradient jumps at cell faces, the
+    observed order is lower and the difference is the safer figure)."""
+    c, f = np.asarray(coarse), np.asarray(fine)
+    e = np.abs(c - f) / (rtol * np.abs(f) + atol)            # (the independent variable -- z, or s for type 's' -- is sampled exactly: 0)
+    return float(e.max()) if e.size else 0.0
+
+
+def choose_substeps(trace, rtol=ODEINT_RTOL, atol=None, start=1, max_substeps=32, safety=0.5):
+    """Step-doubling control of the fixed-step RK4 tracer.  ``trace(substeps)`` returns rays[n,4,N] of the SAMPLE rays.  Returns
+    (substeps, report): the smallest power-of-two multiple of ``start`` whose trajectory differs from the one at twice as many steps
+    by at most ``safety`` x the tolerance (``doubling_error`` <= safety; the factor covers first-order convergence, where the
+    difference is only half the coarse solution's error), or ``max_substeps`` with ``report['met'] = False``.  Each level costs one
+    launch of the sample; levels already traced are reused as the next level's coarse side."""
+    atol = rtol if atol is None else atol
+    s = max(1, int(start))
+    coarse = trace(s)
+    levels = []
+    while True:
+        fine = trace(2 * s)
+        err = doubling_error(coarse, fine, rtol, atol)
+        levels.append({"substeps": s, "against": 2 * s, "error_over_tolerance": err})
+        if err <= safety or 2 * s > max_substeps:
+            met = err <= safety
+            break
+        s, coarse = 2 * s, fine
+    return s, {"rtol": rtol, "atol": atol, "safety": safety, "chosen_substeps": s, "met": met, "levels": levels, "sample_rays": int(np.asarray(coarse).shape[0])}
+
 
 class Fermat(object):
     def __init__(self, ne_tci, frequency=120e6, type='z', straight_line_approx=True, bend=False, kind=None,
-                 substeps=4):
+                 substeps=4, rtol=None, atol=None):
         if type not in ('z', 's'):
             raise ValueError("type must be 'z' or 's'")
         self.type = type
@@ -33,6 +76,8 @@ class Fermat(object):
         self.bend = bend
         self.kind = kind if kind is not None else ("cubic" if bend else "linear")
         self.substeps = substeps
+        self.rtol, self.atol = rtol, atol         # rtol given: ``substeps`` is chosen per batch by step doubling (``choose_substeps``)
+        self.step_report = None                   # ... and what the last choice was based on
         self.ne_tci = ne_tci
 
     def ne2n(self, ne_tci):
@@ -49,8 +94,15 @@ class Fermat(object):
             rays = ctx.trace_straight(o, directions, tmax, N, type=self.type)
         else:
             self.ne_tci.bind(ctx)
+            substeps = self.substeps
+            if self.rtol is not None:
+                of, df = o.reshape(-1, 3), np.asarray(directions, dtype=np.float64).reshape(-1, 3)
+                idx = sample_indices(of.shape[0])
+                substeps, self.step_report = choose_substeps(
+                    lambda sub: ctx.trace_fermat(of[idx], df[idx], tmax, N, self.frequency, bend=self.bend, kind=self.kind,
+                                                 substeps=sub, type=self.type), self.rtol, self.atol)
             rays = ctx.trace_fermat(o, directions, tmax, N, self.frequency, bend=self.bend, kind=self.kind,
-                                    substeps=self.substeps, type=self.type)
+                                    substeps=substeps, type=self.type)
         return rays.reshape(o.shape[:-1] + (4, int(N)))
 
     def integrate_ray(self, origin, direction, tmax, N=100):

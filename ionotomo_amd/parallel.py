@@ -40,9 +40,23 @@ def world_info():
     return 1, 0
 
 
+# Test / measurement switch (tests/test_gpu_engine.py, profiles/tools/nccl_1rank.py): with a process group of ONE rank initialised,
+# run every collective of the multi-rank code paths anyway (a one-rank sum is the identity, so results must not change by a bit).
+# This is how the torch-nccl (= RCCL) launch path, the compact gather / scatter around it and the overlap pipeline are exercised
+# and timed on a 1-GPU box; production never sets it.
+FORCE_COLLECTIVES = False
+
+
+def multi_rank():
+    """True when the collectives of the sharded code paths must run: more than one rank (or the switch above on a 1-rank group)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_COLLECTIVES
+
+
 def all_reduce_sum_(t):
     """In-place sum over ranks (no-op on one rank)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if multi_rank():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -65,8 +79,7 @@ class GradientExchange(object):
 
     def plan(self, touched):
         """``touched``: this rank's gradient of unit ray weights (> 0 exactly at the nodes its rays reach)."""
-        world, _ = world_info()
-        if world == 1 or self.mode == "dense":
+        if not multi_rank() or self.mode == "dense":
             return self
         mask = (touched.reshape(-1) != 0).to(torch.int32)
         dist.all_reduce(mask, op=dist.ReduceOp.MAX)
@@ -78,8 +91,7 @@ class GradientExchange(object):
 
     def sum_(self, g):
         """In-place sum of ``g`` over ranks; nodes outside the plan are zero on every rank and stay so."""
-        world, _ = world_info()
-        if world == 1:
+        if not multi_rank():
             return g
         if self.index is None:
             if self.reduce_dtype is not None and self.reduce_dtype != g.dtype:
@@ -107,6 +119,7 @@ class ShardedRays(object):
         partition by measurement (a few extra launches, once)."""
         self.engine = engine
         self.world, self.rank = world_info()
+        self.multi = multi_rank()           # collectives run (world > 1, or the FORCE_COLLECTIVES switch on a 1-rank group)
         o = torch.as_tensor(origins, dtype=torch.float64)
         d = torch.as_tensor(directions, dtype=torch.float64)
         self.Na, self.P = o.shape[0], o.shape[1]
@@ -135,7 +148,7 @@ class ShardedRays(object):
         if plan and hasattr(engine, "plan_adjoint") and self.R_local > 0:
             # (slab by slab only the planned TRILINEAR back-projection can run -- a tricubic fold's stencil crosses slab boundaries:
             #  a cubic engine keeps one slab and exchanges compactly)
-            if exchange == "overlap" and self.world > 1 and hasattr(engine, "plan_slabs") and getattr(engine, "trilinear", True):
+            if exchange == "overlap" and self.multi and hasattr(engine, "plan_slabs") and getattr(engine, "trilinear", True):
                 self.plan = engine.plan_adjoint(self.origins, self.dirs, self.tmax, self.Ns, slabs=self.OVERLAP_SLABS)
                 # (a segment never leaves its z-layer of boxes -- the plan cuts rays at layer boundaries -- so a slab's node levels are
                 #  final once its units have run even where samples overhang their box image in x or y and go by global atomics)
@@ -157,9 +170,9 @@ class ShardedRays(object):
         self.exchange = GradientExchange(exchange, reduce_dtype)
         self._active = None
         self.slab_ranges = None
-        if self.world > 1 and exchange != "dense":
+        if self.multi and exchange != "dense":
             self.exchange.plan(self._touched())
-        if self.exchange.overlap and self.world > 1:
+        if self.exchange.overlap and self.multi:
             # every rank must have a slab plan with the same node-level boundaries (same grid -> same box layers), else nobody overlaps
             zl = self.slabs[1] if self.slabs else []
             flag = torch.tensor([len(zl)] + (zl + [0] * 9)[:9], dtype=torch.int64, device=dev)
@@ -202,7 +215,7 @@ class ShardedRays(object):
         slab).  The solvers keep their grid-sized vectors compact over this set."""
         if self._active is None:
             mask = (self._touched().reshape(-1) != 0).to(torch.int32)
-            if self.world > 1:
+            if self.multi:
                 dist.all_reduce(mask, op=dist.ReduceOp.MAX)
             idx = mask.nonzero().reshape(-1)
             if self.slabs is not None:
@@ -219,7 +232,7 @@ class ShardedRays(object):
 
     def overlapped(self):
         """exchange="overlap" is in force: the plan has z-slabs every rank agrees on and the engine back-projects slab by slab."""
-        if not (self.world > 1 and self.slabs is not None and self.fused_steps()):
+        if not (self.multi and self.slabs is not None and self.fused_steps()):
             return False
         # ... and the engine's (single) back-projection plan is still the one made here for THESE tensors: a later plan_adjoint on
         # the same engine (another ShardedRays, say) replaces it, and a slab's unit range would mean nothing to the new plan
@@ -252,7 +265,7 @@ class ShardedRays(object):
     def scalar(self, partial):
         """A device scalar from the per-workgroup partial sums of a fused pass: used as is on one rank (the consuming
         kernel sums it in a fixed order), summed and all-reduced to ONE value when rays are sharded."""
-        if self.world == 1:
+        if not self.multi:
             return partial
         t = partial.sum().reshape(1)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -303,7 +316,7 @@ class ShardedRays(object):
 
     def reduce_compact_(self, s_c):
         """In-place sum over ranks of a compact (active-set) vector."""
-        if self.world > 1:
+        if self.multi:
             rd = self.exchange.reduce_dtype
             if rd is not None and rd != s_c.dtype:
                 buf = s_c.to(rd)

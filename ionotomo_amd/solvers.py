@@ -148,7 +148,7 @@ def _history(hist, reduce_over=None):
     if not hist:
         return []
     t = torch.stack([h.sum() for h in hist])
-    if reduce_over is not None and reduce_over.world > 1:
+    if reduce_over is not None and reduce_over.multi:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.SUM)
     return [0.5 * float(v) for v in t.cpu()]
 
@@ -185,7 +185,7 @@ def _run_iterations(n, body, keep):
 def _small(problem, small_pass):
     """One coherence window on one rank: the ray-sized passes of an iteration run as ONE launch (engine.small_ray_pass)."""
     eng = problem.engine
-    return bool(small_pass) and problem.world == 1 and hasattr(eng, "small_ray_pass") and 0 < problem.R_local <= eng.SMALL_RAYS
+    return bool(small_pass) and not problem.multi and hasattr(eng, "small_ray_pass") and 0 < problem.R_local <= eng.SMALL_RAYS
 
 
 def _backproject_weights(problem, w, s_full):
@@ -240,7 +240,7 @@ def sirt(problem, x0, n_iter=50, relax=1.0, nonneg=False, callback=None, stop=No
     x_full.copy_(x0)
     x_c = x0.reshape(-1).index_select(0, il).contiguous()
     s_full = torch.zeros(eng.shape, dtype=torch.float64, device=eng.device)
-    multi, sharded = problem.world > 1, problem.world > 1 and problem.exchange.sharded
+    multi, sharded = problem.multi, problem.multi and problem.exchange.sharded
     n = idx.numel()
     if sharded:
         # reduce-scatter by slab, sharded update, all-gather: every rank sums and updates only its contiguous
@@ -357,7 +357,7 @@ def cgls(problem, x0, n_iter=50, damp=0.0, callback=None, stop=None, pgtol=PGTOL
     idx = problem.active_index()
     il = idx.long()
     Wh = torch.rsqrt(problem.cdct + 1e-15).contiguous()
-    multi = problem.world > 1
+    multi = problem.multi
     eng.bind_values(None)
     _set_x(problem, x0)
     r, rr = eng.rays_combine(problem.forward_tec(), problem.Na, problem.i0, -1.0, 1.0, dobs=problem.dobs, s1=Wh)   # W^1/2 (d - A x0)

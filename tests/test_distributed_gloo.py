@@ -23,7 +23,7 @@ def _free_port():
     return p
 
 
-def _run(world, exchange="dense", engine="oracle", size=None, interp="linear"):
+def _run(world, exchange="dense", engine="oracle", size=None, interp="linear", deterministic=False):
     """Executed by every rank (and with world == 1 in the parent for the reference result).
     ``engine="oracle"``: the CPU stand-in (this file's tests); ``engine="hip"``: the product's RayEngine on GPU 0
     (tests/test_gpu_configs.py runs the same function in two fresh processes sharing the card)."""
@@ -40,6 +40,8 @@ def _run(world, exchange="dense", engine="oracle", size=None, interp="linear"):
         from ionotomo_amd.engine import RayEngine
         eng = RayEngine(0, interp=interp)
         eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
+        if deterministic:            # fixed-point back-projection: run-to-run identical bits, so that two runs can be compared exactly
+            eng.set_deterministic(True)
     else:
         from cpu_engine import OracleEngine
         eng = OracleEngine(w["xvec"], w["yvec"], w["zvec"])
@@ -68,11 +70,21 @@ def _run(world, exchange="dense", engine="oracle", size=None, interp="linear"):
                 xs2=host(xs2), nslab=len(prob.slab_ranges or []))
 
 
-def _worker(rank, world, port, q, exchange, engine="oracle", size=None, interp="linear"):
+def _worker(rank, world, port, q, exchange, engine="oracle", size=None, interp="linear", backend="gloo", force=False, deterministic=False):
+    """``backend="nccl"`` + ``force``: ONE rank on torch's nccl backend (= RCCL) with parallel.FORCE_COLLECTIVES -- every collective of
+    the sharded paths is issued although a one-rank sum is the identity (tests/test_gpu_configs.py)."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    out = _run(world, exchange, engine, size, interp)
+    if backend == "nccl":
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    if force:
+        sys.path.insert(0, os.path.dirname(HERE))
+        from ionotomo_amd import parallel
+        parallel.FORCE_COLLECTIVES = True
+    out = _run(world, exchange, engine, size, interp, deterministic)
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()

@@ -19,21 +19,26 @@ def OC():
     return oracle_c
 
 
-def engine(xv, yv, zv, force_bundle=True, **kw):
-    """``force_bundle``: IONOTOMO_VARIANT=12 while the context is created -- a planned launch then runs k_forward_bundle whatever
-    the number of bundles (by default the library keeps the lanes = samples kernel below two bundles per CU, where it is faster)."""
+def engine(xv, yv, zv, force_bundle=True, env=None, **kw):
+    """``force_bundle``: IONOTOMO_VARIANT=12 while the context is created -- a planned launch then runs k_forward_bundle for EVERY
+    bundle whatever their number and size (by default the plan decides which bundles are worth a workgroup -- all, those of >= T
+    rays with the others' rays going to the lanes = samples kernel in the same call, or none: iono_forward_plan_split).
+    ``env``: further variables read at context creation."""
     import os
     from ionotomo_amd.engine import RayEngine
-    old = os.environ.get("IONOTOMO_VARIANT")
+    env = dict(env or {})
     if force_bundle:
-        os.environ["IONOTOMO_VARIANT"] = "12"
+        env["IONOTOMO_VARIANT"] = "12"
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
     try:
         eng = RayEngine(0, **kw)
     finally:
-        if old is None:
-            os.environ.pop("IONOTOMO_VARIANT", None)
-        else:
-            os.environ["IONOTOMO_VARIANT"] = old
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
     eng.set_grid(xv, yv, zv)
     return eng
 
@@ -94,17 +99,126 @@ def test_bundle_forward_random_geometries(seed, OC):
     again = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
     eng.check_oob()
     assert np.array_equal(again, direct, equal_nan=True)
-    # without the override a small or poor plan (fewer than two bundles per CU, windows that mostly do not fit, bundles of a few
-    # rays) is kept but not used: the lanes = samples kernel's bits
+    # without the override the plan itself decides which bundles are worth a workgroup (iono_forward_plan_split): at these sizes none
+    # -- one lanes = samples launch is modelled (and measured) faster than any bundle launch -- so the plan only orders the walk and
+    # the result carries the lanes = samples kernel's bits
     eng2 = engine(xv, yv, zv, force_bundle=False, quad=quad)
     eng2.set_values(eng2.tensor(M))
     nb2, _, fit2 = eng2.plan_forward(ot, dt, zhi, Ns)
+    sp2 = eng2.forward_plan_split()
+    assert sp2["bundles_served"] == nb2 and sp2["rays_served"] + sp2["rays_tail"] == R and sp2["bundles_cut"] == nb
     small = eng2.forward(ot, dt, zhi, Ns).cpu().numpy()
     eng2.check_oob()
-    if nb2 < 512 or fit2 < 0.5 or R < 16 * nb2:
+    if nb2 == 0 or fit2 < 0.5:
+        assert sp2["min_rays_per_served_bundle"] == 65 or fit2 < 0.5
         assert np.array_equal(small, direct, equal_nan=True)
     elif inside.any():
         assert np.max(np.abs(small[inside] - direct[inside])) <= 2e-13 * np.max(np.abs(direct[inside]))
+
+
+def mixed_rays(rng, xv, yv, zv, n_dense, n_sparse, cubic):
+    """Dense clusters (their bundles fill) + scattered rays (bundles of one or two): what a few timesteps of a sparse array give."""
+    lo = 2 if cubic else 0
+    x0, x1, y0, y1 = xv[lo], xv[-1 - lo], yv[lo], yv[-1 - lo]
+    zlo, zhi = zv[lo] + 1e-9 + 0.1 * (zv[-1] - zv[0]), zv[-1 - lo] - 1e-9 - 0.1 * (zv[-1] - zv[0])
+    hx, hy = xv[1] - xv[0], yv[1] - yv[0]
+    nc = int(rng.integers(1, 5))
+    cx, cy = rng.uniform(x0 + 0.3 * (x1 - x0), x0 + 0.7 * (x1 - x0), nc), rng.uniform(y0 + 0.3 * (y1 - y0), y0 + 0.7 * (y1 - y0), nc)
+    pick = rng.integers(0, nc, n_dense)
+    o1 = np.stack([cx[pick] + rng.normal(size=n_dense) * hx, cy[pick] + rng.normal(size=n_dense) * hy, np.full(n_dense, zlo)], 1)
+    d1 = np.stack([rng.normal(size=n_dense) * 0.004, rng.normal(size=n_dense) * 0.004, np.ones(n_dense)], 1)
+    o2 = np.stack([rng.uniform(x0, x1, n_sparse), rng.uniform(y0, y1, n_sparse), np.full(n_sparse, zlo)], 1)
+    d2 = np.stack([rng.normal(size=n_sparse) * 0.2, rng.normal(size=n_sparse) * 0.2, np.ones(n_sparse)], 1)
+    o, d = np.concatenate([o1, o2]), np.concatenate([d1, d2])
+    p = rng.permutation(len(o))
+    o, d = o[p], d[p]
+    end = o + d * ((zhi - o[:, 2]) / d[:, 2])[:, None]
+    inside = ((o[:, 0] >= x0) & (o[:, 0] <= x1) & (o[:, 1] >= y0) & (o[:, 1] <= y1) &
+              (end[:, 0] >= x0) & (end[:, 0] <= x1) & (end[:, 1] >= y0) & (end[:, 1] <= y1))
+    return o, d, zhi, inside
+
+
+@pytest.mark.parametrize("interp", ["linear", "cubic"])
+@pytest.mark.parametrize("seed", range(SOAK * 6))
+def test_hybrid_dispatch_mixed_geometries(seed, interp, OC):
+    """the choice between the bundle kernels and the lanes = samples kernels is made per BUNDLE.  On geometries that
+    mix well-filled bundles with singletons the served bundles go to k_forward_bundle / k_forward_bundle_lm, the other rays to
+    k_forward_straight_u / _lm in the SAME call: equal to the unplanned launch to 2e-13 (the tail rays bit for bit:
+    the same kernel), to the C oracle to 1e-12, rays that leave the grid NaN + flag on either side of the split."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(4200 + seed)
+    cubic = interp == "cubic"
+    n = [int(v) for v in rng.integers(24, 64, 3)]
+    n[2] += n[2] & 1 if cubic else 0
+    xv, yv, zv = (np.linspace(0.0, float(rng.uniform(60, 200)), m) for m in n)
+    hmin = int(rng.choice([2, 8, 24]))
+    n_dense, n_sparse = int(rng.integers(300, 2500)), int(rng.integers(50, 1500))
+    o, d, zhi, inside = mixed_rays(rng, xv, yv, zv, n_dense, n_sparse, cubic)
+    R, Ns = len(o), int(rng.choice([9, 33, 64, 65, 129]))
+    quad = ["avg", "scipy", "trapz"][seed % 3]
+    eng = engine(xv, yv, zv, force_bundle=False, quad=quad, interp=interp,
+                 env={"IONOTOMO_HYBRID_MIN": hmin})
+    M = rng.uniform(1, 2, size=n)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    direct = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    assert eng.check_oob() == (not inside.all())
+    nb, _, fit = eng.plan_forward(ot, dt, zhi, Ns)
+    sp = eng.forward_plan_split(histogram=True)
+    assert sp["bundles_served"] == nb and sp["rays_served"] + sp["rays_tail"] == R and sp["min_rays_per_served_bundle"] == hmin
+    hist = np.array(sp["bundles_by_ray_count"])
+    assert hist.sum() == sp["bundles_cut"] and (hist * np.arange(65)).sum() == R
+    assert sp["bundles_served"] == hist[hmin:].sum() and sp["rays_served"] == (hist * np.arange(65))[hmin:].sum()
+    assert 0 < sp["rays_tail"] < R, sp                                          # a genuinely mixed launch
+    got = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    assert eng.check_oob() == (not inside.all())
+    assert np.all(np.isnan(got[~inside])) and np.all(np.isfinite(got[inside]))
+    scale = np.max(np.abs(direct[inside]))
+    assert np.max(np.abs(got[inside] - direct[inside])) <= (1e-12 if cubic else 2e-13) * scale, (n, R, Ns, sp)
+    assert np.sum(got[inside] == direct[inside]) >= min(sp["rays_tail"], inside.sum()) - (~inside).sum()    # the tail: the same kernel's bits
+    if not cubic and (quad == "avg" or (quad == "scipy" and Ns % 2 == 1)):
+        ref = OC.forward_tec_straight(xv, yv, zv, M, o[inside], d[inside], zhi, Ns)
+        assert np.max(np.abs(got[inside] - ref)) <= 1e-12 * np.max(np.abs(ref))
+    if cubic and Ns % 2 == 1 and quad != "trapz":
+        sel = np.flatnonzero(inside)[:300]
+        ref = O.forward_tec(O.straight_rays(o[sel], d[sel], zhi, Ns), xv, yv, zv, M, kind=O.INTERP_TRICUBIC)
+        assert np.max(np.abs(got[sel] - ref)) < 1e-11 * np.max(np.abs(ref))
+    # new node values: both halves of the launch see them (the tricubic field arrays of BOTH layouts are rebuilt)
+    M2 = rng.uniform(1, 2, size=n)
+    eng.set_values(eng.tensor(M2))
+    got2 = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    eng.clear_forward_plan()
+    direct2 = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    eng.check_oob()
+    assert np.max(np.abs(got2[inside] - direct2[inside])) <= (1e-12 if cubic else 2e-13) * np.max(np.abs(direct2[inside]))
+    assert not eng.plan_stale()
+
+
+def test_hybrid_dispatch_phase_observable():
+    """The phase forward on a mixed geometry: served bundles through k_forward_bundle<NF>, the tail through k_forward_phase_u with the
+    plan's walk as its ray list; equal to the unplanned launch for 1, 3 and 8 frequencies."""
+    rng = np.random.default_rng(99)
+    n = (40, 44, 48)
+    xv, yv, zv = (np.linspace(0.0, 150.0, m) for m in n)
+    na, nt, nd = 6, 5, 40
+    o, d, zhi, inside = mixed_rays(rng, xv, yv, zv, 1200, 500, False)
+    keep = np.flatnonzero(inside)[:na * nt * nd]
+    o, d = o[keep], d[keep]
+    assert len(o) == na * nt * nd
+    eng = engine(xv, yv, zv, force_bundle=False, env={"IONOTOMO_HYBRID_MIN": 8})
+    eng.set_values(eng.tensor(rng.uniform(1e11, 2e11, size=n)))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    clock, const = eng.tensor(rng.normal(size=(na, nt)) * 1e-9), eng.tensor(rng.normal(size=na))
+    for nf in (1, 3, 8):
+        freqs = np.linspace(110e6, 170e6, nf)
+        eng.clear_forward_plan()
+        direct = eng.forward_phase(ot, dt, na, nt, nd, zhi, 65, freqs, clock, const, 1).cpu().numpy()
+        eng.plan_forward(ot, dt, zhi, 65)
+        sp = eng.forward_plan_split()
+        assert sp["bundles_served"] > 0 and sp["rays_tail"] > 0
+        got = eng.forward_phase(ot, dt, na, nt, nd, zhi, 65, freqs, clock, const, 1).cpu().numpy()
+        assert np.all(np.isfinite(got)) and np.max(np.abs(got - direct)) < 1e-11 * np.max(np.abs(direct)), nf
+    assert not eng.check_oob()
 
 
 def test_tec_does_not_depend_on_the_bundling():

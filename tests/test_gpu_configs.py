@@ -91,6 +91,39 @@ def test_two_process_hip_engine_matches_single_rank(exchange):
             assert not res[r]["overlapped"] and res[r]["nslab"] == 0      # tricubic: compact exchange, one slab
 
 
+@pytest.mark.parametrize("exchange", ["dense", "compact", "sharded", "overlap"])
+def test_one_rank_rccl_group_equals_no_group(exchange):
+    """torch's nccl backend (= RCCL) has to carry the multi-GPU exchange, and a 1-GPU box can only give it ONE rank.
+    With parallel.FORCE_COLLECTIVES the sharded code paths issue every collective on a 1-rank nccl group -- all-reduce of the dense /
+    compact update, reduce-scatter + all-gather, the asynchronous slab pipeline -- and a one-rank sum is the identity: forward,
+    back-projection and the SIRT iterates (fixed-point back-projection, so that two runs CAN agree exactly) must equal the run
+    without a group BIT FOR BIT; CGLS forms <s, s> with another kernel on the multi-rank path (1e-12), the sharded update runs in
+    torch (1e-12)."""
+    import torch.multiprocessing as mp
+    from test_distributed_gloo import _worker, _run, _free_port
+    size = dict(na=6, nd=7, nt=6, n=40, Ns=65)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, exchange, "hip", size, "linear", "nccl", True, True))
+    p.start()
+    rank, res = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0 and rank == 0
+    ref = _run(1, exchange, "hip", size, "linear", True)
+    assert res["block"] == (0, ref["P"])
+    assert np.array_equal(res["fwd"], ref["fwd"]) and np.array_equal(res["adj"], ref["adj"])
+    assert res["compact"] == (exchange != "dense")                          # the forced group really planned its exchange
+    if exchange == "overlap":
+        assert res["overlapped"] and res["nslab"] >= 2                      # the slab pipeline ran, over RCCL
+    if exchange == "sharded":
+        assert np.allclose(res["xs"], ref["xs"], rtol=1e-12, atol=0) and np.allclose(res["hs"], ref["hs"], rtol=1e-12)
+    else:
+        assert np.array_equal(res["xs"], ref["xs"]) and np.array_equal(res["hs"], ref["hs"])
+        assert np.array_equal(res["xs2"], ref["xs2"])
+    assert np.allclose(res["hc"], ref["hc"], rtol=1e-10) and np.max(np.abs(res["xc"] - ref["xc"])) < 1e-10 * np.max(np.abs(ref["xc"]))
+    assert np.max(np.abs(res["adj32"] - ref["adj32"])) < 1e-6 * np.max(np.abs(ref["adj32"]))
+
+
 # --------------------------------------------------------------------------- config 3
 @pytest.mark.parametrize("kind", ["linear", "cubic"])
 def test_config3_fermat_bending_128_cubed(kind, O):
@@ -119,6 +152,46 @@ def test_config3_fermat_bending_128_cubed(kind, O):
         tec = eng.forward_rays(rays_t, kind=tk).cpu().numpy()
         tref = O.forward_tec(rays[idx], w["xvec"], w["yvec"], w["zvec"], w["ne"], kind=ok)
         assert np.max(np.abs(tec[idx] - tref) / np.abs(tref)) < 1e-11
+    assert not eng.check_oob()
+
+
+@pytest.mark.parametrize("kind", ["linear", "cubic"])
+def test_config3_fermat_error_controlled_stepping(kind, O):
+    """the reference integrates with adaptive LSODA (odeint defaults rtol = atol = 1.49e-8,
+    inversion/fermat.py:163-167); here the RK4 step count per output sample is chosen by step doubling on a strided sample of the
+    batch.  The chosen count's estimate must hold against the ORACLE traced 4 x finer on 208 rays, for a loose and for the
+    reference's tolerance; "auto" launches use the choice and remember it until the node values change."""
+    from ionotomo_amd.inversion import fermat as F
+    w = syn.make_workload("cfg2", margin_cells=16)
+    eng = make_engine(w)
+    eng.set_values(eng.tensor(w["ne"]))
+    o, d = w["origins"].reshape(-1, 3), w["directions"].reshape(-1, 3)
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    Ns, freq = w["Ns"], 120e6
+    nM = O.ne_to_n(w["ne"], freq)
+    field = (O.n_field_trilinear if kind == "linear" else O.n_field_tricubic)(w["xvec"], w["yvec"], w["zvec"], nM)
+    idx = F.sample_indices(len(o))
+    assert idx.size == 208
+    for rtol in (1e-5, F.ODEINT_RTOL):
+        sub, rep = eng.choose_fermat_substeps(ot, dt, w["tmax"], Ns, freq, kind=kind, rtol=rtol, max_substeps=16)
+        assert rep["sample_rays"] == 208 and rep["chosen_substeps"] == sub and sub in (1, 2, 4, 8, 16)
+        errs = [l["error_over_tolerance"] for l in rep["levels"]]
+        assert all(a > b for a, b in zip(errs, errs[1:]))                          # halving the step reduces the difference
+        print("fermat step control, %s index, rtol %.3g: substeps %d, met %s, levels %s" % (kind, rtol, sub, rep["met"], errs))
+        if not rep["met"]:
+            continue                                                               # (reported, not hidden: bench.py extra.fermat carries it)
+        got = eng.trace_fermat(ot, dt, w["tmax"], Ns, freq, bend=True, kind=kind, substeps=sub).cpu().numpy()[idx]
+        fine = O.fermat_trace(o[idx], d[idx], w["tmax"], Ns, field, bend=True, substeps=4 * sub)
+        assert F.doubling_error(got, fine, rtol, rtol) <= 1.0, (kind, rtol, sub)      # the tolerance holds against the finer oracle
+    # "auto": the choice at the reference's tolerance, cached per geometry until the values change
+    tec_auto = eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, kind=kind, substeps="auto", ne_scale=1e-13)
+    rep = eng.fermat_step_report
+    tec_same = eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, kind=kind, substeps=rep["chosen_substeps"], ne_scale=1e-13)
+    assert torch.equal(tec_auto, tec_same)
+    assert eng._fermat_substeps("auto", ot, dt, w["tmax"], Ns, freq, True, kind, "z") == rep["chosen_substeps"] and eng.fermat_step_report is rep
+    eng.set_values(eng.tensor(w["ne"] * 1.5))
+    eng.forward_fermat(ot, dt, w["tmax"], Ns, freq, kind=kind, substeps=("auto", 1e-5), ne_scale=1e-13)
+    assert eng.fermat_step_report is not rep and eng.fermat_step_report["rtol"] == 1e-5
     assert not eng.check_oob()
 
 

@@ -138,3 +138,31 @@ def test_walk_orders_are_permutations_on_cpu():
     step = (dn[co][1:] - dn[co][:-1]).norm(dim=1)[same_antenna].median()
     rand = (dn[co][torch.randperm(R)][1:] - dn[co][:-1]).norm(dim=1).median()
     assert float(step) < 0.25 * float(rand)
+
+
+def test_fermat_step_doubling_control_host_logic():
+    """inversion/fermat.py's step control (the reference integrates with adaptive LSODA at rtol = atol = 1.49e-8,
+    inversion/fermat.py:163-167; here fixed-step RK4 with the step count chosen by step doubling on a sample): a synthetic tracer
+    whose error falls like C / s^4 -- the smallest power of two that meets the tolerance is chosen, every level traced once."""
+    from ionotomo_amd.inversion import fermat as F
+    assert F.sample_indices(2604).size == 208 and F.sample_indices(620000).size == 6200 and F.sample_indices(5).tolist() == [0, 1, 2, 3, 4]
+    assert F.sample_indices(0).size == 0
+    calls = []
+
+    def tracer(C):
+        def tr(s):
+            calls.append(s)
+            r = np.zeros((3, 4, 5))
+            r[:, 0], r[:, 1], r[:, 2], r[:, 3] = 100 + C / s ** 4, 50.0, np.linspace(0, 1, 5), 1000 + 10 * C / s ** 4
+            return r
+        return tr
+    sub, rep = F.choose_substeps(tracer(1e-4))
+    assert sub == 4 and rep["met"] and [l["substeps"] for l in rep["levels"]] == [1, 2, 4] and calls == [1, 2, 4, 8]
+    assert rep["levels"][-1]["error_over_tolerance"] <= 0.5 < rep["levels"][-2]["error_over_tolerance"]
+    sub, rep = F.choose_substeps(tracer(1e-9))
+    assert sub == 1 and rep["met"] and len(rep["levels"]) == 1
+    sub, rep = F.choose_substeps(tracer(1e3), max_substeps=8)
+    assert sub == 8 and not rep["met"]
+    sub, rep = F.choose_substeps(tracer(1e-4), rtol=1e-5)
+    assert sub == 1 and rep["rtol"] == rep["atol"] == 1e-5
+    assert F.doubling_error(np.zeros((0, 4, 3)), np.zeros((0, 4, 3)), 1e-8, 1e-8) == 0.0
