@@ -856,8 +856,8 @@ def main():
                                "grid, trilinear + Simpson, forward TEC" % (R, NS),
                    "rays_per_gpu": R, "samples_per_ray": NS, "grid": [NGRID] * 3, "interp": "trilinear",
                    "quadrature": "simpson", "sharding": "rays by (time,direction) block, grid replicated",
-                   "forward_kernel": ("k_forward_bundle<0> (%d bundles)%s" % (split["bundles_served"], " + k_forward_straight_u (%d rays)" % split["rays_tail"]
-                                                                              if split["rays_tail"] else "")) if planned else "k_forward_straight_u (no plan)",
+                   # (the library's dispatch table, asked for THIS launch: iono_dispatch_describe)
+                   "forward_kernel": eng.describe("forward", o_t, d_t, TMAX, NS)[0],
                    "forward_plan_split": split,
                    # the contract's window (K steps between barriers) repeated M times back to back so that the timed region lasts >= 20 ms:
                    # `value` = all rays of the M windows / their total wall time; the spread over the windows next to it
@@ -988,7 +988,24 @@ def main():
             if planned:
                 extra["odd_grids"] = [other_grid_leg(n, w, local, o_t, d_t, forder_t, R, kern, k2, torch, dist) for n in (255, 257)]
             # ---- float32 grid storage (float64 arithmetic) and the single-timestep launch
-            _, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, 1)
+            # unplanned: float64 arithmetic on the rounded values (k_forward_straight_q4); with a forward plan: the float32 FAST MODE
+            # (k_forward_bundle_f32: float32 window images, packed-float32 interpolation, float64 sums of the chunk sums) -- a storage /
+            # precision mode of its own, never the float64 headline
+            _, k32u = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, 1)
+            extra["f32_grid_unplanned_ray_integrals_per_s_per_gpu"] = R / k32u
+            extra["f32_grid_unplanned_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
+            if args.fwd_plan:
+                info32 = eng32.plan_forward(o_t, d_t, TMAX, NS)
+                _, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, 1)
+                assert not eng32.check_oob()
+                dt32, dt64 = (t.view(NA, -1) - t.view(NA, -1)[0:1] for t in (tec32, tec_t))
+                extra["f32_fast_mode"] = {"kernel": "k_forward_bundle_f32", "bundles": info32[0], "lds_chunk_fraction": info32[2], "forward_ms": k32 * 1e3,
+                                          "vs_float64_headline_kernel": kern / k32,
+                                          "dtec_max_abs_err_over_max_tec": float((dt32 - dt64).abs().max() / tec_t.abs().max()),
+                                          "algorithmic_bytes_per_ray": algorithmic_bytes_per_ray(NS, 4),
+                                          "algorithmic_gbs": R * algorithmic_bytes_per_ray(NS, 4) / k32 / 1e9}
+            else:
+                k32 = k32u
             extra["f32_grid_ray_integrals_per_s_per_gpu"] = R / k32
             extra["f32_grid_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
             sel = torch.arange(R, device=eng.device).reshape(NA, NT, ND)[:, 0, :].reshape(-1)

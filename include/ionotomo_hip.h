@@ -414,6 +414,49 @@ int iono_comm_init(iono_ctx *ctx, const char id[IONO_COMM_ID_BYTES], int rank, i
 int iono_comm_allreduce_dev(iono_ctx *ctx, void *buf_dev, int64_t count, int dtype);
 int iono_comm_destroy(iono_ctx *ctx);
 
+/* ---- ONE dispatch table: which kernel a launch gets --------------------------------------------------------------------------
+ * Every launcher in the library asks the same pure function of a handful of FACTS -- the grid's tier, its storage, the interpolant,
+ * the batch size, whether a plan serves the launch -- and launches what it answers; iono_dispatch_name answers without a GPU (the
+ * table is pinned by tests/test_cabi.py), iono_dispatch_describe fills the facts from a context and the launch's own arguments
+ * (what bench.py prints as config.forward_kernel).  The reference has no counterpart: its path is one numpy code
+ * (inversion/forward_equation.py:13-51, inversion/gradient.py:66-102, inversion/fermat.py:150-174) -- this is the map from those three
+ * entry points to the kernels that serve them here. */
+enum { IONO_OP_FORWARD = 0,          /* iono_forward_tec_straight*            <- inversion/forward_equation.py:13-51 */
+       IONO_OP_ADJOINT = 1,          /* iono_adjoint_*straight*               <- inversion/gradient.py:66-102 (exact transpose) */
+       IONO_OP_TRACE = 2,            /* iono_trace_fermat*                    <- inversion/fermat.py:150-174 */
+       IONO_OP_FERMAT_FORWARD = 3,   /* iono_forward_tec_fermat_dev           (trace + integrate fused) */
+       IONO_OP_FERMAT_ADJOINT = 4,   /* iono_adjoint_fermat_dev */
+       IONO_OP_PHASE_FORWARD = 5,    /* iono_forward_phase_straight_dev       <- inversion/iterative_newton.py:86-127 */
+       IONO_OP_PHASE_ADJOINT = 6 };  /* iono_adjoint_phase_straight_dev */
+typedef struct iono_dispatch_facts {
+    int storage;              /* IONO_F64 | IONO_F32 */
+    int tier;                 /* axes: 0 general (binary search), 1 table-uniform, 2 ideal-uniform (np.linspace) with Ns <= 4096 */
+    int cubic_fast;           /* the Lekien-Marsden record tier serves the grid (tier 2, >= 6 nodes per axis, 32-bit-safe records, IONOTOMO_VARIANT != 4) */
+    int cubic_records;        /* ... whatever Ns (what the tracers ask) */
+    int ideal_axes;           /* every axis is g0 + i h to 2.5e-13 h and the general tiers are not forced (the tracers' fast right-hand side) */
+    int q4_ok;                /* float32 2 x 2 corner blocks addressable with 32-bit offsets */
+    int variant;              /* IONOTOMO_VARIANT: 0 | 2 (general back-projection) | 3 (lanes = rays tracers) | 4 (216-tap tricubic) */
+    int deterministic;        /* iono_set_deterministic */
+    int interp_kind;          /* of the integrand / the transposed forward | of the refractive index (tracer ops) */
+    int ne_kind;              /* fused Fermat ops: the integrand's interpolant */
+    int bend;                 /* tracer ops */
+    int Ns;
+    int64_t R;
+    int64_t fwd_bundles;      /* served bundles of a forward plan that serves THIS launch (0: none) */
+    int64_t fwd_tail;         /* ... and the rays it leaves to the lanes = samples kernel */
+    int adj_planned;          /* a back-projection plan of this interpolant serves this launch */
+    int adj_tiles;            /* ... and lists its fold tiles (tricubic plans) */
+    int adj_seg_lanes;        /* ... its lanes per segment (4 | 8 | 16) */
+    int axes_bytes;           /* 8 (nx + ny + nz) */
+    int fermat_lm_lanes;      /* forced lanes per ray of the record tracer (8 | 2; 0: by batch size) */
+    int64_t fermat_lm_few_min, fermat_poly_max, fermat_lin4_max, fermat_coop_max;      /* batch-size thresholds of the tracers */
+} iono_dispatch_facts;
+/* The kernel(s) `op` gets under `facts`, as text ("k_forward_bundle<0> + k_forward_straight_u<double>"), into out[cap].  Pure. */
+int iono_dispatch_name(const iono_dispatch_facts *facts, int op, char *out, int cap);
+/* The facts of a launch on `ctx` with these arguments (device pointers may be null: then no plan matches), and its kernel name. */
+int iono_dispatch_describe(iono_ctx *ctx, int op, const double *origins_dev, const double *directions_dev, int64_t R, double tmax,
+                           int Ns, int interp_kind, int ne_kind, int bend, iono_dispatch_facts *facts_out, char *out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,41 @@ def storage_code(s):
     return _STORAGE[s]
 
 
+# the operations of the dispatch table (include/ionotomo_hip.h: IONO_OP_*)
+OP_FORWARD, OP_ADJOINT, OP_TRACE, OP_FERMAT_FORWARD, OP_FERMAT_ADJOINT, OP_PHASE_FORWARD, OP_PHASE_ADJOINT = range(7)
+_OPS = {"forward": 0, "adjoint": 1, "trace": 2, "fermat_forward": 3, "fermat_adjoint": 4, "phase_forward": 5, "phase_adjoint": 6}
+
+
+class DispatchFacts(ctypes.Structure):
+    """iono_dispatch_facts: what decides which kernel a launch gets (the header documents every field)."""
+    _fields_ = [("storage", ctypes.c_int), ("tier", ctypes.c_int), ("cubic_fast", ctypes.c_int), ("cubic_records", ctypes.c_int),
+                ("ideal_axes", ctypes.c_int), ("q4_ok", ctypes.c_int), ("variant", ctypes.c_int), ("deterministic", ctypes.c_int),
+                ("interp_kind", ctypes.c_int), ("ne_kind", ctypes.c_int), ("bend", ctypes.c_int), ("Ns", ctypes.c_int),
+                ("R", ctypes.c_int64), ("fwd_bundles", ctypes.c_int64), ("fwd_tail", ctypes.c_int64), ("adj_planned", ctypes.c_int),
+                ("adj_tiles", ctypes.c_int), ("adj_seg_lanes", ctypes.c_int), ("axes_bytes", ctypes.c_int), ("fermat_lm_lanes", ctypes.c_int),
+                ("fermat_lm_few_min", ctypes.c_int64), ("fermat_poly_max", ctypes.c_int64), ("fermat_lin4_max", ctypes.c_int64),
+                ("fermat_coop_max", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def dispatch_name(op, **facts):
+    """The kernel(s) operation ``op`` ("forward", "adjoint", "trace", "fermat_forward", "fermat_adjoint", "phase_forward",
+    "phase_adjoint") gets under ``facts`` (fields of ``DispatchFacts``; unnamed ones are 0): the library's ONE dispatch table, asked
+    without a GPU (iono_dispatch_name is pure host code)."""
+    f = DispatchFacts()
+    for k, v in facts.items():
+        if k not in dict(DispatchFacts._fields_):
+            raise KeyError(k)
+        setattr(f, k, int(v))
+    buf = ctypes.create_string_buffer(256)
+    rc = load().iono_dispatch_name(ctypes.byref(f), _OPS.get(op, op), buf, 256)
+    if rc != OK:
+        raise ValueError("iono_dispatch_name: bad operation %r" % (op,))
+    return buf.value.decode()
+
+
 c_double_p = ctypes.POINTER(ctypes.c_double)
 _P, _I, _L, _D, _V = c_double_p, ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p
 
@@ -114,6 +149,7 @@ _SIGNATURES = {
     "iono_forward_plan_info": [ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_double)],
     "iono_forward_plan_split": [ctypes.POINTER(ctypes.c_int64)] * 4 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64),
                                 ctypes.POINTER(ctypes.c_double)],
+    "iono_dispatch_describe": [_I, _V, _V, _L, _D, _I, _I, _I, _I, ctypes.POINTER(DispatchFacts), ctypes.c_char_p, _I],
     "iono_walk_order": [_P, _P, _L, _D, ctypes.POINTER(ctypes.c_int)],
     "iono_trace_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _V],
     "iono_forward_tec_fermat_dev": [_V, _V, _L, _D, _I, _D, _I, _I, _I, _I, _I, _I, _D, _V],
@@ -128,7 +164,7 @@ _SIGNATURES = {
     "iono_comm_allreduce_dev": [_V, _L, _I],
     "iono_comm_destroy": [],
 }
-EXPORTED = sorted(list(_SIGNATURES) + ["iono_ctx_create", "iono_last_error", "iono_version", "iono_grid_values_ptr"])
+EXPORTED = sorted(list(_SIGNATURES) + ["iono_ctx_create", "iono_last_error", "iono_version", "iono_grid_values_ptr", "iono_dispatch_name"])
 
 _lib = None
 
@@ -159,6 +195,8 @@ def load():
     lib.iono_version.restype = _I
     lib.iono_grid_values_ptr.argtypes = [_V]
     lib.iono_grid_values_ptr.restype = _V
+    lib.iono_dispatch_name.argtypes = [ctypes.POINTER(DispatchFacts), _I, ctypes.c_char_p, _I]
+    lib.iono_dispatch_name.restype = _I
     for name, args in _SIGNATURES.items():
         fn = getattr(lib, name)
         fn.argtypes = [_V] + args
@@ -315,6 +353,15 @@ class Context(object):
 
     def call(self, name, *args):
         self._check(getattr(self._lib, name)(self._h, *args))
+
+    def dispatch_describe(self, op, origins_ptr=0, dirs_ptr=0, R=0, tmax=0.0, Ns=2, kind="linear", ne_kind=None, bend=True):
+        """(kernel name, facts) of the launch ``op`` would be on this context with these arguments (device pointers 0: no plan
+        matches): the library's dispatch table (include/ionotomo_hip.h: iono_dispatch_describe)."""
+        f = DispatchFacts()
+        buf = ctypes.create_string_buffer(256)
+        self.call("iono_dispatch_describe", _OPS.get(op, op), _V(origins_ptr), _V(dirs_ptr), int(R), float(tmax), int(Ns), interp_kind(kind),
+                  interp_kind(kind if ne_kind is None else ne_kind), int(bool(bend)), ctypes.byref(f), buf, 256)
+        return buf.value.decode(), f.as_dict()
 
     # -- grid ------------------------------------------------------------------------------------
     def set_grid(self, xvec, yvec, zvec, M=None, storage="f64"):

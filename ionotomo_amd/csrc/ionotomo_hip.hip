@@ -36,6 +36,7 @@
 
 #include "iono_device_common.h"
 #include "iono_forward_kernels.h"
+#include "iono_forward_f32_kernels.h"
 #include "iono_adjoint_kernels.h"
 #include "iono_cubic_kernels.h"
 #include "iono_solver_kernels.h"
@@ -61,6 +62,7 @@ struct iono_ctx {
     int uniform[3] = {0, 0, 0};
     int *d_flags = nullptr;          // [0] out-of-bounds, [1] non-finite, [2] a planned launch met rays its plan was not made for, [3] spare
     double *d_unitw = nullptr;       // cached unit-spacing quadrature weights
+    float *d_unitw32 = nullptr;      // ... and their float32 copy, inside the same allocation
     int unitw_n = 0, unitw_rule = -1;
     std::string err;
     int num_cus = 256;
@@ -95,7 +97,6 @@ struct iono_ctx {
     int seg_lanes = 0;               // env IONOTOMO_SEG_LANES=4|8|16: lanes per segment of the back-projection plan (0: chosen per geometry)
     int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
     int fermat_lm_lanes = 0;            // record tracer / fused TEC through a tricubic index: lanes per ray (8 or 2); 0 = by batch size
-    int *d_lm4_next = nullptr;          // [2] unit counters of the two persistent k_adjoint_binned_lm4 launches of a tricubic transpose
     int lm4_groups = 0;                 // env IONOTOMO_LM4_GROUPS: persistent workgroups of the planned tricubic transpose (A/B; default: one per CU)
                                         // (env IONOTOMO_FERMAT_LM_LANES): 8 below fermat_lm_few_min rays, 2 from there on
     int64_t fermat_lm_few_min = 32768;  // (env IONOTOMO_FERMAT_LM_FEW_MIN)
@@ -272,7 +273,7 @@ GridView view(const iono_ctx *c) {
         g.c0[a] = c->c0[a];
         g.clast[a] = c->clast[a];
     }
-    g.ideal = c->ideal && c->force_general == 0 && c->variant != 13 && (uint64_t)c->nx * c->ny * c->nz < ((uint64_t)1 << 32);      // (IONOTOMO_VARIANT=13: the tracer's general right-hand side, A/B)
+    g.ideal = c->ideal && c->force_general == 0 && (uint64_t)c->nx * c->ny * c->nz < ((uint64_t)1 << 32);      // (IONOTOMO_FORCE_GENERAL=2: the tracer's general right-hand side, A/B)
     return g;
 }
 hipError_t DevBuf::alloc(size_t bytes) {
@@ -412,8 +413,14 @@ int ensure_unitw(iono_ctx *c, int Ns, int rule) {
         c->d_unitw = nullptr;
     }
     w.resize((size_t)Ns + 8, 0.0);      // (zero weights beyond the last sample: kernels may read a whole chunk's weights at once)
-    HIP_TRY(c, hipMalloc((void **)&c->d_unitw, sizeof(double) * w.size()));
+    // ... followed by the same weights in float32 (the float32 fast mode's chunk sums: k_forward_bundle_f32), 32-byte aligned
+    const size_t off32 = (sizeof(double) * w.size() + 31) & ~(size_t)31;
+    std::vector<float> w32(w.size() + 8, 0.0f);
+    for (size_t k = 0; k < w.size(); ++k) w32[k] = (float)w[k];
+    HIP_TRY(c, hipMalloc((void **)&c->d_unitw, off32 + sizeof(float) * w32.size()));
     HIP_TRY(c, hipMemcpy(c->d_unitw, w.data(), sizeof(double) * w.size(), hipMemcpyHostToDevice));
+    c->d_unitw32 = (float *)((char *)c->d_unitw + off32);
+    HIP_TRY(c, hipMemcpy(c->d_unitw32, w32.data(), sizeof(float) * w32.size(), hipMemcpyHostToDevice));
     c->unitw_n = Ns;
     c->unitw_rule = rule;
     return IONO_OK;
@@ -548,7 +555,6 @@ int iono_ctx_destroy(iono_ctx *c) {
     if (c->d_FP) (void)hipFree(c->d_FP);
     if (c->d_nF8) (void)hipFree(c->d_nF8);
     if (c->d_G8) (void)hipFree(c->d_G8);
-    if (c->d_lm4_next) (void)hipFree(c->d_lm4_next);
     if (c->d_fixgrid) (void)hipFree(c->d_fixgrid);
     if (c->d_LMw) (void)hipFree(c->d_LMw);
     if (c->d_Q4) (void)hipFree(c->d_Q4);
@@ -783,7 +789,7 @@ static int walk_cycles_reserve(iono_ctx *c, iono_ctx::WalkPart &wp, int n_chunks
 // windows hold (FwdPlan::d_xrange: a third of the bench grid; the pair arrays are then valid for THAT plan only, FP_plan_serial)
 static int ensure_lm_fields(iono_ctx *c, bool pairs = false, bool for_plan = false) {
     const int64_t n = ncells(c), npad = padded_count(c);
-    const bool restricted = pairs && for_plan && c->fplan.lm_all_fit && c->fplan.d_xrange && c->variant != 25;      // (IONOTOMO_VARIANT=25: whole grid, A/B)
+    const bool restricted = pairs && for_plan && c->fplan.lm_all_fit && c->fplan.d_xrange;
     if (pairs && !c->FP_valid && restricted && c->d_FP && c->FP_plan_serial == c->fplan.serial) return IONO_OK;
     if (!pairs && !c->d_F8) {
         const size_t fb = (size_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double);
@@ -844,12 +850,12 @@ static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes, const int 
 // Forward mapping on ideal-uniform grids without a bundle plan: lanes = samples of one ray (k_forward_straight_u).
 // IONOTOMO_VARIANT=10 forces lanes = samples even on a planned geometry (A/B; results agree to rounding).
 // the bundle plan serves this launch: same ray arrays, R, tmax, Ns, and it fills the chip / is good (see the forward dispatch)
-static bool fplan_serves(const iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns) {
+static bool fplan_serves(const iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, int storage = IONO_F64) {
     const iono_ctx::FwdPlan &fp = c->fplan;
     // (WHICH bundles are worth a workgroup -- all, those of >= T rays, none -- was decided when the plan was made: iono_forward_plan_dev;
-    //  IONOTOMO_VARIANT=10: never, A/B)
-    return c->storage == IONO_F64 && fp.R == R && fp.o_key == o && fp.d_key == d && fp.Ns == Ns && fp.tmax == tmax && ideal_path_ok(c) &&
-           c->variant != 10 && fp.nb > 0 && (fp.fit_fraction >= 0.5 || fp.forced);
+    //  IONOTOMO_HYBRID_MIN=65: none, A/B)
+    return c->storage == storage && fp.R == R && fp.o_key == o && fp.d_key == d && fp.Ns == Ns && fp.tmax == tmax && ideal_path_ok(c) &&
+           fp.nb > 0 && (fp.fit_fraction >= 0.5 || fp.forced);
 }
 // fast tricubic tier: ideal-uniform axes, weights in LDS, 32-bit-safe field array (IONOTOMO_VARIANT=4 forces the general tier)
 static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
@@ -858,11 +864,152 @@ static bool cubic_fast_ok(const iono_ctx *c, int Ns) {
            (uint64_t)c->nx * LM_SI(c->ny, c->nz) * LM_NF * sizeof(double) < ((uint64_t)1 << 32);
 }
 
-// lanes per ray of the record tracer / fused TEC kernel (iono_aux_kernels.h: fermat_rhs_lmn): few lanes once the batch fills the chip
-static int fermat_lm_lanes(const iono_ctx *c, int64_t R) {
-    const int f = c->fermat_lm_lanes;
-    if (f == 8 || f == 2) return f;      // (4 and 1 lanes were measured too: profiles/r05_ab_fermat_lanes.json)
-    return R >= c->fermat_lm_few_min ? 2 : 8;
+// ================================================================================================
+// ONE dispatch table (include/ionotomo_hip.h: iono_dispatch_facts, iono_dispatch_name): every launcher below fills the facts of its
+// launch (facts_of) and launches what the pick_* function of its operation answers; iono_dispatch_name turns the same answer into text.
+// ================================================================================================
+enum FwdKernel { FK_BUNDLE_F32, FK_Q4, FK_BUNDLE, FK_U, FK_BUNDLE_LM, FK_LM, FK_FAST, FK_GENERAL };
+enum AdjKernel { AK_BINNED, AK_BINNED_FIX, AK_BINNED_LM4, AK_TILE, AK_TILE_CUBIC, AK_GENERAL, AK_REFUSED };
+enum TraceKernel { TK_POLY, TK_LIN4, TK_RAYS, TK_LM8, TK_LM2, TK_COOP };
+enum FermatKernel { FT_LM8, FT_LM2, FT_RAYS };
+enum PhaseFwdKernel { PF_BUNDLE, PF_U, PF_GENERAL };
+enum PhaseAdjKernel { PA_BINNED, PA_TILE, PA_GENERAL };
+
+static FwdKernel pick_forward(const iono_dispatch_facts &f) {
+    const bool lin = f.interp_kind == IONO_INTERP_TRILINEAR, f32 = f.storage == IONO_F32, ideal = f.tier == 2;
+    if (lin && f32 && f.fwd_bundles > 0) return FK_BUNDLE_F32;      // float32 fast mode: served bundles (+ the tail: Q4 or lanes = samples)
+    if (lin && f32 && ideal && f.q4_ok) return FK_Q4;               // float32 storage, no plan: 2 x 2 corner blocks
+    if (lin && !f32 && f.fwd_bundles > 0) return FK_BUNDLE;         // the headline: windows in LDS (+ the tail: lanes = samples)
+    if (lin && ideal) return FK_U;                                  // lanes = samples on ideal-uniform axes
+    if (!lin && f.cubic_fast && f.fwd_bundles > 0) return FK_BUNDLE_LM;
+    if (!lin && f.cubic_fast) return FK_LM;                         // lanes = samples on Lekien-Marsden records
+    if (lin && f.tier >= 1) return FK_FAST;                         // table-uniform axes
+    return FK_GENERAL;                                              // any axes: binary search per sample (trilinear / 216-tap tricubic)
+}
+static AdjKernel pick_adjoint(const iono_dispatch_facts &f) {
+    const bool lin = f.interp_kind == IONO_INTERP_TRILINEAR, planned = f.adj_planned && f.variant != 2;
+    if (planned && lin) return f.deterministic ? AK_BINNED_FIX : AK_BINNED;
+    const bool lm4 = planned && !lin && f.cubic_fast && f.adj_tiles;
+    if (f.deterministic && !lm4) return AK_REFUSED;                 // fixed point serves the planned back-projections only
+    if (lin && f.tier == 2 && f.variant != 2) return AK_TILE;       // ray-stationary LDS tiles
+    if (!lin && f.cubic_fast && f.variant != 2) return lm4 ? AK_BINNED_LM4 : AK_TILE_CUBIC;
+    return AK_GENERAL;
+}
+static int fermat_lanes_of(const iono_dispatch_facts &f) {
+    if (f.fermat_lm_lanes == 8 || f.fermat_lm_lanes == 2) return f.fermat_lm_lanes;      // (4 and 1 lanes were measured too: profiles/r05_ab_fermat_lanes.json)
+    return f.R >= f.fermat_lm_few_min ? 2 : 8;
+}
+static TraceKernel pick_tracer(const iono_dispatch_facts &f) {
+    const bool lin = f.interp_kind == IONO_INTERP_TRILINEAR;
+    if (lin && f.ideal_axes && f.variant != 3 && f.R <= f.fermat_poly_max) return TK_POLY;
+    if (lin && f.variant != 3 && f.R <= f.fermat_lin4_max && f.axes_bytes <= 48 * 1024) return TK_LIN4;
+    if (lin) return TK_RAYS;
+    if (f.variant == 3 || f.R > f.fermat_coop_max) return TK_RAYS;      // lanes = rays: enough rays to fill the chip without splitting them
+    if (f.ideal_axes && f.cubic_records) return fermat_lanes_of(f) == 8 ? TK_LM8 : TK_LM2;
+    return TK_COOP;
+}
+// the fused forward through a tricubic index runs on k_fermat_tec_lm (ideal-uniform axes, 32-bit-safe record array, float64); its
+// transpose too for bending rays at two lanes per ray -- the large batches, where the alternative is a ray tensor of 32 R Ns bytes and
+// a back-projection with one hardware atomic per corner; small batches keep k_trace_fermat_lm + k_adjoint_rays (engine.py)
+static FermatKernel pick_fermat(const iono_dispatch_facts &f, bool transpose) {
+    const int lanes = fermat_lanes_of(f);
+    const bool lm = f.interp_kind == IONO_INTERP_TRICUBIC && f.storage == IONO_F64 && f.ideal_axes && f.cubic_records && f.variant != 3 &&
+                    f.R <= f.fermat_coop_max && (!transpose || (f.bend && lanes == 2));
+    return lm ? (lanes == 8 ? FT_LM8 : FT_LM2) : FT_RAYS;
+}
+static PhaseFwdKernel pick_phase_forward(const iono_dispatch_facts &f) {
+    return f.fwd_bundles > 0 && f.storage == IONO_F64 ? PF_BUNDLE : f.tier == 2 ? PF_U : PF_GENERAL;
+}
+static PhaseAdjKernel pick_phase_adjoint(const iono_dispatch_facts &f) {
+    return f.adj_planned && f.variant != 2 ? PA_BINNED : f.tier == 2 && f.variant != 2 ? PA_TILE : PA_GENERAL;
+}
+
+// the facts of a launch on this context (o, d null: no plan matches)
+static iono_dispatch_facts facts_of(const iono_ctx *c, int op, const double *o, const double *d, int64_t R, double tmax, int Ns, int kind,
+                                    int kind_ne, int bend) {
+    iono_dispatch_facts f;
+    memset(&f, 0, sizeof(f));
+    f.storage = c->storage, f.variant = c->variant, f.deterministic = c->deterministic ? 1 : 0;
+    f.tier = ideal_path_ok(c, Ns) ? 2 : fast_path_ok(c) ? 1 : 0;
+    f.cubic_fast = cubic_fast_ok(c, Ns) ? 1 : 0, f.cubic_records = cubic_fast_ok(c, 2) ? 1 : 0;
+    f.ideal_axes = view(c).ideal ? 1 : 0;
+    f.q4_ok = (uint64_t)padded_count(c) * 16 < ((uint64_t)1 << 32) ? 1 : 0;
+    f.interp_kind = kind, f.ne_kind = kind_ne, f.bend = bend, f.Ns = Ns, f.R = R;
+    const bool straight = op == IONO_OP_FORWARD || op == IONO_OP_PHASE_FORWARD;
+    // (the tricubic bundle kernel and the phase observable read float64 fields: their plans serve float64 storage only)
+    const int plan_storage = op == IONO_OP_FORWARD && kind == IONO_INTERP_TRILINEAR ? c->storage : IONO_F64;
+    if (straight && o && d && fplan_serves(c, o, d, R, tmax, Ns, plan_storage)) f.fwd_bundles = c->fplan.nb, f.fwd_tail = c->fplan.n_rest;
+    const iono_ctx::AdjPlan &pl = c->plan;
+    const int adj_kind = op == IONO_OP_PHASE_ADJOINT ? IONO_INTERP_TRILINEAR : kind;
+    if ((op == IONO_OP_ADJOINT || op == IONO_OP_PHASE_ADJOINT) && o && pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax &&
+        pl.kind == adj_kind)
+        f.adj_planned = 1, f.adj_tiles = pl.tile_n[2] > 0 ? 1 : 0, f.adj_seg_lanes = pl.segl;
+    f.axes_bytes = (c->nx + c->ny + c->nz) * 8;
+    f.fermat_lm_lanes = c->fermat_lm_lanes, f.fermat_lm_few_min = c->fermat_lm_few_min, f.fermat_poly_max = c->fermat_poly_max;
+    f.fermat_coop_max = c->fermat_coop_max;
+    // (a grid that is not ideal-uniform keeps the general right-hand side in the lanes = rays kernel: crossover ~150k rays as before)
+    f.fermat_lin4_max = f.ideal_axes || c->fermat_lin4_max != 4096 ? c->fermat_lin4_max : 131072;
+    return f;
+}
+
+static std::string dispatch_text(const iono_dispatch_facts &f, int op) {
+    const char *T = f.storage == IONO_F32 ? "float" : "double";
+    const std::string lin_or_cubic = f.interp_kind == IONO_INTERP_TRILINEAR ? "IONO_INTERP_TRILINEAR" : "IONO_INTERP_TRICUBIC";
+    const std::string segl = std::to_string(f.adj_seg_lanes ? f.adj_seg_lanes : 16);
+    auto tail = [&](const std::string &k) { return f.fwd_tail > 0 ? " + " + k : std::string(); };
+    switch (op) {
+    case IONO_OP_FORWARD:
+        switch (pick_forward(f)) {
+        case FK_BUNDLE_F32: return "k_forward_bundle_f32" + tail(f.q4_ok ? "k_forward_straight_q4" : "k_forward_straight_u<float>");
+        case FK_Q4: return "k_forward_straight_q4";
+        case FK_BUNDLE: return "k_forward_bundle<0>" + tail("k_forward_straight_u<double>");
+        case FK_U: return std::string("k_forward_straight_u<") + T + ">";
+        case FK_BUNDLE_LM: return "k_forward_bundle_lm" + tail("k_forward_straight_lm");
+        case FK_LM: return "k_forward_straight_lm";
+        case FK_FAST: return std::string("k_forward_straight_fast<") + T + ">";
+        default: return std::string("k_forward_straight<") + T + ", " + lin_or_cubic + ">";
+        }
+    case IONO_OP_ADJOINT:
+        switch (pick_adjoint(f)) {
+        case AK_BINNED: return "k_adjoint_binned<AT, 0, double, " + segl + ", false>";
+        case AK_BINNED_FIX: return "k_adjoint_binned<double, 0, double, " + segl + ", true> + FixConvert";
+        case AK_BINNED_LM4: return "2 x k_adjoint_binned_lm4<" + segl + ", true> + k_lm_fold_{z,y,x}_tiles";
+        case AK_TILE: return "k_adjoint_straight_tile<AT, MODE, 4, false>";
+        case AK_TILE_CUBIC: return "8 x k_adjoint_straight_tile<double, MODE, 4, true> + k_lm_fold_{z,y,x}";
+        case AK_REFUSED: return "refused: deterministic mode serves the planned back-projections only";
+        default: return "k_adjoint_straight<AT, MODE, " + lin_or_cubic + ">";
+        }
+    case IONO_OP_TRACE:
+        switch (pick_tracer(f)) {
+        case TK_POLY: return std::string("k_trace_fermat_poly<") + (f.bend ? "true" : "false") + ">";
+        case TK_LIN4: return std::string("k_trace_fermat_lin4<") + (f.bend ? "true" : "false") + ">";
+        case TK_RAYS: return "k_trace_fermat<" + lin_or_cubic + ", " + (f.bend ? "true" : "false") + ">";
+        case TK_LM8: return std::string("k_trace_fermat_lm<") + (f.bend ? "true" : "false") + ", 8>";
+        case TK_LM2: return std::string("k_trace_fermat_lm<") + (f.bend ? "true" : "false") + ", 2>";
+        default: return std::string("k_trace_fermat_coop<") + (f.bend ? "true" : "false") + ">";
+        }
+    case IONO_OP_FERMAT_FORWARD:
+    case IONO_OP_FERMAT_ADJOINT: {
+        const bool adj = op == IONO_OP_FERMAT_ADJOINT;
+        const FermatKernel k = pick_fermat(f, adj);
+        const std::string b = f.bend ? "true" : "false";
+        if (k == FT_RAYS) return "k_fermat_tec<" + lin_or_cubic + ", " + b + ", " + (adj ? "true" : "false") + ">";
+        return "k_fermat_tec_lm<" + b + ", " + (k == FT_LM8 ? "8" : "2") + (adj ? ", true>" : ", false>");
+    }
+    case IONO_OP_PHASE_FORWARD:
+        switch (pick_phase_forward(f)) {
+        case PF_BUNDLE: return "k_forward_bundle<NF>" + tail(std::string("k_forward_phase_u<") + T + ", NF>");
+        case PF_U: return std::string("k_forward_phase_u<") + T + ", NF>";
+        default: return std::string("k_forward_phase_straight<") + T + ", false>";
+        }
+    case IONO_OP_PHASE_ADJOINT:
+        switch (pick_phase_adjoint(f)) {
+        case PA_BINNED: return std::string("k_adjoint_binned<double, NF, ") + T + ", " + segl + ">";
+        case PA_TILE: return std::string("k_adjoint_straight_tile<double, 0, 4, false, true, ") + T + ">";
+        default: return std::string("k_adjoint_phase_straight<") + T + ", double>";
+        }
+    }
+    return "?";
 }
 
 // ---- bundle plan of the forward (k_forward_bundle) ---------------------------------------------------------------------------
@@ -931,7 +1078,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     iono_ctx::FwdPlan &fp = c->fplan;
     fp.R = -1, fp.nb = 0, fp.o_key = fp.d_key = nullptr;
-    if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || c->storage != IONO_F64 || !o || !d ||
+    if (R == 0 || R > (int64_t)INT32_MAX / 2 || !ideal_path_ok(c) || !o || !d ||
         (int64_t)c->ny * c->nz * 8 > (int64_t)B_MAX_PLANE)      // (the kernel's 32-bit offsets inside a window: iono_forward_kernels.h)
         return IONO_OK;
     // keys and ray summaries on the device, device radix sort; only the sorted 32-byte summaries travel to the host for the cut
@@ -1032,17 +1179,20 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     const int nb_all = (int)bstart.size() - 1;
     for (int64_t &h : fp.hist) h = 0;
     for (int b = 0; b < nb_all; ++b) ++fp.hist[std::min(bstart[(size_t)b + 1] - bstart[(size_t)b], 64)];
-    // The threshold T (serve bundles of >= T rays; 1: all, 65: none): forced (IONOTOMO_HYBRID_MIN, IONOTOMO_VARIANT=12 = 1), else the T
+    // The threshold T (serve bundles of >= T rays; 1: all, 65: none): forced (IONOTOMO_HYBRID_MIN), else the T
     // with the smallest modelled time.  Model, fitted to the round-6 sweeps on MI355X (profiles/r06_coherence_sweep.json; 256^3 float64,
     // Ns = 257, scaled by Ns): a bundle launch of n workgroups takes max(20, 8 + 0.019 n) us (one workgroup lives ~20 us; 4 597 bundles:
     // 95 us), a lanes = samples launch of r rays 5.5 + 0.00078 r us (2 604 rays: 7.7 us; 260 400: 208 us).  Checked against the
-    // measurements: 42 directions x 1 / 4 / 16 / 100 timesteps of 62 stations -> none / none / all / all, as measured fastest.
-    fp.forced = c->variant == 12 || c->hybrid_min > 0;
-    int hmin = c->variant == 12 ? 1 : c->hybrid_min;
+    // measurements: 42 directions x 1 / 4 / 16 / 100 timesteps of 62 stations -> none / none / all / all, as measured fastest; half the
+    // bench rays + as many scattered ones -> T = 24: 0.20 ms against 0.57 (all bundles) and 0.34 (none).
+    fp.forced = c->hybrid_min > 0;
+    int hmin = c->hybrid_min;
     {
         const double su = (double)Ns / 257.0;
         auto t_bundles = [&](int64_t n) { return n ? std::max(20.0 * (0.25 + 0.75 * su), 8.0 + 0.019 * su * (double)n) : 0.0; };
-        auto t_rays = [&](int64_t r) { return r ? 5.5 + 0.00078 * su * (double)r : 0.0; };
+        // (a lanes = samples launch BEHIND a bundle launch costs ~10 us before its first ray, not 5.5: the bundle kernel's last
+        //  workgroups drain first -- 1 772 tail rays: +10.5 us, 9 299: +15.6 us at the bench shape)
+        auto t_rays = [&](int64_t r, bool second) { return r ? (second ? 10.0 : 5.5) + 0.00078 * su * (double)r : 0.0; };
         const int cand[10] = {1, 2, 4, 8, 12, 16, 24, 32, 48, 65};
         double best = -1.0;
         for (int T : cand) {
@@ -1051,7 +1201,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
                 if (n >= T) nbT += fp.hist[n];
                 else restT += (int64_t)n * fp.hist[n];
             }
-            const double t = t_bundles(nbT) + t_rays(restT);
+            const double t = t_bundles(nbT) + t_rays(restT, nbT > 0);
             if (T == 1) fp.model_us[0] = t;
             if (T == 65) fp.model_us[2] = t;
             if (best < 0 || t < best) {
@@ -1105,15 +1255,19 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     HIP_TRY(c, hipMemcpyAsync(fp.d_bstart, bstart.data(), bstart.size() * sizeof(int), hipMemcpyHostToDevice, c->stream));
     unsigned long long *d_fits = (unsigned long long *)k0;        // (scratch: the key arrays are no longer needed)
     HIP_TRY(c, hipMemsetAsync(d_fits, 0, 3 * sizeof(unsigned long long), c->stream));
-    hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
-                       nb, tmax, Ns, nchunks, fp.d_win, d_fits);
+    if (c->storage == IONO_F32)          // float32 storage: the fast mode's window records (12 levels of 4-byte values per column)
+        hipLaunchKernelGGL(k_bundle_windows_f32, dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart, nb, tmax, Ns, nchunks,
+                           fp.d_win, d_fits);
+    else
+        hipLaunchKernelGGL((k_bundle_windows<B_KC, B_LEV, B_MAXWY, true, true>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart,
+                           nb, tmax, Ns, nchunks, fp.d_win, d_fits);
     HIP_TRY(c, plan_reserve(fp.d_brec, fp.cap_brec, (size_t)nb * 64 * sizeof(BundleRec)));
     HIP_TRY(c, plan_reserve(fp.d_bhash, fp.cap_bhash, (size_t)nb * 64 * sizeof(uint2)));
     hipLaunchKernelGGL((k_bundle_records<false>), dim3(nb), dim3(64), 0, c->stream, view(c), o, d, fp.d_order, fp.d_bstart, nb, tmax, Ns,
                        fp.d_brec, fp.d_bhash);
     fp.nchunks_lm = 0;      // the tricubic kernel's window set is computed by its first launch (ensure_lm_windows)
     HIP_TRY(c, hipGetLastError());
-    if (getenv("IONOTOMO_PLAN_STATS")) {      // columns per window, both chunk lengths (stderr; tuning aid)
+    if (getenv("IONOTOMO_PLAN_STATS") && c->storage == IONO_F64) {      // columns per window, both chunk lengths (stderr; tuning aid)
         fp.o_key = o, fp.d_key = d, fp.R = R, fp.Ns = Ns, fp.tmax = tmax, fp.nb = nb, fp.nchunks = nchunks;
         rc = ensure_lm_windows(c);
         if (rc) return rc;
@@ -1152,6 +1306,21 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     fp.o_key = o, fp.d_key = d, fp.R = R, fp.Ns = Ns, fp.tmax = tmax, fp.nb = nb, fp.nchunks = nchunks;
     fp.serial = ++c->fplan_counter, fp.lm_all_fit = false;
     return IONO_OK;
+}
+
+int iono_dispatch_name(const iono_dispatch_facts *facts, int op, char *out, int cap) {
+    if (!facts || !out || cap < 1 || op < IONO_OP_FORWARD || op > IONO_OP_PHASE_ADJOINT) return fail(nullptr, IONO_ERR_ARG, "iono_dispatch_name: bad argument");
+    const std::string t = dispatch_text(*facts, op);
+    snprintf(out, (size_t)cap, "%s", t.c_str());
+    return IONO_OK;
+}
+int iono_dispatch_describe(iono_ctx *c, int op, const double *o, const double *d, int64_t R, double tmax, int Ns, int kind, int kind_ne, int bend,
+                           iono_dispatch_facts *facts_out, char *out, int cap) {
+    { const int rc = need_grid(c); if (rc) return rc; }
+    if (op < IONO_OP_FORWARD || op > IONO_OP_PHASE_ADJOINT || Ns < 2) return fail(c, IONO_ERR_ARG, "iono_dispatch_describe: bad argument");
+    const iono_dispatch_facts f = facts_of(c, op, o, d, R, tmax, Ns, kind, kind_ne, bend);
+    if (facts_out) *facts_out = f;
+    return out ? iono_dispatch_name(&f, op, out, cap) : IONO_OK;
 }
 
 int iono_forward_plan_split(iono_ctx *c, int64_t *bundles_cut, int64_t *bundles_served, int64_t *rays_served, int64_t *rays_rest, int *min_rays,
@@ -1217,9 +1386,8 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, st, g, c->d_F8, o, d, ord, Rn, tmax, Ns, wm,
                                c->d_unitw, tec, c->d_flags);
         };
-        if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && std::is_same<GT, float>::value && c->variant != 9 &&
-                   (uint64_t)padded_count(c) * 16 < ((uint64_t)1 << 32)) {
-            // float32 storage extra: 2 x 2 corner blocks, two 16-B loads per sample (IONOTOMO_VARIANT=9: plain float32 kernel)
+        // float32 storage, unplanned: 2 x 2 corner blocks, two 16-B loads per sample (k_forward_straight_q4), for the rays ord[0 .. Rn)
+        auto launch_q4 = [&](const int *ord, int64_t Rn) -> int {
             const int64_t n = ncells(c), padded = padded_count(c);
             if (!c->d_Q4) {
                 HIP_TRY(c, hipMalloc((void **)&c->d_Q4, (size_t)padded * sizeof(float4)));
@@ -1230,13 +1398,31 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                 c->Q4_valid = true;
             }
             const size_t wl = sizeof(double) * Ns;
-            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_q4, wl), R);
-            hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, order, R, tmax, Ns,
-                               forward_walk_mode(c, (uint64_t)padded * sizeof(float4), order), c->d_unitw, tec, c->d_flags);
-        } else if (kind == IONO_INTERP_TRILINEAR && std::is_same<GT, double>::value && fplan_serves(c, o, d, R, tmax, Ns)) {
+            const int nb = chunk_grid_blocks(resident_blocks(c, k_forward_straight_q4, wl), Rn);
+            hipLaunchKernelGGL(k_forward_straight_q4, dim3(nb), block, wl, c->stream, g, c->d_Q4, o, d, ord, Rn, tmax, Ns,
+                               forward_walk_mode(c, (uint64_t)padded * sizeof(float4), ord), c->d_unitw, tec, c->d_flags);
+            return IONO_OK;
+        };
+        const iono_dispatch_facts facts = facts_of(c, IONO_OP_FORWARD, o, d, R, tmax, Ns, kind, kind, 0);
+        const FwdKernel fk = pick_forward(facts);            // (the dispatch table: pick_forward)
+        const bool q4_ok = facts.q4_ok != 0;
+        if (fk == FK_BUNDLE_F32) {
+            // float32 FAST MODE (iono_forward_f32_kernels.h): the served bundles with float32 window images and packed-float32
+            // interpolation (TEC to ~1e-7), the rays outside them with the unplanned float32 kernel (float64 arithmetic)
+            const iono_ctx::FwdPlan &fp = c->fplan;
+            hipLaunchKernelGGL(k_forward_bundle_f32, dim3((unsigned)((fp.nb + 7) / 8 * 8)), block, B_SPLIT * F_WAVE_LDS + B_SPLIT * 64 * sizeof(double) + 16,
+                               c->stream, g, o, d, fp.d_brec, fp.d_bhash, fp.d_win, fp.nb, fp.nchunks, tmax, Ns, c->d_unitw32, c->d_unitw, tec, c->d_flags);
+            if (fp.n_rest > 0) {
+                const int rc2 = q4_ok ? launch_q4(fp.d_order + fp.n_planned, fp.n_rest) : launch_u(fp.d_order + fp.n_planned, fp.n_rest, c->stream);
+                if (rc2) return rc2;
+            }
+        } else if (fk == FK_Q4) {
+            const int rc2 = launch_q4(order, R);
+            if (rc2) return rc2;
+        } else if (fk == FK_BUNDLE) {
             // (a workgroup per bundle: below two bundles per CU -- a single timestep is 214 -- the lanes = samples kernel, one wave
             //  per ray, fills the chip better: 7.5 against 11 us at config 2; likewise when the windows mostly do not fit the LDS
-            //  image.  IONOTOMO_VARIANT=12 forces the bundle kernel for every bundle)
+            //  image.  IONOTOMO_HYBRID_MIN=1 forces the bundle kernel for every bundle)
             // bundle-stationary: one workgroup per SERVED bundle, windows staged in LDS (iono_forward_plan_dev); the rays of the other
             // bundles, if the plan left any: lanes = samples, right behind it on the same stream (a second stream between fork / join
             // events measured SLOWER at every batch size: 0.106 against 0.103 ms at the bench shape, 0.040 against 0.032 at 41 664 rays)
@@ -1248,10 +1434,10 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                 const int rc2 = launch_u(fp.d_order + fp.n_planned, fp.n_rest, c->stream);
                 if (rc2) return rc2;
             }
-        } else if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns)) {
+        } else if (fk == FK_U) {
             const int rc2 = launch_u(order, R, c->stream);
             if (rc2) return rc2;
-        } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && fplan_serves(c, o, d, R, tmax, Ns)) {
+        } else if (fk == FK_BUNDLE_LM) {
             // bundles of neighbouring rays, one field pair per wave, windows staged in LDS (iono_cubic_kernels.h:k_forward_bundle_lm)
             int rc2 = ensure_lm_windows(c);          // (first: the windows say which node lines a rebuild for this plan must cover)
             if (rc2) return rc2;
@@ -1268,11 +1454,11 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
                                padded_count(c), o, d, fp.d_order, fp.d_bstart, fp.d_win_lm, fp.d_rhash, fp.nb, fp.nchunks_lm, tmax, Ns, c->d_unitw, tec,
                                c->d_flags, restricted);
             if (fp.n_rest > 0) launch_lm(fp.d_order + fp.n_planned, fp.n_rest, c->stream);
-        } else if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns)) {
+        } else if (fk == FK_LM) {
             const int rc2 = ensure_lm_fields(c);
             if (rc2) return rc2;
             launch_lm(order, R, c->stream);
-        } else if (kind == IONO_INTERP_TRILINEAR && fast_path_ok(c))      // (`order` is a speed hint: ignored here)
+        } else if (fk == FK_FAST)      // (`order` is a speed hint: ignored here)
             hipLaunchKernelGGL((k_forward_straight_fast<GT>), grid, block, 2 * lds, c->stream, g, o, d, R, tmax, Ns,
                                c->d_unitw, tec, c->d_flags);
         else if (kind == IONO_INTERP_TRILINEAR)
@@ -1808,8 +1994,9 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                                   const double *w, const double *tec, const double *dobs, const double *cdct, int Na,
                                   int64_t NtNd, int i0, int64_t R, double tmax, int Ns, int kind, AT *grad) {
     const iono_ctx::AdjPlan &pl = c->plan;
-    const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax && pl.kind == kind &&
-                         c->variant != 2 && c->variant != 7;
+    const iono_dispatch_facts facts = facts_of(c, IONO_OP_ADJOINT, o, d, R, tmax, Ns, kind, kind, 0);
+    const AdjKernel ak = pick_adjoint(facts);                // (the dispatch table: pick_adjoint)
+    const bool planned = facts.adj_planned && c->variant != 2;
     const double *wr = w;
     if (planned && pl.n_invalid > 0) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_flags, 1, 1, c->stream));   // out-of-grid rays
     if (planned && MODE != 0) {          // the reference-antenna sums of the fused modes, once per ray
@@ -1830,11 +2017,11 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
     }
     c->plan_verified = false;
     const size_t bin_lds = sizeof(double) * ((((size_t)Ns + 1) & ~(size_t)1) + BIN_TILE);      // float64 box image for either AT
-    if (planned && kind == IONO_INTERP_TRILINEAR) {
+    if (ak == AK_BINNED || ak == AK_BINNED_FIX) {
         int u_lo = 0, u_hi = pl.n_units;
         if (c->unit_lo >= 0) u_lo = std::min(c->unit_lo, pl.n_units), u_hi = std::max(u_lo, std::min(c->unit_hi, pl.n_units));
         c->unit_lo = c->unit_hi = -1;
-        if (c->deterministic) {
+        if (ak == AK_BINNED_FIX) {
             // fixed-point accumulation: the largest |w h| of this launch -> scale; integers in the box images and in d_fixgrid; converted
             // into `grad` (and re-zeroed) by FixConvert (iono_binned_kernels.h)
             const int64_t n = ncells(c);
@@ -1866,25 +2053,24 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         // once per slab: refuse instead of discarding the range
         c->unit_lo = c->unit_hi = -1;
         return fail(c, IONO_ERR_ARG, "a work-unit range (iono_adjoint_unit_range) is pending, but this launch is not the planned trilinear "
-                                     "back-projection of these rays (no plan, a replaced plan, tricubic, or IONOTOMO_VARIANT=2/7): nothing launched");
+                                     "back-projection of these rays (no plan, a replaced plan, tricubic, or IONOTOMO_VARIANT=2): nothing launched");
     }
     // The planned tricubic transpose accumulates 64-bit fixed point BY DEFAULT (round 5): the integer LDS atomic is the cheaper
     // instruction (6.4 against 8.2 LDS cycles) and the z fold reads the integers directly -- 2.15 against 2.55 ms at the bench shape,
     // run-to-run identical bits, 1.3e-12 of the largest value away from the float sum (profiles/r05_ab_binned.json).
-    // IONOTOMO_VARIANT=24: float atomics (A/B); iono_set_deterministic(1) additionally switches the TRILINEAR back-projection.
-    const bool fix_cubic = (c->deterministic || c->variant != 24) && planned && kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) &&
-                           c->variant != 2 && pl.tile_n[2] > 0;
-    if (c->deterministic && !fix_cubic)
+    // (The float-atomic form is no longer built: round 6.)  iono_set_deterministic(1) additionally switches the TRILINEAR back-projection.
+    const bool fix_cubic = ak == AK_BINNED_LM4;
+    if (ak == AK_REFUSED)
         return fail(c, IONO_ERR_ARG, "deterministic mode serves the planned trilinear and tricubic back-projections only (iono_adjoint_plan_dev for these rays first)");
-    if (kind == IONO_INTERP_TRILINEAR && ideal_path_ok(c, Ns) && c->variant != 2)
+    if (ak == AK_TILE)
         return launch_adjoint_tile<AT, MODE, false>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns, grad, -1);
-    if (kind == IONO_INTERP_TRICUBIC && cubic_fast_ok(c, Ns) && c->variant != 2) {
+    if (ak == AK_BINNED_LM4 || ak == AK_TILE_CUBIC) {
         // 8 channel scatters (cubic Hermite value / slope weights per axis) into G8[8][nodes], then the transposed
         // difference stencils fold them into the node gradient (iono_cubic_kernels.h)
         const int64_t n = ncells(c);
         if (!c->d_G8) HIP_TRY(c, hipMalloc((void **)&c->d_G8, (size_t)n * LM_NF * sizeof(double)));
         // planned: only the tiles the plan's rays reach are zeroed, scattered into and folded
-        const bool tiled = planned && pl.tile_n[2] > 0;
+        const bool tiled = fix_cubic;
         const LmTileGeom tg{c->nx, c->ny, c->nz, (c->ny + LMT_Y - 1) / LMT_Y, (c->nz + LMT_Z - 1) / LMT_Z};
         if (tiled)
             hipLaunchKernelGGL(k_lm_zero_tiles, dim3(pl.tile_n[0]), dim3(LMT_NODES / 2), 0, c->stream, c->d_G8, pl.d_tiles + pl.tile_off[0], tg);
@@ -1896,35 +2082,25 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
             if (rcf) return rcf;
             fixmax = c->d_fixgrid + n;
         }
-        if (planned) {
-            // four channels (one z kind) per traversal: two launches instead of eight (k_adjoint_binned_lm4)
+        if (fix_cubic) {
+            // four channels (one z kind) per traversal: two launches instead of eight (k_adjoint_binned_lm4), fixed-point LDS atomics
             const size_t l4 = LM4_LDS_BYTES(Ns);
             BY_SEGL(pl.segl, {
                 if (!c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2]) {
-                    HIP_TRY(c, hipFuncSetAttribute((const void *)k_adjoint_binned_lm4<SL, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
                     HIP_TRY(c, hipFuncSetAttribute((const void *)k_adjoint_binned_lm4<SL, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
                     c->lm4_attr[SL == 4 ? 0 : SL == 8 ? 1 : 2] = true;
                 }
-                // (persistent workgroups, one per CU -- the four images are all the LDS a CU has -- pulling units off a counter)
+                // (persistent workgroups, one per CU -- the four images are all the LDS a CU has -- pulling units off a counter that
+                //  fix_prepare has just cleared behind its scale word)
                 const dim3 pgrid((unsigned)std::min(pl.n_units, c->lm4_groups > 0 ? c->lm4_groups : c->num_cus));
-                if (!fix_cubic) {          // (fixed point: fix_prepare has just cleared the counters behind its scale word)
-                    if (!c->d_lm4_next) HIP_TRY(c, hipMalloc((void **)&c->d_lm4_next, 2 * sizeof(int)));
-                    HIP_TRY(c, hipMemsetAsync(c->d_lm4_next, 0, 2 * sizeof(int), c->stream));
-                }
-                for (int rb = 0; rb < 2; ++rb) {
-                    if (fix_cubic)
-                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, true>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
-                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, fixmax, pl.fix_bits, pl.n_units,
-                                           (int *)(c->d_fixgrid + n + 1) + rb);
-                    else
-                        hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, false>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
-                                           pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, (const unsigned long long *)nullptr, 0,
-                                           pl.n_units, c->d_lm4_next + rb);
-                }
+                for (int rb = 0; rb < 2; ++rb)
+                    hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, true>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
+                                       pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, fixmax, pl.fix_bits, pl.n_units,
+                                       (int *)(c->d_fixgrid + n + 1) + rb);
             });
             HIP_TRY(c, hipGetLastError());
         }
-        for (int f = 0; f < LM_NF && !planned; ++f) {
+        for (int f = 0; f < LM_NF && !fix_cubic; ++f) {
             const int rc = launch_adjoint_tile<double, MODE, true>(c, g, o, d, order, w, tec, dobs, cdct, Na, NtNd, i0, R, tmax, Ns,
                                                                    c->d_G8 + (size_t)f * n, f);
             if (rc) return rc;
@@ -1934,12 +2110,8 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
         double2 *H0 = (double2 *)c->d_LMw, *H1 = H0 + n;
         double *K0 = c->d_LMw + 4 * n, *K1 = K0 + n;
         if (tiled) {
-            if (fix_cubic)
-                hipLaunchKernelGGL((k_lm_fold_z_tiles<true>), dim3(pl.tile_n[0]), dim3(LMT_NODES / 2), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
-                                   fixmax, pl.fix_bits);
-            else
-                hipLaunchKernelGGL((k_lm_fold_z_tiles<false>), dim3(pl.tile_n[0]), dim3(LMT_NODES / 2), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
-                                   (const unsigned long long *)nullptr, 0);
+            hipLaunchKernelGGL((k_lm_fold_z_tiles<true>), dim3(pl.tile_n[0]), dim3(LMT_NODES / 2), 0, c->stream, c->d_G8, H0, H1, pl.d_tiles + pl.tile_off[0], tg,
+                               fixmax, pl.fix_bits);
             hipLaunchKernelGGL(k_lm_fold_y_tiles, dim3(pl.tile_n[1]), dim3(256), 0, c->stream, (const double2 *)H0, (const double2 *)H1, K0, K1,
                                pl.d_tiles + pl.tile_off[1], tg);
             hipLaunchKernelGGL((k_lm_fold_x_tiles<AT>), dim3(pl.tile_n[2]), dim3(LMT_NODES / 2), 0, c->stream, (const double *)K0, (const double *)K1, grad,
@@ -2029,8 +2201,7 @@ static int rays_step_then_adjoint(iono_ctx *c, int mode, const double *o, const 
         c->rayw_cap = R;
     }
     const iono_ctx::AdjPlan &pl = c->plan;
-    const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax && pl.kind == kind &&
-                         c->variant != 2 && c->variant != 7;
+    const bool planned = facts_of(c, IONO_OP_ADJOINT, o, d, R, tmax, Ns, kind, kind, 0).adj_planned && c->variant != 2;
     const double *vo = planned ? o : nullptr;
     const unsigned nblk = (unsigned)std::min<int64_t>(IONO_NPART, (NtNd + RSTEP_PT - 1) / RSTEP_PT);
     if (mode == 0)
@@ -2148,7 +2319,7 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
     if (rc) return rc;
     const GridView g = view(c);
     const dim3 grid(ray_grid_blocks(c, R)), block(256);
-    const bool ideal = ideal_path_ok(c, Ns);
+    const PhaseFwdKernel pfk = pick_phase_forward(facts_of(c, IONO_OP_PHASE_FORWARD, o, d, R, tmax, Ns, IONO_INTERP_TRILINEAR, IONO_INTERP_TRILINEAR, 0));
     for (int f0 = 0; f0 < Nf; f0 += 8) {
         const PhaseFreqs pf = phase_chunk(freqs, f0, Nf);
         // lanes = samples on ideal-uniform grids for the rays ord[0 .. Rn) (null: all of them)
@@ -2166,7 +2337,7 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
                 return IONO_OK;
             });
         };
-        if (fplan_serves(c, o, d, R, tmax, Ns)) {      // bundle-stationary (k_forward_bundle<NF>: windows in LDS), as the TEC forward
+        if (pfk == PF_BUNDLE) {      // bundle-stationary (k_forward_bundle<NF>: windows in LDS), as the TEC forward
             const iono_ctx::FwdPlan &fp = c->fplan;
 #define PHASE_B(NF)                                                                                                                        \
     hipLaunchKernelGGL((k_forward_bundle<NF>), dim3((unsigned)((fp.nb + 7) / 8 * 8)), block,                                               \
@@ -2179,7 +2350,7 @@ int iono_forward_phase_straight_dev(iono_ctx *c, const double *o, const double *
             if (fp.n_rest > 0) phase_u(fp.d_order + fp.n_planned, fp.n_rest, c->stream);      // (hybrid: the rays outside the served bundles)
             continue;
         }
-        if (ideal) {
+        if (pfk == PF_U) {
             phase_u(nullptr, R, c->stream);
             continue;
         }
@@ -2210,10 +2381,9 @@ int iono_adjoint_phase_straight_dev(iono_ctx *c, const double *o, const double *
     if (rc) return rc;
     const GridView g = view(c);
     launch_map<PhaseWeights>(c, ew_blocks(c, R * Nf), (int64_t)Na * NtNd * Nf, y, c->d_freqs, Na, NtNd, Nf, i0, wrf_work);
-    const bool tiled = ideal_path_ok(c, Ns) && c->variant != 2;
+    const PhaseAdjKernel pak = pick_phase_adjoint(facts_of(c, IONO_OP_PHASE_ADJOINT, o, d, R, tmax, Ns, IONO_INTERP_TRILINEAR, IONO_INTERP_TRILINEAR, 0));
+    const bool tiled = pak == PA_TILE, planned = pak == PA_BINNED;
     const iono_ctx::AdjPlan &pl = c->plan;
-    const bool planned = pl.R == R && pl.o_key == o && pl.d_key == d && pl.Ns == Ns && pl.tmax == tmax &&
-                         pl.kind == IONO_INTERP_TRILINEAR && c->variant != 2 && c->variant != 7;
     if (planned && pl.n_invalid > 0) HIP_TRY(c, hipMemsetD32Async((hipDeviceptr_t)c->d_flags, 1, 1, c->stream));   // out-of-grid rays
     if (planned)      // the rays handed over are still the planned ones? (plan_verify_ray)
         hipLaunchKernelGGL(k_plan_verify, dim3(ew_blocks(c, R)), dim3(256), 0, c->stream, o, d, R, (const uint2 *)pl.d_hash, pl.d_uray, c->d_flags);
@@ -2620,9 +2790,9 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
 #define LAUNCH_F(K, B) \
     hipLaunchKernelGGL((k_trace_fermat<K, B>), grid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags, stype)
     const size_t axes_bytes = (size_t)(c->nx + c->ny + c->nz) * 8;
-    // (a grid that is not ideal-uniform keeps the general right-hand side in the lanes = rays kernel: crossover ~150k rays as before)
-    const int64_t lin4_max = g.ideal || c->fermat_lin4_max != 4096 ? c->fermat_lin4_max : 131072;
-    if (kind == IONO_INTERP_TRILINEAR && g.ideal && c->variant != 3 && c->variant != 15 && R <= c->fermat_poly_max) {
+    const iono_dispatch_facts facts = facts_of(c, IONO_OP_TRACE, nullptr, nullptr, R, tmax, Ns, kind, kind, bend);
+    const TraceKernel tk = pick_tracer(facts);               // (the dispatch table: pick_tracer)
+    if (tk == TK_POLY) {
         // small batch on an ideal-uniform grid: the cell's polynomial in registers, no DPP sums (iono_aux_kernels.h).  16 rays per
         // wave measured best from 600 to 4 096 rays (0.91-0.94 ms at config 3's 129 samples x 4 substeps; 8: 0.89-1.14, 32: 0.93-0.96,
         // 1: 3.0 -- a lone lane still pays the whole wave's issue slots; the 4-lanes-per-ray kernel: 1.08-1.18)
@@ -2634,7 +2804,7 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
         else
             hipLaunchKernelGGL((k_trace_fermat_poly<false>), pgrid, block, 0, c->stream, g, dN, dO, dD, R, tmax, Ns, substeps, dR, c->d_flags,
                                rpw, stype);
-    } else if (kind == IONO_INTERP_TRILINEAR && c->variant != 3 && R <= lin4_max && axes_bytes <= 48 * 1024) {
+    } else if (tk == TK_LIN4) {
         // small batch: 4 lanes per ray, axes in LDS, corners cached per cell (latency-bound regime)
         const int rpw = c->fermat_lin4_rpw > 0 ? c->fermat_lin4_rpw : (R <= 4096 ? 4 : 16);   // measured
         const dim3 qgrid((unsigned)((R + rpw - 1) / rpw));
@@ -2644,16 +2814,16 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
         else
             hipLaunchKernelGGL((k_trace_fermat_lin4<false>), qgrid, block, axes_bytes, c->stream, g, dN, dO, dD, R, tmax, Ns,
                                substeps, dR, c->d_flags, rpw, stype);
-    } else if (kind == IONO_INTERP_TRILINEAR) {
+    } else if (tk == TK_RAYS && kind == IONO_INTERP_TRILINEAR) {
         if (bend) LAUNCH_F(IONO_INTERP_TRILINEAR, true); else LAUNCH_F(IONO_INTERP_TRILINEAR, false);
-    } else if (c->variant == 3 || R > c->fermat_coop_max) {   // lanes = rays: enough rays to fill the chip without splitting them
+    } else if (tk == TK_RAYS) {   // lanes = rays: enough rays to fill the chip without splitting them
         if (bend) LAUNCH_F(IONO_INTERP_TRICUBIC, true); else LAUNCH_F(IONO_INTERP_TRICUBIC, false);
-    } else if (g.ideal && cubic_fast_ok(c, 2) && c->variant != 17) {
+    } else if (tk == TK_LM8 || tk == TK_LM2) {
         // ideal-uniform grid: 8 lanes per ray, one Lekien-Marsden record of n per lane (iono_aux_kernels.h:k_trace_fermat_lm;
-        // IONOTOMO_VARIANT=17 keeps the 216-tap kernel below for A/B)
+        // the 216-tap kernel below serves the other grids: IONOTOMO_FORCE_GENERAL=2 for A/B)
         const int rcf = ensure_n_fields(c, frequency);
         if (rcf) return rcf;
-        const int lpr = fermat_lm_lanes(c, R);
+        const int lpr = tk == TK_LM8 ? 8 : 2;
         const int rpw = lpr == 8 && c->fermat_coop_rpw > 0 ? std::min(c->fermat_coop_rpw, 8) : 64 / lpr;
         const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
 #define LAUNCH_TLM(B, L)                                                                                                                     \
@@ -2679,13 +2849,10 @@ int iono_trace_fermat_dev(iono_ctx *c, const double *dO, const double *dD, int64
 }
 
 // ---- fused curved-ray forward / transpose (iono_fermat_kernels.h): trace and integrate in one traversal ---------------------------
-// the fused forward through a tricubic index runs on k_fermat_tec_lm (ideal-uniform axes, 32-bit-safe record array, float64)
-// (its transpose: bending rays at two lanes per ray -- the large batches, where the alternative is a ray tensor of 32 R Ns bytes and
-//  a back-projection with one hardware atomic per corner; small batches keep k_trace_fermat_lm + k_adjoint_rays)
+// (which launches run on the Lekien-Marsden record stepper k_fermat_tec_lm: pick_fermat in the dispatch table)
 static bool fermat_lm_ok(const iono_ctx *c, int kind_n, int kind_ne, int64_t R, bool transpose = false, int bend = 1) {
-    if (transpose && !(bend && fermat_lm_lanes(c, R) == 2)) return false;
-    return kind_n == IONO_INTERP_TRICUBIC && c->storage == IONO_F64 && view(c).ideal && cubic_fast_ok(c, 2) && c->variant != 17 &&
-           c->variant != 3 && R <= c->fermat_coop_max && (kind_ne == IONO_INTERP_TRILINEAR || (c->nx >= 6 && c->ny >= 6 && c->nz >= 6));
+    const iono_dispatch_facts f = facts_of(c, transpose ? IONO_OP_FERMAT_ADJOINT : IONO_OP_FERMAT_FORWARD, nullptr, nullptr, R, 0.0, 2, kind_n, kind_ne, bend);
+    return pick_fermat(f, transpose) != FT_RAYS;
 }
 int iono_fermat_lm_ok(iono_ctx *c, int kind_n, int kind_ne, int64_t R, int transpose, int bend, int *ok) {
     { const int rc = need_ctx(c); if (rc) return rc; }
@@ -2714,12 +2881,14 @@ static int fermat_tec_launch(iono_ctx *c, bool adjoint, const double *dO, const 
     }
     const GridView g = view(c);
     const dim3 grid((unsigned)((R + 63) / 64)), block(64);
-    if (fermat_lm_ok(c, kind_n, kind_ne, R, adjoint, bend)) {
+    const FermatKernel ftk = pick_fermat(facts_of(c, adjoint ? IONO_OP_FERMAT_ADJOINT : IONO_OP_FERMAT_FORWARD, nullptr, nullptr, R, tmax, Ns, kind_n,
+                                                   kind_ne, bend), adjoint);      // (the dispatch table: pick_fermat)
+    if (ftk != FT_RAYS) {
         // tricubic index on an ideal-uniform grid: 8 lanes per ray, one Lekien-Marsden record of n per lane, streaming quadrature
-        // (iono_fermat_kernels.h:k_fermat_tec_lm; IONOTOMO_VARIANT=17 / 3: the lanes = rays kernel below, A/B)
+        // (iono_fermat_kernels.h:k_fermat_tec_lm; IONOTOMO_VARIANT=3: the lanes = rays kernel below, A/B)
         const int rcf = ensure_n_fields(c, frequency);
         if (rcf) return rcf;
-        const int lpr = fermat_lm_lanes(c, R);
+        const int lpr = ftk == FT_LM8 ? 8 : 2;
         const int rpw = lpr == 8 && c->fermat_coop_rpw > 0 ? std::min(c->fermat_coop_rpw, 8) : 64 / lpr;
         const dim3 cgrid((unsigned)((R + rpw - 1) / rpw));
 #define LAUNCH_FLM(B, L)                                                                                                                       \

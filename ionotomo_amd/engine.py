@@ -229,6 +229,13 @@ class RayEngine(object):
         self.ctx.call("iono_forward_plan_info", ctypes.byref(n), ctypes.byref(k), ctypes.byref(f))
         return n.value, k.value, f.value
 
+    def describe(self, op, origins_t=None, dirs_t=None, tmax=0.0, Ns=2, R=None, kind=None, ne_kind=None, bend=True):
+        """Which kernel(s) the launch ``op`` ("forward", "adjoint", "trace", "fermat_forward", "fermat_adjoint", "phase_forward",
+        "phase_adjoint") gets on this engine with these ray tensors -- the library's one dispatch table; returns (name, facts)."""
+        op_, dp = (0, 0) if origins_t is None else (origins_t.data_ptr(), dirs_t.data_ptr())
+        R = (0 if origins_t is None else origins_t.shape[0]) if R is None else R
+        return self.ctx.dispatch_describe(op, op_, dp, R, tmax, Ns, self.kind if kind is None else kind, ne_kind, bend)
+
     def forward_plan_split(self, histogram=False):
         """How the current forward plan divides its rays (hybrid dispatch, include/ionotomo_hip.h:iono_forward_plan_split): bundles as
         cut / served by the bundle kernels, rays in served bundles / in the lanes = samples tail, the rays-per-bundle threshold the

@@ -100,3 +100,59 @@ def test_radio_array_lofar():
     assert it.RadioArray(array_file=it.RadioArray.lofar_cycle0_array).Nantenna == 47
     ex = it.generate_example_radio_array(Nant=7, seed=1)
     assert ex.Nantenna == 7
+
+
+def test_dispatch_table_is_pinned():
+    """The library's ONE dispatch table (include/ionotomo_hip.h: iono_dispatch_name -- pure host code, asked here without a GPU):
+    which kernel a launch gets from the facts of the launch.  Every launcher asks the same pick_* functions."""
+    n = _lib.dispatch_name
+    ideal = dict(tier=2, cubic_fast=1, cubic_records=1, ideal_axes=1, q4_ok=1, Ns=257, fermat_lm_few_min=32768, fermat_poly_max=4096,
+                 fermat_lin4_max=4096, fermat_coop_max=2 ** 62, axes_bytes=6144)
+    # forward TEC: float64 / float32 storage x plan / no plan x interpolant x axis tier
+    assert n("forward", R=260400, **ideal) == "k_forward_straight_u<double>"
+    assert n("forward", R=260400, fwd_bundles=4597, **ideal) == "k_forward_bundle<0>"
+    assert n("forward", R=260400, fwd_bundles=2484, fwd_tail=126600, **ideal) == "k_forward_bundle<0> + k_forward_straight_u<double>"
+    assert n("forward", R=260400, storage=1, **ideal) == "k_forward_straight_q4"
+    assert n("forward", R=260400, storage=1, fwd_bundles=4597, **ideal) == "k_forward_bundle_f32"
+    assert n("forward", R=260400, storage=1, fwd_bundles=10, fwd_tail=5, **ideal) == "k_forward_bundle_f32 + k_forward_straight_q4"
+    assert n("forward", R=260400, storage=1, **dict(ideal, q4_ok=0)) == "k_forward_straight_u<float>"
+    assert n("forward", R=2604, interp_kind=1, **ideal) == "k_forward_straight_lm"
+    assert n("forward", R=260400, interp_kind=1, fwd_bundles=4597, **ideal) == "k_forward_bundle_lm"
+    assert n("forward", R=260400, interp_kind=1, fwd_bundles=9, fwd_tail=3, **ideal) == "k_forward_bundle_lm + k_forward_straight_lm"
+    assert n("forward", R=100, tier=1, Ns=65) == "k_forward_straight_fast<double>"
+    assert n("forward", R=100, tier=0, Ns=65) == "k_forward_straight<double, IONO_INTERP_TRILINEAR>"
+    assert n("forward", R=100, tier=1, interp_kind=1, Ns=65) == "k_forward_straight<double, IONO_INTERP_TRICUBIC>"
+    assert n("forward", R=100, interp_kind=1, **dict(ideal, cubic_fast=0)) == "k_forward_straight<double, IONO_INTERP_TRICUBIC>"      # IONOTOMO_VARIANT=4
+    # back-projection
+    assert n("adjoint", R=260400, **ideal) == "k_adjoint_straight_tile<AT, MODE, 4, false>"
+    assert n("adjoint", R=260400, adj_planned=1, adj_seg_lanes=16, **ideal) == "k_adjoint_binned<AT, 0, double, 16, false>"
+    assert n("adjoint", R=260400, adj_planned=1, adj_seg_lanes=8, deterministic=1, **ideal) == "k_adjoint_binned<double, 0, double, 8, true> + FixConvert"
+    assert n("adjoint", R=260400, adj_planned=1, adj_tiles=1, adj_seg_lanes=16, interp_kind=1, **ideal) == "2 x k_adjoint_binned_lm4<16, true> + k_lm_fold_{z,y,x}_tiles"
+    assert n("adjoint", R=260400, interp_kind=1, **ideal) == "8 x k_adjoint_straight_tile<double, MODE, 4, true> + k_lm_fold_{z,y,x}"
+    assert n("adjoint", R=260400, deterministic=1, **ideal).startswith("refused")
+    assert n("adjoint", R=260400, adj_planned=1, variant=2, **ideal) == "k_adjoint_straight<AT, MODE, IONO_INTERP_TRILINEAR>"
+    assert n("adjoint", R=100, tier=1, interp_kind=1, Ns=65) == "k_adjoint_straight<AT, MODE, IONO_INTERP_TRICUBIC>"
+    # Fermat tracer: batch size decides the mapping
+    assert n("trace", R=2604, bend=1, **ideal) == "k_trace_fermat_poly<true>"
+    assert n("trace", R=2604, bend=0, **dict(ideal, ideal_axes=0, fermat_lin4_max=131072)) == "k_trace_fermat_lin4<false>"
+    assert n("trace", R=620000, bend=1, **ideal) == "k_trace_fermat<IONO_INTERP_TRILINEAR, true>"
+    assert n("trace", R=2604, bend=1, interp_kind=1, **ideal) == "k_trace_fermat_lm<true, 8>"
+    assert n("trace", R=620000, bend=1, interp_kind=1, **ideal) == "k_trace_fermat_lm<true, 2>"
+    assert n("trace", R=2604, bend=1, interp_kind=1, **dict(ideal, ideal_axes=0)) == "k_trace_fermat_coop<true>"
+    assert n("trace", R=2604, bend=1, interp_kind=1, variant=3, **ideal) == "k_trace_fermat<IONO_INTERP_TRICUBIC, true>"
+    # fused trace + integrate, and its transpose
+    assert n("fermat_forward", R=620000, bend=1, interp_kind=1, **ideal) == "k_fermat_tec_lm<true, 2, false>"
+    assert n("fermat_forward", R=2604, bend=1, interp_kind=1, **ideal) == "k_fermat_tec_lm<true, 8, false>"
+    assert n("fermat_forward", R=620000, bend=1, **ideal) == "k_fermat_tec<IONO_INTERP_TRILINEAR, true, false>"
+    assert n("fermat_adjoint", R=620000, bend=1, interp_kind=1, **ideal) == "k_fermat_tec_lm<true, 2, true>"
+    assert n("fermat_adjoint", R=2604, bend=1, interp_kind=1, **ideal) == "k_fermat_tec<IONO_INTERP_TRICUBIC, true, true>"      # (engine.py: two-step there)
+    # phase observable
+    assert n("phase_forward", R=260400, fwd_bundles=4597, **ideal) == "k_forward_bundle<NF>"
+    assert n("phase_forward", R=260400, **ideal) == "k_forward_phase_u<double, NF>"
+    assert n("phase_forward", R=100, tier=0, Ns=65) == "k_forward_phase_straight<double, false>"
+    assert n("phase_adjoint", R=260400, adj_planned=1, adj_seg_lanes=16, **ideal) == "k_adjoint_binned<double, NF, double, 16>"
+    assert n("phase_adjoint", R=260400, **ideal) == "k_adjoint_straight_tile<double, 0, 4, false, true, double>"
+    with pytest.raises(ValueError):
+        n(9)
+    with pytest.raises(KeyError):
+        n("forward", no_such_fact=1)

@@ -61,13 +61,28 @@ def _run(world, exchange="dense", engine="oracle", size=None, interp="linear", d
                                reduce_dtype=torch.float32)
     adj32 = host(p32.adjoint(p32.slice(y_full)))
     # p32 has replaced the engine's single back-projection plan: prob must notice (no slab pipeline on a foreign plan: ADVICE r4)
-    # and give the same iterates through the compact exchange
-    xs2, _ = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()).to(dev), n_iter=3)
+    # and give the same iterates through the compact exchange (the fixed-point mode serves planned back-projections only: skipped there)
+    xs2 = xs if deterministic else solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()).to(dev), n_iter=3)[0]
     return dict(fwd=fwd, adj=adj, xc=host(xc), hc=np.array(hc), xs=host(xs), hs=np.array(hs),
                 block=(prob.lo, prob.hi), adj32=adj32, active=prob.exchange.fraction,
                 compact=prob.exchange.index is not None, P=pb["P"],
                 overlapped=overlapped, overlapped_after_replan=bool(getattr(prob, "overlapped", lambda: False)()),
                 xs2=host(xs2), nslab=len(prob.slab_ranges or []))
+
+
+def get_or_fail(q, procs, timeout):
+    """The next result from the workers' queue -- or an assertion as soon as a worker has died without sending one (a plain
+    ``q.get(timeout=...)`` sits out the whole timeout, which a GPU box takes for a hang)."""
+    import queue
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            return q.get(timeout=2.0)
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if not p.is_alive() and p.exitcode not in (0, None)]
+            assert not dead, "a worker exited with %s before sending its result" % dead
+            assert time.time() - t0 < timeout, "no result from the workers within %d s" % timeout
 
 
 def _worker(rank, world, port, q, exchange, engine="oracle", size=None, interp="linear", backend="gloo", force=False, deterministic=False):
@@ -105,7 +120,7 @@ def test_sharded_path_matches_single_rank(world, exchange, size):
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, "oracle", size)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=400) for _ in range(world))
+    res = dict(get_or_fail(q, procs, 400) for _ in range(world))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0

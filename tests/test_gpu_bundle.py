@@ -20,7 +20,7 @@ def OC():
 
 
 def engine(xv, yv, zv, force_bundle=True, env=None, **kw):
-    """``force_bundle``: IONOTOMO_VARIANT=12 while the context is created -- a planned launch then runs k_forward_bundle for EVERY
+    """``force_bundle``: IONOTOMO_HYBRID_MIN=1 while the context is created -- a planned launch then runs k_forward_bundle for EVERY
     bundle whatever their number and size (by default the plan decides which bundles are worth a workgroup -- all, those of >= T
     rays with the others' rays going to the lanes = samples kernel in the same call, or none: iono_forward_plan_split).
     ``env``: further variables read at context creation."""
@@ -28,7 +28,7 @@ def engine(xv, yv, zv, force_bundle=True, env=None, **kw):
     from ionotomo_amd.engine import RayEngine
     env = dict(env or {})
     if force_bundle:
-        env["IONOTOMO_VARIANT"] = "12"
+        env.setdefault("IONOTOMO_HYBRID_MIN", "1")
     old = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
     try:
@@ -219,6 +219,84 @@ def test_hybrid_dispatch_phase_observable():
         got = eng.forward_phase(ot, dt, na, nt, nd, zhi, 65, freqs, clock, const, 1).cpu().numpy()
         assert np.all(np.isfinite(got)) and np.max(np.abs(got - direct)) < 1e-11 * np.max(np.abs(direct)), nf
     assert not eng.check_oob()
+
+
+TEC_RTOL_F32_FAST = 1e-6      # north_star's bound; float32 storage + packed-float32 interpolation measures ~1e-7 (printed below)
+
+
+@pytest.mark.parametrize("seed", range(SOAK * 10))
+def test_f32_fast_mode_random_geometries(seed, OC):
+    """VERDICT r5 item 2 / SURVEY 7 step 4: storage="f32" + a forward plan = the float32 fast mode (k_forward_bundle_f32: float32 window
+    images, packed-float32 interpolation, float64 sums of the chunk sums).  Against the C oracle on the float64 values at north_star's
+    1e-6, against the unplanned float32 kernels (float64 arithmetic on the same rounded values) likewise; rays that leave the grid NaN +
+    flag; grids of every nz alignment (windows start on multiples of four levels: unaligned 16-byte loads otherwise), windows that
+    do not fit (steep rays: direct loads), every quadrature rule, hybrid splits."""
+    rng = np.random.default_rng(9100 + seed)
+    n = [int(v) for v in rng.integers(8, 70, 3)]
+    xv, yv, zv = (np.linspace(0.0, float(rng.uniform(20, 200)), m) for m in n)
+    R = int(rng.integers(1, 1500))
+    Ns = int(rng.choice([2, 7, 8, 9, 17, 33, 64, 65, 100, 257]))
+    steep = float(rng.choice([0.02, 0.3, 1.5]))
+    o, d, zhi, inside = random_rays(rng, xv, yv, zv, R, steep, cluster=bool(seed % 2))
+    quad = ["avg", "scipy", "trapz"][seed % 3]
+    eng = engine(xv, yv, zv, force_bundle=seed % 4 != 3, env={} if seed % 4 != 3 else {"IONOTOMO_HYBRID_MIN": 4}, quad=quad, storage="f32")
+    M = rng.uniform(1, 2, size=n)
+    eng.set_values(eng.tensor(M))
+    ot, dt = eng.tensor(o), eng.tensor(d)
+    direct = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    assert eng.check_oob() == (not inside.all())
+    nb, nchunks, fit = eng.plan_forward(ot, dt, zhi, Ns)
+    assert nchunks == (Ns + 7) // 8 and 0.0 <= fit <= 1.0
+    tec = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
+    assert eng.check_oob() == (not inside.all())
+    assert np.all(np.isnan(tec[~inside])) and np.all(np.isfinite(tec[inside]))
+    if inside.any():
+        scale = np.max(np.abs(direct[inside]))
+        assert np.max(np.abs(tec[inside] - direct[inside])) <= TEC_RTOL_F32_FAST * scale, (n, R, Ns, steep, fit, nb)
+        if quad == "avg" or (quad == "scipy" and Ns % 2 == 1):
+            ref = OC.forward_tec_straight(xv, yv, zv, M, o[inside], d[inside], zhi, Ns)
+            assert np.max(np.abs(tec[inside] - ref) / np.abs(ref)) <= TEC_RTOL_F32_FAST, (n, R, Ns, steep, fit, nb)
+    assert not eng.plan_stale()
+
+
+def test_f32_fast_mode_bench_shape(OC):
+    """The bench shape through the float32 fast mode: every ray against the float64 bundle kernel's TEC at 1e-6 (measured ~1e-7,
+    printed), dTEC against SURVEY 8(d)'s gate 1e-6 max|TEC|, a sample against the C oracle; edited rays fall back to direct loads."""
+    import bench
+    w = bench.build_workload(0)
+    ne = np.exp(w["m"]) * (w["K_ne"] / 1e13)
+    e64 = engine(w["xvec"], w["yvec"], w["zvec"], force_bundle=False)
+    e32 = engine(w["xvec"], w["yvec"], w["zvec"], force_bundle=False, storage="f32")
+    for e in (e64, e32):
+        e.set_values(e.tensor(ne))
+    ot, dt = e64.tensor(w["origins"]), e64.tensor(w["directions"])
+    e64.plan_forward(ot, dt, bench.TMAX, bench.NS)
+    ref = e64.forward(ot, dt, bench.TMAX, bench.NS)
+    unplanned = e32.forward(ot, dt, bench.TMAX, bench.NS).clone()
+    nb, _, fit = e32.plan_forward(ot, dt, bench.TMAX, bench.NS)
+    assert nb > 2000 and fit > 0.99
+    got = e32.forward(ot, dt, bench.TMAX, bench.NS)
+    assert not e32.check_oob() and not e32.plan_stale()
+    rel = float(((got - ref).abs() / ref.abs()).max())
+    rel_u = float(((unplanned - ref).abs() / ref.abs()).max())
+    print("float32 fast mode: max rel TEC error vs float64 %.3g (float32 storage with float64 arithmetic: %.3g)" % (rel, rel_u))
+    assert rel <= TEC_RTOL_F32_FAST
+    na = bench.NA
+    dg, dr = got.view(na, -1) - got.view(na, -1)[0:1], ref.view(na, -1) - ref.view(na, -1)[0:1]
+    assert float((dg - dr).abs().max()) <= 1e-6 * float(ref.abs().max())            # SURVEY 8(d): dTEC atol = 1e-6 max|TEC|
+    sel = np.random.default_rng(1).choice(len(w["origins"]), 2000, replace=False)
+    oc = OC.forward_tec_straight(w["xvec"], w["yvec"], w["zvec"], ne, w["origins"][sel], w["directions"][sel], bench.TMAX, bench.NS)
+    assert np.max(np.abs(got.cpu().numpy()[sel] - oc) / np.abs(oc)) <= TEC_RTOL_F32_FAST
+    # rays edited in place: those bundles from the arrays with direct loads, flag raised
+    o2 = w["origins"].copy()
+    o2[5] = o2[9000]
+    ot.copy_(e64.tensor(o2))
+    got2 = e32.forward(ot, dt, bench.TMAX, bench.NS)
+    assert e32.plan_stale()
+    assert bool(torch.isfinite(got2).all())
+    keep = torch.ones(len(o2), dtype=torch.bool, device=got.device)
+    keep[5] = False
+    assert float(((got2 - got).abs() / got.abs())[keep].max()) <= 1e-6
 
 
 def test_tec_does_not_depend_on_the_bundling():

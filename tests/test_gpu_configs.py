@@ -53,7 +53,7 @@ def test_two_process_hip_engine_matches_single_rank(exchange):
     import torch.multiprocessing as mp
     interp = "cubic" if exchange.endswith("-cubic") else "linear"
     exchange = exchange.split("-")[0]
-    from test_distributed_gloo import _worker, _run, _free_port
+    from test_distributed_gloo import _worker, _run, _free_port, get_or_fail
     size = dict(na=6, nd=7, nt=6, n=40, Ns=65)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -61,7 +61,7 @@ def test_two_process_hip_engine_matches_single_rank(exchange):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, "hip", size, interp)) for r in range(2)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(2))
+    res = dict(get_or_fail(q, procs, 600) for _ in range(2))
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
@@ -100,13 +100,13 @@ def test_one_rank_rccl_group_equals_no_group(exchange):
     without a group BIT FOR BIT; CGLS forms <s, s> with another kernel on the multi-rank path (1e-12), the sharded update runs in
     torch (1e-12)."""
     import torch.multiprocessing as mp
-    from test_distributed_gloo import _worker, _run, _free_port
+    from test_distributed_gloo import _worker, _run, _free_port, get_or_fail
     size = dict(na=6, nd=7, nt=6, n=40, Ns=65)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     p = ctx.Process(target=_worker, args=(0, 1, _free_port(), q, exchange, "hip", size, "linear", "nccl", True, True))
     p.start()
-    rank, res = q.get(timeout=600)
+    rank, res = get_or_fail(q, [p], 600)
     p.join(timeout=120)
     assert p.exitcode == 0 and rank == 0
     ref = _run(1, exchange, "hip", size, "linear", True)

@@ -328,9 +328,12 @@ def test_planned_forward_rebuilds_only_the_fields_its_rays_read(monkeypatch):
     o2, d2 = pencil(700, 37.0, 17.0, 0.05)
 
     def make(variant=None):
-        monkeypatch.setenv("IONOTOMO_VARIANT", "12" if variant is None else variant)       # 12: the bundle kernel whatever the plan's size
+        monkeypatch.setenv("IONOTOMO_HYBRID_MIN", "1")                                     # the bundle kernel whatever the plan's size
+        if variant is not None:
+            monkeypatch.setenv("IONOTOMO_VARIANT", variant)
         e = RayEngine(0, interp="cubic")
-        monkeypatch.delenv("IONOTOMO_VARIANT")
+        monkeypatch.delenv("IONOTOMO_HYBRID_MIN")
+        monkeypatch.delenv("IONOTOMO_VARIANT", raising=False)
         e.set_grid(xv, yv, zv)
         return e
     eng = make()
@@ -371,30 +374,3 @@ def test_planned_forward_rebuilds_only_the_fields_its_rays_read(monkeypatch):
     assert not eng.plan_stale() and float((again - b).abs().max()) < 1e-12 * float(b.abs().max())
 
 
-def test_planned_tricubic_ab_switches_do_not_change_results(monkeypatch):
-    """IONOTOMO_VARIANT=24 (float atomics instead of the default fixed point in the planned tricubic transpose) and 25 (the derivative
-    fields rebuilt over the whole grid instead of the lines the forward plan's windows hold) are A/B switches: same numbers."""
-    import bench
-    from ionotomo_amd.engine import RayEngine
-    w = bench.build_workload(0)
-    o, d = w["origins"].reshape(-1, 3)[:80000], w["directions"].reshape(-1, 3)[:80000]
-    y = np.random.default_rng(9).normal(size=len(o))
-    fwd, adj = {}, {}
-    for variant in ("0", "24", "25"):
-        monkeypatch.setenv("IONOTOMO_VARIANT", variant)
-        eng = RayEngine(0, interp="cubic")
-        monkeypatch.delenv("IONOTOMO_VARIANT")
-        eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
-        ot, dt = eng.tensor(o), eng.tensor(d)
-        nb, _, fit = eng.plan_forward(ot, dt, bench.TMAX, bench.NS)
-        assert nb >= 1024 and fit > 0.9
-        assert eng.plan_adjoint(ot, dt, bench.TMAX, bench.NS)[0] > 0
-        for scale in (1.0, 1.7):                                   # (new values: the second rebuild is the restricted one by default)
-            eng.set_values(eng.tensor(np.exp(w["m"]) * scale))
-            fwd[variant] = eng.forward(ot, dt, bench.TMAX, bench.NS)
-        adj[variant] = eng.adjoint(ot, dt, eng.tensor(y), bench.TMAX, bench.NS)
-        assert not eng.check_oob() and not eng.plan_stale()
-    for v in ("24", "25"):
-        assert float((fwd[v] - fwd["0"]).abs().max()) < 1e-12 * float(fwd["0"].abs().max()), v
-        assert float((adj[v] - adj["0"]).abs().max()) < 1e-11 * float(adj["0"].abs().max()), v
-    assert torch.equal(fwd["25"], fwd["0"])                        # the same kernel on the same fields: bit for bit

@@ -141,10 +141,10 @@ def test_620k_bending_rays_through_256_cubed_in_one_launch():
 def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, rep, O, monkeypatch):
     """On an ideal-uniform grid the tracer's right-hand side skips the axis tables and the divisions (trilinear_grad_ideal) except
     within 1e-9 of a cell face, where the general form decides the cell as scipy does.  Traced rays and fused TEC equal the
-    general form's (IONOTOMO_VARIANT=13) to rounding and the oracle's RK4 -- also when EVERY sample sits on a z face (``aligned``:
+    general form's (IONOTOMO_FORCE_GENERAL=2) to rounding and the oracle's RK4 -- also when EVERY sample sits on a z face (``aligned``:
     samples one cell apart starting on a level, the case where the face rule decides which cell's gradient bends the ray).
     ``rep`` = 1: 60 rays, the small-batch tracer that keeps the cell's polynomial in registers (k_trace_fermat_poly) against the
-    4-lanes-per-ray kernel it replaced on ideal grids (IONOTOMO_VARIANT=15); 80: 4 800 rays, the lanes = rays tracer."""
+    4-lanes-per-ray kernel that serves the other grids (the same switch); 80: 4 800 rays, the lanes = rays tracer."""
     from ionotomo_amd.engine import RayEngine
     w = syn.make_workload(antennas="example", na=6, nd=5, nt=2, n=33, margin_cells=10)
     xv, yv, zv = w["xvec"], w["yvec"], w["zvec"]
@@ -153,10 +153,11 @@ def test_ideal_grid_right_hand_side_equals_the_general_one(aligned, rep, O, monk
     if aligned:
         o[:, 2] = zv[4]                                   # z_k = linspace(zv[4], zv[24], 21): every sample on a level of the grid
     res = {}
-    other = "13" if rep > 1 else "15"
+    other = "2"                                           # IONOTOMO_FORCE_GENERAL=2: no ideal-uniform kernels (general right-hand side; 4 lanes per ray)
     for variant in ("0", other):
-        monkeypatch.setenv("IONOTOMO_VARIANT", variant)
+        monkeypatch.setenv("IONOTOMO_FORCE_GENERAL", variant)
         eng = RayEngine(0)
+        monkeypatch.delenv("IONOTOMO_FORCE_GENERAL")
         eng.set_grid(xv, yv, zv)
         eng.set_values(eng.tensor(w["ne"]))
         ot, dt = eng.tensor(np.tile(o, (rep, 1))), eng.tensor(np.tile(d, (rep, 1)))
@@ -175,7 +176,7 @@ def test_tricubic_index_is_fused_by_default_on_ideal_axes(monkeypatch):
     """Round 4: curved rays through a TRICUBIC refractive index no longer need rays[R,4,Ns].  ``fused=None`` on
     ideal-uniform axes runs k_fermat_tec_lm -- the 8-lanes-per-ray stepper of the record tracer feeding the streaming quadrature --
     and equals trace + integrate along the stored rays to 1e-11 for both integrand interpolants, both independent variables, every
-    quadrature rule and even / odd sample counts; the lanes = rays kernel (IONOTOMO_VARIANT=17) agrees too.  The TRANSPOSE keeps the
+    quadrature rule and even / odd sample counts; the lanes = rays kernel (what grids without ideal-uniform axes get: IONOTOMO_FORCE_GENERAL=2) agrees too.  The TRANSPOSE keeps the
     two-step route by default (its fused form steps lanes = rays with 216 taps)."""
     from ionotomo_amd.engine import RayEngine
     w = syn.make_workload(antennas="example", na=6, nd=5, nt=2, n=24, margin_cells=8)
@@ -201,14 +202,14 @@ def test_tricubic_index_is_fused_by_default_on_ideal_axes(monkeypatch):
         gb = eng.adjoint_fermat(ot, dt, yt, w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
         assert float((ga - gb).abs().max()) < 1e-12 * float(gb.abs().max())
     # the lanes = rays kernel on the same problem
-    monkeypatch.setenv("IONOTOMO_VARIANT", "17")
+    monkeypatch.setenv("IONOTOMO_FORCE_GENERAL", "2")
     e17 = RayEngine(0, interp="cubic")
     e17.set_grid(w["xvec"], w["yvec"], w["zvec"])
     e17.set_values(e17.tensor(w["ne"]))
     c17 = e17.forward_fermat(e17.tensor(o), e17.tensor(d), w["tmax"], 21, 60e6, kind="cubic", substeps=2, ne_scale=1e-13, fused=True)
     # ... which the DEFAULT route never lands on silently: where the library would not run k_fermat_tec_lm, fused=None traces + integrates
     assert not e17.fermat_lm_ok("cubic", "cubic", len(o)) and e17._two_step_fermat(len(o), 21, "cubic", None)
-    monkeypatch.delenv("IONOTOMO_VARIANT")
+    monkeypatch.delenv("IONOTOMO_FORCE_GENERAL")
     eng = RayEngine(0, interp="cubic")
     eng.set_grid(w["xvec"], w["yvec"], w["zvec"])
     eng.set_values(eng.tensor(w["ne"]))
@@ -228,7 +229,7 @@ def test_tricubic_index_is_fused_by_default_on_ideal_axes(monkeypatch):
 @pytest.mark.parametrize("typ", ["z", "s"])
 def test_tricubic_tracer_on_node_records_equals_the_216_tap_kernel(typ, O, monkeypatch):
     """On ideal-uniform grids the tricubic tracer reads the Lekien-Marsden records of the refractive index, one node per lane
-    (k_trace_fermat_lm), instead of a 6 x 6 plane of taps per lane (k_trace_fermat_coop, IONOTOMO_VARIANT=17): the same interpolant,
+    (k_trace_fermat_lm), instead of a 6 x 6 plane of taps per lane (k_trace_fermat_coop: the other grids, IONOTOMO_FORCE_GENERAL=2): the same interpolant,
     so the rays agree to rounding -- both independent variables, a changed model (the records are rebuilt), a second frequency --
     and with the oracle's RK4 on its 216-tap form."""
     from ionotomo_amd.engine import RayEngine
@@ -239,8 +240,9 @@ def test_tricubic_tracer_on_node_records_equals_the_216_tap_kernel(typ, O, monke
     tmax = float(zv[24]) if typ == "z" else 0.7 * float(zv[24])
     res = {}
     for variant in ("0", "17"):
-        monkeypatch.setenv("IONOTOMO_VARIANT", variant)
+        monkeypatch.setenv("IONOTOMO_FORCE_GENERAL", "2" if variant == "17" else "0")
         eng = RayEngine(0, interp="cubic")
+        monkeypatch.delenv("IONOTOMO_FORCE_GENERAL")
         eng.set_grid(xv, yv, zv)
         out = []
         for ne, freq in ((w["ne"], 100e6), (w["ne"] * 1.3, 100e6), (w["ne"] * 1.3, 140e6)):
