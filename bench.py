@@ -587,8 +587,18 @@ def fermat_leg(w, local, torch, dist):
             _, k = time_steps(fn, 10 if name == "cfg3" else 3, 2 if name == "cfg3" else 1, torch, dist, 1)
             assert not e.check_oob(), "bending rays left the grid"
             b = fermat_bytes_per_ray(ns, sub, kind)
+            # error control: step doubling on a strided sample (<= 1 % of the rays, >= 208) at the reference's odeint
+            # tolerance (inversion/fermat.py:163-167).  What the fixed `substeps` of the timed launch means is read off the levels: the
+            # largest position difference (km) and the relative TEC change between s and 2 s steps.  On this turbulent test ionosphere a
+            # trilinear index converges first order (its gradient jumps at cell faces), a tricubic one second order: 1.49e-8 is out of
+            # reach of any affordable fixed step, and the report says so (`met`: false) instead of hiding it.
+            _, rep = e.choose_fermat_substeps(o, d, tmax, ns, freq, kind=kind, max_substeps=16)
             out["%s_%s_index" % (name, kind)] = {
                 "rays": R, "Ns": ns, "substeps": sub, "frequency_hz": freq, "ms": k * 1e3, "rays_per_s": R / k,
+                "step_control": {"rtol": rep["rtol"], "atol": rep["atol"], "sample_rays": rep["sample_rays"], "met_within_16_substeps": rep["met"],
+                                 "levels": rep["levels"],
+                                 "timed_substeps_position_diff_km": next((max(l["max_abs_diff"].values()) for l in rep["levels"] if l["substeps"] == sub), None),
+                                 "timed_substeps_tec_rel_diff": next((l.get("observable_max_rel_diff") for l in rep["levels"] if l["substeps"] == sub), None)},
                 "kernel": ("k_fermat_tec_lm<true, %d, false>" % (2 if R >= 32768 else 8) if e.fermat_lm_ok(kind, "linear", R)
                            else "k_fermat_tec<%d, true, false>" % (kind == "cubic")),      # (lanes per ray: the library's default rule)
                 "algorithmic_bytes_per_ray": b, "algorithmic_gbs": R * b / k / 1e9}
@@ -705,7 +715,7 @@ def main():
     ap.add_argument("--main-only", action="store_true", help="same as --only forward")
     ap.add_argument("--only", default=None,
                     choices=["forward", "adjoint", "cubic_forward", "cubic_adjoint", "cgls", "sirt", "fermat_cubic", "fermat_linear",
-                             "fermat_cfg3", "coherence"],
+                             "fermat_cfg3", "coherence", "f32_forward"],
                     help="time ONE leg alone (clean rocprofv3 --stats / --pmc averages); implies --no-cpu")
     args = ap.parse_args()
     if args.main_only:
@@ -819,6 +829,13 @@ def main():
             t_ = torch.empty(o_.shape[0], dtype=torch.float64, device=e_.device)
             leg = lambda: e_.forward_fermat(o_, d_, tmax_, ns_, freq_, bend=True, kind=kind_, substeps=sub_, out=t_)      # noqa: E731
             k = max(2, min(k, 5))
+        elif args.only == "f32_forward":         # the float32 fast mode (storage="f32" + a forward plan: k_forward_bundle_f32)
+            e32 = RayEngine(local, storage="f32")
+            e32.set_grid(w["xvec"], w["yvec"], w["zvec"])
+            e32.set_log_model(m_t, w["K_ne"] / 1e13)
+            if args.fwd_plan:
+                e32.plan_forward(o_t, d_t, TMAX, NS)
+            leg = e32.forward_launcher(o_t, d_t, TMAX, NS, tec_t, order=forder_t)
         elif args.only in ("cubic_forward", "cubic_adjoint"):
             ec, cf, ca, _ = cubic_legs()
             leg = cf if args.only == "cubic_forward" else ca

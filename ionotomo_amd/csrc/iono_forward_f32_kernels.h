@@ -25,7 +25,15 @@ namespace {
 #define F_PPC 3                // 16-byte pieces per staged column
 #define F_LEV 12               // levels per column: 7 dfz + 2 + up to 3 (a window starts on a multiple of 4 levels)
 #define F_COLB 48              // bytes per column
-#define F_CAPCOLS 200          // columns per wave image
+#ifndef F_CAPCOLS
+#define F_CAPCOLS 133          // columns per wave image: 6 384 B, five workgroups per CU (200 columns / four workgroups: 0.083 against 0.081 ms)
+#endif
+#ifndef F_WPE
+#define F_WPE 4, 5             // waves per SIMD the kernel is compiled for
+#endif
+#ifndef F_LEVEL_MAJOR
+#define F_LEVEL_MAJOR 1        // image layout: 1 = [level][column] (rays of a bundle sit on the same level: their columns fall into
+#endif                         //   different LDS banks), 0 = [column][level] as staged (31 % of the LDS cycles were bank conflicts)
 #define F_WAVE_LDS (F_CAPCOLS * F_COLB)      // 9 600 B per wave, as the float64 kernel: four workgroups per CU
 #define F_SLOTS 21             // columns per wave-load (63 lanes x 16 B)
 #define F_NPF 6                // wave-loads per window, all prefetched through registers
@@ -87,13 +95,23 @@ __device__ __forceinline__ FWin fwin_decode(uint4 w) {
 
 // the eight corners of a sample: (column j, column j + 1) of level k and of level k + 1, rows i (address a) and i + 1 (address a2)
 __device__ __forceinline__ void lds_read8_f32(f32x2 &p0, f32x2 &p1, f32x2 &q0, f32x2 &q1, unsigned a, unsigned a2) {
+#if F_LEVEL_MAJOR
+    // image[level][column], F_CAPCOLS words per level: the next column is the next word, the next level F_CAPCOLS words on
+    asm volatile("ds_read2_b32 %0, %4 offset1:1\n\tds_read2_b32 %1, %4 offset0:%6 offset1:%7\n\t"
+                 "ds_read2_b32 %2, %5 offset1:1\n\tds_read2_b32 %3, %5 offset0:%6 offset1:%7"
+                 : "=&v"(p0), "=&v"(p1), "=&v"(q0), "=&v"(q1)
+                 : "v"(a), "v"(a2), "n"(F_CAPCOLS), "n"(F_CAPCOLS + 1)
+                 : "memory");
+#else
     asm volatile("ds_read2_b32 %0, %4 offset1:12\n\tds_read2_b32 %1, %4 offset0:1 offset1:13\n\t"
                  "ds_read2_b32 %2, %5 offset1:12\n\tds_read2_b32 %3, %5 offset0:1 offset1:13"
                  : "=&v"(p0), "=&v"(p1), "=&v"(q0), "=&v"(q1)
                  : "v"(a), "v"(a2)
                  : "memory");
+#endif
 }
 static_assert(F_COLB == 48, "ds_read2_b32 offset1:12 is the next column");
+static_assert(!F_LEVEL_MAJOR || F_CAPCOLS + 1 <= 255, "ds_read2_b32 offsets are 8 bits");
 // (value of row i, value of row i + 1) -> interpolated: z on both columns at once, x on both columns at once, y last
 __device__ __forceinline__ float lerp8_f32(f32x2 p0, f32x2 p1, f32x2 q0, f32x2 q1, float tx, float ty, float tz) {
     const f32x2 tz2 = {tz, tz}, tx2 = {tx, tx};
@@ -103,7 +121,7 @@ __device__ __forceinline__ float lerp8_f32(f32x2 p0, f32x2 p1, f32x2 q0, f32x2 q
     return __builtin_fmaf(ty, s.y - s.x, s.x);
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) void k_forward_bundle_f32(
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(F_WPE))) void k_forward_bundle_f32(
     GridView g, const double *__restrict__ origins, const double *__restrict__ dirs, const BundleRec *__restrict__ brec,
     const uint2 *__restrict__ bhash, const uint4 *__restrict__ win, int nb, int nchunks, double tmax, int Ns,
     const float *__restrict__ unitw32, const double *__restrict__ unitw, double *__restrict__ tec, int *flags) {
@@ -183,11 +201,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0" : "=&s"(wq), "=&s"(wn) : "s"(unitw32 + k0), "s"(wb + min(c + 1, c1 - 1)) : "memory");
         __builtin_amdgcn_s_waitcnt(0x0f70);                     // vmcnt(0): this chunk's window rows have landed
         if (Wc.fits && act) {
+#if F_LEVEL_MAJOR
+            // transposed on the way in: the lane's piece = 4 levels of one column -> 4 words F_CAPCOLS apart
+            const unsigned lstep = (unsigned)(Wc.rpl * Wc.wy) * 4u;
+            char *dst = img + ((unsigned)(4 * pc) * F_CAPCOLS + (unsigned)cs) * 4u;
+#pragma unroll
+            for (int n = 0; n < F_NPF; ++n)
+                if (n < Wc.nl) {
+                    unsigned *q = (unsigned *)(dst + n * lstep);
+                    q[0] = pre[n].x, q[F_CAPCOLS] = pre[n].y, q[2 * F_CAPCOLS] = pre[n].z, q[3 * F_CAPCOLS] = pre[n].w;
+                }
+#else
             const unsigned lstep = (unsigned)(Wc.rpl * Wc.wy) * F_COLB;
             char *dst = img + lane * 16;
 #pragma unroll
             for (int n = 0; n < F_NPF; ++n)
                 if (n < Wc.nl) *(u32x4 *)(dst + n * lstep) = pre[n];
+#endif
         }
         asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(wq), "+s"(wn)::"memory");
         const FWin Wn = fwin_decode(make_uint4(wn.x, wn.y, wn.z, c + 1 < c1 ? wn.w : 0u));
@@ -195,11 +225,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
         if (Wn.fits) issue(Wn);                                 // the next chunk's window: in flight during this chunk's samples
         Wc = Wn;
         if (Wuse.fits) {
-            // positions relative to the window origin, float32; LDS byte address = image + (ri wy + rj) 48 + rk 4, formed in float32
+            // positions relative to the window origin, float32; LDS byte address = image + ((ri wy + rj) + rk F_CAPCOLS) 4, formed in float32
             const f32x2 rxy = {(float)(fx - (double)Wuse.imin), (float)(fy - (double)Wuse.jmin)};
             const float rz = (float)(fz - (double)Wuse.kz0);
-            const float rowb = (float)(Wuse.wy * F_COLB), imgf = (float)(unsigned)(size_t)img;
+#if F_LEVEL_MAJOR
+            const float rowb = (float)(Wuse.wy * 4), imgf = (float)(unsigned)(size_t)img, colb = 4.0f, levb = (float)(F_CAPCOLS * 4);
+            const unsigned row = (unsigned)(Wuse.wy * 4);
+#else
+            const float rowb = (float)(Wuse.wy * F_COLB), imgf = (float)(unsigned)(size_t)img, colb = (float)F_COLB, levb = 4.0f;
             const unsigned row = (unsigned)(Wuse.wy * F_COLB);
+#endif
             float acc32 = 0.0f;
             auto sample = [&](float uf, f32x2 &p0, f32x2 &p1, f32x2 &q0, f32x2 &q1, float &tx, float &ty, float &tz) {
                 const f32x2 u2 = {uf, uf};
@@ -207,7 +242,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 5))) voi
                 const float pz = __builtin_fmaf(uf, dz, rz);
                 const float fi = __builtin_floorf(__builtin_fabsf(pxy.x)), fj = __builtin_floorf(__builtin_fabsf(pxy.y)), fk = __builtin_floorf(__builtin_fabsf(pz));
                 tx = pxy.x - fi, ty = pxy.y - fj, tz = pz - fk;
-                const unsigned a = (unsigned)__builtin_fmaf(fi, rowb, __builtin_fmaf(fj, (float)F_COLB, __builtin_fmaf(fk, 4.0f, imgf)));
+                const unsigned a = (unsigned)__builtin_fmaf(fi, rowb, __builtin_fmaf(fj, colb, __builtin_fmaf(fk, levb, imgf)));
                 lds_read8_f32(p0, p1, q0, q1, a, a + row);
             };
             if (ke - k0 == F_KC) {

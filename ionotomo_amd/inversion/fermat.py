@@ -44,20 +44,29 @@ def doubling_error(coarse, fine, rtol, atol):
     return float(e.max()) if e.size else 0.0
 
 
-def choose_substeps(trace, rtol=ODEINT_RTOL, atol=None, start=1, max_substeps=32, safety=0.5):
+def choose_substeps(trace, rtol=ODEINT_RTOL, atol=None, start=1, max_substeps=32, safety=0.5, observe=None):
     """Step-doubling control of the fixed-step RK4 tracer.  ``trace(substeps)`` returns rays[n,4,N] of the SAMPLE rays.  Returns
     (substeps, report): the smallest power-of-two multiple of ``start`` whose trajectory differs from the one at twice as many steps
     by at most ``safety`` x the tolerance (``doubling_error`` <= safety; the factor covers first-order convergence, where the
     difference is only half the coarse solution's error), or ``max_substeps`` with ``report['met'] = False``.  Each level costs one
-    launch of the sample; levels already traced are reused as the next level's coarse side."""
+    launch of the sample; levels already traced are reused as the next level's coarse side.  ``observe(substeps)`` (optional): an
+    observable of the sample at that step count -- the TEC along the traced rays -- whose relative change per level is reported too."""
     atol = rtol if atol is None else atol
     s = max(1, int(start))
     coarse = trace(s)
+    oc = None if observe is None else np.asarray(observe(s))
     levels = []
     while True:
         fine = trace(2 * s)
         err = doubling_error(coarse, fine, rtol, atol)
-        levels.append({"substeps": s, "against": 2 * s, "error_over_tolerance": err})
+        diff = np.abs(np.asarray(coarse) - np.asarray(fine))
+        lev = {"substeps": s, "against": 2 * s, "error_over_tolerance": err,
+               "max_abs_diff": {k: float(diff[..., i, :].max()) if diff.size else 0.0 for i, k in enumerate("xyzs")}}
+        if observe is not None:
+            of = np.asarray(observe(2 * s))
+            lev["observable_max_rel_diff"] = float(np.max(np.abs(oc - of) / np.abs(of))) if of.size else 0.0
+            oc = of
+        levels.append(lev)
         if err <= safety or 2 * s > max_substeps:
             met = err <= safety
             break

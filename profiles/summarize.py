@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 tag = sys.argv[1]
 G = os.path.join(ROOT, "gpurun_out")
 P = os.path.join(ROOT, "profiles")
-LEG_KERNEL = {"forward": "k_forward_bundle", "adjoint": "k_adjoint_binned<double, 0, double",
+LEG_KERNEL = {"forward": "k_forward_bundle<", "f32_forward": "k_forward_bundle_f32", "adjoint": "k_adjoint_binned<double, 0, double",
               "cubic_forward": "k_forward_bundle_lm", "cubic_adjoint": "k_adjoint_binned_lm4", "fermat_cubic": "k_fermat_tec_lm",
               "fermat_linear": "k_fermat_tec<0",
               "fermat_cfg3": "k_fermat_tec_lm"}

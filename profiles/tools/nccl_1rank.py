@@ -89,7 +89,9 @@ def main():
             rec = {"multi": bool(prob.multi), "overlapped": bool(prob.overlapped())}
             for name in ("cgls", "sirt"):
                 fn = getattr(solvers, name)
+                eng.set_deterministic(True)             # fixed-point back-projection: two runs CAN agree bit for bit
                 x, hist = fn(prob, x0, n_iter=6)
+                eng.set_deterministic(False)
                 if not forced:
                     ref[name] = (x.clone(), list(hist))
                 elif rd is None:
