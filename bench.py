@@ -1013,7 +1013,7 @@ def main():
             extra["f32_grid_unplanned_max_rel_err_vs_f64"] = float((tec32 - tec_t).abs().div(tec_t.abs()).max().item())
             if args.fwd_plan:
                 info32 = eng32.plan_forward(o_t, d_t, TMAX, NS)
-                _, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), k2, 1, torch, dist, 1)
+                _, k32 = time_steps(lambda: eng32.forward(o_t, d_t, TMAX, NS, out=tec32, order=forder_t), max(k2, 20), 2, torch, dist, 1)
                 assert not eng32.check_oob()
                 dt32, dt64 = (t.view(NA, -1) - t.view(NA, -1)[0:1] for t in (tec32, tec_t))
                 extra["f32_fast_mode"] = {"kernel": "k_forward_bundle_f32", "bundles": info32[0], "lds_chunk_fraction": info32[2], "forward_ms": k32 * 1e3,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box through gpurun:  bash profiles/run_profiles.sh <tag> [part]
 #   part 1: bench line + rocprofv3 --kernel-trace --stats of every leg           (~5 min)
-#   part 2: PMC passes of the forward kernel, one counter set per run            (~5 min)
+#   part 2: PMC passes of the forward kernel (+ the float32 fast mode), one counter set per run   (~6 min)
 #   part 3: PMC passes of the adjoint and the tricubic forward                   (~5 min)
 #   part 5: PMC passes of the Fermat kernels                                     (~2 min)
 # Produces gpurun_out/<tag>_*; `python profiles/summarize.py <tag>` condenses them into profiles/.
@@ -39,6 +39,7 @@ if [ "$PART" = "1" ]; then
   # (--settle-ms 150 as in the default bench run: ~1 000 untimed launches of the leg first, so the average is the SUSTAINED per-launch
   #  duration the bench line times -- bench.py:settle, profiles/r05_clock_ramp.json)
   stats forward --only forward --steps 20 --warmup 3 --settle-ms 600
+  stats f32_forward --only f32_forward --steps 20 --warmup 3 --settle-ms 600
   stats adjoint --only adjoint --steps 10 --warmup 2 --settle-ms 150
   stats cubic_forward --only cubic_forward --steps 10 --warmup 2 --settle-ms 150
   stats cubic_adjoint --only cubic_adjoint --steps 10 --warmup 2 --settle-ms 150
@@ -58,6 +59,7 @@ SETS=("FETCH_SIZE" "WRITE_SIZE"
 FIRST=${3:-1}
 if [ "$PART" = "2" ]; then
   i=0; for C in "${SETS[@]}"; do i=$((i+1)); [ $i -ge $FIRST ] && pmc forward $i "$C"; done
+  for i in 1 3 5 6 7 8 10; do pmc f32_forward $i "${SETS[$((i-1))]}"; done      # the float32 fast mode (k_forward_bundle_f32)
 fi
 if [ "$PART" = "4" ]; then      # selected sets for one leg:  run_profiles.sh <tag> 4 <leg> "<set indices>"
   for i in $4; do pmc $3 $i "${SETS[$((i-1))]}"; done
