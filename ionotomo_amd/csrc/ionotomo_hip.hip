@@ -1181,7 +1181,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     for (int b = 0; b < nb_all; ++b) ++fp.hist[std::min(bstart[(size_t)b + 1] - bstart[(size_t)b], 64)];
     // The threshold T (serve bundles of >= T rays; 1: all, 65: none): forced (IONOTOMO_HYBRID_MIN), else the T
     // with the smallest modelled time.  Model, fitted to the round-6 sweeps on MI355X (profiles/r06_coherence_sweep.json; 256^3 float64,
-    // Ns = 257, scaled by Ns): a bundle launch of n workgroups takes max(20, 8 + 0.019 n) us (one workgroup lives ~20 us; 4 597 bundles:
+    // Ns = 257, scaled by Ns): a bundle launch of n workgroups takes max(22, 8 + 0.019 n) us (one workgroup lives ~20 us; 570 bundles: 22.5 us; 4 597 bundles:
     // 95 us), a lanes = samples launch of r rays 5.5 + 0.00078 r us (2 604 rays: 7.7 us; 260 400: 208 us).  Checked against the
     // measurements: 42 directions x 1 / 4 / 16 / 100 timesteps of 62 stations -> none / none / all / all, as measured fastest; half the
     // bench rays + as many scattered ones -> T = 24: 0.20 ms against 0.57 (all bundles) and 0.34 (none).
@@ -1189,7 +1189,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     int hmin = c->hybrid_min;
     {
         const double su = (double)Ns / 257.0;
-        auto t_bundles = [&](int64_t n) { return n ? std::max(20.0 * (0.25 + 0.75 * su), 8.0 + 0.019 * su * (double)n) : 0.0; };
+        auto t_bundles = [&](int64_t n) { return n ? std::max(22.0 * (0.25 + 0.75 * su), 8.0 + 0.019 * su * (double)n) : 0.0; };
         // (a lanes = samples launch BEHIND a bundle launch costs ~10 us before its first ray, not 5.5: the bundle kernel's last
         //  workgroups drain first -- 1 772 tail rays: +10.5 us, 9 299: +15.6 us at the bench shape)
         auto t_rays = [&](int64_t r, bool second) { return r ? (second ? 10.0 : 5.5) + 0.00078 * su * (double)r : 0.0; };

@@ -169,7 +169,7 @@ def test_hybrid_dispatch_mixed_geometries(seed, interp, OC):
     hist = np.array(sp["bundles_by_ray_count"])
     assert hist.sum() == sp["bundles_cut"] and (hist * np.arange(65)).sum() == R
     assert sp["bundles_served"] == hist[hmin:].sum() and sp["rays_served"] == (hist * np.arange(65))[hmin:].sum()
-    assert 0 < sp["rays_tail"] < R, sp                                          # a genuinely mixed launch
+    assert sp["rays_tail"] < R and (hmin < 8 or sp["rays_tail"] > 0), sp         # a genuinely mixed launch (hmin = 2: unless no ray is alone)
     got = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
     assert eng.check_oob() == (not inside.all())
     assert np.all(np.isnan(got[~inside])) and np.all(np.isfinite(got[inside]))
