@@ -677,7 +677,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_adjoint_binned(GridView g, cons
 #ifndef LM4_THREADS
 #define LM4_THREADS 1024
 #endif
-#define LM4_LDS_BYTES(Ns) (sizeof(double) * ((((size_t)(Ns) + 1) & ~(size_t)1) + 4 * (size_t)BIN_TILE))
+#ifndef LM_NCH
+#define LM_NCH 4      // channels per traversal.  A/B build -DLM_NCH=8 -DBIN_SZ=7 -DBIN_BZP=8: all eight in ONE traversal over half-height boxes
+#endif                //   (eight 14.4 KB images): measured slower, profiles/r06_tricubic_transpose_one_traversal_rejected.json
+#define LM4_LDS_BYTES(Ns) (sizeof(double) * ((((size_t)(Ns) + 1) & ~(size_t)1) + LM_NCH * (size_t)BIN_TILE))
 // FIX: deterministic fixed-point accumulation (k_adjoint_binned<.., FIX>): the images and G8 hold 64-bit integers, which the z fold
 // turns into float64 as it reads them (k_lm_fold_z_tiles<FIX>).
 template <int SEGL, bool FIX = false>
@@ -690,7 +693,7 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
     double *wlds = (double *)smem;                                   // [Ns] quadrature weights
     double *tile = wlds + ((Ns + 1) & ~1);                           // [4][BIN_BX * BIN_BY][BIN_BZP]: channel c = p + 2 q
     for (int t = threadIdx.x; t < Ns; t += LM4_THREADS) wlds[t] = unitw[t];
-    for (int t = threadIdx.x; t < 4 * BIN_TILE; t += LM4_THREADS) tile[t] = 0.0;
+    for (int t = threadIdx.x; t < LM_NCH * BIN_TILE; t += LM4_THREADS) tile[t] = 0.0;
     // PERSISTENT workgroups (the four images leave room for one per CU): a workgroup starts on unit blockIdx.x and then takes the next
     // unit nobody has (`next_unit`, zeroed by the host: the list is sorted largest first, so this is longest-processing-time-first);
     // the images are re-zeroed word by word as they are flushed, the weights are staged once -- a unit no longer pays a workgroup
@@ -760,12 +763,13 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
         const double fi = clampf(__builtin_floor(__builtin_fabs(fx)), lim_x), fj = clampf(__builtin_floor(__builtin_fabs(fy)), lim_y),
                      fk = clampf(__builtin_floor(__builtin_fabs(fz)), lim_z);
         // Hermite value (bit 0) and slope (bit 1) weights of the two nodes per axis: axis_pair (iono_adjoint_kernels.h)
-        double xv0, xv1, xs0, xs1, yv0, yv1, ys0, ys1, z0, z1;
+        double xv0, xv1, xs0, xs1, yv0, yv1, ys0, ys1, z0, z1, zb0 = 0.0, zb1 = 0.0;
         axis_pair(fx - fi, 0, true, xv0, xv1);
         axis_pair(fx - fi, 1, true, xs0, xs1);
         axis_pair(fy - fj, 0, true, yv0, yv1);
         axis_pair(fy - fj, 1, true, ys0, ys1);
-        axis_pair(fz - fk, rbit, true, z0, z1);
+        axis_pair(fz - fk, LM_NCH == 8 ? 0 : rbit, true, z0, z1);
+        if (LM_NCH == 8) axis_pair(fz - fk, 1, true, zb0, zb1);      // (one traversal: both z kinds)
         const int i = (int)fi, j = (int)fj, kz = (int)fk;
         const int lin = active ? (int)mad24(mad24((unsigned)i, (unsigned)g.ny, (unsigned)j), (unsigned)g.nz, (unsigned)kz) : -7;
         const int prev = __builtin_amdgcn_update_dpp(-9, lin, 0x111, 0xf, 0xf, false);          // row_shr:1 (row lane 0 keeps -9)
@@ -775,9 +779,10 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
         const unsigned a = (unsigned)(i - un.x0), b = (unsigned)(j - un.y0), m = (unsigned)(kz - un.z0);
         const bool inside = (a < (unsigned)(BIN_BX - 1)) & (b < (unsigned)(BIN_BY - 1)) & (m < (unsigned)(BIN_BZ - 1));
         const unsigned t0 = tile_base + mad24(mad24(a, BIN_BY, b), BIN_BZP, m) * 8u;
-        const double cz0 = c * z0, cz1 = c * z1;
+        const double cza0 = c * z0, cza1 = c * z1, czb0 = c * zb0, czb1 = c * zb1;
 #pragma unroll
-        for (int ch = 0; ch < 4; ++ch) {
+        for (int ch = 0; ch < LM_NCH; ++ch) {
+            const double cz0 = (ch & 4) ? czb0 : cza0, cz1 = (ch & 4) ? czb1 : cza1;
             const double x0 = (ch & 1) ? xs0 : xv0, x1 = (ch & 1) ? xs1 : xv1, y0 = (ch & 2) ? ys0 : yv0, y1 = (ch & 2) ? ys1 : yv1;
             const double w00 = x0 * y0, w01 = x0 * y1, w10 = x1 * y0, w11 = x1 * y1;
             double l00 = w00 * cz0, l01 = w01 * cz0, l10 = w10 * cz0, l11 = w11 * cz0;
@@ -799,7 +804,7 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
                         if (upper) tile_add4_up(t, u00, u01, u10, u11);
                     }
                 } else {
-                    double *G = G8 + (size_t)(4 * rbit + ch) * nstride;
+                    double *G = G8 + (size_t)(LM_NCH == 8 ? ch : 4 * rbit + ch) * nstride;
                     if (FIX) {
                         global_add4_fix(G, i, j, kz, l00, l01, l10, l11);
                         if (upper) global_add4_fix(G, i, j, kz + 1, u00, u01, u10, u11);
@@ -837,7 +842,7 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
             r0 = load_ray(en0);
         }
         // ---- flush the four images: 16 lanes per (x, y) column, consecutive z -> one 128-B run of global atomics per column ----
-        for (int cc = threadIdx.x / BIN_BZP; cc < 4 * BIN_BX * BIN_BY; cc += LM4_THREADS / BIN_BZP) {
+        for (int cc = threadIdx.x / BIN_BZP; cc < LM_NCH * BIN_BX * BIN_BY; cc += LM4_THREADS / BIN_BZP) {
             const double v = tile[cc * BIN_BZP + mz];
             if (FIX ? __double_as_longlong(v) != 0 : v != 0.0) {
                 tile[cc * BIN_BZP + mz] = 0.0;                       // (the next unit of this workgroup starts from a clean image)
@@ -845,7 +850,7 @@ __global__ __launch_bounds__(LM4_THREADS) void k_adjoint_binned_lm4(GridView g, 
                 const int a = col / BIN_BY, b = col - a * BIN_BY;
                 const int gi = x0 + a, gj = y0 + b, gk = z0 + mz;
                 if (gi >= 0 && gi < g.nx && gj >= 0 && gj < g.ny && gk >= 0 && gk < g.nz) {
-                    double *dst = G8 + (size_t)(4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk;
+                    double *dst = G8 + (size_t)(LM_NCH == 8 ? ch : 4 * rbit + ch) * nstride + ((size_t)gi * g.ny + gj) * g.nz + gk;
                     if (FIX) atomicAdd((unsigned long long *)dst, (unsigned long long)__double_as_longlong(v));
                     else atomicAdd(dst, v);
                 }

@@ -1180,7 +1180,7 @@ int iono_forward_plan_dev(iono_ctx *c, const double *o, const double *d, int64_t
     for (int64_t &h : fp.hist) h = 0;
     for (int b = 0; b < nb_all; ++b) ++fp.hist[std::min(bstart[(size_t)b + 1] - bstart[(size_t)b], 64)];
     // The threshold T (serve bundles of >= T rays; 1: all, 65: none): forced (IONOTOMO_HYBRID_MIN), else the T
-    // with the smallest modelled time.  Model, fitted to the round-6 sweeps on MI355X (profiles/r06_coherence_sweep.json; 256^3 float64,
+    // with the smallest modelled time.  Model, fitted to the round-6 sweeps on MI355X (profiles/r06_coherence_sweep_*_ab.json; 256^3 float64,
     // Ns = 257, scaled by Ns): a bundle launch of n workgroups takes max(22, 8 + 0.019 n) us (one workgroup lives ~20 us; 570 bundles: 22.5 us; 4 597 bundles:
     // 95 us), a lanes = samples launch of r rays 5.5 + 0.00078 r us (2 604 rays: 7.7 us; 260 400: 208 us).  Checked against the
     // measurements: 42 directions x 1 / 4 / 16 / 100 timesteps of 62 stations -> none / none / all / all, as measured fastest; half the
@@ -2093,7 +2093,7 @@ static int adjoint_straight_typed(iono_ctx *c, const GridView &g, const double *
                 // (persistent workgroups, one per CU -- the four images are all the LDS a CU has -- pulling units off a counter that
                 //  fix_prepare has just cleared behind its scale word)
                 const dim3 pgrid((unsigned)std::min(pl.n_units, c->lm4_groups > 0 ? c->lm4_groups : c->num_cus));
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < (LM_NCH == 8 ? 1 : 2); ++rb)      // (-DLM_NCH=8: all eight channels in one traversal, A/B)
                     hipLaunchKernelGGL((k_adjoint_binned_lm4<SL, true>), pgrid, dim3(LM4_THREADS), l4, c->stream, g, pl.d_uray,
                                        pl.d_entries, pl.d_units, wr, Ns, c->d_unitw, c->d_G8, n, rb, fixmax, pl.fix_bits, pl.n_units,
                                        (int *)(c->d_fixgrid + n + 1) + rb);

@@ -280,7 +280,7 @@ def test_f32_fast_mode_bench_shape(OC):
     rel = float(((got - ref).abs() / ref.abs()).max())
     rel_u = float(((unplanned - ref).abs() / ref.abs()).max())
     print("float32 fast mode: max rel TEC error vs float64 %.3g (float32 storage with float64 arithmetic: %.3g)" % (rel, rel_u))
-    assert rel <= TEC_RTOL_F32_FAST
+    assert rel <= 2e-7              # at the bench shape even tests/test_gpu_parity.py's TEC_RTOL_F32 holds (measured 1.06e-7)
     na = bench.NA
     dg, dr = got.view(na, -1) - got.view(na, -1)[0:1], ref.view(na, -1) - ref.view(na, -1)[0:1]
     assert float((dg - dr).abs().max()) <= 1e-6 * float(ref.abs().max())            # dTEC atol = 1e-6 max|TEC|
