@@ -104,7 +104,7 @@ struct iono_ctx {
                                            // measured since it caches its stencil; env IONOTOMO_FERMAT_COOP_MAX for A/B)
     int fermat_coop_rpw = 0;               // rays per wave of that kernel, 1..8: 0 = default (env IONOTOMO_FERMAT_COOP_RPW)
     int64_t fermat_poly_max = 4096;     // trilinear tracer on ideal grids: cell-polynomial kernel (few rays per wave) up to this many rays
-                                        // (env IONOTOMO_FERMAT_POLY_MAX, _RPW; IONOTOMO_VARIANT=15: the 4-lanes-per-ray kernel instead)
+                                        // (env IONOTOMO_FERMAT_POLY_MAX, _RPW; grids without ideal-uniform axes -- IONOTOMO_FORCE_GENERAL=2 -- get the 4-lanes-per-ray kernel)
     int fermat_poly_rpw = 0;
     int64_t fermat_lin4_max = 4096;     // trilinear tracer: 4 lanes per ray up to this many rays, lanes = rays beyond (crossover
                                         // ~5k rays since the lanes = rays right-hand side dropped the axis tables on ideal grids:
@@ -848,7 +848,7 @@ static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes, const int 
     return c->walk_mode_set ? c->walk_mode : (order || array_bytes > ((uint64_t)256 << 20) ? 2 : 0);
 }
 // Forward mapping on ideal-uniform grids without a bundle plan: lanes = samples of one ray (k_forward_straight_u).
-// IONOTOMO_VARIANT=10 forces lanes = samples even on a planned geometry (A/B; results agree to rounding).
+// IONOTOMO_HYBRID_MIN=65 forces lanes = samples even on a planned geometry (A/B; results agree to rounding).
 // the bundle plan serves this launch: same ray arrays, R, tmax, Ns, and it fills the chip / is good (see the forward dispatch)
 static bool fplan_serves(const iono_ctx *c, const double *o, const double *d, int64_t R, double tmax, int Ns, int storage = IONO_F64) {
     const iono_ctx::FwdPlan &fp = c->fplan;

@@ -1,6 +1,6 @@
 """620 000 bending rays x 257 samples through 256^3 (config 4's ray count): the curved-ray TRANSPOSE through a tricubic and a
 trilinear refractive index (trilinear integrand) -- default route, and trace + explicit-sample transpose (fused=False: a 5.1 GB ray
-tensor); IONOTOMO_VARIANT=17 in the environment gives the lanes = rays kernel as the fused route.  One JSON line."""
+tensor); IONOTOMO_VARIANT=3 in the environment gives the lanes = rays kernel as the fused route.  One JSON line."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
