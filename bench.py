@@ -1167,6 +1167,17 @@ def finish_line(line, extra, copy_gbs, clean, ctx):
                 fr["ta_busy"] = cf["TA_TA_BUSY_sum"] / (256.0 * cyc)
             fr["kernel_pmc"] = cf.get("kernel")
         extra["fermat_roofline"] = fr
+    # the float32 fast mode's kernel: busy fractions of its units from the committed PMC pass of this build (leg f32_forward)
+    f32m, c32 = extra.get("f32_fast_mode"), (pmc or {}).get("f32_forward")
+    if f32m and c32 and c32.get("rays") == R and "GRBM_GUI_ACTIVE" in c32:
+        cyc = c32["GRBM_GUI_ACTIVE"] / 8.0
+        f32m["units"] = {k: v for k, v in (
+            ("valu_busy_frac", 4.0 * c32["SQ_ACTIVE_INST_VALU"] / (1024.0 * cyc) if "SQ_ACTIVE_INST_VALU" in c32 else None),
+            ("lds_busy_frac", c32["SQ_LDS_IDX_ACTIVE"] / (256.0 * cyc) if "SQ_LDS_IDX_ACTIVE" in c32 else None),
+            ("lds_bank_conflict_frac", c32.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(c32.get("SQ_LDS_IDX_ACTIVE", 1.0), 1.0)),
+            ("ta_busy_frac", c32["TA_TA_BUSY_sum"] / (256.0 * cyc) if "TA_TA_BUSY_sum" in c32 else None),
+            ("SQ_INSTS_VALU", c32.get("SQ_INSTS_VALU")), ("SQ_INSTS_LDS", c32.get("SQ_INSTS_LDS"))) if v is not None}
+        f32m["lds_read_path_frac_of_guide"] = f32m["algorithmic_gbs"] / LDS_GUIDE_GBS
     line["roofline"] = rl
     line["extra"] = extra
     if rank == 0 and not args.no_cpu:
