@@ -364,7 +364,8 @@ def test_stale_or_foreign_plan_is_never_used(OC):
     assert not eng.check_oob()
 
 
-def test_rays_on_the_grid_faces_and_the_last_bundle(OC):
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+def test_rays_on_the_grid_faces_and_the_last_bundle(OC, storage):
     """Vertical rays exactly on the low / high x and y faces, feet on the bottom face, ends on the top face: windows that touch
     the padded plane / row beyond the grid (weight-0 corners), and a ray count that leaves a one-ray last bundle."""
     n = (12, 10, 16)
@@ -375,14 +376,15 @@ def test_rays_on_the_grid_faces_and_the_last_bundle(OC):
     o = np.array([[x, y, zv[0]] for x, y in feet] * 19 + [[xv[2], yv[2], zv[0]]])             # 134 rays
     d = np.tile([0.0, 0.0, 1.0], (o.shape[0], 1))
     for Ns in (16, 17, 31):
-        eng = engine(xv, yv, zv)
+        eng = engine(xv, yv, zv, storage=storage)            # ("f32": the float32 fast mode's windows touch the same padded plane / row)
         eng.set_values(eng.tensor(M))
         ot, dt = eng.tensor(o), eng.tensor(d)
         assert eng.plan_forward(ot, dt, zv[-1], Ns)[0] >= 3
+        assert eng.describe("forward", ot, dt, zv[-1], Ns)[0].startswith("k_forward_bundle_f32" if storage == "f32" else "k_forward_bundle<0>")
         tec = eng.forward(ot, dt, zv[-1], Ns).cpu().numpy()
         assert not eng.check_oob()
         ref = OC.forward_tec_straight(xv, yv, zv, M, o, d, zv[-1], Ns)
-        assert np.max(np.abs(tec - ref)) < 1e-12 * np.max(np.abs(ref))
+        assert np.max(np.abs(tec - ref)) < (1e-12 if storage == "f64" else TEC_RTOL_F32_FAST) * np.max(np.abs(ref))
 
 
 def test_bundle_forward_bench_shape(OC):
