@@ -277,9 +277,8 @@ __device__ __forceinline__ AdjRay load_adj_ray(const GridView &g, const double *
     return a;
 }
 
-// `dbg` = env IONOTOMO_ADJ_BUNDLE, A/B switches that never change results: 32 smallest bundle 16 instead of 8;
-// 64 / 128 largest bundle 64 / 128 instead of 64 NW.  (Bits 4 / 8 -- drop out-of-window contributions / tile
-// flushes -- are timing ablations compiled in only with -DIONO_ABLATION.)
+// `dbg`: bits 4 / 8 -- drop out-of-window contributions / tile flushes -- are timing ablations compiled in only with
+// -DIONO_ABLATION.  (The bundle-size A/B switches of rounds 1-5, env IONOTOMO_ADJ_BUNDLE, are closed: smallest bundle 8, largest 64 NW.)
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. waits until every global
 // atomic the wave has in flight is acknowledged (2-3 k cycles under load) -- but everything the tile kernel's barriers
 // protect lives in LDS (windows, tile, bundle scratch), and its global atomics are fire-and-forget: they may complete
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
     const int64_t lo = part ? part[chunk] : chunk * base + min(chunk, rem);
     const int64_t hi = part ? part[chunk + 1] : lo + base + (chunk < rem ? 1 : 0);
     const unsigned long long t_start = __builtin_readcyclecounter();
-    int cw = (dbg & 64) ? 64 : ((dbg & 128) ? 128 : 64 * NW);                                   // candidate width of the next bundle
+    int cw = 64 * NW;                                                                          // candidate width of the next bundle
     for (int64_t q0 = lo; q0 < hi;) {
         // ---- candidate bundle: up to 64 NW rays, wave w lanes 0..63 own walk positions q0 + 64 w + l ----------
         // (only the first `cw` walk positions are examined: cw follows the size of the previous bundle, so a sparse
@@ -393,7 +392,7 @@ __global__ __launch_bounds__(64 * NW) void k_adjoint_straight_tile(GridView g, c
                     if (ok) fit = 64 >> lev;
                 }
             }
-            const int cmin = (dbg & 32) ? 16 : 8, cmax = (dbg & 64) ? 64 : ((dbg & 128) ? 128 : 64 * NW);
+            const int cmin = 8, cmax = 64 * NW;
             if (fit < cmin) fit = 0;
             c = min(min(fit ? fit : cmin, cw), cmax);    // nothing fits: cmin rays, their out-of-window parts go straight to global memory
             cw = min(cmax, max(16, 2 * c));

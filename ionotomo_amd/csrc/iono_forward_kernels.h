@@ -308,15 +308,14 @@ struct Chunk {
     int64_t lo, hi, stride;     // walk positions lo, lo+stride, ... < hi
     int64_t widx;               // index of this wave's chunk in walk order
 };
-// mode 0 (default): one contiguous chunk per wave.  mode bit 1: XCD-interleaved (below).  mode bit 0: one contiguous chunk per WORKGROUP, its
-// 4 waves interleaved (wave w takes lo+w, lo+w+4, ...).  mode bit 2: plain block order instead of
-// XCD-major.  Both alternatives measured slower or equal on the bench workload; kept for A/B runs
-// (env IONOTOMO_WALK).
+// mode 0: one contiguous chunk per wave.  mode bit 1 (value 2): XCD-interleaved (below) -- what the host picks when the caller supplies
+// a walk order or the array exceeds the Infinity Cache (forward_walk_mode).  (Two more shapes -- a chunk per workgroup with its waves
+// interleaved, plain block order -- measured slower or equal in rounds 1-3 and went with their switch IONOTOMO_WALK in round 6.)
 // `part` (optional): one boundary per wave + 1, balanced by measured cost (iono_walk_partition_set).
 __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode, const int64_t *__restrict__ part = nullptr) {
     const int wpb = blockDim.x >> 6, wid = threadIdx.x >> 6;
     int64_t bidx;
-    if ((gridDim.x & 7) == 0 && !(mode & 4)) {
+    if ((gridDim.x & 7) == 0) {
         const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
         bidx = (int64_t)xcd * nslot + slot;
     } else {
@@ -338,12 +337,6 @@ __device__ __forceinline__ Chunk wave_chunk(int64_t R, int mode, const int64_t *
         c.hi = lo + base + (xcd < rem ? 1 : 0);
         c.lo = lo + wi;
         c.stride = nwx;
-    } else if (mode & 1) {
-        const int64_t nb = gridDim.x, base = R / nb, rem = R % nb;
-        const int64_t lo = bidx * base + min(bidx, rem);
-        c.hi = lo + base + (bidx < rem ? 1 : 0);
-        c.lo = lo + wid;
-        c.stride = wpb;
     } else {
         const int64_t widx = bidx * wpb + wid, nw = (int64_t)gridDim.x * wpb;
         const int64_t base = R / nw, rem = R % nw;

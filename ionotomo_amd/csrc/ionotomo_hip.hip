@@ -92,10 +92,8 @@ struct iono_ctx {
     int blocks_per_cu_override = 0;  // env IONOTOMO_BLOCKS_PER_CU
     ncclComm_t comm = nullptr;       // iono_comm_init
     int comm_ranks = 0;
-    int walk_mode = 0;               // env IONOTOMO_WALK: forward walk A/B (see wave_chunk); never changes results
-    bool walk_mode_set = false;
     int seg_lanes = 0;               // env IONOTOMO_SEG_LANES=4|8|16: lanes per segment of the back-projection plan (0: chosen per geometry)
-    int adj_mode = 0;                // env IONOTOMO_ADJ_BUNDLE: bundle-size A/B of the tiled adjoint (k_adjoint_straight_tile)
+    int adj_mode = 0;                // -DIONO_ABLATION builds only: timing ablations of the tiled adjoint (env IONOTOMO_ADJ_ABLATE)
     int fermat_lm_lanes = 0;            // record tracer / fused TEC through a tricubic index: lanes per ray (8 or 2); 0 = by batch size
     int lm4_groups = 0;                 // env IONOTOMO_LM4_GROUPS: persistent workgroups of the planned tricubic transpose (A/B; default: one per CU)
                                         // (env IONOTOMO_FERMAT_LM_LANES): 8 below fermat_lm_few_min rays, 2 from there on
@@ -522,10 +520,8 @@ int iono_ctx_create(int device_id, iono_ctx **out) {
     if (const char *e = getenv("IONOTOMO_VARIANT")) c->variant = atoi(e);
     if (const char *e = getenv("IONOTOMO_BLOCKS_PER_CU")) c->blocks_per_cu_override = atoi(e);
     if (const char *e = getenv("IONOTOMO_HYBRID_MIN")) c->hybrid_min = std::min(65, std::max(0, atoi(e)));
-    if (const char *e = getenv("IONOTOMO_WALK")) c->walk_mode = atoi(e) & (1 | 2 | 4), c->walk_mode_set = true;
     if (const char *e = getenv("IONOTOMO_SEG_LANES")) c->seg_lanes = atoi(e);
     if (const char *e = getenv("IONOTOMO_DETERMINISTIC")) c->deterministic = atoi(e) != 0;
-    if (const char *e = getenv("IONOTOMO_ADJ_BUNDLE")) c->adj_mode = atoi(e) & (32 | 64 | 128);
 #ifdef IONO_ABLATION
     if (const char *e = getenv("IONOTOMO_ADJ_ABLATE")) c->adj_mode |= atoi(e) & (4 | 8);     // timing only: WRONG results
 #endif
@@ -845,7 +841,8 @@ static int ensure_n_fields(iono_ctx *c, double frequency) {
 // A caller-supplied walk order means "neighbours in this order are nearly the same ray": interleaved too, so that they run at
 // the same time on neighbouring waves and share lines in the L1 (RayEngine.coherent_order: 0.212 against 0.224 ms).
 static int forward_walk_mode(const iono_ctx *c, uint64_t array_bytes, const int *order) {
-    return c->walk_mode_set ? c->walk_mode : (order || array_bytes > ((uint64_t)256 << 20) ? 2 : 0);
+    (void)c;
+    return order || array_bytes > ((uint64_t)256 << 20) ? 2 : 0;
 }
 // Forward mapping on ideal-uniform grids without a bundle plan: lanes = samples of one ray (k_forward_straight_u).
 // IONOTOMO_HYBRID_MIN=65 forces lanes = samples even on a planned geometry (A/B; results agree to rounding).
@@ -1382,7 +1379,7 @@ int iono_forward_tec_straight_dev(iono_ctx *c, const double *o, const double *d,
             // default walk for this kernel: all the waves of an XCD interleaved in that XCD's eighth of the walk (what is in
             // flight on an XCD is then one short stretch of neighbouring rays whose field records stay in its L2):
             // 1.49 ms against 1.60 with one contiguous chunk per wave
-            const int wm = c->walk_mode_set ? c->walk_mode : 2;
+            const int wm = 2;
             hipLaunchKernelGGL(k_forward_straight_lm, dim3(nb), block, wl, st, g, c->d_F8, o, d, ord, Rn, tmax, Ns, wm,
                                c->d_unitw, tec, c->d_flags);
         };

@@ -19,7 +19,7 @@ def timeit(n=20):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): launch()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-out = {"walk": os.environ.get("IONOTOMO_WALK", "0"), "before_ms": timeit()}
+out = {"before_ms": timeit()}
 g_ref = g.clone()
 for fr in ((1.0,), (0.75, 0.25)):
     st = e.tune_adjoint_partition(launch, R, fractions=fr)

@@ -239,7 +239,6 @@ def test_tricubic_fast_forward_random_geometry(seed, O, monkeypatch):
     b_xy = np.clip(a[:, :2] + rng.uniform(-1, 1, (R, 2)) * reach, lo[:2] + 1e-6, hi[:2] - 1e-6)     # (end point recomputed on the device)
     d = np.concatenate([b_xy - a[:, :2], (z1 - z0)[:, None]], -1)
     d *= rng.uniform(0.5, 2.0, (R, 1))                                                # not normalised on purpose
-    monkeypatch.setenv("IONOTOMO_WALK", str(seed % 4))
     from ionotomo_amd.engine import RayEngine
     eng = RayEngine(0, interp="cubic")
     eng.set_grid(xv, yv, zv)

@@ -94,12 +94,13 @@ def test_rays_grazing_low_faces_forward_and_adjoint(OC, Ns):
     assert checked >= 8 and negatives > 0, "no accepted problem had a negative grid coordinate: the test lost its teeth"
 
 
-@pytest.mark.parametrize("env", [{"IONOTOMO_WALK": v} for v in ("1", "2", "3", "4", "5", "8", "32", "64", "128")] +
-                         [{"IONOTOMO_ADJ_BUNDLE": v} for v in ("32", "64", "128", "4", "8", "12")] +
-                         [{"IONOTOMO_ADJ_ABLATE": "12"}])
+@pytest.mark.parametrize("env", [{"IONOTOMO_HYBRID_MIN": v} for v in ("1", "8", "65")] + [{"IONOTOMO_VARIANT": v} for v in ("2", "3", "4")] +
+                         [{"IONOTOMO_FORCE_GENERAL": v} for v in ("1", "2")] + [{"IONOTOMO_SEG_LANES": v} for v in ("4", "8")] +
+                         [{"IONOTOMO_BLOCKS_PER_CU": "2"}, {"IONOTOMO_ADJ_ABLATE": "12"}, {"IONOTOMO_WALK": "5", "IONOTOMO_ADJ_BUNDLE": "64"}])
 def test_ab_switches_never_change_results(env, monkeypatch, OC):
-    """Every documented A/B variable (and the values that used to reach the timing ablations) leaves forward and
-    adjoint results equal to the oracle's: the ablations exist only in a -DIONO_ABLATION build."""
+    """Every A/B variable the README documents (round 6: IONOTOMO_WALK and IONOTOMO_ADJ_BUNDLE are gone -- set here, they must be
+    ignored; the timing ablations exist only in a -DIONO_ABLATION build) leaves forward and adjoint results, unplanned AND planned,
+    equal to the oracle's."""
     from ionotomo_amd.engine import RayEngine
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -120,6 +121,12 @@ def test_ab_switches_never_change_results(env, monkeypatch, OC):
     for ordr in (None, order):
         g = eng.adjoint(ot, dt, eng.tensor(y), w["tmax"], Ns, order=ordr).cpu().numpy()
         assert np.max(np.abs(g - gref)) < 1e-11 * np.max(np.abs(gref))
+    eng.plan_forward(ot, dt, w["tmax"], Ns)
+    eng.plan_adjoint(ot, dt, w["tmax"], Ns)
+    assert rel(eng.forward(ot, dt, w["tmax"], Ns).cpu().numpy(), ref) < 1e-12
+    g = eng.adjoint(ot, dt, eng.tensor(y), w["tmax"], Ns).cpu().numpy()
+    assert np.max(np.abs(g - gref)) < 1e-11 * np.max(np.abs(gref))
+    assert not eng.check_oob() and not eng.plan_stale()
 
 
 def test_failed_grid_set_leaves_context_intact(OC):
