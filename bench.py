@@ -116,6 +116,14 @@ def build_cfg4(w):
 SETTLE_MS = 0.0             # set from --settle-ms in main()
 
 
+FORCE_GROUP = False          # IONO_BENCH_FORCE_GROUP=1: a process group of ONE rank (torch `nccl` = RCCL) and every collective of the
+                             # multi-rank control flow issued on it -- the rehearsal a 1-GPU box allows (profiles/r06_bench_nccl_1rank_group.json)
+
+
+def grouped(world):
+    return world > 1 or FORCE_GROUP
+
+
 def settle(fn, torch, dist, world, ms):
     """Untimed launches of the SAME leg for about `ms` milliseconds before its W warmups.  Why: after any idle stretch this device
     takes tens of milliseconds of continuous load to reach its sustained state -- the per-launch device time of the headline kernel
@@ -131,7 +139,7 @@ def settle(fn, torch, dist, world, ms):
     fn()
     torch.cuda.synchronize()
     n = int(min(20000, max(1, ms * 1e-3 / max(time.perf_counter() - t0, 2e-5))))
-    if world > 1:                   # a leg may hold a collective: every rank runs the same number of launches
+    if grouped(world):                   # a leg may hold a collective: every rank runs the same number of launches
         t = torch.tensor([n], dtype=torch.int64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         n = int(t.item())
@@ -149,7 +157,7 @@ def time_steps(fn, steps, warmup, torch, dist, world, settle_ms=None):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped(world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -158,11 +166,11 @@ def time_steps(fn, steps, warmup, torch, dist, world, settle_ms=None):
         fn()
     b.record()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped(world):
         dist.barrier()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    if world > 1:
+    if grouped(world):
         t = torch.tensor([wall], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)        # MAX over ranks
         wall = float(t.item())
@@ -186,7 +194,7 @@ def time_windows(fn, steps, warmup, torch, dist, world, min_ms=MIN_TIMED_MS, max
     while len(walls) < m:
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped(world):
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -195,11 +203,11 @@ def time_windows(fn, steps, warmup, torch, dist, world, min_ms=MIN_TIMED_MS, max
             fn()
         b.record()
         torch.cuda.synchronize()
-        if world > 1:
+        if grouped(world):
             dist.barrier()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
-        if world > 1:
+        if grouped(world):
             t = torch.tensor([wall], dtype=torch.float64, device="cuda")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)        # MAX over ranks
             wall = float(t.item())
@@ -663,7 +671,7 @@ def cfg4_leg(w, local, k2, torch, dist, world):
         w50, _ = time_steps(lambda: fn(prob, x0, n_iter=50), 2, 0, torch, dist, world)
         out["%s_50_iterations_ms" % name] = w50 / 2 * 1e3
         out["%s_ms_per_iteration_marginal" % name] = (w50 / 2 - w10 / 3) / 40 * 1e3        # an iteration without the solve's set-up
-    if world > 1:
+    if grouped(world):
         # the same iterations with the exchange hidden behind the back-projection (exchange="overlap": the plan in z-slabs, every slab's
         # finished node levels all-reduced asynchronously while the next slab is back-projected), float64 and float32 on the links
         del prob
@@ -684,6 +692,7 @@ def cfg4_leg(w, local, k2, torch, dist, world):
                     torch.cuda.synchronize()
                     dist.barrier()
                     sub["%s_ms_per_iteration" % name] = (time.perf_counter() - t0) / 10 * 1e3
+                sub["slabs"] = len(pr.slab_ranges or [])             # (the ranges exist once a solver has asked for the active set)
                 out[tag] = sub
                 del pr
                 ok = 1
@@ -738,14 +747,20 @@ def main():
     backend = os.environ.get("IONO_BENCH_BACKEND", "nccl")
     local = local % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
-    if world > 1:
+    global FORCE_GROUP
+    FORCE_GROUP = world == 1 and os.environ.get("IONO_BENCH_FORCE_GROUP", "0") not in ("", "0")
+    if grouped(world):
+        if FORCE_GROUP:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29541")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from ionotomo_amd import parallel, solvers
     from ionotomo_amd.engine import RayEngine
+    parallel.FORCE_COLLECTIVES = FORCE_GROUP        # (the sharded problems then exchange on the one-rank group too)
     w = build_workload(rank)
     R = w["origins"].shape[0]
     eng = RayEngine(local, storage="f64")
@@ -854,7 +869,7 @@ def main():
             per = 10 if args.only in ("cgls", "sirt") else 1
             print(json.dumps({"only": args.only, "n_gpus": world, "steps": k, "ms_per_launch_or_iteration": kern * 1e3 / per,
                               "rays": R, "forward_plan": fwd_plan_info, "csrc_sha": csrc_sha(), "settle_ms": SETTLE_MS}))
-        if world > 1:
+        if grouped(world):
             dist.destroy_process_group()
         return
 
@@ -887,6 +902,9 @@ def main():
                    "settle_ms": SETTLE_MS},
         "csrc_sha": sha,
     }
+    if FORCE_GROUP:
+        line["config"]["forced_one_rank_group"] = {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                                                   "note": "rehearsal: the multi-rank control flow and every collective on a 1-rank group"}
     if rank == 0:
         # the headline is on record before any leg that contains a collective (the ONE stdout line comes at the end)
         print("bench.py headline (repeated in the final stdout line): " + json.dumps(line), file=sys.stderr, flush=True)
@@ -930,7 +948,7 @@ def main():
         os._exit(WATCHDOG_EXIT_CODE)
 
     watchdog = None
-    if world > 1 and args.extras_timeout > 0:
+    if grouped(world) and args.extras_timeout > 0:
         watchdog = threading.Timer(args.extras_timeout, on_timeout)
         watchdog.daemon = True
         watchdog.start()
@@ -938,7 +956,7 @@ def main():
             time.sleep(args.test_hang)
 
     def agree(ok):
-        if world == 1:
+        if not grouped(world):
             return bool(ok)
         flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=eng.device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -1069,11 +1087,11 @@ def main():
             extra["adjoint_roofline"] = {"bound": "lds_atomic" if args.plan else "memory_atomic", "kernel_ms": akern * 1e3,
                                          "kernel": "k_adjoint_binned<double, 0, double" if args.plan
                                          else "k_adjoint_straight_tile<double, 1, 4>"}
-            if world == 1:                                  # single-rank only: reach of the planned kernels beyond the 100-timestep batch
+            if not grouped(world):                          # single-rank only: reach of the planned kernels beyond the 100-timestep batch
                 extra["coherence_sweep"] = coherence_legs(w, local, m_t, k2, torch, dist)
-            if world == 1:                                  # single-rank only: the Fermat integrator (config 3 + config 4's ray count)
+            if not grouped(world):                          # single-rank only: the Fermat integrator (config 3 + config 4's ray count)
                 extra["fermat"] = fermat_leg(w, local, torch, dist)
-            if world == 1:                                  # single-rank only: the solvers at the bench shape
+            if not grouped(world):                          # single-rank only: the solvers at the bench shape
                 prob, x0 = solver_problem()
                 for name in ("cgls", "sirt"):
                     fn = getattr(solvers, name)
@@ -1096,13 +1114,13 @@ def main():
                 def iteration():
                     fwd()
                     adj()
-                    if world > 1:
+                    if grouped(world):
                         dist.all_reduce(grad_t)
                 iwall, _ = time_steps(iteration, k2, 1, torch, dist, world)
                 extra["iteration_ms_fwd_adj_allreduce"] = iwall / k2 * 1e3
             except Exception as exc:                                    # noqa: BLE001
                 extra["error"] = "%s: %s" % (type(exc).__name__, exc)
-        if world > 1 and agree("error" not in extra):
+        if grouped(world) and agree("error" not in extra):
             try:
                 extra["distributed"] = exchange_legs(eng, fwd, adj, grad_t, o_t, d_t, order_t, R, k2, torch, dist, world, backend)
             except Exception as exc:                                    # noqa: BLE001
@@ -1128,7 +1146,7 @@ def finish_line(line, extra, copy_gbs, clean, ctx):
     sits in a leg that did not return -- no collective, no GPU tool."""
     (world, rank, dist, sha, R, kern, grid_bytes, planned, args, w, tec_gpu) = ctx
     pmc, pmc_note = load_pmc(sha)
-    if world > 1 and clean:
+    if grouped(world) and clean:
         # every collective is behind us: leave the group BEFORE rank 0's host-side legs (peaks tool, CPU baseline), so that no
         # rank waits in a collective while rank 0 computes on the host
         dist.barrier()
