@@ -455,7 +455,8 @@ def coherence_legs(w, local, m_t, k2, torch, dist):
         the reference's pipeline forms (one coherence window = 4 timesteps, inversion/inversion_pipeline.py:41-50); the plan decides per
         batch which bundles are worth a workgroup (iono_forward_plan_split) and the launch floor shows.  (c) `mixed`: half the headline
         rays + as many scattered rays (bundles of one or two): the case the per-bundle choice is for, against both all-or-nothing
-        dispatches.  (d) `config2_sized_cgls`: a CGLS iteration at 2,604 and 10,416 rays through 128^3, eager and as a hipGraph."""
+        dispatches.  (d) `config2_sized_cgls`: a CGLS iteration at 2,604 and 10,416 rays through 128^3, eager and as a hipGraph.
+    (e) `parallel_solves`: 1 and 32 single-time-step solves (2,604 rays, 128^3 each) side by side in one set of launches."""
     from ionotomo_amd import parallel, solvers, synthetic as syn
     ants = syn.lofar_enu_km()
 
@@ -550,6 +551,42 @@ def coherence_legs(w, local, m_t, k2, torch, dist):
             rec["cgls_us_per_iteration_marginal_" + tag] = (w40 - w10) / 3 / 30 * 1e6
         out["config2_sized_cgls"].append(rec)
         del prob, e2
+    # (e) the pipeline's own batch -- ONE time step per solve (inversion/inversion_pipeline.py:131-216), `num_parallel_solves` of them at
+    #     once -- as B solves stacked along x in one set of launches (inversion/parallel_solves.py): microseconds PER SOLVE
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    out["parallel_solves"] = []
+    Bs = (1, 32)
+    dirs = syn.rotate_about_pole(syn.facet_directions(ND, 4.0, 1), max(Bs))
+    o_all, d_all = syn.ray_bundle(ants, dirs)                                      # [Na, B, Nd, 3]: the field at B consecutive time steps
+    grid = syn.domain_for(o_all, d_all, 128, TMAX, 4)
+    ne0 = syn.ne_model(*grid, seed=7, corr=30.0) / 1e11
+    for B in Bs:
+        st = StackedSolves(tuple(grid), count=B, device=local)
+        o, d = st.rays([o_all[:, b] for b in range(B)], [d_all[:, b] for b in range(B)], TMAX)
+        es = st.engine
+        models = [torch.as_tensor(ne0 * (1.0 + 0.01 * b)) for b in range(B)]
+        es.set_values(st.stack_grids([m_ * 1.05 for m_ in models]).reshape(-1))
+        ot, dt = es.tensor(o.reshape(-1, 3)), es.tensor(d.reshape(-1, 3))
+        t = es.forward(ot, dt, TMAX, 129).reshape(NA, -1)
+        dobs = (t - t[0:1]).cpu().numpy()
+        prob = parallel.ShardedRays(es, o, d, TMAX, 129, dobs=dobs, cdct=np.full(dobs.shape, 1e-4), i0=0, tune=False)
+        x0 = st.stack_grids(models)
+        es.set_values(x0.reshape(-1))
+        fwd_ = lambda: prob.forward_tec()
+        y = torch.randn(ot.shape[0], dtype=torch.float64, device=es.device)
+        ks = sorted(time_steps(fwd_, 50, 3, torch, dist, 1, settle_ms=20.0 if i == 0 else 0.0)[1] for i in range(3))
+        g = torch.zeros(es.shape, dtype=torch.float64, device=es.device)
+        ka = sorted(time_steps(lambda: es.adjoint(prob.origins, prob.dirs, y, TMAX, 129, out=g, order=prob._adjoint_order()), 30, 3, torch, dist, 1,
+                               settle_ms=0.0)[1] for i in range(3))
+        del g
+        rec = {"solves": B, "rays": int(ot.shape[0]), "grid_per_solve": [128] * 3, "forward_us_per_solve": ks[1] * 1e6 / B,
+               "adjoint_us_per_solve": ka[1] * 1e6 / B, "forward_kernel": es.describe("forward", prob.origins, prob.dirs, TMAX, 129)[0]}
+        solvers.sirt(prob, x0, n_iter=4)
+        w40, _ = time_steps(lambda: solvers.sirt(prob, x0, n_iter=40), 3, 1, torch, dist, 1, settle_ms=0.0)
+        w10, _ = time_steps(lambda: solvers.sirt(prob, x0, n_iter=10), 3, 1, torch, dist, 1, settle_ms=0.0)
+        rec["sirt_us_per_iteration_marginal_per_solve"] = (w40 - w10) / 3 / 30 * 1e6 / B
+        out["parallel_solves"].append(rec)
+        del prob, es, st, x0, y, ot, dt
     return out
 
 

@@ -1,0 +1,140 @@
+"""Independent solves side by side in ONE set of launches: the counterpart of ``num_parallel_solves`` of the reference's pipeline.
+
+The reference solves one time step per task (``inversion/inversion_pipeline.py:131-216``: for every ``time_idx`` its own rays,
+``calc_rays(antennas, patches, times[time_idx:time_idx+1], ...)`` = Na x 1 x Nd rays, its own model ``ne_0`` and its own
+``iterative_newton_solve``) and runs ``num_parallel_solves`` of them at once as dask threads (``:41-50``).  On the GPU a solve of
+2 604 rays is launch-bound (6.9 us per forward whatever its size), and host threads cannot overlap the launches of
+several solves (the Python launch path holds the GIL).  Data parallelism does what the dask threads did: the B models are stacked
+along x into ONE grid of B nx x ny x nz nodes, solve b's rays are moved into slab b of it, and every launch of the hot path
+(forward, dTEC, back-projection, SIRT) then serves all B solves at the rate of a B-times larger batch.
+
+Why this is exact.  Solve b owns the nodes ``[b nx, (b + 1) nx)`` along x; a ray of solve b stays inside its own slab (checked
+here on the host: both ends of every ray inside the solve's own x range -- the stacked grid would otherwise hand a stray ray the
+NEIGHBOUR's nodes instead of the reference's ``bounds_error``), so no sample ever reads or writes another solve's nodes: forward
+and back-projection are block diagonal.  The cell between the last node of slab b and the first of slab b + 1 is never entered
+(at most touched at x == last node, with weight 0 on the neighbour's side).  The reference antenna is subtracted per (time,
+direction) pair, and pairs are concatenated, not mixed.  SIRT's row and column sums are per ray and per node: B stacked SIRT solves
+ARE B separate ones (the one shared number is the cut-off 1e-9 max(col) below which a column counts as empty).  CGLS is different:
+its step lengths are global scalars, so a stacked CGLS is ONE conjugate-gradient solve of the block-diagonal system -- it converges
+to the same B solutions, but its iterates are not those of B separate runs; use SIRT, or the forward / gradient calls, when the
+separate iterates matter.
+
+Trilinear only: the tricubic index takes its node derivatives from central differences across +-2 nodes, which would reach into the
+neighbouring slab; smoothing with ``C_m`` (``solvers.smooth_grid``) would blur across the seams for the same reason.
+Straight rays only (a bent ray is not confined by its end points).  Host-side helper: no kernel knows about it.
+"""
+import numpy as np
+import torch
+
+from ..engine import RayEngine
+
+
+class StackedSolves(object):
+    """B solves on grids of the same shape and spacing (their origins may differ: every solve's rays are moved by its own offset).
+
+    ``grids``: list of ``(xvec, yvec, zvec)``, one per solve, or ONE tuple + ``count``.
+    ``engine``: the ``RayEngine`` holding the stacked grid (``storage``, ``device`` as for any engine; ``interp="linear"``).
+    ``split_grid`` / ``split_rays`` return VIEWS: block b of a stacked result is solve b's result."""
+
+    def __init__(self, grids, count=None, device=0, storage="f64", rtol=1e-9):
+        if isinstance(grids, tuple) and count is not None:
+            grids = [grids] * int(count)
+        if not grids:
+            raise ValueError("StackedSolves: no grid")
+        ax = [[np.asarray(v, dtype=np.float64) for v in g] for g in grids]
+        x0, y0, z0 = ax[0]
+        self.shape1 = (len(x0), len(y0), len(z0))
+        if min(self.shape1) < 2:
+            raise ValueError("StackedSolves: every axis needs two nodes")
+        self.spacing = tuple(float((v[-1] - v[0]) / (len(v) - 1)) for v in ax[0])
+        for b, g in enumerate(ax):
+            if tuple(len(v) for v in g) != self.shape1:
+                raise ValueError("StackedSolves: grid %d has shape %s, grid 0 %s" % (b, tuple(len(v) for v in g), self.shape1))
+            for v, h in zip(g, self.spacing):
+                # uniform, and the same spacing as grid 0 (the stacked axis is ONE uniform axis; y and z axes are shared)
+                if not np.allclose(np.diff(v), h, rtol=rtol, atol=abs(h) * rtol):
+                    raise ValueError("StackedSolves: grid %d is not uniform with the spacing of grid 0" % b)
+        self.B = len(ax)
+        self.nx = self.shape1[0]
+        self.origins = np.array([[g[0][0], g[1][0], g[2][0]] for g in ax])             # first node of every solve
+        self.x_hi = np.array([g[0][-1] for g in ax])
+        self.base = self.origins[0].copy()
+        hx = self.spacing[0]
+        # slab b's first node sits at base_x + b nx hx: the move applied to solve b's rays
+        self.shift = self.base[None, :] - self.origins
+        self.shift[:, 0] += np.arange(self.B) * self.nx * hx
+        self.xvec = self.base[0] + hx * np.arange(self.B * self.nx)
+        self.yvec, self.zvec = y0.copy(), z0.copy()
+        self._device, self._storage, self._engine = device, storage, None
+        self.pairs = None                       # pairs per solve of the last rays() call
+
+    @property
+    def engine(self):
+        """The ``RayEngine`` on the stacked grid (created on first use: it needs the GPU, the geometry above does not)."""
+        if self._engine is None:
+            self._engine = RayEngine(self._device, storage=self._storage, interp="linear")
+            self._engine.set_grid(self.xvec, self.yvec, self.zvec)
+        return self._engine
+
+    # ---- geometry -------------------------------------------------------------------------------------------------------------
+    def rays(self, origins, directions, tmax):
+        """Per-solve ``origins[b]``, ``directions[b]`` of shape [Na, P_b, 3] (P_b = Nt_b x Nd_b pairs) -> the stacked
+        ``[Na, sum P_b, 3]`` arrays (float64 numpy).  Raises ``ValueError`` if a ray leaves its solve's x range before ``tmax``
+        (y and z are checked by the kernels themselves, as for any grid)."""
+        if len(origins) != self.B or len(directions) != self.B:
+            raise ValueError("StackedSolves.rays: %d solves, got %d / %d ray sets" % (self.B, len(origins), len(directions)))
+        oo, dd, self.pairs = [], [], []
+        Na = None
+        for b in range(self.B):
+            o = np.asarray(origins[b], dtype=np.float64)
+            d = np.asarray(directions[b], dtype=np.float64)
+            if o.ndim != 3 or o.shape[2] != 3 or d.shape != o.shape:
+                raise ValueError("StackedSolves.rays: solve %d needs [Na, P, 3] origins and directions" % b)
+            if Na is None:
+                Na = o.shape[0]
+            if o.shape[0] != Na:
+                raise ValueError("StackedSolves.rays: solve %d has %d antennas, solve 0 %d" % (b, o.shape[0], Na))
+            lo, hi = self.origins[b, 0], self.x_hi[b]
+            end = o[..., 0] + float(tmax) * d[..., 0]
+            bad = (o[..., 0] < lo) | (o[..., 0] > hi) | (end < lo) | (end > hi)
+            if bad.any():
+                raise ValueError("StackedSolves.rays: %d ray(s) of solve %d leave its grid along x (a value in x_new is out of "
+                                 "bounds)" % (int(bad.sum()), b))
+            oo.append(o + self.shift[b][None, None, :])
+            dd.append(d)
+            self.pairs.append(o.shape[1])
+        return np.concatenate(oo, axis=1), np.concatenate(dd, axis=1)
+
+    # ---- node fields ------------------------------------------------------------------------------------------------------------
+    def stack_grids(self, models):
+        """B node arrays of shape (nx, ny, nz) (numpy or torch) -> one device tensor (B nx, ny, nz), float64."""
+        if len(models) != self.B:
+            raise ValueError("StackedSolves.stack_grids: %d solves, got %d models" % (self.B, len(models)))
+        eng = self.engine
+        out = torch.empty((self.B * self.nx,) + self.shape1[1:], dtype=torch.float64, device=eng.device)
+        for b, m in enumerate(models):
+            t = m if torch.is_tensor(m) else torch.as_tensor(np.asarray(m, dtype=np.float64))
+            if tuple(t.shape) != self.shape1:
+                raise ValueError("StackedSolves.stack_grids: model %d has shape %s, not %s" % (b, tuple(t.shape), self.shape1))
+            out[b * self.nx:(b + 1) * self.nx].copy_(t)
+        return out
+
+    def split_grid(self, g):
+        """Views of a stacked node tensor, one (nx, ny, nz) block per solve."""
+        g = g.reshape((self.B * self.nx,) + self.shape1[1:])
+        return [g[b * self.nx:(b + 1) * self.nx] for b in range(self.B)]
+
+    def split_rays(self, v, Na):
+        """Views of a stacked per-ray tensor ([Na x sum P_b] or [Na, sum P_b]) -> B tensors [Na, P_b]."""
+        if self.pairs is None:
+            raise ValueError("StackedSolves.split_rays: call rays() first")
+        v = v.reshape(Na, -1)
+        out, lo = [], 0
+        for p in self.pairs:
+            out.append(v[:, lo:lo + p])
+            lo += p
+        return out
+
+    def stack_rays(self, per_solve):
+        """B per-ray arrays [Na, P_b] (e.g. ``dobs``, ``CdCt``) -> [Na, sum P_b] numpy."""
+        return np.concatenate([np.asarray(a, dtype=np.float64) for a in per_solve], axis=1)

@@ -1,0 +1,149 @@
+"""Independent solves stacked along x (ionotomo_amd/inversion/parallel_solves.py, the counterpart of the reference pipeline's
+``num_parallel_solves``: inversion/inversion_pipeline.py:41-50,131-216): every launch of the stacked problem must give, block by
+block, what the solves give one at a time -- forward TEC against the C oracle and against per-solve engines, the exact transpose,
+and SIRT iterates.  Needs a real MI355X: -m gpu."""
+import numpy as np
+import pytest
+import torch
+
+from ionotomo_amd import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def OC():
+    from oracle import oracle_c
+    return oracle_c
+
+
+def solves(B, n=40, na=12, nd=9, seed=0, same_geometry=False):
+    """B single-time-step solves in the shape the pipeline forms them: the same array and facet directions seen at B times (the
+    field rotates about the pole), every solve with its own domain (same shape and spacing, its own origin) and its own model."""
+    rng = np.random.default_rng(seed)
+    ants = syn.example_antennas_km(na, 3)
+    dirs = syn.rotate_about_pole(syn.facet_directions(nd, 4.0, 1), 1 if same_geometry else B)
+    out = []
+    tmax = 600.0
+    o0, d0 = syn.ray_bundle(ants, dirs[:1])
+    xv, yv, zv = syn.domain_for(o0, d0, n, 590.0, 5)
+    for b in range(B):
+        o, d = syn.ray_bundle(ants, dirs[0:1] if same_geometry else dirs[b:b + 1])
+        o, d = o.reshape(na, nd, 3), d.reshape(na, nd, 3)
+        # the same spacing, another origin (a pipeline builds every time step's domain from that step's rays)
+        off = np.zeros(3) if same_geometry else rng.uniform(-3, 3, 3) * np.array([xv[1] - xv[0], yv[1] - yv[0], 0.0])
+        g = (xv + off[0], yv + off[1], zv + off[2])
+        ne = syn.ne_model(*g, seed=100 + b, corr=60.0)
+        out.append(dict(grid=g, ne=ne, o=o + off, d=d))
+    return out, tmax, n + 1
+
+
+def one_by_one(sv, tmax, Ns, fn):
+    from ionotomo_amd.engine import RayEngine
+    res = []
+    for s in sv:
+        e = RayEngine(0)
+        e.set_grid(*s["grid"])
+        res.append(fn(e, s))
+    return res
+
+
+def test_stacked_forward_and_transpose_equal_the_separate_solves(OC):
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    sv, tmax, Ns = solves(5)
+    st = StackedSolves([s["grid"] for s in sv])
+    o, d = st.rays([s["o"] for s in sv], [s["d"] for s in sv], tmax)
+    eng = st.engine
+    Na = o.shape[0]
+    eng.set_values(st.stack_grids([s["ne"] for s in sv]).reshape(-1))
+    ot, dt = eng.tensor(o.reshape(-1, 3)), eng.tensor(d.reshape(-1, 3))
+    tec = eng.forward(ot, dt, tmax, Ns)
+    assert not eng.check_oob()
+    parts = st.split_rays(tec, Na)
+    rng = np.random.default_rng(5)
+    w = [rng.normal(size=(Na, s["o"].shape[1])) for s in sv]
+    g = eng.adjoint(ot, dt, eng.tensor(st.stack_rays(w).reshape(-1)), tmax, Ns)
+    gparts = st.split_grid(g)
+
+    def single(e, s):
+        k = len(single.done)
+        e.set_values(e.tensor(s["ne"]).reshape(-1))
+        o1, d1 = e.tensor(s["o"].reshape(-1, 3)), e.tensor(s["d"].reshape(-1, 3))
+        t1 = e.forward(o1, d1, tmax, Ns).clone()
+        g1 = e.adjoint(o1, d1, e.tensor(w[k].reshape(-1)), tmax, Ns).clone()
+        single.done.append(k)
+        return t1, g1
+    single.done = []
+    ref = one_by_one(sv, tmax, Ns, single)
+    for b, s in enumerate(sv):
+        t1, g1 = ref[b]
+        oc = OC.forward_tec_straight(*s["grid"], s["ne"], s["o"].reshape(-1, 3), s["d"].reshape(-1, 3), tmax, Ns)
+        got = parts[b].reshape(-1).cpu().numpy()
+        # the oracle on the solve's OWN grid and rays (float64: the moved coordinates round differently, nothing else differs)
+        assert np.max(np.abs(got - oc) / np.abs(oc)) < 1e-11, b
+        assert float((parts[b].reshape(-1) - t1).abs().max() / t1.abs().max()) < 1e-12, b
+        assert float((gparts[b] - g1.reshape(gparts[b].shape)).abs().max() / g1.abs().max()) < 1e-11, b
+    # nothing of a solve lands in another one's block: a back-projection of ONE solve's weights leaves the other blocks zero
+    w1 = [np.zeros_like(a) for a in w]
+    w1[2] = w[2]
+    g2 = st.split_grid(eng.adjoint(ot, dt, eng.tensor(st.stack_rays(w1).reshape(-1)), tmax, Ns))
+    for b in range(len(sv)):
+        if b != 2:
+            assert float(g2[b].abs().max()) == 0.0, b
+    assert float((g2[2] - gparts[2]).abs().max()) <= 1e-12 * float(gparts[2].abs().max())
+
+
+def test_stacked_planned_kernels_equal_the_unplanned_ones():
+    """The bundle plan and the back-projection plan are built on the stacked geometry like on any other."""
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    sv, tmax, Ns = solves(8, n=48, na=20, nd=12, seed=2)
+    st = StackedSolves([s["grid"] for s in sv])
+    o, d = st.rays([s["o"] for s in sv], [s["d"] for s in sv], tmax)
+    eng = st.engine
+    eng.set_values(st.stack_grids([s["ne"] for s in sv]).reshape(-1))
+    ot, dt = eng.tensor(o.reshape(-1, 3)), eng.tensor(d.reshape(-1, 3))
+    t0 = eng.forward(ot, dt, tmax, Ns).clone()
+    y = torch.randn(ot.shape[0], dtype=torch.float64, device=eng.device)
+    g0 = eng.adjoint(ot, dt, y, tmax, Ns).clone()
+    eng.plan_forward(ot, dt, tmax, Ns)
+    eng.plan_adjoint(ot, dt, tmax, Ns)
+    t1 = eng.forward(ot, dt, tmax, Ns)
+    g1 = eng.adjoint(ot, dt, y, tmax, Ns)
+    assert float((t1 - t0).abs().max() / t0.abs().max()) < 1e-13
+    assert float((g1 - g0).abs().max() / g0.abs().max()) < 1e-11
+    eng.check_plans()
+
+
+def test_stacked_sirt_is_the_separate_sirt_solves():
+    from ionotomo_amd import parallel, solvers
+    from ionotomo_amd.engine import RayEngine
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    B = 4
+    sv, tmax, Ns = solves(B, same_geometry=True)            # one geometry, B models and data sets (see the module docstring: the
+    st = StackedSolves(sv[0]["grid"], count=B)              # one shared number of SIRT is the column cut-off relative to max(col))
+    o, d = st.rays([s["o"] for s in sv], [s["d"] for s in sv], tmax)
+    eng = st.engine
+    Na, P = sv[0]["o"].shape[:2]
+    x0 = [torch.as_tensor(syn.ne_model(*s["grid"], turbulent=False) / 1e11) for s in sv]
+    dobs, cdct = [], []
+    for b, s in enumerate(sv):
+        e = RayEngine(0)
+        e.set_grid(*s["grid"])
+        e.set_values(e.tensor(s["ne"] / 1e11).reshape(-1))
+        t = e.forward(e.tensor(s["o"].reshape(-1, 3)), e.tensor(s["d"].reshape(-1, 3)), tmax, Ns).reshape(Na, P)
+        dobs.append((t - t[0:1]).cpu().numpy())
+        cdct.append(np.full((Na, P), 1e-4 * (1 + b)))
+    prob = parallel.ShardedRays(eng, o, d, tmax, Ns, dobs=st.stack_rays(dobs), cdct=st.stack_rays(cdct), i0=0, tune=False)
+    xs, hist = solvers.sirt(prob, st.stack_grids(x0), n_iter=6)
+    blocks = st.split_grid(xs)
+    total = 0.0
+    for b, s in enumerate(sv):
+        e = RayEngine(0)
+        e.set_grid(*s["grid"])
+        p1 = parallel.ShardedRays(e, s["o"], s["d"], tmax, Ns, dobs=dobs[b], cdct=cdct[b], i0=0, tune=False)
+        x1, h1 = solvers.sirt(p1, x0[b].to(e.device), n_iter=6)
+        assert float((blocks[b] - x1).abs().max() / x1.abs().max()) < 1e-10, b
+        total = total + np.asarray(h1, dtype=np.float64)
+        assert float((x1 - x0[b].to(e.device)).abs().max()) > 0          # (the solve moved)
+    # the stacked objective is the sum of the solves' objectives, iteration by iteration
+    np.testing.assert_allclose(np.asarray(hist, dtype=np.float64), total, rtol=1e-10)
