@@ -19,8 +19,11 @@ its step lengths are global scalars, so a stacked CGLS is ONE conjugate-gradient
 to the same B solutions, but its iterates are not those of B separate runs; use SIRT, or the forward / gradient calls, when the
 separate iterates matter.
 
-Trilinear only: the tricubic index takes its node derivatives from central differences across +-2 nodes, which would reach into the
-neighbouring slab; smoothing with ``C_m`` (``solvers.smooth_grid``) would blur across the seams for the same reason.
+``interp="cubic"``: the tricubic takes its node derivatives from differences across +-2 nodes (csrc/iono_cubic_kernels.h), one-sided
+next to a face.  In the stacked grid the nodes next to a seam see the neighbour's values instead, so cells 0, 1 and nx - 3, nx - 2
+of a slab interpolate differently from the separate solve; every other cell uses own nodes and the same central formula.  The
+check on the rays is therefore two cells stricter along x (x_2 <= x <= x_{nx-3}); then forward and transpose are again those of the
+separate solves.  Smoothing with ``C_m`` (``solvers.smooth_grid``) would blur across the seams: not offered.
 Straight rays only (a bent ray is not confined by its end points).  Host-side helper: no kernel knows about it.
 """
 import numpy as np
@@ -33,10 +36,14 @@ class StackedSolves(object):
     """B solves on grids of the same shape and spacing (their origins may differ: every solve's rays are moved by its own offset).
 
     ``grids``: list of ``(xvec, yvec, zvec)``, one per solve, or ONE tuple + ``count``.
-    ``engine``: the ``RayEngine`` holding the stacked grid (``storage``, ``device`` as for any engine; ``interp="linear"``).
+    ``engine``: the ``RayEngine`` holding the stacked grid (``storage``, ``device``, ``interp`` as for any engine).
     ``split_grid`` / ``split_rays`` return VIEWS: block b of a stacked result is solve b's result."""
 
-    def __init__(self, grids, count=None, device=0, storage="f64", rtol=1e-9):
+    def __init__(self, grids, count=None, device=0, storage="f64", interp="linear", rtol=1e-9):
+        if interp not in ("linear", "cubic"):
+            raise ValueError("StackedSolves: interp is 'linear' or 'cubic'")
+        self.interp = interp
+        self.margin = 2 if interp == "cubic" else 0         # cells a ray keeps clear of its slab's x faces (module docstring)
         if isinstance(grids, tuple) and count is not None:
             grids = [grids] * int(count)
         if not grids:
@@ -65,6 +72,8 @@ class StackedSolves(object):
         self.shift[:, 0] += np.arange(self.B) * self.nx * hx
         self.xvec = self.base[0] + hx * np.arange(self.B * self.nx)
         self.yvec, self.zvec = y0.copy(), z0.copy()
+        if self.nx < 2 * self.margin + 2:
+            raise ValueError("StackedSolves: %d nodes along x leave no cell two cells away from both faces" % self.nx)
         self._device, self._storage, self._engine = device, storage, None
         self.pairs = None                       # pairs per solve of the last rays() call
 
@@ -72,7 +81,7 @@ class StackedSolves(object):
     def engine(self):
         """The ``RayEngine`` on the stacked grid (created on first use: it needs the GPU, the geometry above does not)."""
         if self._engine is None:
-            self._engine = RayEngine(self._device, storage=self._storage, interp="linear")
+            self._engine = RayEngine(self._device, storage=self._storage, interp=self.interp)
             self._engine.set_grid(self.xvec, self.yvec, self.zvec)
         return self._engine
 
@@ -80,7 +89,7 @@ class StackedSolves(object):
     def rays(self, origins, directions, tmax):
         """Per-solve ``origins[b]``, ``directions[b]`` of shape [Na, P_b, 3] (P_b = Nt_b x Nd_b pairs) -> the stacked
         ``[Na, sum P_b, 3]`` arrays (float64 numpy).  Raises ``ValueError`` if a ray leaves its solve's x range before ``tmax``
-        (y and z are checked by the kernels themselves, as for any grid)."""
+        (``interp="cubic"``: or comes within two cells of its x faces; y and z are checked by the kernels themselves, as for any grid)."""
         if len(origins) != self.B or len(directions) != self.B:
             raise ValueError("StackedSolves.rays: %d solves, got %d / %d ray sets" % (self.B, len(origins), len(directions)))
         oo, dd, self.pairs = [], [], []
@@ -94,12 +103,12 @@ class StackedSolves(object):
                 Na = o.shape[0]
             if o.shape[0] != Na:
                 raise ValueError("StackedSolves.rays: solve %d has %d antennas, solve 0 %d" % (b, o.shape[0], Na))
-            lo, hi = self.origins[b, 0], self.x_hi[b]
+            lo, hi = self.origins[b, 0] + self.margin * self.spacing[0], self.x_hi[b] - self.margin * self.spacing[0]
             end = o[..., 0] + float(tmax) * d[..., 0]
             bad = (o[..., 0] < lo) | (o[..., 0] > hi) | (end < lo) | (end > hi)
             if bad.any():
-                raise ValueError("StackedSolves.rays: %d ray(s) of solve %d leave its grid along x (a value in x_new is out of "
-                                 "bounds)" % (int(bad.sum()), b))
+                raise ValueError("StackedSolves.rays: %d ray(s) of solve %d leave its grid along x%s (a value in x_new is out of "
+                                 "bounds)" % (int(bad.sum()), b, " by less than two cells" if self.margin else ""))
             oo.append(o + self.shift[b][None, None, :])
             dd.append(d)
             self.pairs.append(o.shape[1])

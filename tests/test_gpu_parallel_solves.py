@@ -147,3 +147,38 @@ def test_stacked_sirt_is_the_separate_sirt_solves():
         assert float((x1 - x0[b].to(e.device)).abs().max()) > 0          # (the solve moved)
     # the stacked objective is the sum of the solves' objectives, iteration by iteration
     np.testing.assert_allclose(np.asarray(hist, dtype=np.float64), total, rtol=1e-10)
+
+
+def test_stacked_tricubic_equals_the_separate_solves():
+    """interp="cubic": rays two cells clear of the slab's x faces see the same Lekien-Marsden interpolant as in their own grid."""
+    from ionotomo_amd.engine import RayEngine
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    sv, tmax, Ns = solves(3, n=36, na=10, nd=7, seed=4)
+    st = StackedSolves([s["grid"] for s in sv], interp="cubic")
+    o, d = st.rays([s["o"] for s in sv], [s["d"] for s in sv], tmax)
+    eng = st.engine
+    Na = o.shape[0]
+    eng.set_values(st.stack_grids([s["ne"] for s in sv]).reshape(-1))
+    ot, dt = eng.tensor(o.reshape(-1, 3)), eng.tensor(d.reshape(-1, 3))
+    parts = st.split_rays(eng.forward(ot, dt, tmax, Ns), Na)
+    rng = np.random.default_rng(9)
+    w = [rng.normal(size=(Na, s["o"].shape[1])) for s in sv]
+    gparts = st.split_grid(eng.adjoint(ot, dt, eng.tensor(st.stack_rays(w).reshape(-1)), tmax, Ns))
+    for b, s in enumerate(sv):
+        e = RayEngine(0, interp="cubic")
+        e.set_grid(*s["grid"])
+        e.set_values(e.tensor(s["ne"]).reshape(-1))
+        o1, d1 = e.tensor(s["o"].reshape(-1, 3)), e.tensor(s["d"].reshape(-1, 3))
+        t1 = e.forward(o1, d1, tmax, Ns)
+        assert float((parts[b].reshape(-1) - t1).abs().max() / t1.abs().max()) < 1e-12, b
+        g1 = e.adjoint(o1, d1, e.tensor(w[b].reshape(-1)), tmax, Ns).reshape(gparts[b].shape)
+        assert float((gparts[b] - g1).abs().max() / g1.abs().max()) < 1e-11, b
+    # a ray inside the slab but within two cells of its face is refused for the tricubic (the trilinear stack takes it)
+    s0 = sv[0]
+    o2 = s0["o"].copy()
+    o2[0, 0, 0] = s0["grid"][0][0] + 0.5 * (s0["grid"][0][1] - s0["grid"][0][0])
+    d2 = s0["d"].copy()
+    d2[0, 0] = [0.0, 0.0, 1.0]
+    with pytest.raises(ValueError, match="two cells"):
+        st.rays([o2] + [s["o"] for s in sv[1:]], [d2] + [s["d"] for s in sv[1:]], tmax)
+    StackedSolves([s["grid"] for s in sv]).rays([o2] + [s["o"] for s in sv[1:]], [d2] + [s["d"] for s in sv[1:]], tmax)
