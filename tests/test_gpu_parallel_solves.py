@@ -182,3 +182,31 @@ def test_stacked_tricubic_equals_the_separate_solves():
     with pytest.raises(ValueError, match="two cells"):
         st.rays([o2] + [s["o"] for s in sv[1:]], [d2] + [s["d"] for s in sv[1:]], tmax)
     StackedSolves([s["grid"] for s in sv]).rays([o2] + [s["o"] for s in sv[1:]], [d2] + [s["d"] for s in sv[1:]], tmax)
+
+
+def test_stacked_float32_fast_mode(OC):
+    """storage="f32" + a plan on the stacked geometry: k_forward_bundle_f32 for every bundle (IONOTOMO_HYBRID_MIN=1), each solve's TEC
+    within the fast mode's 1e-6 of the float64 oracle on its own grid (north_star's tolerance for float32 storage)."""
+    import os
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    sv, tmax, Ns = solves(6, n=48, na=24, nd=10, seed=6)
+    st = StackedSolves([s["grid"] for s in sv], storage="f32")
+    o, d = st.rays([s["o"] for s in sv], [s["d"] for s in sv], tmax)
+    old = os.environ.get("IONOTOMO_HYBRID_MIN")
+    os.environ["IONOTOMO_HYBRID_MIN"] = "1"
+    try:
+        eng = st.engine
+    finally:
+        if old is None:
+            os.environ.pop("IONOTOMO_HYBRID_MIN", None)
+        else:
+            os.environ["IONOTOMO_HYBRID_MIN"] = old
+    eng.set_values(st.stack_grids([s["ne"] for s in sv]).reshape(-1))
+    ot, dt = eng.tensor(o.reshape(-1, 3)), eng.tensor(d.reshape(-1, 3))
+    info = eng.plan_forward(ot, dt, tmax, Ns)
+    assert info[0] > 0 and eng.describe("forward", ot, dt, tmax, Ns)[0].startswith("k_forward_bundle_f32")
+    parts = st.split_rays(eng.forward(ot, dt, tmax, Ns), o.shape[0])
+    assert not eng.check_oob()
+    for b, s in enumerate(sv):
+        oc = OC.forward_tec_straight(*s["grid"], s["ne"], s["o"].reshape(-1, 3), s["d"].reshape(-1, 3), tmax, Ns)
+        assert np.max(np.abs(parts[b].reshape(-1).cpu().numpy() - oc) / np.abs(oc)) < 1e-6, b
