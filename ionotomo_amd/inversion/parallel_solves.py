@@ -32,6 +32,21 @@ import torch
 from ..engine import RayEngine
 
 
+def solve_share(n_solves, world=None, rank=None):
+    """The solves rank ``rank`` of ``world`` stacks (default: this process's torch.distributed rank): contiguous blocks, sizes
+    differing by at most one.  Solves are independent, so several GPUs need NO exchange: every rank builds a ``StackedSolves`` of its
+    own share (``inversion_pipeline.py:131-216``: the tasks of different time steps only meet in the final list of solutions)."""
+    if world is None or rank is None:
+        import torch.distributed as dist
+        on = dist.is_available() and dist.is_initialized()
+        world, rank = (dist.get_world_size(), dist.get_rank()) if on else (1, 0)
+    if not 0 <= rank < world:
+        raise ValueError("solve_share: rank %d of %d" % (rank, world))
+    per, extra = divmod(int(n_solves), int(world))
+    lo = rank * per + min(rank, extra)
+    return range(lo, lo + per + (1 if rank < extra else 0))
+
+
 class StackedSolves(object):
     """B solves on grids of the same shape and spacing (their origins may differ: every solve's rays are moved by its own offset).
 

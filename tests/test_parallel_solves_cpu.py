@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from ionotomo_amd.inversion.parallel_solves import StackedSolves
+from ionotomo_amd.inversion.parallel_solves import StackedSolves, solve_share
 
 
 def grids():
@@ -65,3 +65,13 @@ def test_what_is_refused():
         st.rays([o], [d], 50.0)
     with pytest.raises(ValueError, match="antennas"):
         st.rays([o, o[:1]], [d, d[:1]], 50.0)
+
+
+def test_solves_are_shared_over_ranks_without_overlap():
+    for n, world in ((10, 4), (3, 8), (64, 8), (0, 2), (7, 1)):
+        got = [list(solve_share(n, world, r)) for r in range(world)]
+        assert sorted(sum(got, [])) == list(range(n))
+        assert max(len(g) for g in got) - min(len(g) for g in got) <= 1
+    assert list(solve_share(5)) == [0, 1, 2, 3, 4]               # no process group: one rank
+    with pytest.raises(ValueError):
+        solve_share(4, 2, 2)
