@@ -86,6 +86,7 @@ class StackedSolves(object):
         self.shift = self.base[None, :] - self.origins
         self.shift[:, 0] += np.arange(self.B) * self.nx * hx
         self.xvec = self.base[0] + hx * np.arange(self.B * self.nx)
+        self.xvec[:self.nx] = x0                # (a stack of ONE solve is that solve's grid, node for node)
         self.yvec, self.zvec = y0.copy(), z0.copy()
         if self.nx < 2 * self.margin + 2:
             raise ValueError("StackedSolves: %d nodes along x leave no cell two cells away from both faces" % self.nx)

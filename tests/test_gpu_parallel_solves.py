@@ -51,8 +51,11 @@ def one_by_one(sv, tmax, Ns, fn):
 def test_stacked_forward_and_transpose_equal_the_separate_solves(OC):
     from ionotomo_amd.inversion.parallel_solves import StackedSolves
     sv, tmax, Ns = solves(5)
+    sv[1]["o"], sv[1]["d"] = sv[1]["o"][:, :4], sv[1]["d"][:, :4]          # ragged: the solves need not hold the same number of pairs
+    sv[3]["o"], sv[3]["d"] = sv[3]["o"][:, 2:3], sv[3]["d"][:, 2:3]        # ... down to a single direction
     st = StackedSolves([s["grid"] for s in sv])
     o, d = st.rays([s["o"] for s in sv], [s["d"] for s in sv], tmax)
+    assert st.pairs == [9, 4, 9, 1, 9]
     eng = st.engine
     Na = o.shape[0]
     eng.set_values(st.stack_grids([s["ne"] for s in sv]).reshape(-1))
@@ -91,6 +94,13 @@ def test_stacked_forward_and_transpose_equal_the_separate_solves(OC):
         if b != 2:
             assert float(g2[b].abs().max()) == 0.0, b
     assert float((g2[2] - gparts[2]).abs().max()) <= 1e-12 * float(gparts[2].abs().max())
+    # a stack of ONE solve is that solve
+    s1 = StackedSolves([sv[4]["grid"]])
+    o1, d1 = s1.rays([sv[4]["o"]], [sv[4]["d"]], tmax)
+    assert np.array_equal(o1, sv[4]["o"]) and np.array_equal(s1.xvec, sv[4]["grid"][0])
+    s1.engine.set_values(s1.stack_grids([sv[4]["ne"]]).reshape(-1))
+    t4 = s1.engine.forward(s1.engine.tensor(o1.reshape(-1, 3)), s1.engine.tensor(d1.reshape(-1, 3)), tmax, Ns)
+    assert torch.equal(t4, ref[4][0])
 
 
 def test_stacked_planned_kernels_equal_the_unplanned_ones():
