@@ -160,6 +160,15 @@ class StackedSolves(object):
             lo += p
         return out
 
+    def per_solve_sum(self, v, Na):
+        """Sum of a stacked per-ray tensor over the rays of every solve -> tensor [B] on ``v``'s device (e.g. the solves' own
+        objectives 1/2 sum r^2 / CdCt from the stacked residual: the reference's stop rule is per solve, iterative_newton.py:542-554)."""
+        if self.pairs is None:
+            raise ValueError("StackedSolves.per_solve_sum: call rays() first")
+        per_pair = v.reshape(Na, -1).sum(dim=0)
+        ids = torch.repeat_interleave(torch.arange(self.B, device=v.device), torch.as_tensor(self.pairs, device=v.device))
+        return torch.zeros(self.B, dtype=per_pair.dtype, device=v.device).index_add_(0, ids, per_pair)
+
     def stack_rays(self, per_solve):
         """B per-ray arrays [Na, P_b] (e.g. ``dobs``, ``CdCt``) -> [Na, sum P_b] numpy."""
         return np.concatenate([np.asarray(a, dtype=np.float64) for a in per_solve], axis=1)

@@ -41,6 +41,8 @@ def test_rays_land_in_their_own_slab_at_the_same_grid_coordinates():
     blocks = st.split_grid(g)
     assert [tuple(b_.shape) for b_ in blocks] == [(11, 6, 21)] * 3 and float(blocks[2][0, 0, 0]) == 22 * 6 * 21
     assert st.stack_rays([np.ones((4, 5)) * b for b in range(3)]).shape == (4, 15)
+    sums = st.per_solve_sum(torch.as_tensor(st.stack_rays([np.ones((4, 5)) * (b + 1) for b in range(3)])), 4)
+    assert sums.tolist() == [20.0, 40.0, 60.0]
 
 
 def test_what_is_refused():
