@@ -1,0 +1,32 @@
+"""The two example scripts run end to end on one GPU (child processes, one at a time).  Needs a real MI355X: -m gpu."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run(args):
+    r = subprocess.run([sys.executable] + args, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-2000:]
+    return json.loads(lines[-1])
+
+
+def test_run_parallel_solves_example():
+    out = run(["examples/run_parallel_solves.py", "--solves", "6", "--iters", "8", "--n", "64"])
+    assert out["solves"] == list(range(6)) and out["rays"] == 6 * 62 * 42
+    before, after = out["objective_before"], out["objective_after"]
+    assert len(before) == 6 and all(a < 0.5 * b for a, b in zip(after, before))
+    # the stacked objective is the sum of the solves' own
+    assert abs(out["stacked_objective_history_first_last"][0] - sum(before)) <= 1e-9 * sum(before)
+
+
+def test_run_inversion_example():
+    out = run(["examples/run_inversion.py", "--size", "small", "--solver", "sirt", "--iters", "10"])
+    assert out["iterations"] == 10 and out["objective_last"] < out["objective_first"]
