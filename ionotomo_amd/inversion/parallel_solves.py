@@ -32,6 +32,13 @@ import torch
 from ..engine import RayEngine
 
 
+def _is_axis(v):
+    try:
+        return np.asarray(v, dtype=np.float64).ndim == 1
+    except (ValueError, TypeError):
+        return False
+
+
 def solve_share(n_solves, world=None, rank=None):
     """The solves rank ``rank`` of ``world`` stacks (default: this process's torch.distributed rank): contiguous blocks, sizes
     differing by at most one.  Solves are independent, so several GPUs need NO exchange: every rank builds a ``StackedSolves`` of its
@@ -59,8 +66,10 @@ class StackedSolves(object):
             raise ValueError("StackedSolves: interp is 'linear' or 'cubic'")
         self.interp = interp
         self.margin = 2 if interp == "cubic" else 0         # cells a ray keeps clear of its slab's x faces (module docstring)
-        if isinstance(grids, tuple) and count is not None:
-            grids = [grids] * int(count)
+        if len(grids) == 3 and all(_is_axis(v) for v in grids):              # ONE (xvec, yvec, zvec): `count` solves on it
+            grids = [tuple(grids)] * int(1 if count is None else count)
+        elif count is not None:
+            raise ValueError("StackedSolves: count goes with ONE (xvec, yvec, zvec)")
         if not grids:
             raise ValueError("StackedSolves: no grid")
         ax = [[np.asarray(v, dtype=np.float64) for v in g] for g in grids]

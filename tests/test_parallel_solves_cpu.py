@@ -53,6 +53,9 @@ def test_what_is_refused():
         StackedSolves([gs[0], (gs[1][0] * 1.5, gs[1][1], gs[1][2])])
     with pytest.raises(ValueError, match="no grid"):
         StackedSolves([])
+    assert StackedSolves(gs[0]).B == 1 and StackedSolves(gs[0], count=3).B == 3 and StackedSolves([gs[0]] * 3).B == 3
+    with pytest.raises(ValueError, match="count"):
+        StackedSolves(gs, count=2)
     st = StackedSolves(gs[0], count=2)
     o = np.zeros((2, 3, 3))
     d = np.tile(np.array([0.0, 0.0, 1.0]), (2, 3, 1))
