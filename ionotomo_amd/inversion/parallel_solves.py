@@ -15,9 +15,9 @@ and back-projection are block diagonal.  The cell between the last node of slab 
 (at most touched at x == last node, with weight 0 on the neighbour's side).  The reference antenna is subtracted per (time,
 direction) pair, and pairs are concatenated, not mixed.  SIRT's row and column sums are per ray and per node: B stacked SIRT solves
 ARE B separate ones (the one shared number is the cut-off 1e-9 max(col) below which a column counts as empty).  CGLS is different:
-its step lengths are global scalars, so a stacked CGLS is ONE conjugate-gradient solve of the block-diagonal system -- it converges
-to the same B solutions, but its iterates are not those of B separate runs; use SIRT, or the forward / gradient calls, when the
-separate iterates matter.
+its step lengths are global scalars, so ``solvers.cgls`` on the stacked problem is ONE conjugate-gradient solve of the block-diagonal
+system -- it converges to the same B solutions, but its iterates are not those of B separate runs; ``StackedSolves.cgls`` keeps one
+alpha and one beta per solve and IS B separate runs.
 
 ``interp="cubic"``: the tricubic takes its node derivatives from differences across +-2 nodes (csrc/iono_cubic_kernels.h), one-sided
 next to a face.  In the stacked grid the nodes next to a seam see the neighbour's values instead, so cells 0, 1 and nx - 3, nx - 2
@@ -100,7 +100,7 @@ class StackedSolves(object):
         if self.nx < 2 * self.margin + 2:
             raise ValueError("StackedSolves: %d nodes along x leave no cell two cells away from both faces" % self.nx)
         self._device, self._storage, self._engine = device, storage, None
-        self.pairs = None                       # pairs per solve of the last rays() call
+        self.pairs, self._pair_ids = None, {}   # pairs per solve of the last rays() call
 
     @property
     def engine(self):
@@ -117,7 +117,7 @@ class StackedSolves(object):
         (``interp="cubic"``: or comes within two cells of its x faces; y and z are checked by the kernels themselves, as for any grid)."""
         if len(origins) != self.B or len(directions) != self.B:
             raise ValueError("StackedSolves.rays: %d solves, got %d / %d ray sets" % (self.B, len(origins), len(directions)))
-        oo, dd, self.pairs = [], [], []
+        oo, dd, self.pairs, self._pair_ids = [], [], [], {}
         Na = None
         for b in range(self.B):
             o = np.asarray(origins[b], dtype=np.float64)
@@ -175,8 +175,96 @@ class StackedSolves(object):
         if self.pairs is None:
             raise ValueError("StackedSolves.per_solve_sum: call rays() first")
         per_pair = v.reshape(Na, -1).sum(dim=0)
-        ids = torch.repeat_interleave(torch.arange(self.B, device=v.device), torch.as_tensor(self.pairs, device=v.device))
-        return torch.zeros(self.B, dtype=per_pair.dtype, device=v.device).index_add_(0, ids, per_pair)
+        return torch.zeros(self.B, dtype=per_pair.dtype, device=v.device).index_add_(0, self.pair_solve(v.device), per_pair)
+
+    def pair_solve(self, device):
+        """int64 tensor [sum P_b]: the solve every (time, direction) pair of the stacked layout belongs to (built once per device:
+        a host-to-device copy in the middle of a loop would wait for every queued launch)."""
+        key = str(device)
+        if key not in self._pair_ids:
+            ids = np.repeat(np.arange(self.B, dtype=np.int64), self.pairs)
+            self._pair_ids[key] = torch.as_tensor(ids).to(device)
+        return self._pair_ids[key]
+
+    def cgls(self, problem, x0, n_iter=50, damp=0.0):
+        """B SEPARATE CGLS solves in one loop: the arithmetic of ``solvers.cgls`` (min 1/2 ||W^(1/2) (A x - d)||^2 + damp/2 ||x||^2 per
+        solve) with one step length alpha_b and one beta_b PER SOLVE, so block b's iterates are those of solve b alone
+        (``solvers.cgls`` on the stacked problem shares the two scalars: one conjugate-gradient solve of the block system).
+        ``problem``: ``ShardedRays`` on ``self.engine`` and the rays of ``self.rays`` (one rank).  Per iteration ONE forward and ONE
+        back-projection launch for all solves; the grid-sized vectors are kept compact over the nodes the rays reach
+        (``problem.active_index()``, as in ``solvers.cgls``) and updated by torch passes with the per-solve scalars looked up per
+        node / per ray; the search direction is scattered into a buffer the kernels read in place (``bind_values``).
+        ``damp`` acts on the reached nodes (the others never move).
+        Returns (x, history [n_iter][B] of the solves' objectives 1/2 sum r^2 / CdCt)."""
+        if self.pairs is None:
+            raise ValueError("StackedSolves.cgls: call rays() first")
+        if getattr(problem, "multi", False):
+            raise NotImplementedError("StackedSolves.cgls: one rank per stack (share the SOLVES over ranks: solve_share)")
+        eng, Na, B, i0 = problem.engine, problem.Na, self.B, problem.i0
+        dev = eng.device
+        idx = problem.active_index()
+        il = idx.long()
+        nid = il // int(np.prod(self.shape1))                               # active node -> solve
+        rid = self.pair_solve(dev).unsqueeze(0).expand(Na, -1).reshape(-1)  # ray -> solve ([Na, sum P_b] layout)
+
+        def ray_dot(a, b):
+            return self.per_solve_sum(a * b, Na)
+
+        # (the active index is sorted: a solve's reached nodes are one contiguous run of the compact vectors -- segment sums, not B
+        #  bins hammered by millions of atomic adds)
+        runs = torch.bincount(nid, minlength=B)
+        if nid.numel() > 1 and not bool((nid[1:] >= nid[:-1]).all()):
+            raise ValueError("StackedSolves.cgls: the problem's active index is not sorted by node (exchange=\"overlap\" is for several ranks)")
+
+        def node_dot(a, b):
+            return torch.segment_reduce(a * b, "sum", lengths=runs, unsafe=True)
+
+        Wh = torch.rsqrt(problem.cdct.reshape(-1) + 1e-15)
+        s_full = torch.zeros(eng.shape, dtype=torch.float64, device=dev)
+        x_c = x0.reshape(-1).index_select(0, il).contiguous()
+
+        def normal_residual(r_):                # compact A^T W^(1/2) r - damp x; leaves s_full zero again
+            y = (Wh * r_).view(Na, -1)
+            w = y.clone()
+            w[i0] -= y.sum(dim=0)
+            eng.adjoint(problem.origins, problem.dirs, w.reshape(-1), problem.tmax, problem.Ns, out=s_full, order=problem._adjoint_order())
+            s_c, _ = eng.compact_gather(s_full, idx, zero=True, want_dot=False)
+            return s_c.sub_(x_c, alpha=damp) if damp != 0.0 else s_c
+
+        eng.bind_values(None)
+        eng.set_values(x0.reshape(-1).contiguous())
+        r = Wh * (problem.dobs.reshape(-1) - problem.forward())
+        s = normal_residual(r)
+        p = s.clone()
+        gamma = node_dot(s, s)
+        p_pad, p_full = eng.new_grid_buffer()
+        hist = []
+        try:
+            eng.bind_values(p_pad)
+            for _ in range(n_iter):
+                hist.append(0.5 * ray_dot(r, r))
+                eng.compact_scatter(p_full, idx, p)
+                eng.values_changed()
+                q = Wh * problem.forward()
+                den = ray_dot(q, q)
+                if damp != 0.0:
+                    den = den + damp * node_dot(p, p)
+                # a solve whose residual is already zero keeps alpha = beta = 0 (0 / 0 otherwise)
+                alpha = torch.where(den > 0, gamma / den, torch.zeros_like(den))
+                x_c.addcmul_(alpha[nid], p)
+                r = r - alpha[rid] * q
+                s = normal_residual(r)
+                gnew = node_dot(s, s)
+                beta = torch.where(gamma > 0, gnew / gamma, torch.zeros_like(gamma))
+                p = s + beta[nid] * p
+                gamma = gnew
+        finally:
+            eng.bind_values(None)
+        x = x0.clone()
+        x.view(-1)[il] = x_c
+        eng.set_values(x.reshape(-1).contiguous())
+        h = torch.stack(hist).cpu().numpy() if hist else np.zeros((0, B))
+        return x, h
 
     def stack_rays(self, per_solve):
         """B per-ray arrays [Na, P_b] (e.g. ``dobs``, ``CdCt``) -> [Na, sum P_b] numpy."""

@@ -87,6 +87,17 @@ def main():
                 torch.cuda.synchronize()
                 ts[k] = (time.perf_counter() - t0) / 3
             rec[name + "_us_per_iteration_marginal"] = (ts[30] - ts[10]) / 20 * 1e6
+        # B SEPARATE CGLS solves (one alpha / beta per solve: StackedSolves.cgls, torch vector passes)
+        st.cgls(prob, x0, n_iter=3)
+        torch.cuda.synchronize()
+        ts = {}
+        for k in (5, 15):
+            t0 = time.perf_counter()
+            for _ in range(3):
+                st.cgls(prob, x0, n_iter=k)
+            torch.cuda.synchronize()
+            ts[k] = (time.perf_counter() - t0) / 3
+        rec["cgls_separate_us_per_iteration_marginal"] = (ts[15] - ts[5]) / 10 * 1e6
         for k in list(rec):
             if k.endswith("_us") or k.endswith("_marginal"):
                 rec[k.replace("_us", "_us_per_solve") if k.endswith("_us") else k + "_per_solve"] = rec[k] / B

@@ -220,3 +220,42 @@ def test_stacked_float32_fast_mode(OC):
     for b, s in enumerate(sv):
         oc = OC.forward_tec_straight(*s["grid"], s["ne"], s["o"].reshape(-1, 3), s["d"].reshape(-1, 3), tmax, Ns)
         assert np.max(np.abs(parts[b].reshape(-1).cpu().numpy() - oc) / np.abs(oc)) < 1e-6, b
+
+
+def test_stacked_cgls_with_per_solve_step_lengths_is_the_separate_cgls_solves():
+    """StackedSolves.cgls: one alpha and one beta per solve -- block b's iterates and objective history are those of solve b alone,
+    for solves of DIFFERENT geometry and weights (solvers.cgls on the stacked problem is one solve of the block system instead)."""
+    from ionotomo_amd import parallel, solvers
+    from ionotomo_amd.engine import RayEngine
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    B = 4
+    sv, tmax, Ns = solves(B, seed=11)
+    st = StackedSolves([s["grid"] for s in sv])
+    o, d = st.rays([s["o"] for s in sv], [s["d"] for s in sv], tmax)
+    Na, P = sv[0]["o"].shape[:2]
+    x0 = [torch.as_tensor(syn.ne_model(*s["grid"], turbulent=False) / 1e11) for s in sv]
+    dobs, cdct = [], []
+    for b, s in enumerate(sv):
+        e = RayEngine(0)
+        e.set_grid(*s["grid"])
+        e.set_values(e.tensor(s["ne"] / 1e11).reshape(-1))
+        t = e.forward(e.tensor(s["o"].reshape(-1, 3)), e.tensor(s["d"].reshape(-1, 3)), tmax, Ns).reshape(Na, P)
+        dobs.append((t - t[0:1]).cpu().numpy())
+        cdct.append(np.full((Na, P), 1e-4 * 3 ** b))                # weights three times apart from solve to solve
+    prob = parallel.ShardedRays(st.engine, o, d, tmax, Ns, dobs=st.stack_rays(dobs), cdct=st.stack_rays(cdct), i0=0, tune=False)
+    xs, hist = st.cgls(prob, st.stack_grids(x0), n_iter=8)
+    assert hist.shape == (8, B)
+    blocks = st.split_grid(xs)
+    shared, _ = solvers.cgls(prob, st.stack_grids(x0), n_iter=8)
+    differs = 0
+    for b, s in enumerate(sv):
+        e = RayEngine(0)
+        e.set_grid(*s["grid"])
+        p1 = parallel.ShardedRays(e, s["o"], s["d"], tmax, Ns, dobs=dobs[b], cdct=cdct[b], i0=0, tune=False)
+        x1, h1 = solvers.cgls(p1, x0[b].to(e.device), n_iter=8)
+        scale = float((x1 - x0[b].to(e.device)).abs().max())
+        assert scale > 0
+        assert float((blocks[b] - x1).abs().max()) < 1e-7 * scale, b        # (8 CG steps amplify the summation order: solvers' own tests)
+        np.testing.assert_allclose(hist[:, b], np.asarray(h1, dtype=np.float64)[:8], rtol=1e-7)
+        differs += float((st.split_grid(shared)[b] - x1).abs().max()) > 1e-3 * scale
+    assert differs >= B - 1          # the shared-scalar solve takes other steps (what this method is for)
