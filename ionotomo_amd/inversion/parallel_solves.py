@@ -59,9 +59,10 @@ class StackedSolves(object):
 
     ``grids``: list of ``(xvec, yvec, zvec)``, one per solve, or ONE tuple + ``count``.
     ``engine``: the ``RayEngine`` holding the stacked grid (``storage``, ``device``, ``interp`` as for any engine).
-    ``split_grid`` / ``split_rays`` return VIEWS: block b of a stacked result is solve b's result."""
+    ``split_grid`` / ``split_rays`` return VIEWS: block b of a stacked result is solve b's result.
+    The stacked grid must stay below 4 GiB (32 solves of 256^3 float64 nodes, 256 of 128^3): see ``allow_general``."""
 
-    def __init__(self, grids, count=None, device=0, storage="f64", interp="linear", rtol=1e-9):
+    def __init__(self, grids, count=None, device=0, storage="f64", interp="linear", rtol=1e-9, allow_general=False):
         if interp not in ("linear", "cubic"):
             raise ValueError("StackedSolves: interp is 'linear' or 'cubic'")
         self.interp = interp
@@ -97,6 +98,13 @@ class StackedSolves(object):
         self.xvec = self.base[0] + hx * np.arange(self.B * self.nx)
         self.xvec[:self.nx] = x0                # (a stack of ONE solve is that solve's grid, node for node)
         self.yvec, self.zvec = y0.copy(), z0.copy()
+        # the library's planned / lanes = samples kernels address the grid with 32-bit BYTE offsets (csrc/ionotomo_hip.hip:
+        # fast_path_ok); a larger grid falls to the general kernels, several times slower -- several stacks serve it better
+        item = 4 if str(storage) in ("f32", "float32") else 8
+        if self.B * int(np.prod(self.shape1)) * item >= 2 ** 32 and not allow_general:
+            per = 2 ** 32 // (int(np.prod(self.shape1)) * item)
+            raise ValueError("StackedSolves: %d solves of %s nodes exceed the 4 GiB the fast kernels address; stack at most %d of them "
+                             "(allow_general=True runs the general kernels instead)" % (self.B, self.shape1, max(per - 1, 1)))
         if self.nx < 2 * self.margin + 2:
             raise ValueError("StackedSolves: %d nodes along x leave no cell two cells away from both faces" % self.nx)
         self._device, self._storage, self._engine = device, storage, None

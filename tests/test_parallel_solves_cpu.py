@@ -56,6 +56,11 @@ def test_what_is_refused():
     assert StackedSolves(gs[0]).B == 1 and StackedSolves(gs[0], count=3).B == 3 and StackedSolves([gs[0]] * 3).B == 3
     with pytest.raises(ValueError, match="count"):
         StackedSolves(gs, count=2)
+    big = (np.linspace(0, 1, 256), np.linspace(0, 1, 256), np.linspace(0, 1, 256))
+    with pytest.raises(ValueError, match="4 GiB"):
+        StackedSolves(big, count=32)
+    assert StackedSolves(big, count=31).B == 31 and StackedSolves(big, count=32, storage="f32").B == 32
+    assert StackedSolves(big, count=32, allow_general=True).B == 32
     st = StackedSolves(gs[0], count=2)
     o = np.zeros((2, 3, 3))
     d = np.tile(np.array([0.0, 0.0, 1.0]), (2, 3, 1))
