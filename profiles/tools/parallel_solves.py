@@ -21,6 +21,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--B", type=int, nargs="+", default=[1, 4, 16, 32, 64])
     ap.add_argument("--n", type=int, default=128)
+    ap.add_argument("--nt", type=int, default=1, help="time steps per solve (4 = one coherence window of the reference's pipeline)")
+    ap.add_argument("--no-solvers", action="store_true")
     args = ap.parse_args()
     import torch
     import bench
@@ -30,12 +32,15 @@ def main():
     Ns = n + 1
     ants = syn.lofar_enu_km()
     Bmax = max(args.B)
-    dirs = syn.rotate_about_pole(syn.facet_directions(42, 4.0, 1), Bmax)          # the field at Bmax consecutive time steps
-    o_all, d_all = syn.ray_bundle(ants, dirs)                                       # [Na, Bmax, Nd, 3]
+    nt = args.nt
+    dirs = syn.rotate_about_pole(syn.facet_directions(42, 4.0, 1), Bmax * nt)     # the field at Bmax * nt consecutive time steps
+    o_all, d_all = syn.ray_bundle(ants, dirs)                                       # [Na, Bmax nt, Nd, 3]
     grid = syn.domain_for(o_all, d_all, n, tmax, 4)
-    Na, Nd = o_all.shape[0], o_all.shape[2]
+    Na, Nd = o_all.shape[0], o_all.shape[2] * nt
+    o_all = o_all.reshape(Na, Bmax, Nd, 3)                                          # solve b = time steps [b nt, (b + 1) nt)
+    d_all = d_all.reshape(Na, Bmax, Nd, 3)
     ne0 = syn.ne_model(*grid, seed=7, corr=30.0) / 1e11
-    out = {"what": __doc__.split("\n\n")[0], "grid": [n] * 3, "rays_per_solve": Na * Nd, "Ns": Ns, "csrc_sha": bench.csrc_sha(), "points": []}
+    out = {"what": __doc__.split("\n\n")[0], "grid": [n] * 3, "rays_per_solve": Na * Nd, "time_steps_per_solve": nt, "Ns": Ns, "csrc_sha": bench.csrc_sha(), "points": []}
     bench.SETTLE_MS = 50.0
 
     def med(fn, steps):
@@ -69,6 +74,15 @@ def main():
         del g, y
         eng.clear_forward_plan()
         eng.clear_adjoint_plan()
+        if args.no_solvers:
+            for k in list(rec):
+                if k.endswith("_us"):
+                    rec[k.replace("_us", "_us_per_solve")] = rec[k] / B
+            out["points"].append(rec)
+            print(json.dumps(rec), file=sys.stderr, flush=True)
+            del st, eng, ot, dt, tec
+            torch.cuda.empty_cache()
+            continue
         # SIRT on the stacked problem (the solves' own data: forward of a perturbed model)
         eng.set_values(st.stack_grids([m * 1.05 for m in models]).reshape(-1))
         t = eng.forward(ot, dt, tmax, Ns).reshape(Na, -1)
