@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--solves", type=int, default=16, help="time steps = independent solves (all ranks together)")
     ap.add_argument("--iters", type=int, default=30)
-    ap.add_argument("--n", type=int, default=96, help="nodes per axis of every solve's grid")
+    ap.add_argument("--grid", type=int, default=96, help="nodes per axis of every solve's grid")
     ap.add_argument("--backend", default=os.environ.get("IONO_BENCH_BACKEND", "nccl"))
     args = ap.parse_args()
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
@@ -41,8 +41,9 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
             dist.init_process_group(args.backend)
-    mine = list(solve_share(args.solves, world, rank))             # this rank's time steps; nothing is exchanged between ranks
-    n, tmax, Ns = args.n, 1000.0, args.n + 1
+    mine = list(solve_share(args.solves, world, rank))             # this rank's time steps; nothing is exchanged between ranks:
+    parallel.INDEPENDENT_RANKS = True                              # ... the rank's stacked problem is whole, not a shard
+    n, tmax, Ns = args.grid, 1000.0, args.grid + 1
     ants = syn.lofar_enu_km()
     dirs = syn.rotate_about_pole(syn.facet_directions(42, 4.0, 1), args.solves)            # the field at every time step
     o_all, d_all = syn.ray_bundle(ants, dirs)                                              # [Na, Nt, Nd, 3]

@@ -42,7 +42,9 @@ def _is_axis(v):
 def solve_share(n_solves, world=None, rank=None):
     """The solves rank ``rank`` of ``world`` stacks (default: this process's torch.distributed rank): contiguous blocks, sizes
     differing by at most one.  Solves are independent, so several GPUs need NO exchange: every rank builds a ``StackedSolves`` of its
-    own share (``inversion_pipeline.py:131-216``: the tasks of different time steps only meet in the final list of solutions)."""
+    own share (``inversion_pipeline.py:131-216``: the tasks of different time steps only meet in the final list of solutions) and
+    sets ``ionotomo_amd.parallel.INDEPENDENT_RANKS = True`` first, so that ``ShardedRays`` / the solvers treat the rank's problem as
+    whole instead of as one shard of a problem all ranks share.  (The share is taken from the process group whatever that flag says.)"""
     if world is None or rank is None:
         import torch.distributed as dist
         on = dist.is_available() and dist.is_initialized()

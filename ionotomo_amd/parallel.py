@@ -34,8 +34,14 @@ def pair_block(n_pairs, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+# Every rank solves ITS OWN problems (independent solves shared over the ranks: inversion/parallel_solves.py:solve_share) although a
+# process group exists: the sharded code paths then see one rank -- no pair blocks, no collective, nothing to wait for on a rank
+# that holds other solves.  Set it before building the ``ShardedRays`` and leave it set while they are in use.
+INDEPENDENT_RANKS = False
+
+
 def world_info():
-    if dist.is_available() and dist.is_initialized():
+    if dist.is_available() and dist.is_initialized() and not INDEPENDENT_RANKS:
         return dist.get_world_size(), dist.get_rank()
     return 1, 0
 
@@ -49,7 +55,7 @@ FORCE_COLLECTIVES = False
 
 def multi_rank():
     """True when the collectives of the sharded code paths must run: more than one rank (or the switch above on a 1-rank group)."""
-    if not (dist.is_available() and dist.is_initialized()):
+    if INDEPENDENT_RANKS or not (dist.is_available() and dist.is_initialized()):
         return False
     return dist.get_world_size() > 1 or FORCE_COLLECTIVES
 

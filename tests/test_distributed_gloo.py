@@ -140,3 +140,72 @@ def test_sharded_path_matches_single_rank(world, exchange, size):
         assert res[r]["compact"] == (exchange in ("compact", "sharded") or (exchange == "auto" and res[r]["active"] < 0.6))
         if exchange != "dense":
             assert 0.0 < res[r]["active"] < 1.0 and res[r]["active"] == res[0]["active"]
+
+
+def _independent_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sys.path.insert(0, HERE)
+        sys.path.insert(0, os.path.dirname(HERE))
+        from ionotomo_amd import parallel, solvers
+        from ionotomo_amd.inversion.parallel_solves import solve_share
+        from problems import small_problem
+        from cpu_engine import OracleEngine
+        parallel.INDEPENDENT_RANKS = True
+        mine = list(solve_share(5, None, None))              # (the share still comes from the process group)
+        res = {}
+        for t in mine:                                       # every rank: ITS solves, different from rank to rank, different in number
+            pb = small_problem(na=3, nd=4, nt=1 + t % 2, n=10, Ns=11)
+            w = pb["w"]
+            eng = OracleEngine(w["xvec"], w["yvec"], w["zvec"])
+            rng = np.random.default_rng(10 + t)
+            d = rng.normal(size=(pb["na"], pb["P"])) * 0.01
+            prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d, cdct=np.full(d.shape, 1e-4), i0=pb["i0"])
+            assert (prob.world, prob.rank, prob.multi, prob.lo, prob.hi) == (1, 0, False, 0, pb["P"])
+            x, h = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()), n_iter=3)
+            xc, hc = solvers.cgls(prob, torch.from_numpy(pb["x0"].copy()), n_iter=3)
+            res[t] = (x.numpy(), np.array(h), xc.numpy(), np.array(hc))
+        q.put((rank, mine, res))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_independent_ranks_solve_their_own_problems_without_any_collective():
+    """parallel.INDEPENDENT_RANKS: with a process group of two ranks, every rank's ShardedRays is a whole problem (solves shared
+    over ranks, inversion/parallel_solves.py:solve_share): 3 + 2 solves of different sizes, no collective (a mismatch would hang or
+    abort gloo), results equal to the same solves without any group."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_independent_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    shares = {}
+    for _ in range(world):
+        rank, mine, res = get_or_fail(q, procs, 240)
+        shares[rank] = mine
+        got.update(res)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert shares == {0: [0, 1, 2], 1: [3, 4]} and sorted(got) == [0, 1, 2, 3, 4]
+    sys.path.insert(0, HERE)
+    from ionotomo_amd import parallel, solvers
+    from problems import small_problem
+    from cpu_engine import OracleEngine
+    assert parallel.INDEPENDENT_RANKS is False
+    for t in range(5):
+        pb = small_problem(na=3, nd=4, nt=1 + t % 2, n=10, Ns=11)
+        w = pb["w"]
+        eng = OracleEngine(w["xvec"], w["yvec"], w["zvec"])
+        d = np.random.default_rng(10 + t).normal(size=(pb["na"], pb["P"])) * 0.01
+        prob = parallel.ShardedRays(eng, pb["o"], pb["d"], pb["tmax"], pb["Ns"], dobs=d, cdct=np.full(d.shape, 1e-4), i0=pb["i0"])
+        x, h = solvers.sirt(prob, torch.from_numpy(pb["x0"].copy()), n_iter=3)
+        xc, hc = solvers.cgls(prob, torch.from_numpy(pb["x0"].copy()), n_iter=3)
+        np.testing.assert_array_equal(got[t][0], x.numpy())
+        np.testing.assert_array_equal(got[t][1], np.array(h))
+        np.testing.assert_array_equal(got[t][2], xc.numpy())
+        np.testing.assert_array_equal(got[t][3], np.array(hc))
