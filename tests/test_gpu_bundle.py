@@ -169,7 +169,12 @@ def test_hybrid_dispatch_mixed_geometries(seed, interp, OC):
     hist = np.array(sp["bundles_by_ray_count"])
     assert hist.sum() == sp["bundles_cut"] and (hist * np.arange(65)).sum() == R
     assert sp["bundles_served"] == hist[hmin:].sum() and sp["rays_served"] == (hist * np.arange(65))[hmin:].sum()
-    assert sp["rays_tail"] < R and (hmin < 8 or sp["rays_tail"] > 0), sp         # a genuinely mixed launch (hmin = 2: unless no ray is alone)
+    # a genuinely mixed launch whenever the cut left bundles on both sides of the threshold (it need not: samples coarser than the
+    # z cells fit no window and every ray stays alone -- the plan then serves nothing --, and a small grid can bundle every ray)
+    if hist[hmin:].sum() > 0 and hist[1:hmin].sum() > 0:
+        assert 0 < sp["rays_tail"] < R, sp
+    else:
+        assert sp["rays_tail"] in (0, R), sp
     got = eng.forward(ot, dt, zhi, Ns).cpu().numpy()
     assert eng.check_oob() == (not inside.all())
     assert np.all(np.isnan(got[~inside])) and np.all(np.isfinite(got[inside]))
