@@ -65,8 +65,14 @@ def test_fixed_point_back_projection_is_reproducible_and_equals_the_float_one(se
     z = eng.adjoint(ot, dt, torch.zeros_like(wt), zhi, Ns)
     assert float(z.abs().max()) == 0.0
     wn = wt.clone()
-    wn[::3] = float("nan")                                  # (some of them belong to rays inside the grid)
-    assert bool(torch.isnan(eng.adjoint(ot, dt, wn, zhi, Ns)).any())
+    wn[::3] = float("nan")
+    end = o + d * ((zhi - o[:, 2]) / d[:, 2])[:, None]
+    inside = np.flatnonzero((end[:, 0] >= xv[0]) & (end[:, 0] <= xv[-1]) & (end[:, 1] >= yv[0]) & (end[:, 1] <= yv[-1]))
+    if inside.size:                                         # (a steep seed can leave every third ray outside the grid: poison one inside)
+        wn[int(inside[0])] = float("nan")
+        assert bool(torch.isnan(eng.adjoint(ot, dt, wn, zhi, Ns)).any())
+    else:
+        eng.adjoint(ot, dt, wn, zhi, Ns)
     eng.check_oob()
     # ... and the integer grid is clean again afterwards
     assert torch.equal(eng.adjoint(ot, dt, wt, zhi, Ns), runs[0])
