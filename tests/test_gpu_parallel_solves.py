@@ -9,6 +9,7 @@ import torch
 from ionotomo_amd import synthetic as syn
 
 pytestmark = pytest.mark.gpu
+SOAK = int(__import__("os").environ.get("IONO_SOAK", "1"))
 
 
 @pytest.fixture(scope="module")
@@ -259,3 +260,45 @@ def test_stacked_cgls_with_per_solve_step_lengths_is_the_separate_cgls_solves():
         np.testing.assert_allclose(hist[:, b], np.asarray(h1, dtype=np.float64)[:8], rtol=1e-7)
         differs += float((st.split_grid(shared)[b] - x1).abs().max()) > 1e-3 * scale
     assert differs >= B - 1          # the shared-scalar solve takes other steps (what this method is for)
+
+
+@pytest.mark.parametrize("seed", range(SOAK * 3))
+def test_stacked_random_solves(seed, OC):
+    """Random numbers of solves, grid shapes, arrays and pair counts, with and without plans: block b of the stacked forward equals the
+    C oracle on solve b's own grid, the stacked transpose is the transpose of the stacked forward (dot-product test) and leaves
+    every other solve's block untouched."""
+    from ionotomo_amd.inversion.parallel_solves import StackedSolves
+    rng = np.random.default_rng(900 + seed)
+    B = int(rng.integers(2, 9))
+    sv, tmax, Ns = solves(B, n=int(rng.integers(20, 56)), na=int(rng.integers(3, 24)), nd=int(rng.integers(2, 14)), seed=seed)
+    for s_ in sv:                                                           # ragged pair counts
+        keep = int(rng.integers(1, s_["o"].shape[1] + 1))
+        s_["o"], s_["d"] = s_["o"][:, :keep], s_["d"][:, :keep]
+    st = StackedSolves([s_["grid"] for s_ in sv])
+    o, d = st.rays([s_["o"] for s_ in sv], [s_["d"] for s_ in sv], tmax)
+    eng = st.engine
+    Na = o.shape[0]
+    x = st.stack_grids([s_["ne"] for s_ in sv])
+    eng.set_values(x.reshape(-1))
+    ot, dt = eng.tensor(o.reshape(-1, 3)), eng.tensor(d.reshape(-1, 3))
+    if seed % 2:
+        eng.plan_forward(ot, dt, tmax, Ns)
+        eng.plan_adjoint(ot, dt, tmax, Ns)
+    tec = eng.forward(ot, dt, tmax, Ns)
+    assert not eng.check_oob()
+    for b, (part, s_) in enumerate(zip(st.split_rays(tec, Na), sv)):
+        oc = OC.forward_tec_straight(*s_["grid"], s_["ne"], s_["o"].reshape(-1, 3), s_["d"].reshape(-1, 3), tmax, Ns)
+        assert np.max(np.abs(part.reshape(-1).cpu().numpy() - oc) / np.abs(oc)) < 1e-11, (seed, b)
+    y = torch.as_tensor(rng.normal(size=tec.shape[0])).to(eng.device)
+    g = eng.adjoint(ot, dt, y, tmax, Ns)
+    lhs, rhs = float(torch.dot(tec, y)), float(torch.dot(x.reshape(-1), g.reshape(-1)))
+    assert abs(lhs - rhs) <= 1e-11 * max(abs(lhs), abs(rhs), float(tec.abs().max() * y.abs().max())), (seed, lhs, rhs)
+    k = int(rng.integers(0, B))
+    yk = torch.zeros_like(y).reshape(Na, -1)
+    lo = sum(st.pairs[:k])
+    yk[:, lo:lo + st.pairs[k]] = y.reshape(Na, -1)[:, lo:lo + st.pairs[k]]
+    gk = st.split_grid(eng.adjoint(ot, dt, yk.reshape(-1).contiguous(), tmax, Ns))
+    for b in range(B):
+        if b != k:
+            assert float(gk[b].abs().max()) == 0.0, (seed, b, k)
+    assert float((gk[k] - st.split_grid(g)[k]).abs().max()) <= 1e-11 * float(g.abs().max())
